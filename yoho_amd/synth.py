@@ -1,0 +1,118 @@
+"""Synthetic workloads for tests, golden fixtures, smoke() and bench.py.
+
+3DMatch data, FCGF features and the pretrained checkpoints are absent from the reference
+tree (.MISSING_LARGE_BLOBS), so every workload is synthetic:
+unit-norm group features (FCGF features are L2-normalised, fcgf_model/resunet.py:187-190) and
+fragment pairs built by permuting the group axis with 60_60.npy[i] + noise + outlier rows, with
+keypoints related by a rigid motion.
+
+Everything is derived from ``weights.hash_uniform`` with only element-wise IEEE ops
+(+,-,*,/,sqrt) and explicitly ordered reductions, so the same bits come out on any machine
+and the golden fixtures can store seeds instead of megabytes of inputs.
+"""
+import numpy as np
+from .weights import hash_uniform
+from .tables import default_tables, G, F
+
+
+def _gauss(seed, name, n, dtype=np.float32):
+    """Approximately N(0,1): Irwin-Hall sum of 4 uniforms, exact arithmetic only."""
+    u = hash_uniform(seed, name, 4 * n).astype(np.float64).reshape(4, n)
+    v = (((u[0] + u[1]) + u[2]) + u[3] - 2.0) * 1.7320508075688772
+    return v.astype(dtype)
+
+
+def _unit_norm_rows(x):
+    """L2-normalise (K,32,60) over axis 1 with a fixed (sequential) summation order."""
+    s = x[:, 0, :] * x[:, 0, :]
+    for c in range(1, x.shape[1]):
+        s = s + x[:, c, :] * x[:, c, :]
+    return (x / np.sqrt(s)[:, None, :]).astype(np.float32)
+
+
+def unit_features(K, seed=0, name="feat"):
+    """(K,32,60) f32, unit norm over the 32 channels for every (keypoint, group element)."""
+    x = _gauss(seed, name, K * F * G).reshape(K, F, G)
+    return _unit_norm_rows(x)
+
+
+def quat_to_mat64(q):
+    w, x, y, z = q
+    return np.array([[1 - 2 * y * y - 2 * z * z, 2 * x * y - 2 * z * w, 2 * x * z + 2 * y * w],
+                     [2 * x * y + 2 * z * w, 1 - 2 * x * x - 2 * z * z, 2 * y * z - 2 * x * w],
+                     [2 * x * z - 2 * y * w, 2 * y * z + 2 * x * w, 1 - 2 * x * x - 2 * y * y]], dtype=np.float64)
+
+
+def _apply_rt(k, R, t):
+    """k @ R.T + t with an explicit operation order (no BLAS)."""
+    out = np.empty_like(k)
+    for r in range(3):
+        out[:, r] = ((k[:, 0] * R[r, 0] + k[:, 1] * R[r, 1]) + k[:, 2] * R[r, 2]) + t[r]
+    return out
+
+
+def make_pair(K, seed=0, tables=None, noise=0.02, outlier_frac=0.4, key_noise=0.01, max_res_deg=15.0):
+    """Synthetic fragment pair.
+
+    fragment 1 = random unit features / keys U[0,3]^3;  fragment 0 = fragment 1 with the group
+    axis permuted by P[gi] (+noise, renormalised), a fraction of rows replaced by fresh random
+    features (outliers), rows shuffled; keys0 = keys1 @ (R_res R_gi)^T + t + noise.
+    Returns dict(feat0, feat1 (K,32,60) f32, keys0, keys1 (K,3) f64, gi, gt (3,4), perm).
+    """
+    tb = tables or default_tables()
+    u = hash_uniform(seed, "pairmeta", 16).astype(np.float64)
+    gi = int(u[0] * G) % G
+    feat1 = unit_features(K, seed, "feat1")
+    keys1 = hash_uniform(seed, "keys1", K * 3).astype(np.float64).reshape(K, 3) * 3.0
+
+    # residual rotation: small-angle quaternion about a hashed axis (<= max_res_deg)
+    ax = u[1:4] - 0.5
+    ax = ax / np.sqrt((ax[0] * ax[0] + ax[1] * ax[1]) + ax[2] * ax[2])
+    half = 0.5 * np.deg2rad(max_res_deg) * u[4]
+    s = half - half ** 3 / 6.0                      # sin/cos by short series: exact-op only
+    c = np.sqrt(1.0 - s * s)
+    Rres = quat_to_mat64(np.array([c, ax[0] * s, ax[1] * s, ax[2] * s]))
+    Rg = tb.R64[gi]
+    R = np.empty((3, 3))
+    for i in range(3):
+        for j in range(3):
+            R[i, j] = (Rres[i, 0] * Rg[0, j] + Rres[i, 1] * Rg[1, j]) + Rres[i, 2] * Rg[2, j]
+    t = (u[5:8] - 0.5) * 2.0
+
+    # fragment 0 rows: a hashed permutation of fragment 1's rows (argsort of uniforms: integer result)
+    perm = np.argsort(hash_uniform(seed, "rowperm", K), kind="stable")
+    f0 = feat1[perm][:, :, tb.P[gi]] + np.float32(noise) * _gauss(seed, "fnoise", K * F * G).reshape(K, F, G)
+    fresh = unit_features(K, seed, "outliers")
+    is_out = hash_uniform(seed, "isout", K) < outlier_frac
+    f0[is_out] = fresh[is_out]
+    feat0 = _unit_norm_rows(f0)
+    keys0 = _apply_rt(keys1[perm], R, t) + key_noise * _gauss(seed, "knoise", K * 3, np.float64).reshape(K, 3)
+    fresh_k = hash_uniform(seed, "outkeys", K * 3).astype(np.float64).reshape(K, 3) * 3.0
+    keys0[is_out] = fresh_k[is_out]
+    gt = np.concatenate([R, t[:, None]], axis=1)
+    return dict(feat0=np.ascontiguousarray(feat0), feat1=np.ascontiguousarray(feat1),
+                keys0=np.ascontiguousarray(keys0), keys1=np.ascontiguousarray(keys1),
+                gi=gi, gt=gt, perm=perm, is_out=is_out)
+
+
+def estimator_case(M=1500, H=1000, seed=0, inlier_frac=0.3, tables=None):
+    """Estimator micro-benchmark inputs: M matches, M per-match hypotheses of which
+    ~inlier_frac are close to the true motion."""
+    tb = tables or default_tables()
+    u = hash_uniform(seed, "estmeta", 16).astype(np.float64)
+    gi = int(u[0] * G) % G
+    R = tb.R64[gi]
+    t = (u[5:8] - 0.5) * 2.0
+    k1 = hash_uniform(seed, "ek1", M * 3).astype(np.float64).reshape(M, 3) * 3.0
+    k0 = _apply_rt(k1, R, t) + 0.01 * _gauss(seed, "eknoise", M * 3, np.float64).reshape(M, 3)
+    inl = hash_uniform(seed, "einl", M) < inlier_frac
+    rnd = hash_uniform(seed, "ernd", M * 3).astype(np.float64).reshape(M, 3) * 3.0
+    k0[~inl] = rnd[~inl]
+    # per-match hypotheses: inliers get R (+ tiny perturbation through t), outliers random group rot
+    gidx = (hash_uniform(seed, "egidx", M) * G).astype(np.int64) % G
+    gidx[inl] = gi
+    T = np.empty((M, 3, 4))
+    T[:, :, :3] = tb.R64[gidx]
+    for r in range(3):
+        T[:, r, 3] = k0[:, r] - ((k1[:, 0] * T[:, r, 0] + k1[:, 1] * T[:, r, 1]) + k1[:, 2] * T[:, r, 2])
+    return dict(k0=k0, k1=k1, T=T, dr=gidx, gi=gi, gt=np.concatenate([R, t[:, None]], 1), inl=inl)
