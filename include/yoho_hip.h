@@ -1,0 +1,141 @@
+/*
+ * yoho_hip.h - C ABI of libyoho_hip.so: MI355X (gfx950) kernels for YOHO's 60-rotation
+ * group-equivariant descriptor path and the YOHO-O / YOHO-C transformation estimators.
+ *
+ * The reference (HpWang-whu/YOHO) is pure Python/PyTorch on this path and has no FFI of its
+ * own; the entry points below are what a binding for that path replaces, one per reference
+ * call site (file:line relative to the reference root, see DESIGN.md / INTEGRATION.md):
+ *
+ *   yoho_partI_forward      PartI_test.forward            utils/network.py:86-105,140-147
+ *   yoho_group_mean_np      np.mean(feats, axis=-1)       tests/matcher.py:35-36
+ *   yoho_nn_search          modified_knn_matcher.__call__ utils/knn_search.py:17-66,138-154
+ *   yoho_mutual_nn          matcher_dual.match inner loop tests/matcher.py:37-48
+ *   yoho_des2r              Batch_Des2R_torch             tests/extractor.py:74-78
+ *   yoho_partII_forward     PartII_test.forward           utils/network.py:259-278
+ *   yoho_hyp_from_quat      quat -> [R|t] loops           tests/extractor.py:187-199, utils/r_eval.py:94-110
+ *   yoho_o_score            yohoo.ransac scoring loop     tests/estimator.py:330-336, :286-290
+ *   yoho_c_ransac           yohoc.ransac loop body        tests/estimator.py:119-137, :55-70
+ *   yoho_group_gather       60-fold FCGF feature gather   YOHO_testset.py:153-166
+ *
+ * Conventions
+ *   - return 0 on success, a negative YOHO_E* code on error; yoho_last_error() gives a
+ *     thread-local message.  No C++ exception crosses the ABI.
+ *   - every data pointer is a DEVICE pointer owned by the caller (contiguous, 16-byte
+ *     aligned), except the yoho_load_* / yoho_ctx_create inputs which are HOST pointers.
+ *   - calls are asynchronous on the given hipStream_t (pass NULL for the default stream);
+ *     the library allocates only its own workspace inside the ctx (which may synchronise
+ *     the stream the first time a larger problem is seen).
+ *   - one ctx per device; a ctx is not thread-safe, different ctxs are independent.
+ *   - tensors use the reference's layouts: group features (K,32,60) f32 with the group axis
+ *     innermost, keypoints (K,3) f64, transforms (.,3,4) f64, indices int64.
+ */
+#ifndef YOHO_HIP_H
+#define YOHO_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define YOHO_OK            0
+#define YOHO_EINVAL       -1   /* bad argument */
+#define YOHO_EHIP         -2   /* HIP runtime error (message has the hipError string) */
+#define YOHO_ENOWEIGHTS   -3   /* forward called before yoho_load_* */
+#define YOHO_ENOMEM       -4
+
+typedef struct yoho_ctx yoho_ctx;
+
+/* host pointers into a checkpoint's tensors, torch layouts (conv: (Cout,Cin,1,K) row-major) */
+typedef struct { const float *weight, *bias; } yoho_conv_w;
+typedef struct { const float *gamma, *beta, *mean, *var; } yoho_bn_w;   /* BatchNorm2d eval, eps 1e-5 */
+
+/* PartI_test state dict (utils/network.py:76-78) */
+typedef struct {
+    yoho_conv_w conv_in;                       /* PartI_net.Conv_in.0                   32->256, K=13 */
+    yoho_bn_w   res_in_bn;   yoho_conv_w res_in;   /* SO3_Conv_layers.0.comb_layer_in.{0,2}  256->512 */
+    yoho_bn_w   res_out_bn;  yoho_conv_w res_out;  /* SO3_Conv_layers.0.comb_layer_out.{0,2} 512->256 */
+    yoho_bn_w   out_bn;      yoho_conv_w conv_out; /* Conv_out.comb_layer.{0,2}              256->32  */
+} yoho_partI_weights;
+
+/* PartII_test state dict (utils/network.py:228-241) */
+typedef struct {
+    yoho_bn_w   init_bn;     yoho_conv_w init;     /* Conv_init.comb_layer.{0,2}            128->256 */
+    yoho_bn_w   res_in_bn;   yoho_conv_w res_in;   /* PartII_SO3_Conv_layers.0.comb_layer_in  256->512 */
+    yoho_bn_w   res_out_bn;  yoho_conv_w res_out;  /* PartII_SO3_Conv_layers.0.comb_layer_out 512->256 */
+    yoho_conv_w fc0;  yoho_bn_w fc0_bn;            /* PartII_To_R_FC.{0,1}  256->512, K=1 */
+    yoho_conv_w fc1;  yoho_bn_w fc1_bn;            /* PartII_To_R_FC.{3,4}  512->128 */
+    yoho_conv_w fc2;                               /* PartII_To_R_FC.6      128->4   */
+} yoho_partII_weights;
+
+const char* yoho_last_error(void);
+const char* yoho_version(void);
+
+/* Rotation.npy as (60,3,3) f32, Nei_Index_in_SO3_ordered_13.npy as (60,13) u8, 60_60.npy as (60,60) u8 */
+int yoho_ctx_create(int device, const float* R60x9, const uint8_t* N60x13, const uint8_t* P60x60, yoho_ctx** out);
+int yoho_ctx_destroy(yoho_ctx* ctx);
+
+int yoho_load_partI(yoho_ctx* ctx, const yoho_partI_weights* w);
+int yoho_load_partII(yoho_ctx* ctx, const yoho_partII_weights* w);
+
+/* x (B,32,60) -> eqv (B,32,60) L2-normalised over channels, inv (B,32) (network's normalised
+ * invariant feature; may be NULL), inv_np (B,32) = numpy-order fp32 mean of eqv over the group
+ * axis, i.e. what the matcher consumes (may be NULL).  Any B >= 1. */
+int yoho_partI_forward(yoho_ctx* ctx, const float* x, int B, float* eqv, float* inv, float* inv_np, void* stream);
+
+/* out (B,32) = np.mean(eqv (B,32,60), axis=-1) bit-exactly (numpy pairwise order, fp32) */
+int yoho_group_mean_np(yoho_ctx* ctx, const float* eqv, int B, float* out, void* stream);
+
+/* for every row of src (Ns,D) the index (and distance, may be NULL) of the nearest row of
+ * tgt (Nt,D): argmin_j sqrt(sum_f (s_f - t_jf)^2 + 1e-7), fp32, first minimum wins.  D = 32
+ * (descriptor matching, torch-CPU summation order) or D = 3. */
+int yoho_nn_search(yoho_ctx* ctx, const float* src, int Ns, const float* tgt, int Nt, int D,
+                   int64_t* idx, float* dist, void* stream);
+
+/* mutual nearest neighbours of a (Na,32) in b (Nb,32): pairs (M,2) int64 in ascending a-index,
+ * buffer must hold Na rows; *M_out (device int) receives M. */
+int yoho_mutual_nn(yoho_ctx* ctx, const float* a, int Na, const float* b, int Nb,
+                   int64_t* pairs, int* M_out, void* stream);
+
+/* idx[m] = argmax_a sum_{f,g} d1[m,f,P[a,g]] * d2[m,f,g]; cor (M,60) may be NULL */
+int yoho_des2r(yoho_ctx* ctx, const float* d1, const float* d2, int M, int64_t* idx, float* cor, void* stream);
+
+/* inputs as the network receives them (after batch_create's 0<->1 exchange); NOT modified.
+ * quat (M,4) unit quaternions. */
+int yoho_partII_forward(yoho_ctx* ctx, const float* before_eqv0, const float* before_eqv1,
+                        const float* after_eqv0, const float* after_eqv1, const int64_t* pre_idx,
+                        int M, float* quat, void* stream);
+
+/* T[m] = [R | t], R = quat2mat_f32(quat[m]) * Rgroup_f32[idx[m]] (f64), t = k0[m] - R k1[m] */
+int yoho_hyp_from_quat(yoho_ctx* ctx, const float* quat, const int64_t* idx, const double* k0,
+                       const double* k1, int M, double* T, void* stream);
+
+/* inlier counts of hypotheses T[order[h]], h < H, over M matches with threshold d; best_h /
+ * best_count (device ints) = first strict maximum (best_count 0 -> no hypothesis beats 0);
+ * counts (H) int32 may be NULL; order may be NULL (identity). */
+int yoho_o_score(yoho_ctx* ctx, const double* k0, const double* k1, int M, const double* T,
+                 const int64_t* order, int H, double d, int* best_h, int* best_count,
+                 int32_t* counts, void* stream);
+
+/* 3-point Kabsch per triple + inlier vote.  reflect (I) u8 may be NULL (proper rotations);
+ * reflect[i] != 0 reproduces the reference's det = -1 solution for that iteration.
+ * T_out (I,3,4) may be NULL; best_T (3,4); best_iter is 1-based, 0 = none. */
+int yoho_c_ransac(yoho_ctx* ctx, const double* k0, const double* k1, int M, const int64_t* triples,
+                  const uint8_t* reflect, int I, double d, double* best_T, int* best_iter,
+                  int* best_count, double* T_out, int32_t* counts, void* stream);
+
+/* one group element of the 60-fold gather: rotate keys (K,3) f64 by Rg (3x3 f64, host ptr),
+ * 1-NN among pts (n,3) f32 in f64, copy feat (n,32) rows into out[:, :, g] of (K,32,60);
+ * nn_idx (K) int64 may be NULL. */
+int yoho_group_gather(yoho_ctx* ctx, const double* keys, int K, const float* pts, const float* feat,
+                      int n, int g, const double* Rg_host, float* out, int64_t* nn_idx, void* stream);
+
+/* timing hook for bench.py: average device time (ms) of the last yoho_partI_forward's dominant
+ * group-conv launches, measured with hipEvents on the call's own stream.  <0 if unavailable. */
+int yoho_set_profiling(yoho_ctx* ctx, int enable);
+int yoho_get_kernel_ms(yoho_ctx* ctx, int which, float* ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* YOHO_HIP_H */

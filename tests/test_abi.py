@@ -1,0 +1,44 @@
+"""CPU test: the C-ABI library builds/loads and exports every symbol include/yoho_hip.h declares
+(no compute calls: there is no GPU in the build container)."""
+import os
+import re
+import ctypes
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    txt = open(os.path.join(REPO, "include", "yoho_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(yoho_[a-zA-Z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_header_symbols():
+    from yoho_amd import build, hip
+    lib_path = build.build(verbose=False)
+    assert os.path.exists(lib_path)
+    lib = hip.load_library()
+    fns = header_functions()
+    assert len(fns) >= 16
+    for f in fns:
+        assert hasattr(lib, f), f"libyoho_hip.so does not export {f}"
+    assert set(fns) == set(hip.SYMBOLS)
+    assert b"gfx950" in lib.yoho_version()
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from yoho_amd import hip
+    monkeypatch.setattr(hip, "_lib", None)
+    monkeypatch.setattr(hip, "_LIB_PATH", "/nonexistent/libyoho_hip.so")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        hip.load_library()
+
+
+def test_context_requires_gpu():
+    import torch
+    from yoho_amd import hip
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError):
+        hip.Context()

@@ -1,0 +1,352 @@
+// C-ABI entry points: context, checkpoint loading (BN folding + MFMA weight packing) and the
+// PartI / PartII forward passes.  See include/yoho_hip.h for the contract.
+#include "common.h"
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <cmath>
+#include <vector>
+
+namespace yoho {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int hip_fail(hipError_t e, const char* what, const char* file, int line) {
+    set_error("HIP error %d (%s) at %s:%d: %s", (int)e, hipGetErrorString(e), file, line, what);
+    return YOHO_EHIP;
+}
+
+static int upload(const void* h, size_t bytes, void** d) {
+    HIPCHK(hipMalloc(d, bytes));
+    HIPCHK(hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice));
+    return 0;
+}
+
+static void free_layer(Layer& L) {
+    if (L.wp) (void)hipFree(L.wp);
+    if (L.bias) (void)hipFree(L.bias);
+    if (L.bn_s) (void)hipFree(L.bn_s);
+    if (L.bn_t) (void)hipFree(L.bn_t);
+    L = Layer();
+}
+
+// BatchNorm2d(eval, eps = 1e-5) as y = x*s + t
+static void bn_affine(const yoho_bn_w& bn, int c, int cpad, std::vector<float>& s, std::vector<float>& t) {
+    s.assign(cpad, 0.f);
+    t.assign(cpad, 0.f);
+    for (int i = 0; i < c; ++i) {
+        const float sc = bn.gamma[i] / std::sqrt(bn.var[i] + 1e-5f);
+        s[i] = sc;
+        t[i] = bn.beta[i] - bn.mean[i] * sc;
+    }
+}
+
+// conv weight (cout,cin,1,ntaps) -> A-fragment order [ob][c8][tap][lane = h*32+i][s]:
+//   value = W[ob*32 + i][c8*8 + 4h + s][tap]
+static int build_layer(Layer& L, const yoho_conv_w& cw, int cin, int cout, int ntaps, const yoho_bn_w* bn_after) {
+    free_layer(L);
+    if (!cw.weight || !cw.bias) { set_error("null conv weight/bias pointer"); return YOHO_EINVAL; }
+    L.cin = cin; L.cout = cout; L.ntaps = ntaps;
+    L.cout_pad = (cout + 31) / 32 * 32;
+    const int nob = L.cout_pad / 32, c8n = cin / 8;
+    std::vector<float> wp((size_t)nob * c8n * ntaps * 256, 0.f);
+    for (int ob = 0; ob < nob; ++ob)
+        for (int c8 = 0; c8 < c8n; ++c8)
+            for (int tap = 0; tap < ntaps; ++tap) {
+                float* dst = &wp[(((size_t)ob * c8n + c8) * ntaps + tap) * 256];
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int h = lane >> 5, o = ob * 32 + (lane & 31);
+                    if (o >= cout) continue;
+                    for (int s = 0; s < 4; ++s) {
+                        const int c = c8 * 8 + 4 * h + s;
+                        dst[lane * 4 + s] = cw.weight[((size_t)o * cin + c) * ntaps + tap];
+                    }
+                }
+            }
+    std::vector<float> bias(L.cout_pad, 0.f);
+    std::memcpy(bias.data(), cw.bias, sizeof(float) * cout);
+    int rc;
+    if ((rc = upload(wp.data(), wp.size() * sizeof(float), (void**)&L.wp))) return rc;
+    if ((rc = upload(bias.data(), bias.size() * sizeof(float), (void**)&L.bias))) return rc;
+    if (bn_after) {
+        if (!bn_after->gamma || !bn_after->beta || !bn_after->mean || !bn_after->var) {
+            set_error("null batch-norm pointer"); return YOHO_EINVAL;
+        }
+        std::vector<float> s, t;
+        bn_affine(*bn_after, cout, L.cout_pad, s, t);
+        if ((rc = upload(s.data(), s.size() * sizeof(float), (void**)&L.bn_s))) return rc;
+        if ((rc = upload(t.data(), t.size() * sizeof(float), (void**)&L.bn_t))) return rc;
+    }
+    return 0;
+}
+
+int ensure_ws(yoho_ctx* ctx, size_t bytes, hipStream_t s) {
+    if (ctx->ws.bytes >= bytes) return 0;
+    if (ctx->ws.p) {
+        HIPCHK(hipStreamSynchronize(s));
+        HIPCHK(hipDeviceSynchronize());
+        HIPCHK(hipFree(ctx->ws.p));
+        ctx->ws.p = nullptr; ctx->ws.bytes = 0;
+    }
+    const size_t want = bytes + bytes / 8;
+    hipError_t e = hipMalloc(&ctx->ws.p, want);
+    if (e != hipSuccess) { set_error("workspace allocation of %zu bytes failed: %s", want, hipGetErrorString(e)); return YOHO_ENOMEM; }
+    ctx->ws.bytes = want;
+    return 0;
+}
+
+static ConvArgs conv_args(const Layer& L, const float* X, int nTiles, const float* res, float* out_raw, float* out_act, bool osplit) {
+    ConvArgs a;
+    a.X = X; a.Wp = L.wp; a.bias = L.bias; a.bn_s = L.bn_s; a.bn_t = L.bn_t;
+    a.res = res; a.out_raw = out_raw; a.out_act = out_act;
+    a.nTiles = nTiles; a.cin8 = L.cin / 8; a.cout8 = L.cout_pad / 8;
+    a.nOB = osplit ? L.cout_pad / 128 : L.cout_pad / 32;
+    a.ntaps = L.ntaps;
+    return a;
+}
+
+}  // namespace yoho
+
+using namespace yoho;
+
+extern "C" {
+
+const char* yoho_last_error(void) { return g_err; }
+const char* yoho_version(void) { return "yoho_hip 0.1.0 (gfx950)"; }
+
+int yoho_ctx_create(int device, const float* R, const uint8_t* N, const uint8_t* P, yoho_ctx** out) {
+    if (!R || !N || !P || !out) { set_error("yoho_ctx_create: null argument"); return YOHO_EINVAL; }
+    for (int i = 0; i < G * NTAP; ++i) if (N[i] >= G) { set_error("Nei table entry out of range"); return YOHO_EINVAL; }
+    for (int i = 0; i < G * G; ++i) if (P[i] >= G) { set_error("60_60 table entry out of range"); return YOHO_EINVAL; }
+    HIPCHK(hipSetDevice(device));
+    yoho_ctx* c = new yoho_ctx();
+    c->device = device;
+    std::memcpy(c->hN, N, sizeof(c->hN));
+    std::memcpy(c->hP, P, sizeof(c->hP));
+    std::memcpy(c->hR, R, sizeof(c->hR));
+    std::vector<int> n32(G * NTAP), p32(G * G);
+    std::vector<double> r64(G * 9);
+    for (int i = 0; i < G * NTAP; ++i) n32[i] = N[i];
+    for (int i = 0; i < G * G; ++i) p32[i] = P[i];
+    for (int i = 0; i < G * 9; ++i) r64[i] = (double)R[i];
+    int rc;
+    if ((rc = upload(R, sizeof(float) * G * 9, (void**)&c->dR32)) || (rc = upload(r64.data(), sizeof(double) * G * 9, (void**)&c->dR64)) ||
+        (rc = upload(n32.data(), sizeof(int) * G * NTAP, (void**)&c->dN)) || (rc = upload(p32.data(), sizeof(int) * G * G, (void**)&c->dP))) {
+        delete c; return rc;
+    }
+    // slot tables: which output group elements each configuration computes
+    std::vector<int> slab(NCFG * NTAP * G, 0), outg(NCFG * G, -1);
+    auto fill = [&](int cfg, const std::vector<int>& glist, int gpw, bool replicate) {
+        const int nslots = 4 * gpw;
+        for (int sl = 0; sl < nslots; ++sl) {
+            int g = -1;
+            if (replicate) g = glist[0];
+            else if (sl < (int)glist.size()) g = glist[sl];
+            outg[cfg * G + sl] = g;
+        }
+        // kernel indexes c_slabtab[cfg][(tap*4 + ws)*GPW + j] = [tap][slot] with row length 4*GPW
+        for (int tap = 0; tap < NTAP; ++tap)
+            for (int sl = 0; sl < nslots; ++sl) {
+                const int g = outg[cfg * G + sl];
+                slab[cfg * NTAP * G + tap * nslots + sl] = (g < 0 ? 0 : (int)N[g * NTAP + tap]) * 1024;
+            }
+    };
+    std::vector<int> all(G); for (int i = 0; i < G; ++i) all[i] = i;
+    std::vector<int> one(NTAP); for (int k = 0; k < NTAP; ++k) one[k] = N[k];          // N[0][k]
+    std::vector<bool> in2(G, false);
+    for (int k = 0; k < NTAP; ++k) for (int k2 = 0; k2 < NTAP; ++k2) in2[N[one[k] * NTAP + k2]] = true;
+    std::vector<int> two; for (int g = 0; g < G; ++g) if (in2[g]) two.push_back(g);
+    if (two.size() > 48) { set_error("2-hop cone of group element 0 has %zu > 48 elements", two.size()); delete c; return YOHO_EINVAL; }
+    fill(CFG_FULL, all, 15, false);
+    fill(CFG_C45, two, 12, false);
+    fill(CFG_C13, one, 4, false);
+    fill(CFG_C1, std::vector<int>{0}, 1, true);
+    if ((rc = upload_slot_tables(slab.data(), outg.data())) || (rc = gconv_init())) { delete c; return rc; }
+    *out = c;
+    return 0;
+}
+
+int yoho_ctx_destroy(yoho_ctx* c) {
+    if (!c) return 0;
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    for (auto& L : c->p1) free_layer(L);
+    for (auto& L : c->p2) free_layer(L);
+    if (c->p2_init_bn_s) (void)hipFree(c->p2_init_bn_s);
+    if (c->p2_init_bn_t) (void)hipFree(c->p2_init_bn_t);
+    if (c->ws.p) (void)hipFree(c->ws.p);
+    if (c->dR32) (void)hipFree(c->dR32);
+    if (c->dR64) (void)hipFree(c->dR64);
+    if (c->dN) (void)hipFree(c->dN);
+    if (c->dP) (void)hipFree(c->dP);
+    if (c->ev_created) for (auto& e : c->ev) (void)hipEventDestroy(e);
+    delete c;
+    return 0;
+}
+
+int yoho_load_partI(yoho_ctx* c, const yoho_partI_weights* w) {
+    if (!c || !w) { set_error("yoho_load_partI: null argument"); return YOHO_EINVAL; }
+    HIPCHK(hipSetDevice(c->device));
+    c->has_partI = false;
+    int rc;
+    // each layer carries the BN+ReLU that precedes the NEXT conv as its epilogue
+    if ((rc = build_layer(c->p1[0], w->conv_in, 32, 256, NTAP, &w->res_in_bn))) return rc;
+    if ((rc = build_layer(c->p1[1], w->res_in, 256, 512, NTAP, &w->res_out_bn))) return rc;
+    if ((rc = build_layer(c->p1[2], w->res_out, 512, 256, NTAP, &w->out_bn))) return rc;
+    if ((rc = build_layer(c->p1[3], w->conv_out, 256, 32, NTAP, nullptr))) return rc;
+    c->has_partI = true;
+    return 0;
+}
+
+int yoho_load_partII(yoho_ctx* c, const yoho_partII_weights* w) {
+    if (!c || !w) { set_error("yoho_load_partII: null argument"); return YOHO_EINVAL; }
+    HIPCHK(hipSetDevice(c->device));
+    c->has_partII = false;
+    int rc;
+    std::vector<float> s, t;
+    if (!w->init_bn.gamma || !w->init_bn.beta || !w->init_bn.mean || !w->init_bn.var) { set_error("null batch-norm pointer"); return YOHO_EINVAL; }
+    bn_affine(w->init_bn, 128, 128, s, t);
+    if (c->p2_init_bn_s) { (void)hipFree(c->p2_init_bn_s); c->p2_init_bn_s = nullptr; }
+    if (c->p2_init_bn_t) { (void)hipFree(c->p2_init_bn_t); c->p2_init_bn_t = nullptr; }
+    if ((rc = upload(s.data(), 128 * sizeof(float), (void**)&c->p2_init_bn_s))) return rc;
+    if ((rc = upload(t.data(), 128 * sizeof(float), (void**)&c->p2_init_bn_t))) return rc;
+    if ((rc = build_layer(c->p2[0], w->init, 128, 256, NTAP, &w->res_in_bn))) return rc;
+    if ((rc = build_layer(c->p2[1], w->res_in, 256, 512, NTAP, &w->res_out_bn))) return rc;
+    if ((rc = build_layer(c->p2[2], w->res_out, 512, 256, NTAP, nullptr))) return rc;
+    if ((rc = build_layer(c->p2[3], w->fc0, 256, 512, 1, &w->fc0_bn))) return rc;
+    if ((rc = build_layer(c->p2[4], w->fc1, 512, 128, 1, &w->fc1_bn))) return rc;
+    if ((rc = build_layer(c->p2[5], w->fc2, 128, 4, 1, nullptr))) return rc;
+    c->has_partII = true;
+    return 0;
+}
+
+int yoho_set_profiling(yoho_ctx* c, int enable) {
+    if (!c) { set_error("null ctx"); return YOHO_EINVAL; }
+    HIPCHK(hipSetDevice(c->device));
+    if (enable && !c->ev_created) {
+        for (auto& e : c->ev) HIPCHK(hipEventCreate(&e));
+        c->ev_created = true;
+    }
+    c->profiling = enable != 0;
+    for (auto& m : c->kernel_ms) m = -1.f;
+    return 0;
+}
+
+// which: 0..3 = PartI group-conv layers (conv_in, res_in, res_out, conv_out) of the last profiled
+// yoho_partI_forward pass; 4 = pack, 5 = finalize.  Synchronises on the recorded events.
+int yoho_get_kernel_ms(yoho_ctx* c, int which, float* ms) {
+    if (!c || !ms || which < 0 || which > 5) { set_error("yoho_get_kernel_ms: bad argument"); return YOHO_EINVAL; }
+    if (!c->ev_created) { set_error("profiling was not enabled"); return YOHO_EINVAL; }
+    // event order: e0 pack e1 L0 e2 L1 e3 L2 e4 L3 e5 fin e6
+    static const int first[6] = {1, 2, 3, 4, 0, 5};
+    HIPCHK(hipEventSynchronize(c->ev[6]));
+    HIPCHK(hipEventElapsedTime(ms, c->ev[first[which]], c->ev[first[which] + 1]));
+    return 0;
+}
+
+static int partI_pass(yoho_ctx* c, const float* x, int B, float* eqv, float* inv, float* inv_np, hipStream_t s) {
+    const int nT = (B + TILE - 1) / TILE;
+    const size_t ch = (size_t)CHUNK_FLOATS * sizeof(float);
+    const size_t nX = (size_t)nT * 4, n256 = (size_t)nT * 32, n512 = (size_t)nT * 64;
+    int rc;
+    if ((rc = ensure_ws(c, (nX * 2 + n256 * 2 + n512) * ch, s))) return rc;
+    float* bX = (float*)c->ws.p;
+    float* bH0 = bX + nX * CHUNK_FLOATS;
+    float* bA = bH0 + n256 * CHUNK_FLOATS;        // a0, later a2
+    float* bA1 = bA + n256 * CHUNK_FLOATS;
+    float* bY = bA1 + n512 * CHUNK_FLOATS;
+    const bool prof = c->profiling && c->ev_created;
+    auto mark = [&](int i) { if (prof) (void)hipEventRecord(c->ev[i], s); };
+    mark(0);
+    if ((rc = launch_pack_partI(x, B, nT, bX, s))) return rc;
+    mark(1);
+    if ((rc = launch_gconv(conv_args(c->p1[0], bX, nT, nullptr, bH0, bA, false), 15, EPI_RAW | EPI_ACT, s))) return rc;
+    mark(2);
+    if ((rc = launch_gconv(conv_args(c->p1[1], bA, nT, nullptr, nullptr, bA1, false), 15, EPI_ACT, s))) return rc;
+    mark(3);
+    if ((rc = launch_gconv(conv_args(c->p1[2], bA1, nT, bH0, nullptr, bA, false), 15, EPI_RES | EPI_ACT, s))) return rc;
+    mark(4);
+    if ((rc = launch_gconv(conv_args(c->p1[3], bA, nT, nullptr, bY, nullptr, false), 15, EPI_RAW, s))) return rc;
+    mark(5);
+    if ((rc = launch_finalize_partI(bY, x, B, eqv, inv, inv_np, s))) return rc;
+    mark(6);
+    return 0;
+}
+
+int yoho_partI_forward(yoho_ctx* c, const float* x, int B, float* eqv, float* inv, float* inv_np, void* stream) {
+    if (!c || !x || !eqv || B < 1) { set_error("yoho_partI_forward: bad argument (B=%d)", B); return YOHO_EINVAL; }
+    if (!c->has_partI) { set_error("yoho_partI_forward: PartI weights not loaded"); return YOHO_ENOWEIGHTS; }
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    const int MAXB = 8192;                       // bounds the workspace to ~2.2 GB
+    for (int b0 = 0; b0 < B; b0 += MAXB) {
+        const int nb = B - b0 < MAXB ? B - b0 : MAXB;
+        int rc = partI_pass(c, x + (size_t)b0 * F * G, nb, eqv + (size_t)b0 * F * G, inv ? inv + (size_t)b0 * F : nullptr,
+                            inv_np ? inv_np + (size_t)b0 * F : nullptr, s);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+int yoho_group_mean_np(yoho_ctx* c, const float* eqv, int B, float* out, void* stream) {
+    if (!c || !eqv || !out || B < 0) { set_error("yoho_group_mean_np: bad argument"); return YOHO_EINVAL; }
+    if (B == 0) return 0;
+    HIPCHK(hipSetDevice(c->device));
+    return launch_group_mean_np(eqv, B, out, (hipStream_t)stream);
+}
+
+static int partII_pass(yoho_ctx* c, const float* s0, const float* s1, const float* s2, const float* s3, const int64_t* idx,
+                       int M, float* quat, hipStream_t s) {
+    const int nT = (M + TILE - 1) / TILE;
+    const size_t ch = (size_t)CHUNK_FLOATS * sizeof(float);
+    const size_t n128 = (size_t)nT * 16, n256 = (size_t)nT * 32, n512 = (size_t)nT * 64, n32 = (size_t)nT * 4;
+    int rc;
+    if ((rc = ensure_ws(c, (n128 + 3 * n256 + 2 * n512 + n128 + n32) * ch, s))) return rc;
+    float* bX = (float*)c->ws.p;                       // 128 ch
+    float* bH0 = bX + n128 * CHUNK_FLOATS;             // 256 raw
+    float* bA0 = bH0 + n256 * CHUNK_FLOATS;            // 256 act
+    float* bA1 = bA0 + n256 * CHUNK_FLOATS;            // 512 act
+    float* bF = bA1 + n512 * CHUNK_FLOATS;             // 256 raw (g = 0)
+    float* bF0 = bF + n256 * CHUNK_FLOATS;             // 512 act
+    float* bF1 = bF0 + n512 * CHUNK_FLOATS;            // 128 act
+    float* bQ = bF1 + n128 * CHUNK_FLOATS;             // 32 raw (4 used)
+    if ((rc = launch_pack_partII(s0, s1, s2, s3, idx, c->dP, c->p2_init_bn_s, c->p2_init_bn_t, M, nT, bX, s))) return rc;
+    // Only group element 0 of the last feature map is consumed (utils/network.py:273-276), so the
+    // convs run on its receptive cone: 45 -> 13 -> 1 group elements.
+    if ((rc = launch_gconv(conv_args(c->p2[0], bX, nT, nullptr, bH0, bA0, false), 12, EPI_RAW | EPI_ACT, s))) return rc;
+    if ((rc = launch_gconv(conv_args(c->p2[1], bA0, nT, nullptr, nullptr, bA1, false), 4, EPI_ACT, s))) return rc;
+    if ((rc = launch_gconv(conv_args(c->p2[2], bA1, nT, bH0, bF, nullptr, true), -1, EPI_RES | EPI_RAW, s))) return rc;
+    if ((rc = launch_gconv(conv_args(c->p2[3], bF, nT, nullptr, nullptr, bF0, true), -1, EPI_ACT, s))) return rc;
+    if ((rc = launch_gconv(conv_args(c->p2[4], bF0, nT, nullptr, nullptr, bF1, true), -1, EPI_ACT, s))) return rc;
+    if ((rc = launch_gconv(conv_args(c->p2[5], bF1, nT, nullptr, bQ, nullptr, false), 1, EPI_RAW, s))) return rc;
+    return launch_quat_norm(bQ, M, quat, s);
+}
+
+int yoho_partII_forward(yoho_ctx* c, const float* before_eqv0, const float* before_eqv1, const float* after_eqv0,
+                        const float* after_eqv1, const int64_t* pre_idx, int M, float* quat, void* stream) {
+    if (!c || !before_eqv0 || !before_eqv1 || !after_eqv0 || !after_eqv1 || !pre_idx || !quat || M < 0) {
+        set_error("yoho_partII_forward: bad argument"); return YOHO_EINVAL;
+    }
+    if (!c->has_partII) { set_error("yoho_partII_forward: PartII weights not loaded"); return YOHO_ENOWEIGHTS; }
+    if (M == 0) return 0;
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    const int MAXM = 8192;
+    for (int m0 = 0; m0 < M; m0 += MAXM) {
+        const int nm = M - m0 < MAXM ? M - m0 : MAXM;
+        const size_t o = (size_t)m0 * F * G;
+        int rc = partII_pass(c, before_eqv0 + o, before_eqv1 + o, after_eqv0 + o, after_eqv1 + o, pre_idx + m0, nm,
+                             quat + (size_t)m0 * 4, s);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+}  // extern "C"

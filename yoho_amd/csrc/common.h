@@ -1,0 +1,100 @@
+// Internal declarations shared by the translation units of libyoho_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "yoho_hip.h"
+
+namespace yoho {
+
+constexpr int G = 60;          // icosahedral rotation group order
+constexpr int NTAP = 13;       // self + 12 neighbours (Nei_Index_in_SO3_ordered_13)
+constexpr int F = 32;          // FCGF feature width
+constexpr int TILE = 32;       // keypoints (or matches) per tile = MFMA N dimension
+// One "slab" = the 8 channels of one c8-chunk for one group element and one tile:
+// [h=2][kp=32][e=4] floats; channel c = c8*8 + h*4 + e.  A chunk = 60 slabs.
+constexpr int SLAB_FLOATS = 2 * TILE * 4;          // 256 floats = 1 KiB
+constexpr int CHUNK_FLOATS = G * SLAB_FLOATS;      // 15360 floats = 60 KiB
+
+void set_error(const char* fmt, ...);
+int hip_fail(hipError_t e, const char* what, const char* file, int line);
+
+#define HIPCHK(expr)                                                         \
+    do {                                                                     \
+        hipError_t e_ = (expr);                                              \
+        if (e_ != hipSuccess) return ::yoho::hip_fail(e_, #expr, __FILE__, __LINE__); \
+    } while (0)
+
+// One group-conv (or 1x1) layer as it lives on the device.
+struct Layer {
+    int cin = 0, cout = 0, cout_pad = 0, ntaps = 0;
+    float* wp = nullptr;      // packed MFMA A-fragments [ob][c8][tap][lane64][4]
+    float* bias = nullptr;    // [cout_pad]
+    float* bn_s = nullptr;    // [cout_pad] scale of the BN that FOLLOWS this conv (applied with ReLU in the epilogue)
+    float* bn_t = nullptr;    // [cout_pad] shift
+};
+
+// epilogue flags
+enum { EPI_RES = 1, EPI_RAW = 2, EPI_ACT = 4 };
+
+struct ConvArgs {
+    const float* X;        // activated input, internal layout [tile][cin/8][60 slabs][256]
+    const float* Wp;
+    const float* bias;
+    const float* bn_s;
+    const float* bn_t;
+    const float* res;      // raw residual, layout of the output (EPI_RES)
+    float* out_raw;        // EPI_RAW
+    float* out_act;        // EPI_ACT: relu(v*bn_s + bn_t)
+    int nTiles, cin8, cout8, nOB, ntaps;
+};
+
+// slot-table configurations (constant memory, see gconv.hip)
+enum { CFG_FULL = 0, CFG_C45 = 1, CFG_C13 = 2, CFG_C1 = 3, NCFG = 4 };
+int upload_slot_tables(const int* slab_h /*[NCFG][13*60]*/, const int* outg_h /*[NCFG][60]*/);
+int launch_gconv(const ConvArgs& a, int gpw, int flags, hipStream_t s);
+int gconv_init();   // sets the dynamic-LDS attribute of every instantiation
+
+int launch_pack_partI(const float* x, int B, int nTiles, float* out, hipStream_t s);
+int launch_finalize_partI(const float* y, const float* x, int B, float* eqv, float* inv, float* inv_np, hipStream_t s);
+int launch_group_mean_np(const float* eqv, int B, float* out, hipStream_t s);
+int launch_pack_partII(const float* s0, const float* s1, const float* s2, const float* s3, const int64_t* pre_idx,
+                       const int* P, const float* bn_s, const float* bn_t, int M, int nTiles, float* out, hipStream_t s);
+int launch_quat_norm(const float* y, int M, float* quat, hipStream_t s);
+
+struct Workspace;
+}  // namespace yoho
+struct yoho_ctx;
+namespace yoho {
+int ensure_ws(yoho_ctx* ctx, size_t bytes, hipStream_t s);
+
+struct Workspace {
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+
+}  // namespace yoho
+
+struct yoho_ctx {
+    int device = 0;
+    // tables
+    float* dR32 = nullptr;       // (60,9)
+    double* dR64 = nullptr;      // (60,9) widened from f32 exactly as the reference's f64 @ f32 promotes
+    int* dN = nullptr;           // (60,13) int32
+    int* dP = nullptr;           // (60,60) int32
+    uint8_t hN[60 * 13];
+    uint8_t hP[60 * 60];
+    float hR[60 * 9];
+    // weights
+    bool has_partI = false, has_partII = false;
+    yoho::Layer p1[4];           // conv_in, res_in, res_out, conv_out
+    yoho::Layer p2[6];           // init, res_in, res_out, fc0, fc1, fc2
+    float *p2_init_bn_s = nullptr, *p2_init_bn_t = nullptr;  // BN(128) applied by the PartII pack kernel
+    // workspace (grown on demand)
+    yoho::Workspace ws;
+    // profiling
+    bool profiling = false;
+    hipEvent_t ev[16];
+    bool ev_created = false;
+    float kernel_ms[8];
+};

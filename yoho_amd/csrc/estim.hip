@@ -1,0 +1,396 @@
+// Transformation estimators (f64 end to end, as the reference: keypoints come from open3d as f64).
+//
+//   hyp_kernel      quat -> [R|t] per match      tests/extractor.py:187-199, utils/r_eval.py:94-110
+//   score_kernel    overlap_cal per hypothesis   tests/estimator.py:286-290 (yohoo), :66-70 (yohoc)
+//   argbest_kernel  strict '>' running best      tests/estimator.py:330-336 / :131-137
+//   kabsch_kernel   Threepps2Tran                tests/estimator.py:55-63
+//   gather_kernel   60-fold FCGF feature gather  YOHO_testset.py:153-166
+#include "common.h"
+
+namespace yoho {
+
+// ---- quaternion -> rotation, evaluated in fp32 in the reference's operation order (the
+// quaternion is a float32 numpy vector, so utils/r_eval.py:94-110 runs in fp32) ----------------
+__device__ __forceinline__ void quat2mat_f32(const float* q, double* m) {
+    const float w = q[0], x = q[1], y = q[2], z = q[3];
+    const float two = 2.0f;
+#define MUL(a, b) __fmul_rn(a, b)
+#define SUB(a, b) __fsub_rn(a, b)
+#define ADD(a, b) __fadd_rn(a, b)
+    m[0] = (double)SUB(SUB(1.0f, MUL(MUL(two, y), y)), MUL(MUL(two, z), z));
+    m[1] = (double)SUB(MUL(MUL(two, x), y), MUL(MUL(two, z), w));
+    m[2] = (double)ADD(MUL(MUL(two, x), z), MUL(MUL(two, y), w));
+    m[3] = (double)ADD(MUL(MUL(two, x), y), MUL(MUL(two, z), w));
+    m[4] = (double)SUB(SUB(1.0f, MUL(MUL(two, x), x)), MUL(MUL(two, z), z));
+    m[5] = (double)SUB(MUL(MUL(two, y), z), MUL(MUL(two, x), w));
+    m[6] = (double)SUB(MUL(MUL(two, x), z), MUL(MUL(two, y), w));
+    m[7] = (double)ADD(MUL(MUL(two, y), z), MUL(MUL(two, x), w));
+    m[8] = (double)SUB(SUB(1.0f, MUL(MUL(two, x), x)), MUL(MUL(two, y), y));
+#undef MUL
+#undef SUB
+#undef ADD
+}
+
+__global__ __launch_bounds__(256) void hyp_kernel(const float* __restrict__ quat, const int64_t* __restrict__ idx,
+                                                  const double* __restrict__ k0, const double* __restrict__ k1,
+                                                  const double* __restrict__ Rg64, int M, double* __restrict__ T) {
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= M) return;
+    double rr[9];
+    quat2mat_f32(quat + (size_t)m * 4, rr);
+    long long gi = idx[m];
+    gi = gi < 0 ? 0 : (gi > 59 ? 59 : gi);
+    const double* A = Rg64 + gi * 9;
+    double R[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            R[i * 3 + j] = fma(rr[i * 3 + 2], A[6 + j], fma(rr[i * 3 + 1], A[3 + j], rr[i * 3] * A[j]));
+    const double* p0 = k0 + (size_t)m * 3;
+    const double* p1 = k1 + (size_t)m * 3;
+    double* o = T + (size_t)m * 12;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const double d = fma(p1[2], R[i * 3 + 2], fma(p1[1], R[i * 3 + 1], p1[0] * R[i * 3]));
+        o[i * 4 + 0] = R[i * 3 + 0]; o[i * 4 + 1] = R[i * 3 + 1]; o[i * 4 + 2] = R[i * 3 + 2];
+        o[i * 4 + 3] = __dsub_rn(p0[i], d);
+    }
+}
+
+// inlier test of one match under one [R|t] (3x4 row-major)
+__device__ __forceinline__ bool inlier(const double* T, const double* a, const double* b, double d2thr) {
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const double p = __dadd_rn(fma(b[2], T[i * 4 + 2], fma(b[1], T[i * 4 + 1], b[0] * T[i * 4])), T[i * 4 + 3]);
+        const double e = __dsub_rn(a[i], p);
+        const double q = __dmul_rn(e, e);
+        s = i == 0 ? q : __dadd_rn(s, q);
+    }
+    return s < d2thr;
+}
+
+__device__ __forceinline__ int block_count(bool flag_acc_unused, int local, int* red) {
+    // sum `local` over a 256-thread workgroup
+    for (int o = 32; o >= 1; o >>= 1) local += __shfl_xor(local, o);
+    const int wv = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) red[wv] = local;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+// one workgroup per hypothesis h: counts[h] = #{m : |k0[m] - (R k1[m] + t)|^2 < d^2}, T taken at order[h]
+__global__ __launch_bounds__(256) void score_kernel(const double* __restrict__ k0, const double* __restrict__ k1, int M,
+                                                    const double* __restrict__ T, const int64_t* __restrict__ order,
+                                                    double d2thr, int32_t* __restrict__ counts) {
+    __shared__ double Ts[12];
+    __shared__ int red[4];
+    const int h = blockIdx.x;
+    const size_t ti = order ? (size_t)order[h] : (size_t)h;
+    if (threadIdx.x < 12) Ts[threadIdx.x] = T[ti * 12 + threadIdx.x];
+    __syncthreads();
+    int local = 0;
+    for (int m = threadIdx.x; m < M; m += 256) local += inlier(Ts, k0 + (size_t)m * 3, k1 + (size_t)m * 3, d2thr) ? 1 : 0;
+    const int tot = block_count(false, local, red);
+    if (threadIdx.x == 0) counts[h] = tot;
+}
+
+// first strict maximum over counts[0..H): reproduces `if overlap > best_overlap` with best = 0 initially
+__global__ __launch_bounds__(256) void argbest_kernel(const int32_t* __restrict__ counts, int H, int* __restrict__ best_h,
+                                                      int* __restrict__ best_count) {
+    __shared__ int sv[256];
+    __shared__ int si[256];
+    int bv = 0, bi = -1;
+    for (int h = threadIdx.x; h < H; h += 256) {
+        const int c = counts[h];
+        if (c > bv) { bv = c; bi = h; }
+    }
+    sv[threadIdx.x] = bv; si[threadIdx.x] = bi;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int v = 0, i = -1;
+        for (int k = 0; k < 256; ++k) {
+            if (sv[k] > v) { v = sv[k]; i = si[k]; }
+            else if (sv[k] == v && v > 0 && si[k] < i) i = si[k];
+        }
+        *best_h = i < 0 ? 0 : i;
+        *best_count = v;
+    }
+}
+
+// ---- 3-point Kabsch (rank <= 2 covariance) --------------------------------------------------
+// m = (k1 - c1)^T (k0 - c0) = U S V^T;  reference R = V U^T with no determinant fix.  One-sided
+// Jacobi (Hestenes) on the columns of m gives  m V = U S;  the third singular direction is taken
+// as the cross product so that det(U) = det(V) = +1 (proper rotation).  `reflect` reproduces the
+// reference's det = -1 answer:  R_ref = R (I - 2 n n^T), n = normal of the centred k1 triangle.
+__device__ __forceinline__ void cross3(const double* a, const double* b, double* c) {
+    c[0] = a[1] * b[2] - a[2] * b[1];
+    c[1] = a[2] * b[0] - a[0] * b[2];
+    c[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+__device__ __forceinline__ void any_orthogonal(const double* a, double* o) {
+    // unit vector orthogonal to unit vector a
+    double e[3] = {0.0, 0.0, 0.0};
+    const double ax = fabs(a[0]), ay = fabs(a[1]), az = fabs(a[2]);
+    e[(ax <= ay && ax <= az) ? 0 : (ay <= az ? 1 : 2)] = 1.0;
+    cross3(a, e, o);
+    const double n = sqrt(o[0] * o[0] + o[1] * o[1] + o[2] * o[2]);
+    o[0] /= n; o[1] /= n; o[2] /= n;
+}
+
+__device__ void kabsch3(const double* a0, const double* a1, bool reflect, double* T) {
+    // a0: 3 points of fragment 0 (target), a1: 3 points of fragment 1 (source), row-major (3,3)
+    double c0[3], c1[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        c0[j] = ((a0[j] + a0[3 + j]) + a0[6 + j]) / 3.0;
+        c1[j] = ((a1[j] + a1[3 + j]) + a1[6 + j]) / 3.0;
+    }
+    double A[9];       // columns of A are rotated by Jacobi; A = m
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            double s = 0.0;
+#pragma unroll
+            for (int p = 0; p < 3; ++p) s += (a1[p * 3 + i] - c1[i]) * (a0[p * 3 + j] - c0[j]);
+            A[i * 3 + j] = s;
+        }
+    double V[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        double offmax = 0.0;
+#pragma unroll
+        for (int pq = 0; pq < 3; ++pq) {
+            const int p = pq == 2 ? 1 : 0, q = pq == 0 ? 1 : 2;
+            const double al = A[p] * A[p] + A[3 + p] * A[3 + p] + A[6 + p] * A[6 + p];
+            const double be = A[q] * A[q] + A[3 + q] * A[3 + q] + A[6 + q] * A[6 + q];
+            const double ga = A[p] * A[q] + A[3 + p] * A[3 + q] + A[6 + p] * A[6 + q];
+            const double lim = 1e-30 + 1e-16 * sqrt(al * be);
+            if (fabs(ga) > lim) {
+                offmax = fmax(offmax, fabs(ga) / (sqrt(al * be) + 1e-300));
+                const double zeta = (be - al) / (2.0 * ga);
+                const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                const double cs = 1.0 / sqrt(1.0 + t * t), sn = cs * t;
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    const double ap = A[r * 3 + p], aq = A[r * 3 + q];
+                    A[r * 3 + p] = cs * ap - sn * aq;
+                    A[r * 3 + q] = sn * ap + cs * aq;
+                    const double vp = V[r * 3 + p], vq = V[r * 3 + q];
+                    V[r * 3 + p] = cs * vp - sn * vq;
+                    V[r * 3 + q] = sn * vp + cs * vq;
+                }
+            }
+        }
+        if (offmax < 1e-15) break;
+    }
+    // singular values = column norms; order the two largest
+    double sg[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) sg[j] = sqrt(A[j] * A[j] + A[3 + j] * A[3 + j] + A[6 + j] * A[6 + j]);
+    int i1 = 0;
+    if (sg[1] > sg[i1]) i1 = 1;
+    if (sg[2] > sg[i1]) i1 = 2;
+    int i2 = (i1 + 1) % 3, i3 = (i1 + 2) % 3;
+    if (sg[i3] > sg[i2]) { const int t = i2; i2 = i3; i3 = t; }
+    double u1[3], u2[3], u3[3], v1[3], v2[3], v3[3];
+    double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    if (sg[i1] > 1e-300) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) { u1[r] = A[r * 3 + i1] / sg[i1]; v1[r] = V[r * 3 + i1]; }
+        if (sg[i2] > 1e-13 * sg[i1]) {
+#pragma unroll
+            for (int r = 0; r < 3; ++r) { u2[r] = A[r * 3 + i2] / sg[i2]; v2[r] = V[r * 3 + i2]; }
+            // re-orthogonalise u2 against u1 (cheap insurance for nearly collinear triangles)
+            const double d = u1[0] * u2[0] + u1[1] * u2[1] + u1[2] * u2[2];
+            u2[0] -= d * u1[0]; u2[1] -= d * u1[1]; u2[2] -= d * u1[2];
+            const double n = sqrt(u2[0] * u2[0] + u2[1] * u2[1] + u2[2] * u2[2]);
+            u2[0] /= n; u2[1] /= n; u2[2] /= n;
+        } else {            // rank 1 (two sampled matches coincide): roll about u1/v1 is arbitrary
+            any_orthogonal(u1, u2);
+            any_orthogonal(v1, v2);
+        }
+        cross3(u1, u2, u3);
+        cross3(v1, v2, v3);
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) R[i * 3 + j] = v1[i] * u1[j] + v2[i] * u2[j] + v3[i] * u3[j];
+        if (reflect) {      // R <- R (I - 2 u3 u3^T)
+            double Ru[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) Ru[i] = R[i * 3] * u3[0] + R[i * 3 + 1] * u3[1] + R[i * 3 + 2] * u3[2];
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) R[i * 3 + j] -= 2.0 * Ru[i] * u3[j];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        T[i * 4] = R[i * 3]; T[i * 4 + 1] = R[i * 3 + 1]; T[i * 4 + 2] = R[i * 3 + 2];
+        T[i * 4 + 3] = c0[i] - (c1[0] * R[i * 3] + c1[1] * R[i * 3 + 1] + c1[2] * R[i * 3 + 2]);
+    }
+}
+
+// one workgroup per RANSAC iteration: Kabsch on the sampled triple, then the inlier vote
+__global__ __launch_bounds__(256) void kabsch_score_kernel(const double* __restrict__ k0, const double* __restrict__ k1, int M,
+                                                           const int64_t* __restrict__ triples, const uint8_t* __restrict__ reflect,
+                                                           double d2thr, double* __restrict__ T_out, int32_t* __restrict__ counts) {
+    __shared__ double Ts[12];
+    __shared__ int red[4];
+    const int it = blockIdx.x;
+    if (threadIdx.x == 0) {
+        double a0[9], a1[9];
+        for (int p = 0; p < 3; ++p) {
+            long long mi = triples[(size_t)it * 3 + p];
+            mi = mi < 0 ? 0 : (mi >= M ? M - 1 : mi);
+            for (int j = 0; j < 3; ++j) { a0[p * 3 + j] = k0[(size_t)mi * 3 + j]; a1[p * 3 + j] = k1[(size_t)mi * 3 + j]; }
+        }
+        double T[12];
+        kabsch3(a0, a1, reflect ? reflect[it] != 0 : false, T);
+        for (int i = 0; i < 12; ++i) { Ts[i] = T[i]; T_out[(size_t)it * 12 + i] = T[i]; }
+    }
+    __syncthreads();
+    int local = 0;
+    for (int m = threadIdx.x; m < M; m += 256) local += inlier(Ts, k0 + (size_t)m * 3, k1 + (size_t)m * 3, d2thr) ? 1 : 0;
+    const int tot = block_count(false, local, red);
+    if (threadIdx.x == 0) counts[it] = tot;
+}
+
+__global__ void pick_T_kernel(const double* __restrict__ T_all, const int* __restrict__ best_h, const int* __restrict__ best_count,
+                              double* __restrict__ best_T, int* __restrict__ best_iter) {
+    const int i = threadIdx.x;
+    const bool any = *best_count > 0;
+    if (i < 12) best_T[i] = any ? T_all[(size_t)(*best_h) * 12 + i] : ((i % 5 == 0) ? 1.0 : 0.0);   // eye(4)[:3]
+    if (i == 0) *best_iter = any ? *best_h + 1 : 0;
+}
+
+// ---- group-feature gather (one group element) ------------------------------------------------
+// kr = keys @ Rg^T (f64); NN among pts (f32, widened) with sqrt(D2 + 1e-7) in f64; copy feature row.
+constexpr int GG_SPLIT = 16, GG_ROWS = 16, GG_TT = 1024;
+struct Mat3 { double m[9]; };
+
+__global__ __launch_bounds__(256) void gather_kernel(const double* __restrict__ keys, int K, const float* __restrict__ pts,
+                                                     const float* __restrict__ feat, int n, int g, Mat3 Rg,
+                                                     float* __restrict__ out, int64_t* __restrict__ nn_idx) {
+    __shared__ float tile[GG_TT * 3];
+    __shared__ double rd[GG_ROWS * GG_SPLIT];
+    __shared__ int ri[GG_ROWS * GG_SPLIT];
+    const int r = threadIdx.x % GG_ROWS, sp = threadIdx.x / GG_ROWS;
+    const int row = blockIdx.x * GG_ROWS + r;
+    const int rowc = row < K ? row : K - 1;
+    const double* kk = keys + (size_t)rowc * 3;
+    double kr[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) kr[i] = fma(kk[2], Rg.m[i * 3 + 2], fma(kk[1], Rg.m[i * 3 + 1], kk[0] * Rg.m[i * 3]));
+    double best = __builtin_inf();
+    int besti = 0;
+    for (int t0 = 0; t0 < n; t0 += GG_TT) {
+        const int nt = n - t0 < GG_TT ? n - t0 : GG_TT;
+        __syncthreads();
+        for (int i = threadIdx.x; i < nt * 3; i += 256) tile[i] = pts[(size_t)t0 * 3 + i];
+        __syncthreads();
+        for (int t = sp; t < nt; t += GG_SPLIT) {
+            const double d0 = __dsub_rn(kr[0], (double)tile[t * 3]);
+            const double d1 = __dsub_rn(kr[1], (double)tile[t * 3 + 1]);
+            const double d2 = __dsub_rn(kr[2], (double)tile[t * 3 + 2]);
+            const double s = __dadd_rn(__dadd_rn(__dmul_rn(d0, d0), __dmul_rn(d1, d1)), __dmul_rn(d2, d2));
+            const double d = __dsqrt_rn(__dadd_rn(s, 1e-7));
+            if (d < best) { best = d; besti = t0 + t; }
+        }
+    }
+    rd[r * GG_SPLIT + sp] = best;
+    ri[r * GG_SPLIT + sp] = besti;
+    __syncthreads();
+    if (row < K) {
+        double bd = rd[r * GG_SPLIT];
+        int bi = ri[r * GG_SPLIT];
+        for (int k = 1; k < GG_SPLIT; ++k) {
+            const double d = rd[r * GG_SPLIT + k];
+            const int i = ri[r * GG_SPLIT + k];
+            if (d < bd || (d == bd && i < bi)) { bd = d; bi = i; }
+        }
+        if (sp == 0 && nn_idx) nn_idx[row] = bi;
+        // 16 threads of this row copy the 32-D feature row (2 channels each)
+        const float* fr = feat + (size_t)bi * F;
+        float* o = out + (size_t)row * F * G + g;
+        o[(size_t)(2 * sp) * G] = fr[2 * sp];
+        o[(size_t)(2 * sp + 1) * G] = fr[2 * sp + 1];
+    }
+}
+
+}  // namespace yoho
+
+using namespace yoho;
+
+extern "C" {
+
+int yoho_hyp_from_quat(yoho_ctx* c, const float* quat, const int64_t* idx, const double* k0, const double* k1, int M, double* T,
+                       void* stream) {
+    if (!c || !quat || !idx || !k0 || !k1 || !T || M < 0) { set_error("yoho_hyp_from_quat: bad argument"); return YOHO_EINVAL; }
+    if (M == 0) return 0;
+    HIPCHK(hipSetDevice(c->device));
+    hipLaunchKernelGGL(hyp_kernel, dim3((M + 255) / 256), dim3(256), 0, (hipStream_t)stream, quat, idx, k0, k1, c->dR64, M, T);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int yoho_o_score(yoho_ctx* c, const double* k0, const double* k1, int M, const double* T, const int64_t* order, int H, double d,
+                 int* best_h, int* best_count, int32_t* counts, void* stream) {
+    if (!c || !k0 || !k1 || !T || !best_h || !best_count || M < 1 || H < 1) { set_error("yoho_o_score: bad argument"); return YOHO_EINVAL; }
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    int rc;
+    int32_t* cnt = counts;
+    if (!cnt) {
+        if ((rc = ensure_ws(c, sizeof(int32_t) * (size_t)H, s))) return rc;
+        cnt = (int32_t*)c->ws.p;
+    }
+    hipLaunchKernelGGL(score_kernel, dim3(H), dim3(256), 0, s, k0, k1, M, T, order, d * d, cnt);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(argbest_kernel, dim3(1), dim3(256), 0, s, cnt, H, best_h, best_count);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int yoho_c_ransac(yoho_ctx* c, const double* k0, const double* k1, int M, const int64_t* triples, const uint8_t* reflect, int I,
+                  double d, double* best_T, int* best_iter, int* best_count, double* T_out, int32_t* counts, void* stream) {
+    if (!c || !k0 || !k1 || !triples || !best_T || !best_iter || !best_count || M < 1 || I < 1) {
+        set_error("yoho_c_ransac: bad argument"); return YOHO_EINVAL;
+    }
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    int rc;
+    // workspace: T (I,12) f64 | counts (I) i32 | best_h i32
+    const size_t need = sizeof(double) * 12 * (size_t)I + sizeof(int32_t) * ((size_t)I + 4);
+    if ((rc = ensure_ws(c, need, s))) return rc;
+    double* Tall = T_out ? T_out : (double*)c->ws.p;
+    int32_t* cnt = counts ? counts : (int32_t*)((char*)c->ws.p + sizeof(double) * 12 * (size_t)I);
+    int* bh = (int*)((char*)c->ws.p + sizeof(double) * 12 * (size_t)I + sizeof(int32_t) * (size_t)I);
+    hipLaunchKernelGGL(kabsch_score_kernel, dim3(I), dim3(256), 0, s, k0, k1, M, triples, reflect, d * d, Tall, cnt);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(argbest_kernel, dim3(1), dim3(256), 0, s, cnt, I, bh, best_count);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(pick_T_kernel, dim3(1), dim3(64), 0, s, Tall, bh, best_count, best_T, best_iter);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int yoho_group_gather(yoho_ctx* c, const double* keys, int K, const float* pts, const float* feat, int n, int g,
+                      const double* Rg_host, float* out, int64_t* nn_idx, void* stream) {
+    if (!c || !keys || !pts || !feat || !Rg_host || !out || K < 1 || n < 1 || g < 0 || g >= G) {
+        set_error("yoho_group_gather: bad argument"); return YOHO_EINVAL;
+    }
+    HIPCHK(hipSetDevice(c->device));
+    Mat3 R;
+    for (int i = 0; i < 9; ++i) R.m[i] = Rg_host[i];
+    hipLaunchKernelGGL(gather_kernel, dim3((K + GG_ROWS - 1) / GG_ROWS), dim3(256), 0, (hipStream_t)stream, keys, K, pts, feat, n, g, R,
+                       out, nn_idx);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+}  // extern "C"

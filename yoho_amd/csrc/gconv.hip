@@ -1,0 +1,179 @@
+// Icosahedral group convolution on fp32 MFMA (v_mfma_f32_32x32x2_f32), gfx950.
+//
+// Replaces, per layer, the reference's  x[:,:,Nei] gather -> (B,C,60,13) -> Conv2d(C,Cout,(1,13))
+// (utils/network.py:46-52,80-84 data_process; :12-21 Comb_Conv; :23-65 Residual_Comb_Conv).
+//
+//   out[b, o, g] = bias[o] + sum_k sum_c W[o, c, 0, k] * act[b, c, N[g, k]]
+//
+// MI355X formulation.  A tile is 32 keypoints.  For a tile, every group element g' owns a
+// "slab" act[:, g', c-chunk] of shape (32 kp x 8 ch).  The conv is then, for every output g and
+// tap k, a 32(o) x 32(kp) x 8(c) matrix product whose B operand is simply slab N[g,k]: the gather
+// index is wave-uniform, no per-lane gather exists anywhere.  D = W_tap (32 o x K) * slab (K x 32 kp)
+// so a lane ends up with 4 consecutive channels of one keypoint per accumulator quad, which is
+// exactly the [c8][g][h][kp][4] layout the next layer stages into LDS with linear 16-B DMA.
+//
+// Workgroup = 4 waves, one per SIMD, 1 workgroup per CU (accumulators: 15 g x 16 regs per wave).
+//   wave w owns output slots [w*GPW, (w+1)*GPW)  (GPW=15: all 60 group elements)
+//   or, in OSPLIT mode (single output group element), wave w owns o-block 4*blk + w.
+// LDS: two 60 KiB buffers holding one 8-channel chunk of all 60 slabs (double buffered,
+// filled by global_load_lds DMA while the previous chunk is being multiplied).
+// Weights are pre-packed in MFMA A-fragment order, one contiguous 1 KiB per (o-block, c8, tap),
+// and stream L2 -> VGPR with a one-tap-ahead prefetch.
+#include "common.h"
+
+namespace yoho {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+constexpr int CHUNK_BYTES = CHUNK_FLOATS * 4;         // 61440
+constexpr int LDS_BYTES = 2 * CHUNK_BYTES;            // 122880
+
+// Slot tables live in constant memory so that the wave-uniform lookups are scalar (s_load) and
+// never touch the vector-memory counter the LDS DMA and the weight prefetch depend on.
+//   c_slabtab[cfg][tap][slot] = LDS byte offset of input slab N[g(slot), tap];  c_outg[cfg][slot] = g or -1
+__constant__ int c_slabtab[NCFG][NTAP * G];
+__constant__ int c_outg[NCFG][G];
+
+int upload_slot_tables(const int* slab_h, const int* outg_h) {
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_slabtab), slab_h, sizeof(int) * NCFG * NTAP * G));
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_outg), outg_h, sizeof(int) * NCFG * G));
+    return 0;
+}
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+// stage `npieces` 1 KiB pieces of a chunk: piece p -> LDS bytes [p*1024, p*1024+1024)
+__device__ __forceinline__ void stage_chunk(const float* src, char* dst, int w, int lane, int npieces) {
+    for (int p = w; p < npieces; p += 4) {
+        const float* s = src + p * SLAB_FLOATS + lane * 4;
+        char* d = dst + p * 1024;      // wave-uniform; hardware adds lane*16
+        __builtin_amdgcn_global_load_lds((gptr_t)s, (lptr_t)d, 16, 0, 0);
+    }
+}
+
+template <int GPW, bool OSPLIT>
+__global__ __launch_bounds__(256, 1) void gconv_kernel(ConvArgs a, int flags, int nstage, int cfg) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // XCD-aware bijective block remap: blocks b, b+8, b+16.. (same XCD) get consecutive work ids,
+    // so the workgroups sharing one tile's activations (different o-blocks) share an L2.
+    const int nwg = gridDim.x, b = blockIdx.x;
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = b & 7, slot8 = b >> 3;
+    const int v = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot8;
+    const int tile = v / a.nOB;
+    const int obk = v - tile * a.nOB;
+    const int ob = OSPLIT ? obk * 4 + w : obk;            // this wave's 32-channel output block
+    const int ws = OSPLIT ? 0 : w;                        // this wave's slot group
+
+    floatx16 acc[GPW];
+#pragma unroll
+    for (int j = 0; j < GPW; ++j)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
+
+    const float* Xt = a.X + (size_t)tile * a.cin8 * CHUNK_FLOATS;
+    const int ntaps = a.ntaps;
+    const int total = a.cin8 * ntaps;
+    const floatx4* Wb = reinterpret_cast<const floatx4*>(a.Wp) + (size_t)ob * total * 64 + lane;
+
+    stage_chunk(Xt, smem, w, lane, nstage);
+    floatx4 wnext = Wb[0];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    int it = 0;
+    for (int c8 = 0; c8 < a.cin8; ++c8) {
+        if (c8 + 1 < a.cin8)
+            stage_chunk(Xt + (size_t)(c8 + 1) * CHUNK_FLOATS, smem + ((c8 + 1) & 1) * CHUNK_BYTES, w, lane, nstage);
+        const char* xb = smem + (c8 & 1) * CHUNK_BYTES + lane * 16;
+        for (int tap = 0; tap < ntaps; ++tap) {
+            const floatx4 wc = wnext;
+            ++it;
+            if (it < total) wnext = Wb[(size_t)it * 64];
+            const int* st = &c_slabtab[cfg][(tap * 4 + ws) * GPW];
+#pragma unroll
+            for (int j = 0; j < GPW; ++j) {
+                const int so = st[j];                                   // wave-uniform (scalar load)
+                const floatx4 xf = *reinterpret_cast<const floatx4*>(xb + so);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc.x, xf.x, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc.y, xf.y, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc.z, xf.z, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc.w, xf.w, acc[j], 0, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    // ---- epilogue: D[i=o][j=kp]; lane (kp = lane&31, half = lane>>5), reg r -> o = (r&3) + 8*(r>>2) + 4*half
+    const int kp = lane & 31, half = lane >> 5;
+    const int* og = &c_outg[cfg][ws * GPW];
+#pragma unroll
+    for (int j = 0; j < GPW; ++j) {
+        const int g = og[j];
+        if (g < 0) continue;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int ch = ob * 32 + q * 8 + half * 4;
+            floatx4 val;
+            val.x = acc[j][4 * q + 0]; val.y = acc[j][4 * q + 1];
+            val.z = acc[j][4 * q + 2]; val.w = acc[j][4 * q + 3];
+            val += *reinterpret_cast<const floatx4*>(a.bias + ch);
+            const size_t off = (((((size_t)tile * a.cout8 + ob * 4 + q) * G + g) * 2 + half) * TILE + kp) * 4;
+            if (flags & EPI_RES) val += *reinterpret_cast<const floatx4*>(a.res + off);
+            if (flags & EPI_RAW) *reinterpret_cast<floatx4*>(a.out_raw + off) = val;
+            if (flags & EPI_ACT) {
+                const floatx4 s = *reinterpret_cast<const floatx4*>(a.bn_s + ch);
+                const floatx4 t = *reinterpret_cast<const floatx4*>(a.bn_t + ch);
+                floatx4 y = val * s + t;
+                y.x = fmaxf(y.x, 0.f); y.y = fmaxf(y.y, 0.f); y.z = fmaxf(y.z, 0.f); y.w = fmaxf(y.w, 0.f);
+                *reinterpret_cast<floatx4*>(a.out_act + off) = y;
+            }
+        }
+    }
+}
+
+template <int GPW, bool OSPLIT>
+static int launch_t(const ConvArgs& a, int flags, int nstage, int cfg, hipStream_t s) {
+    const int grid = a.nTiles * a.nOB;
+    hipLaunchKernelGGL((gconv_kernel<GPW, OSPLIT>), dim3(grid), dim3(256), LDS_BYTES, s, a, flags, nstage, cfg);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+template <int GPW, bool OSPLIT>
+static int init_t() {
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gconv_kernel<GPW, OSPLIT>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    return 0;
+}
+
+int gconv_init() {
+    int rc;
+    if ((rc = init_t<15, false>())) return rc;
+    if ((rc = init_t<12, false>())) return rc;
+    if ((rc = init_t<4, false>())) return rc;
+    if ((rc = init_t<1, false>())) return rc;
+    if ((rc = init_t<1, true>())) return rc;
+    return 0;
+}
+
+// gpw: 15 / 12 / 4 / 1; gpw == -1 selects the o-split single-group-element variant.
+int launch_gconv(const ConvArgs& a, int gpw, int flags, hipStream_t s) {
+    int nstage = G;
+    switch (gpw) {
+        case 15: return launch_t<15, false>(a, flags, nstage, CFG_FULL, s);
+        case 12: return launch_t<12, false>(a, flags, nstage, CFG_C45, s);
+        case 4:  return launch_t<4, false>(a, flags, nstage, CFG_C13, s);
+        case 1:  return launch_t<1, false>(a, flags, a.ntaps == 1 ? 1 : nstage, CFG_C1, s);
+        case -1: return launch_t<1, true>(a, flags, a.ntaps == 1 ? 1 : nstage, CFG_C1, s);
+        default: set_error("launch_gconv: unsupported slots-per-wave %d", gpw); return YOHO_EINVAL;
+    }
+}
+
+}  // namespace yoho

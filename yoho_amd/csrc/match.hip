@@ -1,0 +1,206 @@
+// Brute-force nearest neighbour, mutual matching and the coarse-rotation index.
+//
+//   nn_kernel        modified_knn_matcher.pdist / find_nn_gpu   utils/knn_search.py:17-20,26-66
+//   mutual kernels   matcher_dual.match                         tests/matcher.py:37-48
+//   des2r_kernel     extractor_dr_index.Batch_Des2R_torch       tests/extractor.py:74-78
+//
+// The reference takes argmin of sqrt(sum((a-b)^2) + 1e-7) over an explicit difference (not the
+// GEMM expansion); indices must be bit-exact, so the arithmetic below is written with explicit
+// round-to-nearest intrinsics (no FMA contraction) in the summation order torch's CPU reduction
+// uses for a contiguous 32-float row: 8 lane sums over x[l], x[8+l], x[16+l], x[24+l], lanes then
+// added 0..7 in sequence (pinned by tests/golden/pdist.npz).  The first minimum wins.
+#include "common.h"
+
+namespace yoho {
+
+constexpr int NN_ROWS = 16;     // source rows per workgroup
+constexpr int NN_SPLIT = 16;    // target interleave per source row
+constexpr int NN_TT = 256;      // target rows per LDS tile
+
+template <int D>
+__device__ __forceinline__ float dist2_f32(const float* a, const float* b) {
+    if constexpr (D == 32) {
+        float l[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const float d = __fsub_rn(a[k], b[k]); l[k] = __fmul_rn(d, d); }
+#pragma unroll
+        for (int blk = 1; blk < 4; ++blk)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float d = __fsub_rn(a[8 * blk + k], b[8 * blk + k]);
+                l[k] = __fadd_rn(l[k], __fmul_rn(d, d));
+            }
+        float s = l[0];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) s = __fadd_rn(s, l[k]);
+        return s;
+    } else {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            const float d = __fsub_rn(a[k], b[k]);
+            const float q = __fmul_rn(d, d);
+            s = k == 0 ? q : __fadd_rn(s, q);
+        }
+        return s;
+    }
+}
+
+// src (Ns,D) f32, tgt (Nt,D) f32 -> idx (Ns) int64, dist (Ns) f32 (optional)
+template <int D>
+__global__ __launch_bounds__(256) void nn_kernel(const float* __restrict__ src, int Ns, const float* __restrict__ tgt, int Nt,
+                                                 int64_t* __restrict__ idx, float* __restrict__ dist) {
+    __shared__ float tile[NN_TT * D];
+    __shared__ float rd[NN_ROWS * NN_SPLIT];
+    __shared__ int ri[NN_ROWS * NN_SPLIT];
+    const int r = threadIdx.x % NN_ROWS, sp = threadIdx.x / NN_ROWS;
+    const int row = blockIdx.x * NN_ROWS + r;
+    float a[D];
+    const int rowc = row < Ns ? row : Ns - 1;
+#pragma unroll
+    for (int k = 0; k < D; ++k) a[k] = src[(size_t)rowc * D + k];
+    float best = __builtin_inff();
+    int besti = 0;
+    for (int t0 = 0; t0 < Nt; t0 += NN_TT) {
+        const int nt = Nt - t0 < NN_TT ? Nt - t0 : NN_TT;
+        __syncthreads();
+        for (int i = threadIdx.x; i < nt * D; i += 256) tile[i] = tgt[(size_t)t0 * D + i];
+        __syncthreads();
+        for (int t = sp; t < nt; t += NN_SPLIT) {
+            const float d2 = dist2_f32<D>(a, tile + t * D);
+            const float d = __fsqrt_rn(__fadd_rn(d2, 1e-7f));
+            if (d < best) { best = d; besti = t0 + t; }
+        }
+    }
+    rd[r * NN_SPLIT + sp] = best;
+    ri[r * NN_SPLIT + sp] = besti;
+    __syncthreads();
+    if (sp == 0 && row < Ns) {
+        float bd = rd[r * NN_SPLIT];
+        int bi = ri[r * NN_SPLIT];
+        for (int k = 1; k < NN_SPLIT; ++k) {
+            const float d = rd[r * NN_SPLIT + k];
+            const int i = ri[r * NN_SPLIT + k];
+            if (d < bd || (d == bd && i < bi)) { bd = d; bi = i; }
+        }
+        idx[row] = bi;
+        if (dist) dist[row] = bd;
+    }
+}
+
+int launch_nn(const float* src, int Ns, const float* tgt, int Nt, int D, int64_t* idx, float* dist, hipStream_t s) {
+    const int grid = (Ns + NN_ROWS - 1) / NN_ROWS;
+    if (D == 32) hipLaunchKernelGGL(nn_kernel<32>, dim3(grid), dim3(256), 0, s, src, Ns, tgt, Nt, idx, dist);
+    else if (D == 3) hipLaunchKernelGGL(nn_kernel<3>, dim3(grid), dim3(256), 0, s, src, Ns, tgt, Nt, idx, dist);
+    else { set_error("yoho_nn_search: D must be 32 or 3 (got %d)", D); return YOHO_EINVAL; }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// keep i with back[fwd[i]] == i, ascending i (tests/matcher.py:42-47).  Single workgroup scan.
+__global__ __launch_bounds__(1024) void mutual_compact_kernel(const int64_t* __restrict__ fwd, const int64_t* __restrict__ back,
+                                                              int Na, int64_t* __restrict__ pairs, int* __restrict__ M_out) {
+    __shared__ int wsum[16];
+    __shared__ int base;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) base = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < Na; i0 += 1024) {
+        const int i = i0 + tid;
+        bool keep = false;
+        int64_t j = 0;
+        if (i < Na) { j = fwd[i]; keep = back[j] == (int64_t)i; }
+        const unsigned long long m = __ballot(keep);
+        const int before = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) wsum[wv] = __popcll(m);
+        __syncthreads();
+        int off = base;
+        for (int k = 0; k < wv; ++k) off += wsum[k];
+        if (keep) { pairs[2 * (size_t)(off + before)] = i; pairs[2 * (size_t)(off + before) + 1] = j; }
+        __syncthreads();
+        if (tid == 0) { int t = 0; for (int k = 0; k < 16; ++k) t += wsum[k]; base += t; }
+        __syncthreads();
+    }
+    if (tid == 0) *M_out = base;
+}
+
+int launch_mutual_compact(const int64_t* fwd, const int64_t* back, int Na, int64_t* pairs, int* M_out, hipStream_t s) {
+    hipLaunchKernelGGL(mutual_compact_kernel, dim3(1), dim3(1024), 0, s, fwd, back, Na, pairs, M_out);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// cor[m, a] = sum_g sum_f d1[m, f, P[a, g]] * d2[m, f, g];  idx[m] = argmax_a (first maximum).
+// One 64-lane workgroup per match; lane a < 60 owns one candidate rotation.
+__global__ __launch_bounds__(64) void des2r_kernel(const float* __restrict__ d1, const float* __restrict__ d2, const int* __restrict__ P,
+                                                   int M, int64_t* __restrict__ idx, float* __restrict__ cor) {
+    __shared__ float s1[F * G];
+    __shared__ float s2[F * G];
+    const int m = blockIdx.x, lane = threadIdx.x;
+    const float4* p1 = reinterpret_cast<const float4*>(d1 + (size_t)m * F * G);
+    const float4* p2 = reinterpret_cast<const float4*>(d2 + (size_t)m * F * G);
+    for (int i = lane; i < F * G / 4; i += 64) {
+        reinterpret_cast<float4*>(s1)[i] = p1[i];
+        reinterpret_cast<float4*>(s2)[i] = p2[i];
+    }
+    __syncthreads();
+    const int a = lane < G ? lane : G - 1;
+    float acc = 0.f;
+    for (int g = 0; g < G; ++g) {
+        const int pg = P[a * G + g];
+#pragma unroll 8
+        for (int f = 0; f < F; ++f) acc = fmaf(s1[f * G + pg], s2[f * G + g], acc);
+    }
+    if (cor && lane < G) cor[(size_t)m * G + lane] = acc;
+    float bv = lane < G ? acc : -__builtin_inff();
+    int bi = lane;
+    for (int o = 32; o >= 1; o >>= 1) {
+        const float ov = __shfl_xor(bv, o);
+        const int oi = __shfl_xor(bi, o);
+        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    if (lane == 0) idx[m] = bi;
+}
+
+int launch_des2r(const float* d1, const float* d2, const int* P, int M, int64_t* idx, float* cor, hipStream_t s) {
+    hipLaunchKernelGGL(des2r_kernel, dim3(M), dim3(64), 0, s, d1, d2, P, M, idx, cor);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+}  // namespace yoho
+
+using namespace yoho;
+
+extern "C" {
+
+int yoho_nn_search(yoho_ctx* c, const float* src, int Ns, const float* tgt, int Nt, int D, int64_t* idx, float* dist, void* stream) {
+    if (!c || !src || !tgt || !idx || Ns < 0 || Nt < 1) { set_error("yoho_nn_search: bad argument"); return YOHO_EINVAL; }
+    if (Ns == 0) return 0;
+    HIPCHK(hipSetDevice(c->device));
+    return launch_nn(src, Ns, tgt, Nt, D, idx, dist, (hipStream_t)stream);
+}
+
+int yoho_mutual_nn(yoho_ctx* c, const float* a, int Na, const float* b, int Nb, int64_t* pairs, int* M_out, void* stream) {
+    if (!c || !a || !b || !pairs || !M_out || Na < 1 || Nb < 1) { set_error("yoho_mutual_nn: bad argument"); return YOHO_EINVAL; }
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    // workspace: fwd (Na) + back (Nb) int64, placed after everything the descriptor passes use
+    const size_t need = sizeof(int64_t) * ((size_t)Na + Nb);
+    int rc;
+    if ((rc = ensure_ws(c, need, s))) return rc;
+    int64_t* fwd = (int64_t*)c->ws.p;
+    int64_t* back = fwd + Na;
+    if ((rc = launch_nn(a, Na, b, Nb, 32, fwd, nullptr, s))) return rc;     // NN of every a-row in b  (KNN(feats1, feats0))
+    if ((rc = launch_nn(b, Nb, a, Na, 32, back, nullptr, s))) return rc;    // NN of every b-row in a  (KNN(feats0, feats1))
+    return launch_mutual_compact(fwd, back, Na, pairs, M_out, s);
+}
+
+int yoho_des2r(yoho_ctx* c, const float* d1, const float* d2, int M, int64_t* idx, float* cor, void* stream) {
+    if (!c || !d1 || !d2 || !idx || M < 0) { set_error("yoho_des2r: bad argument"); return YOHO_EINVAL; }
+    if (M == 0) return 0;
+    HIPCHK(hipSetDevice(c->device));
+    return launch_des2r(d1, d2, c->dP, M, idx, cor, (hipStream_t)stream);
+}
+
+}  // extern "C"

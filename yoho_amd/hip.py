@@ -1,0 +1,301 @@
+"""ctypes binding of libyoho_hip.so (include/yoho_hip.h) + a thin tensor-level wrapper.
+
+PyTorch-ROCm tensors are the device-memory container only: every method passes
+``tensor.data_ptr()`` and the current HIP stream to the C ABI.  There is NO CPU fallback: if the
+library cannot be loaded, importing a GPU op raises.
+"""
+import ctypes as C
+import os
+import numpy as np
+import torch  # must be imported before the library so that both share one HIP runtime (libamdhip64.so.7)
+
+from . import tables as _tables
+from . import weights as _weights
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libyoho_hip.so")
+_lib = None
+
+SYMBOLS = [
+    "yoho_last_error", "yoho_version", "yoho_ctx_create", "yoho_ctx_destroy", "yoho_load_partI",
+    "yoho_load_partII", "yoho_partI_forward", "yoho_group_mean_np", "yoho_nn_search", "yoho_mutual_nn",
+    "yoho_des2r", "yoho_partII_forward", "yoho_hyp_from_quat", "yoho_o_score", "yoho_c_ransac",
+    "yoho_group_gather", "yoho_set_profiling", "yoho_get_kernel_ms",
+]
+
+
+class ConvW(C.Structure):
+    _fields_ = [("weight", C.c_void_p), ("bias", C.c_void_p)]
+
+
+class BnW(C.Structure):
+    _fields_ = [("gamma", C.c_void_p), ("beta", C.c_void_p), ("mean", C.c_void_p), ("var", C.c_void_p)]
+
+
+class PartIWeights(C.Structure):
+    _fields_ = [("conv_in", ConvW), ("res_in_bn", BnW), ("res_in", ConvW), ("res_out_bn", BnW),
+                ("res_out", ConvW), ("out_bn", BnW), ("conv_out", ConvW)]
+
+
+class PartIIWeights(C.Structure):
+    _fields_ = [("init_bn", BnW), ("init", ConvW), ("res_in_bn", BnW), ("res_in", ConvW),
+                ("res_out_bn", BnW), ("res_out", ConvW), ("fc0", ConvW), ("fc0_bn", BnW),
+                ("fc1", ConvW), ("fc1_bn", BnW), ("fc2", ConvW)]
+
+
+def lib_path():
+    return _LIB_PATH
+
+
+def load_library():
+    """Load libyoho_hip.so; raises (never falls back) when it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise RuntimeError(
+            f"{_LIB_PATH} not found: build it with `python -m yoho_amd.build` "
+            "(there is no CPU fallback for the YOHO hot path)")
+    lib = C.CDLL(_LIB_PATH, mode=C.RTLD_GLOBAL)
+    for s in SYMBOLS:
+        if not hasattr(lib, s):
+            raise RuntimeError(f"libyoho_hip.so does not export {s}")
+    lib.yoho_last_error.restype = C.c_char_p
+    lib.yoho_version.restype = C.c_char_p
+    vp, ci = C.c_void_p, C.c_int
+    lib.yoho_ctx_create.argtypes = [ci, vp, vp, vp, C.POINTER(vp)]
+    lib.yoho_ctx_destroy.argtypes = [vp]
+    lib.yoho_load_partI.argtypes = [vp, C.POINTER(PartIWeights)]
+    lib.yoho_load_partII.argtypes = [vp, C.POINTER(PartIIWeights)]
+    lib.yoho_partI_forward.argtypes = [vp, vp, ci, vp, vp, vp, vp]
+    lib.yoho_group_mean_np.argtypes = [vp, vp, ci, vp, vp]
+    lib.yoho_nn_search.argtypes = [vp, vp, ci, vp, ci, ci, vp, vp, vp]
+    lib.yoho_mutual_nn.argtypes = [vp, vp, ci, vp, ci, vp, vp, vp]
+    lib.yoho_des2r.argtypes = [vp, vp, vp, ci, vp, vp, vp]
+    lib.yoho_partII_forward.argtypes = [vp, vp, vp, vp, vp, vp, ci, vp, vp]
+    lib.yoho_hyp_from_quat.argtypes = [vp, vp, vp, vp, vp, ci, vp, vp]
+    lib.yoho_o_score.argtypes = [vp, vp, vp, ci, vp, vp, ci, C.c_double, vp, vp, vp, vp]
+    lib.yoho_c_ransac.argtypes = [vp, vp, vp, ci, vp, vp, ci, C.c_double, vp, vp, vp, vp, vp, vp]
+    lib.yoho_group_gather.argtypes = [vp, vp, ci, vp, vp, ci, ci, vp, vp, vp, vp]
+    lib.yoho_set_profiling.argtypes = [vp, ci]
+    lib.yoho_get_kernel_ms.argtypes = [vp, ci, C.POINTER(C.c_float)]
+    for s in SYMBOLS[2:]:
+        getattr(lib, s).restype = ci
+    _lib = lib
+    return lib
+
+
+class YohoError(RuntimeError):
+    pass
+
+
+def _check(rc):
+    if rc != 0:
+        raise YohoError(f"libyoho_hip error {rc}: {_lib.yoho_last_error().decode()}")
+
+
+def _np_ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev(t, dtype, name):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda):
+        raise TypeError(f"{name}: expected a CUDA/HIP tensor")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: tensor must be contiguous")
+    return C.c_void_p(t.data_ptr())
+
+
+class Context:
+    """One yoho_ctx per device: group tables + (optionally) PartI / PartII weights."""
+
+    def __init__(self, device=None, so3_dir=None):
+        lib = load_library()
+        if not torch.cuda.is_available():
+            raise RuntimeError("yoho_amd.hip.Context needs a visible MI355X (torch.cuda.is_available() is False)")
+        self.device = torch.cuda.current_device() if device is None else int(device)
+        self.tables = _tables.GroupTables(so3_dir)
+        h = C.c_void_p()
+        R = np.ascontiguousarray(self.tables.R32.reshape(60, 9))
+        _check(lib.yoho_ctx_create(self.device, _np_ptr(R), _np_ptr(self.tables.N_u8), _np_ptr(self.tables.P_u8), C.byref(h)))
+        self._h = h
+        self._lib = lib
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.yoho_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- weights ---------------------------------------------------------------------------
+    @staticmethod
+    def _conv(sd, k, keep):
+        w = np.ascontiguousarray(sd[k + ".weight"], dtype=np.float32)
+        b = np.ascontiguousarray(sd[k + ".bias"], dtype=np.float32)
+        keep += [w, b]
+        return ConvW(w.ctypes.data, b.ctypes.data)
+
+    @staticmethod
+    def _bn(sd, k, keep):
+        arrs = [np.ascontiguousarray(sd[k + s], dtype=np.float32) for s in (".weight", ".bias", ".running_mean", ".running_var")]
+        keep += arrs
+        return BnW(*[a.ctypes.data for a in arrs])
+
+    def load_partI(self, sd):
+        sd = _weights.to_numpy_state_dict(sd)
+        _weights.check_state_dict(sd, _weights.PARTI_SPEC, strict=False)
+        keep = []
+        p, r = "PartI_net.", "PartI_net.SO3_Conv_layers.0."
+        w = PartIWeights(self._conv(sd, p + "Conv_in.0", keep),
+                         self._bn(sd, r + "comb_layer_in.0", keep), self._conv(sd, r + "comb_layer_in.2", keep),
+                         self._bn(sd, r + "comb_layer_out.0", keep), self._conv(sd, r + "comb_layer_out.2", keep),
+                         self._bn(sd, p + "Conv_out.comb_layer.0", keep), self._conv(sd, p + "Conv_out.comb_layer.2", keep))
+        _check(self._lib.yoho_load_partI(self._h, C.byref(w)))
+
+    def load_partII(self, sd):
+        sd = _weights.to_numpy_state_dict(sd)
+        _weights.check_state_dict(sd, _weights.PARTII_SPEC, strict=False)
+        keep = []
+        r, f = "PartII_SO3_Conv_layers.0.", "PartII_To_R_FC."
+        w = PartIIWeights(self._bn(sd, "Conv_init.comb_layer.0", keep), self._conv(sd, "Conv_init.comb_layer.2", keep),
+                          self._bn(sd, r + "comb_layer_in.0", keep), self._conv(sd, r + "comb_layer_in.2", keep),
+                          self._bn(sd, r + "comb_layer_out.0", keep), self._conv(sd, r + "comb_layer_out.2", keep),
+                          self._conv(sd, f + "0", keep), self._bn(sd, f + "1", keep),
+                          self._conv(sd, f + "3", keep), self._bn(sd, f + "4", keep), self._conv(sd, f + "6", keep))
+        _check(self._lib.yoho_load_partII(self._h, C.byref(w)))
+
+    # ---- descriptor path -------------------------------------------------------------------
+    def partI_forward(self, x, want_inv=True, want_inv_np=False):
+        """x (B,32,60) f32 cuda -> dict(eqv, inv[, inv_np])."""
+        B = x.shape[0]
+        if x.dim() != 3 or x.shape[1] != 32 or x.shape[2] != 60:
+            raise ValueError(f"group feature must be (B,32,60), got {tuple(x.shape)}")
+        eqv = torch.empty_like(x)
+        inv = torch.empty((B, 32), dtype=torch.float32, device=x.device) if want_inv else None
+        inv_np = torch.empty((B, 32), dtype=torch.float32, device=x.device) if want_inv_np else None
+        _check(self._lib.yoho_partI_forward(self._h, _dev(x, torch.float32, "x"), B, C.c_void_p(eqv.data_ptr()),
+                                            C.c_void_p(inv.data_ptr()) if want_inv else None,
+                                            C.c_void_p(inv_np.data_ptr()) if want_inv_np else None, _stream()))
+        out = {"eqv": eqv}
+        if want_inv:
+            out["inv"] = inv
+        if want_inv_np:
+            out["inv_np"] = inv_np
+        return out
+
+    def group_mean_np(self, eqv):
+        B = eqv.shape[0]
+        out = torch.empty((B, 32), dtype=torch.float32, device=eqv.device)
+        _check(self._lib.yoho_group_mean_np(self._h, _dev(eqv, torch.float32, "eqv"), B, C.c_void_p(out.data_ptr()), _stream()))
+        return out
+
+    def nn_search(self, src, tgt, want_dist=True):
+        """src (Ns,D), tgt (Nt,D) f32, D in {32,3} -> (dist (Ns) f32 or None, idx (Ns) int64)."""
+        Ns, D = src.shape
+        Nt = tgt.shape[0]
+        idx = torch.empty((Ns,), dtype=torch.int64, device=src.device)
+        dist = torch.empty((Ns,), dtype=torch.float32, device=src.device) if want_dist else None
+        _check(self._lib.yoho_nn_search(self._h, _dev(src, torch.float32, "src"), Ns, _dev(tgt, torch.float32, "tgt"), Nt, D,
+                                        C.c_void_p(idx.data_ptr()), C.c_void_p(dist.data_ptr()) if want_dist else None, _stream()))
+        return dist, idx
+
+    def mutual_nn(self, a, b):
+        """a (Na,32), b (Nb,32) -> (M,2) int64 mutual nearest neighbours, ascending in a."""
+        Na, Nb = a.shape[0], b.shape[0]
+        pairs = torch.empty((Na, 2), dtype=torch.int64, device=a.device)
+        m = torch.zeros((1,), dtype=torch.int32, device=a.device)
+        _check(self._lib.yoho_mutual_nn(self._h, _dev(a, torch.float32, "a"), Na, _dev(b, torch.float32, "b"), Nb,
+                                        C.c_void_p(pairs.data_ptr()), C.c_void_p(m.data_ptr()), _stream()))
+        return pairs[: int(m.item())]
+
+    def des2r(self, d1, d2, want_cor=False):
+        M = d1.shape[0]
+        idx = torch.empty((M,), dtype=torch.int64, device=d1.device)
+        cor = torch.empty((M, 60), dtype=torch.float32, device=d1.device) if want_cor else None
+        _check(self._lib.yoho_des2r(self._h, _dev(d1, torch.float32, "d1"), _dev(d2, torch.float32, "d2"), M,
+                                    C.c_void_p(idx.data_ptr()), C.c_void_p(cor.data_ptr()) if want_cor else None, _stream()))
+        return (idx, cor) if want_cor else idx
+
+    def partII_forward(self, before_eqv0, before_eqv1, after_eqv0, after_eqv1, pre_idx):
+        M = before_eqv0.shape[0]
+        quat = torch.empty((M, 4), dtype=torch.float32, device=before_eqv0.device)
+        _check(self._lib.yoho_partII_forward(
+            self._h, _dev(before_eqv0, torch.float32, "before_eqv0"), _dev(before_eqv1, torch.float32, "before_eqv1"),
+            _dev(after_eqv0, torch.float32, "after_eqv0"), _dev(after_eqv1, torch.float32, "after_eqv1"),
+            _dev(pre_idx, torch.int64, "pre_idx"), M, C.c_void_p(quat.data_ptr()), _stream()))
+        return quat
+
+    # ---- estimators ------------------------------------------------------------------------
+    def hyp_from_quat(self, quat, idx, k0, k1):
+        M = quat.shape[0]
+        T = torch.empty((M, 3, 4), dtype=torch.float64, device=quat.device)
+        _check(self._lib.yoho_hyp_from_quat(self._h, _dev(quat, torch.float32, "quat"), _dev(idx, torch.int64, "idx"),
+                                            _dev(k0, torch.float64, "k0"), _dev(k1, torch.float64, "k1"), M,
+                                            C.c_void_p(T.data_ptr()), _stream()))
+        return T
+
+    def o_score(self, k0, k1, T, order, H, d):
+        """Returns (best_h, best_count, counts (H) int32) as device tensors."""
+        M = k0.shape[0]
+        res = torch.zeros((2,), dtype=torch.int32, device=k0.device)
+        counts = torch.empty((H,), dtype=torch.int32, device=k0.device)
+        _check(self._lib.yoho_o_score(self._h, _dev(k0, torch.float64, "k0"), _dev(k1, torch.float64, "k1"), M,
+                                      _dev(T, torch.float64, "T"), _dev(order, torch.int64, "order") if order is not None else None,
+                                      H, float(d), C.c_void_p(res.data_ptr()), C.c_void_p(res.data_ptr() + 4),
+                                      C.c_void_p(counts.data_ptr()), _stream()))
+        return res, counts
+
+    def c_ransac(self, k0, k1, triples, reflect, d, want_all=False):
+        M, I = k0.shape[0], triples.shape[0]
+        best_T = torch.empty((3, 4), dtype=torch.float64, device=k0.device)
+        res = torch.zeros((2,), dtype=torch.int32, device=k0.device)
+        T_all = torch.empty((I, 3, 4), dtype=torch.float64, device=k0.device) if want_all else None
+        counts = torch.empty((I,), dtype=torch.int32, device=k0.device) if want_all else None
+        _check(self._lib.yoho_c_ransac(self._h, _dev(k0, torch.float64, "k0"), _dev(k1, torch.float64, "k1"), M,
+                                       _dev(triples, torch.int64, "triples"),
+                                       _dev(reflect, torch.uint8, "reflect") if reflect is not None else None, I, float(d),
+                                       C.c_void_p(best_T.data_ptr()), C.c_void_p(res.data_ptr()), C.c_void_p(res.data_ptr() + 4),
+                                       C.c_void_p(T_all.data_ptr()) if want_all else None,
+                                       C.c_void_p(counts.data_ptr()) if want_all else None, _stream()))
+        return best_T, res, T_all, counts
+
+    def group_gather(self, keys, pts, feat, g, out, want_idx=False):
+        K, n = keys.shape[0], pts.shape[0]
+        Rg = np.ascontiguousarray(self.tables.R64[g], dtype=np.float64)
+        nn_idx = torch.empty((K,), dtype=torch.int64, device=keys.device) if want_idx else None
+        _check(self._lib.yoho_group_gather(self._h, _dev(keys, torch.float64, "keys"), K, _dev(pts, torch.float32, "pts"),
+                                           _dev(feat, torch.float32, "feat"), n, int(g), _np_ptr(Rg),
+                                           _dev(out, torch.float32, "out"), C.c_void_p(nn_idx.data_ptr()) if want_idx else None,
+                                           _stream()))
+        return nn_idx
+
+    # ---- profiling hook (bench.py) ------------------------------------------------------------
+    def set_profiling(self, on=True):
+        _check(self._lib.yoho_set_profiling(self._h, 1 if on else 0))
+
+    def kernel_ms(self, which):
+        ms = C.c_float(-1.0)
+        _check(self._lib.yoho_get_kernel_ms(self._h, int(which), C.byref(ms)))
+        return float(ms.value)
+
+
+_ctx_cache = {}
+
+
+def get_context(device=None, so3_dir=None):
+    """Process-wide context per (device, table directory)."""
+    dev = torch.cuda.current_device() if device is None else int(device)
+    key = (dev, os.path.abspath(so3_dir) if so3_dir else None)
+    if key not in _ctx_cache:
+        _ctx_cache[key] = Context(dev, so3_dir)
+    return _ctx_cache[key]
