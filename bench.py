@@ -32,7 +32,7 @@ FLOP_PER_KP = 434_503_680       # 2 * 60 * (416*256 + 3328*512 + 6656*256 + 3328
 FP32_MFMA_PEAK = 157.3          # TFLOP/s, MI355X_MICROARCH.md (v_mfma_f32_32x32x2_f32 = vector rate)
 
 
-def cpu_baseline(K=900):
+def cpu_baseline(K=600):
     """The oracle (a port of the reference's op sequence, torch-CPU kernels for the convs exactly as
     the reference's CPU path, numpy for the rest) on a bounded sample of the same workload:
     one synthetic pair with K keypoints per fragment, test_batch_size 900 / 1000."""

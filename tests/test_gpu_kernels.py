@@ -155,7 +155,7 @@ def test_quat2mat_bitexact(ctx, gold):
     idx = np.zeros(M, np.int64)                      # group element 0 = identity
     T = ctx.hyp_from_quat(cu(g["q"]), cu(idx), cu(z), cu(z)).cpu().numpy()
     R0 = np.load(os.path.join(ctx.tables.dir, "Rotation.npy")).astype(np.float32)[0].astype(np.float64)
-    assert np.allclose(T[:, :, :3], g["mats"] @ R0, atol=1e-15)
+    assert np.allclose(T[:, :, :3], g["mats"] @ R0, rtol=0, atol=1e-15)
 
 
 def test_yohoo_golden_and_micro(ctx, gold):
@@ -193,13 +193,13 @@ def test_kabsch_and_yohoc(ctx, gold):
     refl = (dets < 0).astype(np.uint8)
     assert 0 < refl.sum() < n
     _, _, T_all, _ = ctx.c_ransac(cu(k0), cu(k1), cu(tri), cu(refl), 0.07, want_all=True)
-    assert np.allclose(T_all.cpu().numpy(), g["T"], atol=1e-9)          # incl. the reference's reflections
+    assert np.allclose(T_all.cpu().numpy(), g["T"], rtol=0, atol=1e-9)          # incl. the reference's reflections
     _, _, T_prop, _ = ctx.c_ransac(cu(k0), cu(k1), cu(tri), None, 0.07, want_all=True)
     Tp = T_prop.cpu().numpy()
     assert np.allclose(np.linalg.det(Tp[:, :, :3]), 1, atol=1e-9)
     for i in range(n):
         To, _ = orc.threepps2tran(g["k0"][i], g["k1"][i], proper=True)
-        assert np.allclose(Tp[i], To, atol=1e-9)
+        assert np.allclose(Tp[i], To, rtol=0, atol=1e-9)
     # full YOHO-C on the golden chain with the reference's RNG stream
     c = gold("chain.npz")
     pr = synth.make_pair(int(c["K"]), seed=int(c["pair_seed"]))
@@ -214,7 +214,7 @@ def test_kabsch_and_yohoc(ctx, gold):
     assert np.array_equal(counts.cpu().numpy()[nodup], ref_counts[nodup])
     bi, bc = res.cpu().numpy()
     assert bi == it == int(c["yohoc_recall"]) and bc == cnt
-    assert np.allclose(best_T.cpu().numpy(), c["yohoc_trans"], atol=1e-9)
+    assert np.allclose(best_T.cpu().numpy(), c["yohoc_trans"], rtol=0, atol=1e-9)
 
 
 def test_group_gather(ctx, tables):

@@ -16,6 +16,10 @@ CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "libyoho_hip.so")
 SOURCES = ["api.hip", "gconv.hip", "layout.hip", "match.hip", "estim.hip"]
+# Kernels whose results must be bit-exact against numpy / torch-CPU arithmetic are compiled without
+# FMA contraction (hipcc defaults to -ffp-contract=fast and __fmul_rn/__fadd_rn are plain operators
+# in this ROCm, so they would fuse); explicit fma()/fmaf() calls are unaffected.
+EXTRA = {"layout.hip": ["-ffp-contract=off"], "match.hip": ["-ffp-contract=off"], "estim.hip": ["-ffp-contract=off"]}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-I" + os.path.join(REPO, "include"), "-I" + CSRC]
 
@@ -39,7 +43,7 @@ def build(force=False, verbose=True):
     procs = []
     for src in SOURCES:
         obj = os.path.join(LIBDIR, src.replace(".hip", ".o"))
-        cmd = [hipcc] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc] + FLAGS + EXTRA.get(src, []) + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd)))

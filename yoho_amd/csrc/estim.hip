@@ -5,6 +5,7 @@
 //   argbest_kernel  strict '>' running best      tests/estimator.py:330-336 / :131-137
 //   kabsch_kernel   Threepps2Tran                tests/estimator.py:55-63
 //   gather_kernel   60-fold FCGF feature gather  YOHO_testset.py:153-166
+// This file is compiled with -ffp-contract=off (yoho_amd/build.py): only explicit fma() fuses.
 #include "common.h"
 
 namespace yoho {
@@ -298,7 +299,7 @@ __global__ __launch_bounds__(256) void gather_kernel(const double* __restrict__ 
             const double d1 = __dsub_rn(kr[1], (double)tile[t * 3 + 1]);
             const double d2 = __dsub_rn(kr[2], (double)tile[t * 3 + 2]);
             const double s = __dadd_rn(__dadd_rn(__dmul_rn(d0, d0), __dmul_rn(d1, d1)), __dmul_rn(d2, d2));
-            const double d = __dsqrt_rn(__dadd_rn(s, 1e-7));
+            const double d = sqrt(__dadd_rn(s, 1e-7));
             if (d < best) { best = d; besti = t0 + t; }
         }
     }

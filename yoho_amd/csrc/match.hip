@@ -9,6 +9,7 @@
 // round-to-nearest intrinsics (no FMA contraction) in the summation order torch's CPU reduction
 // uses for a contiguous 32-float row: 8 lane sums over x[l], x[8+l], x[16+l], x[24+l], lanes then
 // added 0..7 in sequence (pinned by tests/golden/pdist.npz).  The first minimum wins.
+// This file is compiled with -ffp-contract=off (yoho_amd/build.py).
 #include "common.h"
 
 namespace yoho {
@@ -68,7 +69,7 @@ __global__ __launch_bounds__(256) void nn_kernel(const float* __restrict__ src, 
         __syncthreads();
         for (int t = sp; t < nt; t += NN_SPLIT) {
             const float d2 = dist2_f32<D>(a, tile + t * D);
-            const float d = __fsqrt_rn(__fadd_rn(d2, 1e-7f));
+            const float d = (float)sqrt((double)__fadd_rn(d2, 1e-7f));   // correctly rounded fp32 sqrt
             if (d < best) { best = d; besti = t0 + t; }
         }
     }

@@ -104,7 +104,7 @@ def to_numpy_state_dict(sd):
         v = np.asarray(v)
         if v.dtype.kind == "f":
             v = v.astype(np.float32)
-        out[k] = np.ascontiguousarray(v)
+        out[k] = np.ascontiguousarray(v) if v.ndim else v.copy()
     return out
 
 
@@ -128,6 +128,8 @@ def check_state_dict(sd, spec, strict=True):
         if name not in sd:
             if strict or not name.endswith("num_batches_tracked"):
                 raise KeyError(f"missing key in state_dict: {name}")
+            continue
+        if name.endswith("num_batches_tracked"):
             continue
         if tuple(sd[name].shape) != tuple(shape):
             raise ValueError(f"{name}: shape {tuple(sd[name].shape)} != {tuple(shape)}")
