@@ -87,9 +87,12 @@ int yoho_partI_forward(yoho_ctx* ctx, const float* x, int B, float* eqv, float* 
 int yoho_group_mean_np(yoho_ctx* ctx, const float* eqv, int B, float* out, void* stream);
 
 /* for every row of src (Ns,D) the index (and distance, may be NULL) of the nearest row of
- * tgt (Nt,D): argmin_j sqrt(sum_f (s_f - t_jf)^2 + 1e-7), fp32, first minimum wins.  D = 32
- * (descriptor matching, torch-CPU summation order) or D = 3. */
-int yoho_nn_search(yoho_ctx* ctx, const float* src, int Ns, const float* tgt, int Nt, int D,
+ * tgt (Nt,D), fp32, first minimum wins.  dist_type YOHO_DIST_L2: argmin_j sqrt(sum_f (s_f - t_jf)^2
+ * + 1e-7) (pdist 'L2'); YOHO_DIST_SQUARE_L2: argmin_j sum_f (s_f - t_jf)^2 (pdist 'SquareL2').
+ * D = 32 (descriptor matching, torch-CPU summation order) or D = 3. */
+#define YOHO_DIST_L2        0
+#define YOHO_DIST_SQUARE_L2 1
+int yoho_nn_search(yoho_ctx* ctx, const float* src, int Ns, const float* tgt, int Nt, int D, int dist_type,
                    int64_t* idx, float* dist, void* stream);
 
 /* mutual nearest neighbours of a (Na,32) in b (Nb,32): pairs (M,2) int64 in ascending a-index,

@@ -48,7 +48,7 @@ __device__ __forceinline__ float dist2_f32(const float* a, const float* b) {
 }
 
 // src (Ns,D) f32, tgt (Nt,D) f32 -> idx (Ns) int64, dist (Ns) f32 (optional)
-template <int D>
+template <int D, bool SQUARED>
 __global__ __launch_bounds__(256) void nn_kernel(const float* __restrict__ src, int Ns, const float* __restrict__ tgt, int Nt,
                                                  int64_t* __restrict__ idx, float* __restrict__ dist) {
     __shared__ float tile[NN_TT * D];
@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void nn_kernel(const float* __restrict__ src, 
         __syncthreads();
         for (int t = sp; t < nt; t += NN_SPLIT) {
             const float d2 = dist2_f32<D>(a, tile + t * D);
-            const float d = (float)sqrt((double)__fadd_rn(d2, 1e-7f));   // correctly rounded fp32 sqrt
+            const float d = SQUARED ? d2 : (float)sqrt((double)__fadd_rn(d2, 1e-7f));   // correctly rounded fp32 sqrt
             if (d < best) { best = d; besti = t0 + t; }
         }
     }
@@ -89,10 +89,14 @@ __global__ __launch_bounds__(256) void nn_kernel(const float* __restrict__ src, 
     }
 }
 
-int launch_nn(const float* src, int Ns, const float* tgt, int Nt, int D, int64_t* idx, float* dist, hipStream_t s) {
+int launch_nn(const float* src, int Ns, const float* tgt, int Nt, int D, int dist_type, int64_t* idx, float* dist, hipStream_t s) {
     const int grid = (Ns + NN_ROWS - 1) / NN_ROWS;
-    if (D == 32) hipLaunchKernelGGL(nn_kernel<32>, dim3(grid), dim3(256), 0, s, src, Ns, tgt, Nt, idx, dist);
-    else if (D == 3) hipLaunchKernelGGL(nn_kernel<3>, dim3(grid), dim3(256), 0, s, src, Ns, tgt, Nt, idx, dist);
+    const bool sq = dist_type == YOHO_DIST_SQUARE_L2;
+    if (dist_type != YOHO_DIST_L2 && !sq) { set_error("yoho_nn_search: unknown dist_type %d", dist_type); return YOHO_EINVAL; }
+    if (D == 32 && !sq) hipLaunchKernelGGL((nn_kernel<32, false>), dim3(grid), dim3(256), 0, s, src, Ns, tgt, Nt, idx, dist);
+    else if (D == 32) hipLaunchKernelGGL((nn_kernel<32, true>), dim3(grid), dim3(256), 0, s, src, Ns, tgt, Nt, idx, dist);
+    else if (D == 3 && !sq) hipLaunchKernelGGL((nn_kernel<3, false>), dim3(grid), dim3(256), 0, s, src, Ns, tgt, Nt, idx, dist);
+    else if (D == 3) hipLaunchKernelGGL((nn_kernel<3, true>), dim3(grid), dim3(256), 0, s, src, Ns, tgt, Nt, idx, dist);
     else { set_error("yoho_nn_search: D must be 32 or 3 (got %d)", D); return YOHO_EINVAL; }
     HIPCHK(hipGetLastError());
     return 0;
@@ -175,11 +179,12 @@ using namespace yoho;
 
 extern "C" {
 
-int yoho_nn_search(yoho_ctx* c, const float* src, int Ns, const float* tgt, int Nt, int D, int64_t* idx, float* dist, void* stream) {
+int yoho_nn_search(yoho_ctx* c, const float* src, int Ns, const float* tgt, int Nt, int D, int dist_type, int64_t* idx, float* dist,
+                   void* stream) {
     if (!c || !src || !tgt || !idx || Ns < 0 || Nt < 1) { set_error("yoho_nn_search: bad argument"); return YOHO_EINVAL; }
     if (Ns == 0) return 0;
     HIPCHK(hipSetDevice(c->device));
-    return launch_nn(src, Ns, tgt, Nt, D, idx, dist, (hipStream_t)stream);
+    return launch_nn(src, Ns, tgt, Nt, D, dist_type, idx, dist, (hipStream_t)stream);
 }
 
 int yoho_mutual_nn(yoho_ctx* c, const float* a, int Na, const float* b, int Nb, int64_t* pairs, int* M_out, void* stream) {
@@ -192,8 +197,8 @@ int yoho_mutual_nn(yoho_ctx* c, const float* a, int Na, const float* b, int Nb, 
     if ((rc = ensure_ws(c, need, s))) return rc;
     int64_t* fwd = (int64_t*)c->ws.p;
     int64_t* back = fwd + Na;
-    if ((rc = launch_nn(a, Na, b, Nb, 32, fwd, nullptr, s))) return rc;     // NN of every a-row in b  (KNN(feats1, feats0))
-    if ((rc = launch_nn(b, Nb, a, Na, 32, back, nullptr, s))) return rc;    // NN of every b-row in a  (KNN(feats0, feats1))
+    if ((rc = launch_nn(a, Na, b, Nb, 32, YOHO_DIST_L2, fwd, nullptr, s))) return rc;     // NN of every a-row in b  (KNN(feats1, feats0))
+    if ((rc = launch_nn(b, Nb, a, Na, 32, YOHO_DIST_L2, back, nullptr, s))) return rc;    // NN of every b-row in a  (KNN(feats0, feats1))
     return launch_mutual_compact(fwd, back, Na, pairs, M_out, s);
 }
 

@@ -68,7 +68,7 @@ def load_library():
     lib.yoho_load_partII.argtypes = [vp, C.POINTER(PartIIWeights)]
     lib.yoho_partI_forward.argtypes = [vp, vp, ci, vp, vp, vp, vp]
     lib.yoho_group_mean_np.argtypes = [vp, vp, ci, vp, vp]
-    lib.yoho_nn_search.argtypes = [vp, vp, ci, vp, ci, ci, vp, vp, vp]
+    lib.yoho_nn_search.argtypes = [vp, vp, ci, vp, ci, ci, ci, vp, vp, vp]
     lib.yoho_mutual_nn.argtypes = [vp, vp, ci, vp, ci, vp, vp, vp]
     lib.yoho_des2r.argtypes = [vp, vp, vp, ci, vp, vp, vp]
     lib.yoho_partII_forward.argtypes = [vp, vp, vp, vp, vp, vp, ci, vp, vp]
@@ -199,13 +199,14 @@ class Context:
         _check(self._lib.yoho_group_mean_np(self._h, _dev(eqv, torch.float32, "eqv"), B, C.c_void_p(out.data_ptr()), _stream()))
         return out
 
-    def nn_search(self, src, tgt, want_dist=True):
-        """src (Ns,D), tgt (Nt,D) f32, D in {32,3} -> (dist (Ns) f32 or None, idx (Ns) int64)."""
+    def nn_search(self, src, tgt, want_dist=True, squared=False):
+        """src (Ns,D), tgt (Nt,D) f32, D in {32,3} -> (dist (Ns) f32 or None, idx (Ns) int64).
+        squared=False: pdist 'L2' (sqrt(D2 + 1e-7)); True: 'SquareL2' (D2)."""
         Ns, D = src.shape
         Nt = tgt.shape[0]
         idx = torch.empty((Ns,), dtype=torch.int64, device=src.device)
         dist = torch.empty((Ns,), dtype=torch.float32, device=src.device) if want_dist else None
-        _check(self._lib.yoho_nn_search(self._h, _dev(src, torch.float32, "src"), Ns, _dev(tgt, torch.float32, "tgt"), Nt, D,
+        _check(self._lib.yoho_nn_search(self._h, _dev(src, torch.float32, "src"), Ns, _dev(tgt, torch.float32, "tgt"), Nt, D, 1 if squared else 0,
                                         C.c_void_p(idx.data_ptr()), C.c_void_p(dist.data_ptr()) if want_dist else None, _stream()))
         return dist, idx
 

@@ -1,0 +1,67 @@
+"""Drop-in for simple_yoho/yoho_extract.py: one-cloud API  pc -> (kpts, inv, eqv).
+
+    extractor = yoho_extractor(fcgf_ckpt, yoho_ckpt, fcgf=my_backbone)
+    kpts, feat_inv, feat_eqv = extractor.run(pc, voxel_size=0.025, nkpts=5000)
+
+The FCGF sparse-conv backbone (simple_yoho/fcgf_feat.py on MinkowskiEngine, CUDA-only) is out of
+scope for this path: pass any object with ``run(pc, voxel_size) ->
+(ds_points (n,3), unit-norm feats (n,32))`` as ``fcgf``.  Everything after the backbone - the 60-fold
+NN feature transfer and the PartI group conv - runs on the HIP library.
+
+Differences from the reference (all deliberate):
+  * no argparse at import time (simple_yoho/yoho_extract.py:11-13 breaks under pytest / other argv);
+  * the NN result is unpacked as (dists, inds) - the reference names them the other way round
+    (:37) and would index the features with distances;
+  * any number of keypoints works (no "avoid B == 1" last-batch merge needed, :55-58).
+"""
+import numpy as np
+import torch
+
+from . import hip
+from . import weights as W
+from .utils import transform_points
+
+
+class yoho_extractor():
+    def __init__(self, fcgf_ckpt='model/Backbone/best_val_checkpoint.pth', yoho_ckpt='model/PartI_train/model_best.pth',
+                 fcgf=None, so3_dir=None):
+        self.ctx = hip.get_context(so3_dir=so3_dir)
+        self.grs = self.ctx.tables.R64
+        self.fcgf = fcgf
+        self.fcgf_ckpt = fcgf_ckpt
+        self.yoho_ckpt = yoho_ckpt
+        self._load_model()
+        self.bs = 500
+
+    def _load_model(self):
+        sd = self.yoho_ckpt if isinstance(self.yoho_ckpt, dict) else W.load_checkpoint(self.yoho_ckpt)[0]
+        W.check_state_dict(W.to_numpy_state_dict(sd), W.PARTI_SPEC, strict=False)
+        self.ctx.load_partI(sd)
+
+    def _feature_transfer_xyz(self, query, source, source_f):
+        """NN in xyz (fp32, 'SquareL2') and feature row transfer (simple_yoho/yoho_extract.py:33-39)."""
+        q = torch.from_numpy(np.asarray(query).astype(np.float32)).cuda().contiguous()
+        s = (source if isinstance(source, torch.Tensor) else torch.from_numpy(np.asarray(source))).to(device="cuda", dtype=torch.float32).contiguous()
+        f = (source_f if isinstance(source_f, torch.Tensor) else torch.from_numpy(np.asarray(source_f))).to(device="cuda", dtype=torch.float32)
+        dist, idx = self.ctx.nn_search(q, s, want_dist=False, squared=True)
+        return f[idx]
+
+    def extract_features(self, pc, voxel_size, nkpts=5000):
+        if self.fcgf is None:
+            raise NotImplementedError("no FCGF backbone: pass fcgf=<object with run(pc, voxel_size)> "
+                                      "(the MinkowskiEngine backbone is outside this path's scope)")
+        kpts_index = np.random.permutation(len(pc))[0:nkpts]
+        kpts = pc[kpts_index]
+        kpts_f = torch.empty((kpts.shape[0], 32, 60), dtype=torch.float32, device="cuda")
+        for i in range(self.grs.shape[0]):
+            kptsi = transform_points(kpts.copy(), self.grs[i])
+            pci = transform_points(pc.copy(), self.grs[i])
+            pci_ds, pci_f = self.fcgf.run(pci, voxel_size)
+            kpts_f[:, :, i] = self._feature_transfer_xyz(kptsi, pci_ds, pci_f)
+        out = self.ctx.partI_forward(kpts_f.contiguous(), want_inv=True)
+        # output: n*32; n*32*60 (cpu tensors, as the reference)
+        return kpts, out["inv"].cpu(), out["eqv"].cpu()
+
+    def run(self, pc, voxel_size=0.025, nkpts=5000):
+        kpts, feat_inv, feat_eqv = self.extract_features(pc, voxel_size, nkpts=nkpts)
+        return kpts, feat_inv, feat_eqv
