@@ -25,9 +25,11 @@ def cu(a):
 
 @pytest.fixture(scope="module")
 def ctx(hip, sd1, sd2):
+    """context with the fp32-MFMA group conv (the bf16x3 default is exercised by ctx16 and the drop-in tests)"""
     c = hip.Context()
     c.load_partI(sd1)
     c.load_partII(sd2)
+    c.set_gconv_mode("f32")
     return c
 
 
@@ -63,6 +65,40 @@ def test_partI_equivariance_at_full_size(ctx, tables):
     # unit norm over channels
     n = torch.linalg.norm(e0, dim=1)
     assert (n - 1).abs().max().item() < 1e-5
+
+
+@pytest.fixture(scope="module")
+def ctx16(hip, sd1, sd2):
+    """second context running the PartI group conv on the bf16x3 split MFMA path"""
+    c = hip.Context()
+    c.load_partI(sd1)
+    c.load_partII(sd2)
+    c.set_gconv_mode("bf16x3")
+    return c
+
+
+def test_partI_bf16x3_golden_and_vs_f32(ctx, ctx16, gold, sd1, tables):
+    g = gold("partI.npz")
+    out = ctx16.partI_forward(cu(g["x"]), want_inv=True, want_inv_np=True)
+    eqv, inv = out["eqv"].cpu().numpy(), out["inv"].cpu().numpy()
+    print("bf16x3 golden: rel err eqv %.3g inv %.3g" % (rel(eqv, g["eqv"]), rel(inv, g["inv"])))
+    assert rel(eqv, g["eqv"]) < TOL and rel(inv, g["inv"]) < TOL
+    assert np.array_equal(out["inv_np"].cpu().numpy(), np.mean(eqv, axis=-1))
+    for B in (1, 2, 15, 16, 17, 33, 100):
+        x = synth.unit_features(B, seed=200 + B)
+        o = ctx16.partI_forward(cu(x))
+        e, i = orc.partI_forward(x, sd1, tables.N)
+        assert rel(o["eqv"].cpu().numpy(), e) < TOL and rel(o["inv"].cpu().numpy(), i) < TOL, B
+    # the two arithmetic paths agree to fp32 rounding at full size
+    x = cu(synth.unit_features(5000, seed=1))
+    e32 = ctx.partI_forward(x)["eqv"]
+    e16 = ctx16.partI_forward(x)["eqv"]
+    d = (e32 - e16).abs().max().item()
+    print("bf16x3 vs f32 MFMA at 5000 kp: max abs diff %.3g" % d)
+    assert d < 5e-6
+    P = torch.from_numpy(tables.P).cuda()
+    ei = ctx16.partI_forward(x[:, :, P[17]].contiguous())["eqv"]
+    assert (ei - e16[:, :, P[17]]).abs().max().item() < 2e-5
 
 
 def test_group_mean_np_bitexact(ctx):
@@ -106,7 +142,9 @@ def test_mutual_match_golden_and_full_size(ctx, gold):
     assert (np.diff(mm[:, 0]) > 0).all() and len(set(mm[:, 1])) == len(mm)
 
 
-def test_des2r_golden(ctx, gold, sd1, tables):
+@pytest.mark.parametrize("mode", ["f32", "bf16x3"])
+def test_des2r_golden(ctx, ctx16, mode, gold, sd1, tables):
+    ctx = ctx if mode == "f32" else ctx16
     g = gold("chain.npz")
     pr = synth.make_pair(int(g["K"]), seed=int(g["pair_seed"]))
     e0 = ctx.partI_forward(cu(pr["feat0"]))["eqv"]

@@ -1,0 +1,13 @@
+"""Workload for the PMC passes: a few PartI forward passes on 5000 keypoints (bf16x3 and fp32 modes)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from yoho_amd import hip, synth, weights as W
+ctx = hip.Context(0)
+ctx.load_partI(W.synth_state_dict(W.PARTI_SPEC, 7))
+x = torch.from_numpy(synth.unit_features(5000, seed=1)).cuda()
+for mode in ("bf16x3", "f32"):
+    ctx.set_gconv_mode(mode)
+    for _ in range(2):
+        ctx.partI_forward(x, want_inv=False, want_inv_np=True)
+torch.cuda.synchronize()

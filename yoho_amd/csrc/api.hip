@@ -4,6 +4,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <cmath>
 #include <vector>
 
@@ -31,6 +32,7 @@ static int upload(const void* h, size_t bytes, void** d) {
 
 static void free_layer(Layer& L) {
     if (L.wp) (void)hipFree(L.wp);
+    if (L.wp16) (void)hipFree(L.wp16);
     if (L.bias) (void)hipFree(L.bias);
     if (L.bn_s) (void)hipFree(L.bn_s);
     if (L.bn_t) (void)hipFree(L.bn_t);
@@ -46,6 +48,47 @@ static void bn_affine(const yoho_bn_w& bn, int c, int cpad, std::vector<float>& 
         s[i] = sc;
         t[i] = bn.beta[i] - bn.mean[i] * sc;
     }
+}
+
+static inline unsigned bf16_rne_bits(float x) {
+    unsigned u;
+    std::memcpy(&u, &x, 4);
+    return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+static inline float bf16_to_float(unsigned h) {
+    unsigned u = h << 16;
+    float f;
+    std::memcpy(&f, &u, 4);
+    return f;
+}
+
+// 13-tap conv weight -> bf16x3 planes in MFMA 32x32x16 A-fragment order
+//   [ob][c8][tp][plane][lane = 32h + i][e]:  W[ob*32+i][c8*8+e][2*tp+h], split x = hi + mid + lo (RNE each)
+static int build_wp16(Layer& L, const yoho_conv_w& cw) {
+    const int nob = (L.cout_pad + 63) / 64 * 2;       // the 2-block kernel variant walks pairs of o-blocks
+    const int c8n = L.cin / 8;
+    std::vector<unsigned short> wp((size_t)nob * c8n * 7 * 3 * 64 * 8, 0);
+    for (int ob = 0; ob < nob; ++ob)
+        for (int c8 = 0; c8 < c8n; ++c8)
+            for (int tp = 0; tp < 7; ++tp) {
+                unsigned short* dst = &wp[(((size_t)ob * c8n + c8) * 7 + tp) * 3 * 512];
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int h = lane >> 5, o = ob * 32 + (lane & 31), tap = 2 * tp + h;
+                    if (o >= L.cout || tap >= L.ntaps) continue;
+                    for (int e = 0; e < 8; ++e) {
+                        const float x = cw.weight[((size_t)o * L.cin + c8 * 8 + e) * L.ntaps + tap];
+                        const unsigned hi = bf16_rne_bits(x);
+                        const float r1 = x - bf16_to_float(hi);
+                        const unsigned mi = bf16_rne_bits(r1);
+                        const float r2 = r1 - bf16_to_float(mi);
+                        const unsigned lo = bf16_rne_bits(r2);
+                        dst[0 * 512 + lane * 8 + e] = (unsigned short)hi;
+                        dst[1 * 512 + lane * 8 + e] = (unsigned short)mi;
+                        dst[2 * 512 + lane * 8 + e] = (unsigned short)lo;
+                    }
+                }
+            }
+    return upload(wp.data(), wp.size() * sizeof(unsigned short), &L.wp16);
 }
 
 // conv weight (cout,cin,1,ntaps) -> A-fragment order [ob][c8][tap][lane = h*32+i][s]:
@@ -70,17 +113,19 @@ static int build_layer(Layer& L, const yoho_conv_w& cw, int cin, int cout, int n
                     }
                 }
             }
-    std::vector<float> bias(L.cout_pad, 0.f);
+    const int cpad64 = (L.cout_pad + 63) / 64 * 64;      // the bf16x3 kernel touches o-blocks in pairs
+    std::vector<float> bias(cpad64, 0.f);
     std::memcpy(bias.data(), cw.bias, sizeof(float) * cout);
     int rc;
     if ((rc = upload(wp.data(), wp.size() * sizeof(float), (void**)&L.wp))) return rc;
+    if (ntaps == NTAP && (rc = build_wp16(L, cw))) return rc;
     if ((rc = upload(bias.data(), bias.size() * sizeof(float), (void**)&L.bias))) return rc;
     if (bn_after) {
         if (!bn_after->gamma || !bn_after->beta || !bn_after->mean || !bn_after->var) {
             set_error("null batch-norm pointer"); return YOHO_EINVAL;
         }
         std::vector<float> s, t;
-        bn_affine(*bn_after, cout, L.cout_pad, s, t);
+        bn_affine(*bn_after, cout, cpad64, s, t);
         if ((rc = upload(s.data(), s.size() * sizeof(float), (void**)&L.bn_s))) return rc;
         if ((rc = upload(t.data(), t.size() * sizeof(float), (void**)&L.bn_t))) return rc;
     }
@@ -169,6 +214,23 @@ int yoho_ctx_create(int device, const float* R, const uint8_t* N, const uint8_t*
     fill(CFG_C13, one, 4, false);
     fill(CFG_C1, std::vector<int>{0}, 1, true);
     if ((rc = upload_slot_tables(slab.data(), outg.data())) || (rc = gconv_init())) { delete c; return rc; }
+    // bf16x3 variant: unit u = output group elements (2u, 2u+1); tap pair tp = taps (2tp, 2tp+1), tap 13 = zero weights
+    {
+        std::vector<int> slab4(7 * 32, 0), unitg(32 * 2, -1);
+        for (int u = 0; u < 30; ++u) { unitg[2 * u] = 2 * u; unitg[2 * u + 1] = 2 * u + 1; }
+        for (int tp = 0; tp < 7; ++tp)
+            for (int u = 0; u < 32; ++u)
+                for (int gs = 0; gs < 2; ++gs)
+                    for (int h = 0; h < 2; ++h) {
+                        const int g = unitg[2 * u + gs];
+                        int tap = 2 * tp + h;
+                        if (tap >= NTAP) tap = 2 * tp;                 // weights are zero there; any finite slab will do
+                        slab4[tp * 32 + u] |= (g < 0 ? 0 : (int)N[g * NTAP + tap]) << (8 * (2 * gs + h));
+                    }
+        if ((rc = upload_slot_tables16(slab4.data(), unitg.data())) || (rc = gconv16_init())) { delete c; return rc; }
+    }
+    c->gconv_mode = 1;      // default: bf16x3 split MFMA (fp32-accurate, ~1.8x the fp32-MFMA kernel); YOHO_GCONV=f32 selects fp32 MFMA
+    if (const char* m = std::getenv("YOHO_GCONV")) c->gconv_mode = std::strcmp(m, "f32") == 0 ? 0 : 1;
     *out = c;
     return 0;
 }
@@ -227,6 +289,12 @@ int yoho_load_partII(yoho_ctx* c, const yoho_partII_weights* w) {
     return 0;
 }
 
+int yoho_set_gconv_mode(yoho_ctx* c, int mode) {
+    if (!c || (mode != 0 && mode != 1)) { set_error("yoho_set_gconv_mode: mode must be 0 (fp32 MFMA) or 1 (bf16x3 MFMA)"); return YOHO_EINVAL; }
+    c->gconv_mode = mode;
+    return 0;
+}
+
 int yoho_set_profiling(yoho_ctx* c, int enable) {
     if (!c) { set_error("null ctx"); return YOHO_EINVAL; }
     HIPCHK(hipSetDevice(c->device));
@@ -251,7 +319,39 @@ int yoho_get_kernel_ms(yoho_ctx* c, int which, float* ms) {
     return 0;
 }
 
+// bf16x3 variant: 16-keypoint tiles, bf16 plane activations, fp32 raw residual / output
+static int partI_pass16(yoho_ctx* c, const float* x, int B, float* eqv, float* inv, float* inv_np, hipStream_t s) {
+    const int nT = (B + 15) / 16;
+    const size_t chunk = 46080, rawslabs = (size_t)G * 128 * sizeof(float);      // bytes per (tile, c8)
+    const size_t szX = (size_t)nT * 4 * chunk, szA = (size_t)nT * 32 * chunk, szA1 = (size_t)nT * 64 * chunk;
+    const size_t szH0 = (size_t)nT * 32 * rawslabs, szY = (size_t)nT * 8 * rawslabs;   // Y padded to 64 channels
+    int rc;
+    if ((rc = ensure_ws(c, szX + szA + szA1 + szH0 + szY, s))) return rc;
+    char* bX = (char*)c->ws.p;
+    char* bA = bX + szX;
+    char* bA1 = bA + szA;
+    float* bH0 = (float*)(bA1 + szA1);
+    float* bY = (float*)((char*)bH0 + szH0);
+    const bool prof = c->profiling && c->ev_created;
+    auto mark = [&](int i) { if (prof) (void)hipEventRecord(c->ev[i], s); };
+    mark(0);
+    if ((rc = launch_pack16_partI(x, B, nT, bX, s))) return rc;
+    mark(1);
+    if ((rc = launch_gconv16(c->p1[0], bX, nT, nullptr, bH0, bA, EPI_RAW | EPI_ACT, s))) return rc;
+    mark(2);
+    if ((rc = launch_gconv16(c->p1[1], bA, nT, nullptr, nullptr, bA1, EPI_ACT, s))) return rc;
+    mark(3);
+    if ((rc = launch_gconv16(c->p1[2], bA1, nT, bH0, nullptr, bA, EPI_RES | EPI_ACT, s))) return rc;
+    mark(4);
+    if ((rc = launch_gconv16(c->p1[3], bA, nT, nullptr, bY, nullptr, EPI_RAW, s))) return rc;
+    mark(5);
+    if ((rc = launch_finalize_partI(bY, x, B, eqv, inv, inv_np, 1, s))) return rc;
+    mark(6);
+    return 0;
+}
+
 static int partI_pass(yoho_ctx* c, const float* x, int B, float* eqv, float* inv, float* inv_np, hipStream_t s) {
+    if (c->gconv_mode == 1) return partI_pass16(c, x, B, eqv, inv, inv_np, s);
     const int nT = (B + TILE - 1) / TILE;
     const size_t ch = (size_t)CHUNK_FLOATS * sizeof(float);
     const size_t nX = (size_t)nT * 4, n256 = (size_t)nT * 32, n512 = (size_t)nT * 64;
@@ -275,7 +375,7 @@ static int partI_pass(yoho_ctx* c, const float* x, int B, float* eqv, float* inv
     mark(4);
     if ((rc = launch_gconv(conv_args(c->p1[3], bA, nT, nullptr, bY, nullptr, false), 15, EPI_RAW, s))) return rc;
     mark(5);
-    if ((rc = launch_finalize_partI(bY, x, B, eqv, inv, inv_np, s))) return rc;
+    if ((rc = launch_finalize_partI(bY, x, B, eqv, inv, inv_np, 0, s))) return rc;
     mark(6);
     return 0;
 }

@@ -29,6 +29,7 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line);
 struct Layer {
     int cin = 0, cout = 0, cout_pad = 0, ntaps = 0;
     float* wp = nullptr;      // packed MFMA A-fragments [ob][c8][tap][lane64][4]
+    void* wp16 = nullptr;     // bf16x3 planes [ob][c8][tap-pair 7][plane 3][lane64][8] (13-tap layers only)
     float* bias = nullptr;    // [cout_pad]
     float* bn_s = nullptr;    // [cout_pad] scale of the BN that FOLLOWS this conv (applied with ReLU in the epilogue)
     float* bn_t = nullptr;    // [cout_pad] shift
@@ -56,7 +57,12 @@ int launch_gconv(const ConvArgs& a, int gpw, int flags, hipStream_t s);
 int gconv_init();   // sets the dynamic-LDS attribute of every instantiation
 
 int launch_pack_partI(const float* x, int B, int nTiles, float* out, hipStream_t s);
-int launch_finalize_partI(const float* y, const float* x, int B, float* eqv, float* inv, float* inv_np, hipStream_t s);
+int launch_finalize_partI(const float* y, const float* x, int B, float* eqv, float* inv, float* inv_np, int layout16, hipStream_t s);
+// bf16x3 variant (gconv16.hip)
+int upload_slot_tables16(const int* slab4_h, const int* unitg_h);
+int gconv16_init();
+int launch_gconv16(const Layer& L, const char* X, int nTiles, const float* res, float* out_raw, char* out_act, int flags, hipStream_t s);
+int launch_pack16_partI(const float* x, int B, int nTiles, char* out, hipStream_t s);
 int launch_group_mean_np(const float* eqv, int B, float* out, hipStream_t s);
 int launch_pack_partII(const float* s0, const float* s1, const float* s2, const float* s3, const int64_t* pre_idx,
                        const int* P, const float* bn_s, const float* bn_t, int M, int nTiles, float* out, hipStream_t s);
@@ -90,6 +96,7 @@ struct yoho_ctx {
     yoho::Layer p1[4];           // conv_in, res_in, res_out, conv_out
     yoho::Layer p2[6];           // init, res_in, res_out, fc0, fc1, fc2
     float *p2_init_bn_s = nullptr, *p2_init_bn_t = nullptr;  // BN(128) applied by the PartII pack kernel
+    int gconv_mode = 1;          // 0: fp32 MFMA group conv, 1: bf16x3 split MFMA (PartI; default)
     // workspace (grown on demand)
     yoho::Workspace ws;
     // profiling

@@ -61,18 +61,24 @@ __device__ __forceinline__ float np_pairwise_mean60(const float* v) {
     return __fdiv_rn(s, 60.0f);
 }
 
+// fp32 raw layout of the bf16x3 variant: [tile16][c8][g][kp16][8 ch]
+__device__ __forceinline__ size_t iidx16(int tile, int C8, int c, int g, int kp) {
+    return (((size_t)tile * C8 + (c >> 3)) * G + g) * 128 + kp * 8 + (c & 7);
+}
+
 __global__ __launch_bounds__(64) void finalize_partI_kernel(const float* __restrict__ y, const float* __restrict__ x, int B,
                                                             float* __restrict__ eqv, float* __restrict__ inv,
-                                                            float* __restrict__ inv_np) {
+                                                            float* __restrict__ inv_np, int layout16) {
     __shared__ float e[F * G];
     __shared__ float rn[G];
     const int b = blockIdx.x;
     const int lane = threadIdx.x;
-    const int tile = b / TILE, kp = b - tile * TILE;
+    const int tw = layout16 ? 16 : TILE;
+    const int tile = b / tw, kp = b - tile * tw;
     const float* xb = x + (size_t)b * (F * G);
     for (int i = lane; i < F * G; i += 64) {
         const int c = i / G, g = i - c * G;
-        e[i] = y[iidx(tile, 4, c, g, kp)] + xb[i];
+        e[i] = y[layout16 ? iidx16(tile, 4, c, g, kp) : iidx(tile, 4, c, g, kp)] + xb[i];
     }
     __syncthreads();
     if (lane < G) {
@@ -102,8 +108,8 @@ __global__ __launch_bounds__(64) void finalize_partI_kernel(const float* __restr
     }
 }
 
-int launch_finalize_partI(const float* y, const float* x, int B, float* eqv, float* inv, float* inv_np, hipStream_t s) {
-    hipLaunchKernelGGL(finalize_partI_kernel, dim3(B), dim3(64), 0, s, y, x, B, eqv, inv, inv_np);
+int launch_finalize_partI(const float* y, const float* x, int B, float* eqv, float* inv, float* inv_np, int layout16, hipStream_t s) {
+    hipLaunchKernelGGL(finalize_partI_kernel, dim3(B), dim3(64), 0, s, y, x, B, eqv, inv, inv_np, layout16);
     HIPCHK(hipGetLastError());
     return 0;
 }

@@ -19,7 +19,7 @@ SYMBOLS = [
     "yoho_last_error", "yoho_version", "yoho_ctx_create", "yoho_ctx_destroy", "yoho_load_partI",
     "yoho_load_partII", "yoho_partI_forward", "yoho_group_mean_np", "yoho_nn_search", "yoho_mutual_nn",
     "yoho_des2r", "yoho_partII_forward", "yoho_hyp_from_quat", "yoho_o_score", "yoho_c_ransac",
-    "yoho_group_gather", "yoho_set_profiling", "yoho_get_kernel_ms",
+    "yoho_group_gather", "yoho_set_profiling", "yoho_get_kernel_ms", "yoho_set_gconv_mode",
 ]
 
 
@@ -77,6 +77,7 @@ def load_library():
     lib.yoho_c_ransac.argtypes = [vp, vp, vp, ci, vp, vp, ci, C.c_double, vp, vp, vp, vp, vp, vp]
     lib.yoho_group_gather.argtypes = [vp, vp, ci, vp, vp, ci, ci, vp, vp, vp, vp]
     lib.yoho_set_profiling.argtypes = [vp, ci]
+    lib.yoho_set_gconv_mode.argtypes = [vp, ci]
     lib.yoho_get_kernel_ms.argtypes = [vp, ci, C.POINTER(C.c_float)]
     for s in SYMBOLS[2:]:
         getattr(lib, s).restype = ci
@@ -279,6 +280,10 @@ class Context:
                                            _dev(out, torch.float32, "out"), C.c_void_p(nn_idx.data_ptr()) if want_idx else None,
                                            _stream()))
         return nn_idx
+
+    def set_gconv_mode(self, mode):
+        """'f32' (fp32 MFMA) or 'bf16x3' (fp32-accurate 3-way bf16 split MFMA) for the PartI group conv."""
+        _check(self._lib.yoho_set_gconv_mode(self._h, {"f32": 0, "bf16x3": 1}[mode]))
 
     # ---- profiling hook (bench.py) ------------------------------------------------------------
     def set_profiling(self, on=True):
