@@ -133,8 +133,9 @@ int yoho_c_ransac(yoho_ctx* ctx, const double* k0, const double* k1, int M, cons
 int yoho_group_gather(yoho_ctx* ctx, const double* keys, int K, const float* pts, const float* feat,
                       int n, int g, const double* Rg_host, float* out, int64_t* nn_idx, void* stream);
 
-/* PartI group-conv arithmetic: 0 = fp32 MFMA (v_mfma_f32_32x32x2_f32), 1 = fp32-accurate 3-way bf16 split
- * on v_mfma_f32_32x32x16_bf16 (6 products per term).  Both meet the 1e-4 parity tolerance. */
+/* PartI group-conv formulation: 0 = direct 13-tap conv on fp32 MFMA (v_mfma_f32_32x32x2_f32), 1 = direct conv with an
+ * fp32-accurate 3-way bf16 split on v_mfma_f32_32x32x16_bf16 (6 products per term), 2 = group-Fourier domain conv
+ * (244 instead of 780 slab products per chunk) on fp32 MFMA.  All meet the 1e-4 parity tolerance. */
 int yoho_set_gconv_mode(yoho_ctx* ctx, int mode);
 
 /* timing hook for bench.py: average device time (ms) of the last yoho_partI_forward's dominant

@@ -33,6 +33,7 @@ static int upload(const void* h, size_t bytes, void** d) {
 static void free_layer(Layer& L) {
     if (L.wp) (void)hipFree(L.wp);
     if (L.wp16) (void)hipFree(L.wp16);
+    if (L.wpf) (void)hipFree(L.wpf);
     if (L.bias) (void)hipFree(L.bias);
     if (L.bn_s) (void)hipFree(L.bn_s);
     if (L.bn_t) (void)hipFree(L.bn_t);
@@ -93,7 +94,7 @@ static int build_wp16(Layer& L, const yoho_conv_w& cw) {
 
 // conv weight (cout,cin,1,ntaps) -> A-fragment order [ob][c8][tap][lane = h*32+i][s]:
 //   value = W[ob*32 + i][c8*8 + 4h + s][tap]
-static int build_layer(Layer& L, const yoho_conv_w& cw, int cin, int cout, int ntaps, const yoho_bn_w* bn_after) {
+static int build_layer(Layer& L, const yoho_conv_w& cw, int cin, int cout, int ntaps, const yoho_bn_w* bn_after, const FourierBasis* fb = nullptr) {
     free_layer(L);
     if (!cw.weight || !cw.bias) { set_error("null conv weight/bias pointer"); return YOHO_EINVAL; }
     L.cin = cin; L.cout = cout; L.ntaps = ntaps;
@@ -119,6 +120,11 @@ static int build_layer(Layer& L, const yoho_conv_w& cw, int cin, int cout, int n
     int rc;
     if ((rc = upload(wp.data(), wp.size() * sizeof(float), (void**)&L.wp))) return rc;
     if (ntaps == NTAP && (rc = build_wp16(L, cw))) return rc;
+    if (ntaps == NTAP && fb) {
+        std::vector<float> wf;
+        pack_fourier_weights(*fb, cw.weight, cin, cout, L.cout_pad, wf);
+        if ((rc = upload(wf.data(), wf.size() * sizeof(float), (void**)&L.wpf))) return rc;
+    }
     if ((rc = upload(bias.data(), bias.size() * sizeof(float), (void**)&L.bias))) return rc;
     if (bn_after) {
         if (!bn_after->gamma || !bn_after->beta || !bn_after->mean || !bn_after->var) {
@@ -229,8 +235,16 @@ int yoho_ctx_create(int device, const float* R, const uint8_t* N, const uint8_t*
                     }
         if ((rc = upload_slot_tables16(slab4.data(), unitg.data())) || (rc = gconv16_init())) { delete c; return rc; }
     }
-    c->gconv_mode = 1;      // default: bf16x3 split MFMA (fp32-accurate, ~1.8x the fp32-MFMA kernel); YOHO_GCONV=f32 selects fp32 MFMA
-    if (const char* m = std::getenv("YOHO_GCONV")) c->gconv_mode = std::strcmp(m, "f32") == 0 ? 0 : 1;
+    c->gconv_mode = 2;      // default: group-Fourier conv on fp32 MFMA; YOHO_GCONV=f32 | bf16x3 select the direct-conv kernels
+    if (const char* m = std::getenv("YOHO_GCONV")) c->gconv_mode = std::strcmp(m, "f32") == 0 ? 0 : (std::strcmp(m, "bf16x3") == 0 ? 1 : 2);
+    // group-Fourier basis (irreps of the table's group)
+    c->fb = new FourierBasis();
+    if ((rc = build_fourier(N, P, *c->fb))) { delete c->fb; delete c; return rc; }
+    {
+        std::vector<float> fpad(64 * 64, 0.f);
+        for (int s = 0; s < G; ++s) for (int g = 0; g < G; ++g) fpad[s * 64 + g] = (float)c->fb->F[s * G + g];
+        if ((rc = upload(fpad.data(), fpad.size() * sizeof(float), (void**)&c->dFpad)) || (rc = gft_init())) { delete c->fb; delete c; return rc; }
+    }
     *out = c;
     return 0;
 }
@@ -248,6 +262,8 @@ int yoho_ctx_destroy(yoho_ctx* c) {
     if (c->dR64) (void)hipFree(c->dR64);
     if (c->dN) (void)hipFree(c->dN);
     if (c->dP) (void)hipFree(c->dP);
+    if (c->dFpad) (void)hipFree(c->dFpad);
+    delete c->fb;
     if (c->ev_created) for (auto& e : c->ev) (void)hipEventDestroy(e);
     delete c;
     return 0;
@@ -259,10 +275,10 @@ int yoho_load_partI(yoho_ctx* c, const yoho_partI_weights* w) {
     c->has_partI = false;
     int rc;
     // each layer carries the BN+ReLU that precedes the NEXT conv as its epilogue
-    if ((rc = build_layer(c->p1[0], w->conv_in, 32, 256, NTAP, &w->res_in_bn))) return rc;
-    if ((rc = build_layer(c->p1[1], w->res_in, 256, 512, NTAP, &w->res_out_bn))) return rc;
-    if ((rc = build_layer(c->p1[2], w->res_out, 512, 256, NTAP, &w->out_bn))) return rc;
-    if ((rc = build_layer(c->p1[3], w->conv_out, 256, 32, NTAP, nullptr))) return rc;
+    if ((rc = build_layer(c->p1[0], w->conv_in, 32, 256, NTAP, &w->res_in_bn, c->fb))) return rc;
+    if ((rc = build_layer(c->p1[1], w->res_in, 256, 512, NTAP, &w->res_out_bn, c->fb))) return rc;
+    if ((rc = build_layer(c->p1[2], w->res_out, 512, 256, NTAP, &w->out_bn, c->fb))) return rc;
+    if ((rc = build_layer(c->p1[3], w->conv_out, 256, 32, NTAP, nullptr, c->fb))) return rc;
     c->has_partI = true;
     return 0;
 }
@@ -290,7 +306,7 @@ int yoho_load_partII(yoho_ctx* c, const yoho_partII_weights* w) {
 }
 
 int yoho_set_gconv_mode(yoho_ctx* c, int mode) {
-    if (!c || (mode != 0 && mode != 1)) { set_error("yoho_set_gconv_mode: mode must be 0 (fp32 MFMA) or 1 (bf16x3 MFMA)"); return YOHO_EINVAL; }
+    if (!c || mode < 0 || mode > 2) { set_error("yoho_set_gconv_mode: mode must be 0 (fp32 MFMA), 1 (bf16x3 MFMA) or 2 (group-Fourier fp32 MFMA)"); return YOHO_EINVAL; }
     c->gconv_mode = mode;
     return 0;
 }
@@ -307,14 +323,21 @@ int yoho_set_profiling(yoho_ctx* c, int enable) {
     return 0;
 }
 
-// which: 0..3 = PartI group-conv layers (conv_in, res_in, res_out, conv_out) of the last profiled
-// yoho_partI_forward pass; 4 = pack, 5 = finalize.  Synchronises on the recorded events.
+// which: 0..3 = PartI group-conv launches (conv_in, res_in, res_out, conv_out) of the last profiled
+// yoho_partI_forward pass; 4 = head (pack [+ forward transform]), 5 = tail ([inverse transform +] finalize),
+// 6 = the inter-layer transform kernels (group-Fourier mode).  Synchronises on the recorded events.
 int yoho_get_kernel_ms(yoho_ctx* c, int which, float* ms) {
-    if (!c || !ms || which < 0 || which > 5) { set_error("yoho_get_kernel_ms: bad argument"); return YOHO_EINVAL; }
+    if (!c || !ms || which < 0 || which > 6) { set_error("yoho_get_kernel_ms: bad argument"); return YOHO_EINVAL; }
     if (!c->ev_created) { set_error("profiling was not enabled"); return YOHO_EINVAL; }
-    // event order: e0 pack e1 L0 e2 L1 e3 L2 e4 L3 e5 fin e6
-    static const int first[6] = {1, 2, 3, 4, 0, 5};
-    HIPCHK(hipEventSynchronize(c->ev[6]));
+    // event order: e0 head e1 conv0 e2 xf e3 conv1 e4 xf e5 conv2 e6 xf e7 conv3 e8 tail e9
+    static const int first[6] = {1, 3, 5, 7, 0, 8};
+    HIPCHK(hipEventSynchronize(c->ev[9]));
+    if (which == 6) {            // the three inter-layer transform kernels (group-Fourier mode; ~0 otherwise)
+        float t = 0.f, d = 0.f;
+        for (int i = 2; i <= 6; i += 2) { HIPCHK(hipEventElapsedTime(&d, c->ev[i], c->ev[i + 1])); t += d; }
+        *ms = t;
+        return 0;
+    }
     HIPCHK(hipEventElapsedTime(ms, c->ev[first[which]], c->ev[first[which] + 1]));
     return 0;
 }
@@ -338,20 +361,61 @@ static int partI_pass16(yoho_ctx* c, const float* x, int B, float* eqv, float* i
     if ((rc = launch_pack16_partI(x, B, nT, bX, s))) return rc;
     mark(1);
     if ((rc = launch_gconv16(c->p1[0], bX, nT, nullptr, bH0, bA, EPI_RAW | EPI_ACT, s))) return rc;
-    mark(2);
+    mark(2); mark(3);
     if ((rc = launch_gconv16(c->p1[1], bA, nT, nullptr, nullptr, bA1, EPI_ACT, s))) return rc;
-    mark(3);
+    mark(4); mark(5);
     if ((rc = launch_gconv16(c->p1[2], bA1, nT, bH0, nullptr, bA, EPI_RES | EPI_ACT, s))) return rc;
-    mark(4);
+    mark(6); mark(7);
     if ((rc = launch_gconv16(c->p1[3], bA, nT, nullptr, bY, nullptr, EPI_RAW, s))) return rc;
-    mark(5);
+    mark(8);
     if ((rc = launch_finalize_partI(bY, x, B, eqv, inv, inv_np, 1, s))) return rc;
+    mark(9);
+    return 0;
+}
+
+// group-Fourier variant: 244 instead of 780 slab products per chunk; BN+ReLU between layers in the group domain
+static int partI_passF(yoho_ctx* c, const float* x, int B, float* eqv, float* inv, float* inv_np, hipStream_t s) {
+    const int nT = (B + TILE - 1) / TILE;
+    const size_t nX = (size_t)nT * 4, n256 = (size_t)nT * 32, n512 = (size_t)nT * 64;
+    int rc;
+    if ((rc = ensure_ws(c, (nX * 4 + n256 * 2 + n512) * CHUNK_FLOATS * sizeof(float), s))) return rc;
+    float* bS = (float*)c->ws.p;                  // packed input, group domain
+    float* bX = bS + nX * CHUNK_FLOATS;           // its Fourier coefficients
+    float* bH0 = bX + nX * CHUNK_FLOATS;          // raw h0 (Fourier), kept for the residual
+    float* bA = bH0 + n256 * CHUNK_FLOATS;        // act(h0), later h2 / act(h2)
+    float* bM = bA + n256 * CHUNK_FLOATS;         // mid 512 (in place raw -> act)
+    float* bY = bM + n512 * CHUNK_FLOATS;         // conv_out raw (Fourier)
+    float* bYs = bY + nX * CHUNK_FLOATS;          // conv_out raw (group domain)
+    const bool prof = c->profiling && c->ev_created;
+    auto mark = [&](int i) { if (prof) (void)hipEventRecord(c->ev[i], s); };
+    const Layer* L = c->p1;
+    mark(0);
+    if ((rc = launch_pack_partI(x, B, nT, bS, s))) return rc;
+    if ((rc = launch_gft(0, bS, bX, c->dFpad, nullptr, nullptr, nT, 4, s))) return rc;
+    mark(1);
+    if ((rc = launch_gconvf(L[0], bX, nT, nullptr, bH0, 0, s))) return rc;
+    mark(2);
+    if ((rc = launch_gft(2, bH0, bA, c->dFpad, L[0].bn_s, L[0].bn_t, nT, 32, s))) return rc;
+    mark(3);
+    if ((rc = launch_gconvf(L[1], bA, nT, nullptr, bM, 0, s))) return rc;
+    mark(4);
+    if ((rc = launch_gft(2, bM, bM, c->dFpad, L[1].bn_s, L[1].bn_t, nT, 64, s))) return rc;
+    mark(5);
+    if ((rc = launch_gconvf(L[2], bM, nT, bH0, bA, EPI_RES, s))) return rc;
     mark(6);
+    if ((rc = launch_gft(2, bA, bA, c->dFpad, L[2].bn_s, L[2].bn_t, nT, 32, s))) return rc;
+    mark(7);
+    if ((rc = launch_gconvf(L[3], bA, nT, nullptr, bY, 0, s))) return rc;
+    mark(8);
+    if ((rc = launch_gft(1, bY, bYs, c->dFpad, nullptr, nullptr, nT, 4, s))) return rc;
+    if ((rc = launch_finalize_partI(bYs, x, B, eqv, inv, inv_np, 0, s))) return rc;
+    mark(9);
     return 0;
 }
 
 static int partI_pass(yoho_ctx* c, const float* x, int B, float* eqv, float* inv, float* inv_np, hipStream_t s) {
     if (c->gconv_mode == 1) return partI_pass16(c, x, B, eqv, inv, inv_np, s);
+    if (c->gconv_mode == 2) return partI_passF(c, x, B, eqv, inv, inv_np, s);
     const int nT = (B + TILE - 1) / TILE;
     const size_t ch = (size_t)CHUNK_FLOATS * sizeof(float);
     const size_t nX = (size_t)nT * 4, n256 = (size_t)nT * 32, n512 = (size_t)nT * 64;
@@ -368,15 +432,15 @@ static int partI_pass(yoho_ctx* c, const float* x, int B, float* eqv, float* inv
     if ((rc = launch_pack_partI(x, B, nT, bX, s))) return rc;
     mark(1);
     if ((rc = launch_gconv(conv_args(c->p1[0], bX, nT, nullptr, bH0, bA, false), 15, EPI_RAW | EPI_ACT, s))) return rc;
-    mark(2);
+    mark(2); mark(3);
     if ((rc = launch_gconv(conv_args(c->p1[1], bA, nT, nullptr, nullptr, bA1, false), 15, EPI_ACT, s))) return rc;
-    mark(3);
+    mark(4); mark(5);
     if ((rc = launch_gconv(conv_args(c->p1[2], bA1, nT, bH0, nullptr, bA, false), 15, EPI_RES | EPI_ACT, s))) return rc;
-    mark(4);
+    mark(6); mark(7);
     if ((rc = launch_gconv(conv_args(c->p1[3], bA, nT, nullptr, bY, nullptr, false), 15, EPI_RAW, s))) return rc;
-    mark(5);
+    mark(8);
     if ((rc = launch_finalize_partI(bY, x, B, eqv, inv, inv_np, 0, s))) return rc;
-    mark(6);
+    mark(9);
     return 0;
 }
 

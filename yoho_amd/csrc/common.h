@@ -30,6 +30,7 @@ struct Layer {
     int cin = 0, cout = 0, cout_pad = 0, ntaps = 0;
     float* wp = nullptr;      // packed MFMA A-fragments [ob][c8][tap][lane64][4]
     void* wp16 = nullptr;     // bf16x3 planes [ob][c8][tap-pair 7][plane 3][lane64][8] (13-tap layers only)
+    float* wpf = nullptr;     // group-Fourier weights [ob][c8][frag 60][lane64][4] (13-tap layers only)
     float* bias = nullptr;    // [cout_pad]
     float* bn_s = nullptr;    // [cout_pad] scale of the BN that FOLLOWS this conv (applied with ReLU in the epilogue)
     float* bn_t = nullptr;    // [cout_pad] shift
@@ -58,6 +59,20 @@ int gconv_init();   // sets the dynamic-LDS attribute of every instantiation
 
 int launch_pack_partI(const float* x, int B, int nTiles, float* out, hipStream_t s);
 int launch_finalize_partI(const float* y, const float* x, int B, float* eqv, float* inv, float* inv_np, int layout16, hipStream_t s);
+// group-Fourier variant (fourier.hip)
+struct FourierBasis {
+    double rho[5][60][25];    // rho[r][g][a*d + b], real orthogonal irreps of dimension 1, 3, 3, 4, 5
+    double F[60 * 60];        // F[(r,i,j)][g] = sqrt(d/60) rho_r(g)[i][j]  (orthogonal 60 x 60)
+    int n0[13];               // N[0][k]
+};
+int build_fourier(const uint8_t* N, const uint8_t* P, FourierBasis& fb);
+}  // namespace yoho
+#include <vector>
+namespace yoho {
+void pack_fourier_weights(const FourierBasis& fb, const float* W, int cin, int cout, int cout_pad, std::vector<float>& out);
+int gft_init();
+int launch_gconvf(const Layer& L, const float* X, int nTiles, const float* res, float* out, int flags, hipStream_t s);
+int launch_gft(int mode, const float* in, float* out, const float* Fpad, const float* bn_s, const float* bn_t, int nTiles, int C8, hipStream_t s);
 // bf16x3 variant (gconv16.hip)
 int upload_slot_tables16(const int* slab4_h, const int* unitg_h);
 int gconv16_init();
@@ -96,7 +111,9 @@ struct yoho_ctx {
     yoho::Layer p1[4];           // conv_in, res_in, res_out, conv_out
     yoho::Layer p2[6];           // init, res_in, res_out, fc0, fc1, fc2
     float *p2_init_bn_s = nullptr, *p2_init_bn_t = nullptr;  // BN(128) applied by the PartII pack kernel
-    int gconv_mode = 1;          // 0: fp32 MFMA group conv, 1: bf16x3 split MFMA (PartI; default)
+    int gconv_mode = 2;          // 0: direct conv fp32 MFMA, 1: direct conv bf16x3 split MFMA, 2: group-Fourier conv fp32 MFMA (default)
+    yoho::FourierBasis* fb = nullptr;
+    float* dFpad = nullptr;      // F padded to 64 x 64 (device)
     // workspace (grown on demand)
     yoho::Workspace ws;
     // profiling

@@ -282,8 +282,9 @@ class Context:
         return nn_idx
 
     def set_gconv_mode(self, mode):
-        """'f32' (fp32 MFMA) or 'bf16x3' (fp32-accurate 3-way bf16 split MFMA) for the PartI group conv."""
-        _check(self._lib.yoho_set_gconv_mode(self._h, {"f32": 0, "bf16x3": 1}[mode]))
+        """'f32' (direct conv, fp32 MFMA), 'bf16x3' (direct conv, fp32-accurate 3-way bf16 split MFMA) or
+        'fourier' (group-Fourier domain conv, fp32 MFMA) for the PartI group conv."""
+        _check(self._lib.yoho_set_gconv_mode(self._h, {"f32": 0, "bf16x3": 1, "fourier": 2}[mode]))
 
     # ---- profiling hook (bench.py) ------------------------------------------------------------
     def set_profiling(self, on=True):
