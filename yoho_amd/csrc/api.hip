@@ -241,8 +241,12 @@ int yoho_ctx_create(int device, const float* R, const uint8_t* N, const uint8_t*
     c->fb = new FourierBasis();
     if ((rc = build_fourier(N, P, *c->fb))) { delete c->fb; delete c; return rc; }
     {
-        std::vector<float> fpad(64 * 64, 0.f);
-        for (int s = 0; s < G; ++s) for (int g = 0; g < G; ++g) fpad[s * 64 + g] = (float)c->fb->F[s * G + g];
+        std::vector<float> fpad(2 * 64 * 64, 0.f);             // F padded to 64x64, then its transpose
+        for (int s = 0; s < G; ++s)
+            for (int g = 0; g < G; ++g) {
+                fpad[s * 64 + g] = (float)c->fb->F[s * G + g];
+                fpad[64 * 64 + g * 64 + s] = (float)c->fb->F[s * G + g];
+            }
         if ((rc = upload(fpad.data(), fpad.size() * sizeof(float), (void**)&c->dFpad)) || (rc = gft_init())) { delete c->fb; delete c; return rc; }
     }
     *out = c;

@@ -396,8 +396,18 @@ __global__ __launch_bounds__(256, 1) void gconvf_kernel(ConvFArgs a, int flags) 
     const int nwg = gridDim.x, b = blockIdx.x;
     const int q8 = nwg >> 3, r8 = nwg & 7, xcd = b & 7, slot8 = b >> 3;
     const int v = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot8;
-    const int tile = v / a.nOB;
-    const int ob = v - tile * a.nOB;
+    // The 32 workgroups an XCD runs concurrently cover 4 tiles x 8 o-blocks: both the activation stream (shared by
+    // the o-blocks of a tile) and the weight stream (shared by the tiles of an o-block) are then reused in L2,
+    // instead of 2 tiles x 16 o-blocks where every weight block has only two readers.
+    const int obg = a.nOB < 8 ? a.nOB : 8;                 // o-blocks per group
+    const int ngrp = a.nOB / obg;
+    const int per_quad = 4 * a.nOB;                        // work items per 4 tiles
+    const int tq = v / per_quad, rq = v - tq * per_quad;
+    const int og = rq / (4 * obg), r2 = rq - og * (4 * obg);
+    const int tile = tq * 4 + r2 / obg;
+    const int ob = og * obg + (r2 % obg);
+    (void)ngrp;
+    if (tile >= a.nTiles) return;
     if (w == 0) gconvf_wave<0>(a, flags, smem, lane, tile, ob);
     else if (w == 1) gconvf_wave<1>(a, flags, smem, lane, tile, ob);
     else if (w == 2) gconvf_wave<2>(a, flags, smem, lane, tile, ob);
@@ -408,7 +418,7 @@ int launch_gconvf(const Layer& L, const float* X, int nTiles, const float* res, 
     ConvFArgs a;
     a.X = X; a.Wp = L.wpf; a.bias = L.bias; a.res = res; a.out = out;
     a.nTiles = nTiles; a.cin8 = L.cin / 8; a.cout8 = L.cout_pad / 8; a.nOB = L.cout_pad / 32;
-    hipLaunchKernelGGL(gconvf_kernel, dim3(nTiles * a.nOB), dim3(256), LDS_BYTES_F, s, a, flags);
+    hipLaunchKernelGGL(gconvf_kernel, dim3((nTiles + 3) / 4 * 4 * a.nOB), dim3(256), LDS_BYTES_F, s, a, flags);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -460,15 +470,17 @@ __global__ __launch_bounds__(256, 2) void gft_kernel(const float* __restrict__ i
     float4* l4 = reinterpret_cast<float4*>(ldsA);
     for (int i = tid; i < 4 * 256 / 4; i += 256) l4[CHUNK_FLOATS / 4 + i] = make_float4(0.f, 0.f, 0.f, 0.f);   // rows 60..63
 
-    // transform matrices as MFMA A fragments.  Fpad is F padded to 64x64 (row = coefficient, col = group element).
+    // transform matrices as MFMA A fragments.  Fpad holds F padded to 64x64 (row = coefficient, col = group
+    // element) followed by its transpose, so that both fragment loads are coalesced (lane index = fastest axis).
     float aF[2][32], aFt[2][32];
     const int ai = lane & 31, ak = lane >> 5;
+    const float* FpadT = Fpad + 64 * 64;
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
         for (int t = 0; t < 32; ++t) {
-            if (MODE != GFT_INV) aF[rb][t] = Fpad[(rb * 32 + ai) * 64 + 2 * t + ak];          // T = F
-            if (MODE != GFT_FWD) aFt[rb][t] = Fpad[(2 * t + ak) * 64 + rb * 32 + ai];         // T = F^T
+            if (MODE != GFT_INV) aF[rb][t] = FpadT[(2 * t + ak) * 64 + rb * 32 + ai];         // T = F:   F[row][k] = F^T[k][row]
+            if (MODE != GFT_FWD) aFt[rb][t] = Fpad[(2 * t + ak) * 64 + rb * 32 + ai];         // T = F^T: F^T[row][k] = F[k][row]
         }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
