@@ -26,7 +26,7 @@ sys.path.insert(0, REPO)
 
 from yoho_amd import weights as W          # noqa: E402  (generator + spec only; no HIP)
 from yoho_amd.tables import GroupTables    # noqa: E402
-from yoho_amd.synth import make_pair, unit_features  # noqa: E402
+from yoho_amd.synth import make_pair, unit_features, make_scene, write_scene_files  # noqa: E402
 
 
 def import_reference():
@@ -35,6 +35,7 @@ def import_reference():
     torch.Tensor.cuda = lambda self, *a, **k: self
     torch.nn.Module.cuda = lambda self, *a, **k: self
     sys.modules["tensorboardX"] = types.SimpleNamespace(SummaryWriter=object)
+    sys.modules["open3d"] = types.ModuleType("open3d")          # utils/dataset.py imports it; only .ply reading would use it
     sys.argv = ["x"]
     sys.path.insert(0, REF)
     import utils.network as network
@@ -43,6 +44,14 @@ def import_reference():
     import tests.estimator as estimator
     import utils.knn_search as knn_search
     import utils.r_eval as r_eval
+    # nibabel is not installed: utils/RR_cal.py only uses nibabel.quaternions.mat2quat, which is the same
+    # K-matrix + eigh algorithm as the reference's own utils/r_eval.quaternion_from_matrix - use that.
+    nq = types.ModuleType("nibabel.quaternions")
+    nq.mat2quat = lambda M: r_eval.quaternion_from_matrix(np.asarray(M, dtype=np.float64))
+    nib = types.ModuleType("nibabel")
+    nib.quaternions = nq
+    sys.modules["nibabel"] = nib
+    sys.modules["nibabel.quaternions"] = nq
     return network, extractor, matcher, estimator, knn_search, r_eval
 
 
@@ -190,6 +199,43 @@ def main():
         k1 = rs.rand(50, 3, 3) * 3
         Ts = np.stack([est_c.Threepps2Tran(k0[i], k1[i]) for i in range(50)])
         np.savez(os.path.join(GOLD, "kabsch.npz"), k0=k0, k1=k1, T=Ts)
+        # ---------------- 12. evaluator: FMR + Registration Recall on a 4-fragment scene -----------
+        import tests.evaluator as evaluator      # imports utils.RR_cal (nibabel stub) and utils.dataset (open3d stub)
+        import utils.dataset as rdataset
+        import utils.RR_cal as rr
+        sc = make_scene(4, 64, seed=21, tables=tb)
+        sroot = os.path.join(work, "origin", "synth4", "room")
+        sname = "synth4/room"
+        scache = os.path.join(work, "cache", "Testset", sname)
+        write_scene_files(sc, sroot, scache)
+        ds4 = rdataset.ThrDMatchPartDataset(sroot, 4)
+        ds4.name = sname
+        # the reference's get_kps needs the fragment .ply (open3d) or trips over an undefined attribute
+        # (utils/dataset.py:107); the synthetic scene only has Keypoints_PC/*.npy - the file the hot path reads.
+        ds4.get_kps = lambda cid: np.load(ds4.kps_pc_fn[int(cid)])
+        datasets = {"wholesetname": "synth4", "room": ds4}
+        outs = {}
+        for part, Ev, it, sign, seedv in (("PartI", evaluator.Evaluator_PartI, 100, "YOHO_C", 5), ("PartII", evaluator.Evaluator_PartII, 1000, "YOHO_O", 6)):
+            c = cfg(part)
+            c.extractor, c.matcher, c.estimator, c.descriptor = part, "Match", ("yohoc" if part == "PartI" else "yohoo"), "YOHO"
+            c.fmr_ratio, c.ok_match_dist_threshold, c.RR_dist_threshold, c.testset_name = 0.05, 0.1, 0.2, "synth4"
+            ev = Ev(c, it)
+            np.random.seed(seedv)
+            ev.run_onescene(ds4)
+            FMR, pair_fmrs = ev.Feature_match_Recall(ds4, ratio=c.fmr_ratio)
+            RR, c_flags, c_errors = rr.benchmark(c, datasets, it, yoho_sign=sign)
+            pre = open(os.path.join(scache, "Match", sign, f"{it}iters", "pre.log")).read()
+            res_txt = open(os.path.join(work, "cache", "Testset", "synth4", "Eval_results", f"{sign}_RR", f"{it}iters", "result.txt")).read()
+            outs[part] = dict(FMR=FMR, pair_fmrs=pair_fmrs, RR=RR, flags=np.array(c_flags[sname]), errors=np.array(c_errors[sname]),
+                              prelog=np.array(pre), result_txt=np.array(res_txt))
+            print(f"evaluator {part}: FMR={FMR:.3f} RR={RR:.3f} flags={c_flags[sname]}")
+        matches = {f"match_{a}_{b}": np.load(os.path.join(scache, "Match", f"{a}-{b}.npy")) for (a, b) in sc["pairs"]}
+        gtp = rdataset.ThrDMatchPartDataset.parse_gt_fn(os.path.join(sroot, "PointCloud", "gt.log"))
+        np.savez(os.path.join(GOLD, "scene4.npz"), seed=21, K=64, nfrag=4,
+                 gt_log=np.array(open(os.path.join(sroot, "PointCloud", "gt.log")).read()),
+                 gt_info=np.array(open(os.path.join(sroot, "PointCloud", "gt.info")).read()),
+                 parsed_keys=np.array(sorted(gtp.keys())), parsed_T=np.stack([gtp[k] for k in sorted(gtp.keys())]),
+                 **{f"{part}_{k}": v for part, o in outs.items() for k, v in o.items()}, **matches)
     finally:
         shutil.rmtree(work, ignore_errors=True)
     print("golden fixtures written to", GOLD, {f: os.path.getsize(os.path.join(GOLD, f)) for f in os.listdir(GOLD)})

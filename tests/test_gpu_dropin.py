@@ -172,3 +172,50 @@ def test_yoho_extractor_with_stub_backbone(sd1, tables):
     assert np.array_equal(kpts, pc[kidx]) and rel(eqv.numpy(), e) < 1e-4 and rel(inv.numpy(), i) < 1e-4
     with pytest.raises(NotImplementedError):
         yoho_extractor(yoho_ckpt=sd1).run(pc)
+
+
+@pytest.mark.parametrize("part,it,seedv", [("PartI", 100, 5), ("PartII", 1000, 6)])
+def test_evaluator_fmr_and_registration_recall(gold, tmp_path, sd1, sd2, part, it, seedv):
+    """Evaluator_PartI/II.eval on a 4-fragment synthetic scene reproduces the reference's FMR,
+    per-pair flags and Registration Recall (golden: tests/evaluator.py + utils/RR_cal.py run on the reference)."""
+    from yoho_amd import evaluator, store
+    from yoho_amd.dataset import ThrDMatchPartDataset
+    store.clear()
+    g = gold("scene4.npz")
+    sc = synth.make_scene(int(g["nfrag"]), int(g["K"]), seed=int(g["seed"]))
+    sroot = tmp_path / "origin" / "synth4" / "room"
+    cache = tmp_path / "cache"
+    synth.write_scene_files(sc, str(sroot), str(cache / "Testset" / "synth4/room"))
+    model_fn = tmp_path / "model"
+    for sub, sd in (("PartI_train", sd1), ("PartII_train", sd2)):
+        os.makedirs(model_fn / sub)
+        W.save_checkpoint(str(model_fn / sub / "model_best.pth"), sd, 0.5)
+    ds = ThrDMatchPartDataset(str(sroot), 4)
+    ds.name = "synth4/room"
+    datasets = {"wholesetname": "synth4", "room": ds}
+
+    def cfg(p):
+        return types.SimpleNamespace(
+            SO3_related_files=None, model_fn=str(model_fn), output_cache_fn=str(cache), origin_data_dir=str(tmp_path / "origin"),
+            test_network_type=f"{p}_test", train_network_type=f"{p}_train", test_batch_size=40 if p == "PartI" else 50,
+            ransac_c_inlinerdist=0.07, ransac_o_inlinerdist=0.09, extractor=p, matcher="Match",
+            estimator="yohoc" if p == "PartI" else "yohoo", descriptor="YOHO", fmr_ratio=0.05,
+            ok_match_dist_threshold=0.1, RR_dist_threshold=0.2, testset_name="synth4")
+    if part == "PartII":      # the PartII evaluator assumes the PartI descriptors are already cached (tests/evaluator.py:112-117)
+        from yoho_amd import extractor
+        extractor.extractor_PartI(cfg("PartI")).Extract(ds)
+    ev = evaluator.name2evaluator[part](cfg(part), it)
+    np.random.seed(seedv)
+    RR, FMRS, pair_fmrs = ev.eval(datasets, results_log=str(tmp_path / "results.log"))
+    for (a, b) in sc["pairs"]:
+        assert np.array_equal(np.load(cache / "Testset" / "synth4/room" / "Match" / f"{a}-{b}.npy"), g[f"match_{a}_{b}"])
+    assert np.array_equal(pair_fmrs, g[f"{part}_pair_fmrs"]) and FMRS[0] == float(g[f"{part}_FMR"])
+    assert RR == float(g[f"{part}_RR"])
+    sign = "YOHO_C" if part == "PartI" else "YOHO_O"
+    from yoho_amd import RR_cal
+    _, mine = RR_cal.read_pre_trajectory(str(cache / "Testset" / "synth4/room" / "Match" / sign / f"{it}iters" / "pre.log"))
+    ref_log = tmp_path / "ref_pre.log"
+    ref_log.write_text(str(g[f"{part}_prelog"]))
+    _, ref = RR_cal.read_pre_trajectory(str(ref_log))
+    assert rel(mine, ref) < 1e-4
+    assert "Mean_Registration_Recall" in (tmp_path / "results.log").read_text()

@@ -1,0 +1,85 @@
+"""CPU tests for the SURVEY section 8(f) "next" rows #1/#2: the Registration-Recall benchmark (utils/RR_cal.py) and
+the evaluation-dataset description (utils/dataset.py), against outputs of the reference itself
+(tests/golden/scene4.npz, produced by oracle/gen_golden.py)."""
+import os
+import types
+import numpy as np
+import pytest
+
+from yoho_amd import RR_cal, synth
+from yoho_amd.dataset import ThrDMatchPartDataset, get_dataset_name, read_ply_xyz
+
+
+def _lay_out(tmp_path, g):
+    root = tmp_path / "origin" / "synth4" / "room"
+    os.makedirs(root / "PointCloud")
+    (root / "PointCloud" / "gt.log").write_text(str(g["gt_log"]))
+    (root / "PointCloud" / "gt.info").write_text(str(g["gt_info"]))
+    return root
+
+
+def test_scene_generator_reproduces_golden_inputs(gold, tmp_path):
+    g = gold("scene4.npz")
+    sc = synth.make_scene(int(g["nfrag"]), int(g["K"]), seed=int(g["seed"]))
+    synth.write_scene_files(sc, str(tmp_path / "s"))
+    assert (tmp_path / "s" / "PointCloud" / "gt.log").read_text() == str(g["gt_log"])
+    assert (tmp_path / "s" / "PointCloud" / "gt.info").read_text() == str(g["gt_info"])
+
+
+def test_parse_gt_and_dataset(gold, tmp_path):
+    g = gold("scene4.npz")
+    root = _lay_out(tmp_path, g)
+    parsed = ThrDMatchPartDataset.parse_gt_fn(str(root / "PointCloud" / "gt.log"))
+    assert sorted(parsed.keys()) == list(g["parsed_keys"])
+    for k, T in zip(g["parsed_keys"], g["parsed_T"]):
+        assert parsed[k].dtype == np.float32 and np.array_equal(parsed[k], T)
+    ds = ThrDMatchPartDataset(str(root), 4)
+    assert ds.pc_ids == ["0", "1", "2", "3"] and ds.pair_ids[0] == ("0", "1") and ds.get_pair_nums() == 6
+    assert np.array_equal(ds.get_transform("1", "3"), parsed["1-3"])
+    os.makedirs(root / "Keypoints_PC")
+    k = np.random.RandomState(0).rand(7, 3)
+    np.save(root / "Keypoints_PC" / "cloud_bin_2Keypoints.npy", k)
+    assert np.array_equal(ds.get_kps("2"), k)
+    d = get_dataset_name("3dLomatch", "/data") if False else None     # constructing real sets needs their gt files
+    with pytest.raises(NotImplementedError):
+        get_dataset_name("nope", "/x")
+
+
+def test_ply_reader(tmp_path):
+    pts = np.random.RandomState(1).rand(11, 3).astype(np.float32)
+    hdr = "ply\nformat binary_little_endian 1.0\nelement vertex 11\nproperty float x\nproperty float y\nproperty float z\nproperty uchar red\nend_header\n"
+    rec = np.zeros(11, dtype=[("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("red", "u1")])
+    rec["x"], rec["y"], rec["z"] = pts[:, 0], pts[:, 1], pts[:, 2]
+    (tmp_path / "a.ply").write_bytes(hdr.encode() + rec.tobytes())
+    assert np.array_equal(read_ply_xyz(str(tmp_path / "a.ply")), pts.astype(np.float64))
+    asc = "ply\nformat ascii 1.0\nelement vertex 2\nproperty float x\nproperty float y\nproperty float z\nend_header\n1 2 3\n4 5 6\n"
+    (tmp_path / "b.ply").write_text(asc)
+    assert np.array_equal(read_ply_xyz(str(tmp_path / "b.ply")), [[1, 2, 3], [4, 5, 6]])
+
+
+@pytest.mark.parametrize("part,sign,it", [("PartI", "YOHO_C", 100), ("PartII", "YOHO_O", 1000)])
+def test_benchmark_matches_reference(gold, tmp_path, part, sign, it):
+    g = gold("scene4.npz")
+    root = _lay_out(tmp_path, g)
+    cache = tmp_path / "cache"
+    pre_dir = cache / "Testset" / "synth4/room" / "Match" / sign / f"{it}iters"
+    os.makedirs(pre_dir)
+    (pre_dir / "pre.log").write_text(str(g[f"{part}_prelog"]))
+    ds = types.SimpleNamespace(name="synth4/room", gt_dir=str(root / "PointCloud" / "gt.log"))
+    cfg = types.SimpleNamespace(output_cache_fn=str(cache), RR_dist_threshold=0.2)
+    RR, flags, errors = RR_cal.benchmark(cfg, {"wholesetname": "synth4", "room": ds}, it, yoho_sign=sign)
+    assert RR == float(g[f"{part}_RR"])
+    assert flags["synth4/room"] == list(g[f"{part}_flags"])
+    assert np.allclose(errors["synth4/room"], g[f"{part}_errors"], rtol=1e-9, atol=1e-12)
+    txt = (cache / "Testset" / "synth4" / "Eval_results" / f"{sign}_RR" / f"{it}iters" / "result.txt").read_text()
+    assert txt == str(g[f"{part}_result_txt"])
+
+
+def test_rr_helpers():
+    assert np.allclose(RR_cal.mat2quat(np.eye(3)), [1, 0, 0, 0])
+    R = np.array([[0., -1, 0], [1, 0, 0], [0, 0, 1]])
+    assert np.allclose(RR_cal.mat2quat(R), [np.sqrt(.5), 0, 0, np.sqrt(.5)])
+    assert np.allclose(RR_cal.rotation_error(np.eye(3)[None], R[None]), 90.0)
+    assert np.allclose(RR_cal.translation_error(np.zeros((1, 3, 1)), np.ones((1, 3, 1))), np.sqrt(3))
+    T = np.eye(4); T[:3, :3] = R; T[:3, 3] = [1, 2, 3]
+    assert np.isclose(RR_cal.computeTransformationErr(T, np.eye(6)), 14 + 0.5)

@@ -116,3 +116,84 @@ def estimator_case(M=1500, H=1000, seed=0, inlier_frac=0.3, tables=None):
     for r in range(3):
         T[:, r, 3] = k0[:, r] - ((k1[:, 0] * T[:, r, 0] + k1[:, 1] * T[:, r, 1]) + k1[:, 2] * T[:, r, 2])
     return dict(k0=k0, k1=k1, T=T, dr=gidx, gi=gi, gt=np.concatenate([R, t[:, None]], 1), inl=inl)
+
+
+def make_scene(nfrag=4, K=64, seed=0, tables=None, noise=0.02, outlier_frac=0.3, key_noise=0.01):
+    """A synthetic multi-fragment scene for the evaluator / Registration-Recall rows.
+
+    Every fragment f is a copy of one base fragment moved by its own rigid motion T_f = [Rres_f R_{g_f} | t_f] with
+    the group axis of its features permuted by P[g_f] (+ noise, outliers, row shuffle).  Returns
+    dict(feats [nfrag](K,32,60) f32, keys [nfrag](K,3) f64, poses [nfrag](3,4), pairs [(i,j) i<j],
+         gt {(i,j): (4,4) with keys_i = R keys_j + t}).
+    """
+    tb = tables or default_tables()
+    base_f = unit_features(K, seed, "scene_base")
+    base_k = hash_uniform(seed, "scene_keys", K * 3).astype(np.float64).reshape(K, 3) * 3.0
+    feats, keys, poses, perms = [], [], [], []
+    for f in range(nfrag):
+        u = hash_uniform(seed, f"scene_meta{f}", 16).astype(np.float64)
+        gi = int(u[0] * G) % G
+        ax = u[1:4] - 0.5
+        ax = ax / np.sqrt((ax[0] * ax[0] + ax[1] * ax[1]) + ax[2] * ax[2])
+        half = 0.5 * np.deg2rad(15.0) * u[4]
+        s = half - half ** 3 / 6.0
+        c = np.sqrt(1.0 - s * s)
+        Rres = quat_to_mat64(np.array([c, ax[0] * s, ax[1] * s, ax[2] * s]))
+        Rg = tb.R64[gi]
+        R = np.empty((3, 3))
+        for i in range(3):
+            for j in range(3):
+                R[i, j] = (Rres[i, 0] * Rg[0, j] + Rres[i, 1] * Rg[1, j]) + Rres[i, 2] * Rg[2, j]
+        t = (u[5:8] - 0.5) * 2.0
+        perm = np.argsort(hash_uniform(seed, f"scene_perm{f}", K), kind="stable")
+        ff = base_f[perm][:, :, tb.P[gi]] + np.float32(noise) * _gauss(seed, f"scene_fn{f}", K * F * G).reshape(K, F, G)
+        is_out = hash_uniform(seed, f"scene_out{f}", K) < outlier_frac
+        fresh = unit_features(K, seed, f"scene_fresh{f}")
+        ff[is_out] = fresh[is_out]
+        kk = _apply_rt(base_k[perm], R, t) + key_noise * _gauss(seed, f"scene_kn{f}", K * 3, np.float64).reshape(K, 3)
+        fk = hash_uniform(seed, f"scene_ok{f}", K * 3).astype(np.float64).reshape(K, 3) * 3.0
+        kk[is_out] = fk[is_out]
+        feats.append(np.ascontiguousarray(_unit_norm_rows(ff)))
+        keys.append(np.ascontiguousarray(kk))
+        poses.append(np.concatenate([R, t[:, None]], 1))
+        perms.append(perm)
+    pairs = [(i, j) for i in range(nfrag) for j in range(i + 1, nfrag)]
+    gt = {}
+    for (i, j) in pairs:                       # keys_i = Ri Rj^T (keys_j - tj) + ti
+        Ri, ti, Rj, tj = poses[i][:, :3], poses[i][:, 3], poses[j][:, :3], poses[j][:, 3]
+        Rij = np.empty((3, 3))
+        for a in range(3):
+            for b in range(3):
+                Rij[a, b] = (Ri[a, 0] * Rj[b, 0] + Ri[a, 1] * Rj[b, 1]) + Ri[a, 2] * Rj[b, 2]
+        tij = np.array([ti[a] - ((Rij[a, 0] * tj[0] + Rij[a, 1] * tj[1]) + Rij[a, 2] * tj[2]) for a in range(3)])
+        T = np.eye(4)
+        T[:3, :3] = Rij
+        T[:3, 3] = tij
+        gt[(i, j)] = T
+    return dict(feats=feats, keys=keys, poses=poses, pairs=pairs, gt=gt)
+
+
+def write_scene_files(scene, root, cache_scene_dir=None):
+    """Lay a make_scene() result out as the reference expects: {root}/PointCloud/gt.log + gt.info (Redwood format),
+    {root}/Keypoints_PC/cloud_bin_{k}Keypoints.npy and, optionally, the FCGF_Input_Group_feature cache."""
+    import os
+    n = len(scene["feats"])
+    os.makedirs(f"{root}/PointCloud", exist_ok=True)
+    os.makedirs(f"{root}/Keypoints_PC", exist_ok=True)
+    with open(f"{root}/PointCloud/gt.log", "w") as f:
+        for (i, j) in scene["pairs"]:
+            T = scene["gt"][(i, j)]
+            f.write(f"{i}\t{j}\t{n}\n")
+            for r in range(4):
+                f.write("\t".join(repr(float(v)) for v in T[r]) + "\n")
+    with open(f"{root}/PointCloud/gt.info", "w") as f:
+        for (i, j) in scene["pairs"]:
+            f.write(f"{i}\t{j}\t{n}\n")
+            for r in range(6):
+                f.write("\t".join(repr(float(1.0 + 0.25 * r if r == c else 0.0)) for c in range(6)) + "\n")
+    for k in range(n):
+        np.save(f"{root}/Keypoints_PC/cloud_bin_{k}Keypoints.npy", scene["keys"][k])
+    if cache_scene_dir is not None:
+        os.makedirs(f"{cache_scene_dir}/FCGF_Input_Group_feature", exist_ok=True)
+        for k in range(n):
+            np.save(f"{cache_scene_dir}/FCGF_Input_Group_feature/{k}.npy", scene["feats"][k])
