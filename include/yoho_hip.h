@@ -138,6 +138,9 @@ int yoho_group_gather(yoho_ctx* ctx, const double* keys, int K, const float* pts
  * (244 instead of 780 slab products per chunk) on fp32 MFMA.  All meet the 1e-4 parity tolerance. */
 int yoho_set_gconv_mode(yoho_ctx* ctx, int mode);
 
+/* PartII cone layers (128->256 @45 group elements, 256->512 @13): 0 = fp32 MFMA, 1 = bf16x3 split MFMA (default). */
+int yoho_set_partII_mode(yoho_ctx* ctx, int mode);
+
 /* timing hook for bench.py: average device time (ms) of the last yoho_partI_forward's dominant
  * group-conv launches, measured with hipEvents on the call's own stream.  <0 if unavailable. */
 int yoho_set_profiling(yoho_ctx* ctx, int enable);

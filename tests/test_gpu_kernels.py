@@ -30,6 +30,7 @@ def ctx(hip, sd1, sd2):
     c.load_partI(sd1)
     c.load_partII(sd2)
     c.set_gconv_mode("f32")
+    c.set_partII_mode("f32")
     return c
 
 
@@ -74,6 +75,7 @@ def ctx16(hip, sd1, sd2):
     c.load_partI(sd1)
     c.load_partII(sd2)
     c.set_gconv_mode("bf16x3")
+    c.set_partII_mode("bf16x3")
     return c
 
 
@@ -184,7 +186,9 @@ def test_des2r_golden(ctx, ctx16, mode, gold, sd1, tables):
         assert (ctx.des2r(ea, eb).cpu().numpy() == i).all()
 
 
-def test_partII_hyp_golden(ctx, gold, sd1, sd2, tables):
+@pytest.mark.parametrize("mode", ["f32", "bf16x3"])
+def test_partII_hyp_golden(ctx, ctx16, mode, gold, sd1, sd2, tables):
+    ctx = ctx if mode == "f32" else ctx16
     g = gold("chain.npz")
     pr = synth.make_pair(int(g["K"]), seed=int(g["pair_seed"]))
     m, dr = g["match"], g["dr_index"]
@@ -196,6 +200,7 @@ def test_partII_hyp_golden(ctx, gold, sd1, sd2, tables):
     q = ctx.partII_forward(*args, cu(dr))
     assert all(torch.equal(a, k) for a, k in zip(args, keep)), "inputs must not be modified"
     qo = orc.partII_forward(b["before_eqv0"], b["before_eqv1"], b["after_eqv0"], b["after_eqv1"], dr, sd2, tables.N, tables.P)
+    print("partII %s: rel err vs oracle %.3g (M=%d)" % (mode, rel(q.cpu().numpy(), qo), len(dr)))
     assert rel(q.cpu().numpy(), qo) < TOL
     assert rel(q.cpu().numpy()[:16], g["quat16"]) < TOL
     k0, k1 = pr["keys0"][m[:, 0]], pr["keys1"][m[:, 1]]

@@ -222,20 +222,27 @@ int yoho_ctx_create(int device, const float* R, const uint8_t* N, const uint8_t*
     if ((rc = upload_slot_tables(slab.data(), outg.data())) || (rc = gconv_init())) { delete c; return rc; }
     // bf16x3 variant: unit u = output group elements (2u, 2u+1); tap pair tp = taps (2tp, 2tp+1), tap 13 = zero weights
     {
-        std::vector<int> slab4(7 * 32, 0), unitg(32 * 2, -1);
-        for (int u = 0; u < 30; ++u) { unitg[2 * u] = 2 * u; unitg[2 * u + 1] = 2 * u + 1; }
-        for (int tp = 0; tp < 7; ++tp)
-            for (int u = 0; u < 32; ++u)
-                for (int gs = 0; gs < 2; ++gs)
-                    for (int h = 0; h < 2; ++h) {
-                        const int g = unitg[2 * u + gs];
-                        int tap = 2 * tp + h;
-                        if (tap >= NTAP) tap = 2 * tp;                 // weights are zero there; any finite slab will do
-                        slab4[tp * 32 + u] |= (g < 0 ? 0 : (int)N[g * NTAP + tap]) << (8 * (2 * gs + h));
-                    }
+        std::vector<int> slab4(3 * 7 * 32, 0), unitg(3 * 32 * 2, -1);
+        const std::vector<int>* lists[3] = {&all, &two, &one};       // cfg 0: 60 outputs, 1: 45-cone, 2: 13-cone
+        for (int cfg = 0; cfg < 3; ++cfg) {
+            const std::vector<int>& gl = *lists[cfg];
+            int* ug = &unitg[cfg * 64];
+            for (size_t k = 0; k < gl.size(); ++k) ug[k] = gl[k];      // unit u = (gl[2u], gl[2u+1]); a trailing -1 = unused half
+            for (int tp = 0; tp < 7; ++tp)
+                for (int u = 0; u < 32; ++u)
+                    for (int gs = 0; gs < 2; ++gs)
+                        for (int h = 0; h < 2; ++h) {
+                            int g = ug[2 * u + gs];
+                            if (g < 0) g = ug[2 * u];                   // unused half: read the partner's (valid, finite) slabs
+                            int tap = 2 * tp + h;
+                            if (tap >= NTAP) tap = 2 * tp;              // weights are zero there; any finite slab will do
+                            slab4[(cfg * 7 + tp) * 32 + u] |= (g < 0 ? 0 : (int)N[g * NTAP + tap]) << (8 * (2 * gs + h));
+                        }
+        }
         if ((rc = upload_slot_tables16(slab4.data(), unitg.data())) || (rc = gconv16_init())) { delete c; return rc; }
     }
     c->gconv_mode = 2;      // default: group-Fourier conv on fp32 MFMA; YOHO_GCONV=f32 | bf16x3 select the direct-conv kernels
+    if (const char* m = std::getenv("YOHO_PARTII")) c->partII_mode = std::strcmp(m, "f32") == 0 ? 0 : 1;
     if (const char* m = std::getenv("YOHO_GCONV")) c->gconv_mode = std::strcmp(m, "f32") == 0 ? 0 : (std::strcmp(m, "bf16x3") == 0 ? 1 : 2);
     // group-Fourier basis (irreps of the table's group)
     c->fb = new FourierBasis();
@@ -312,6 +319,12 @@ int yoho_load_partII(yoho_ctx* c, const yoho_partII_weights* w) {
 int yoho_set_gconv_mode(yoho_ctx* c, int mode) {
     if (!c || mode < 0 || mode > 2) { set_error("yoho_set_gconv_mode: mode must be 0 (fp32 MFMA), 1 (bf16x3 MFMA) or 2 (group-Fourier fp32 MFMA)"); return YOHO_EINVAL; }
     c->gconv_mode = mode;
+    return 0;
+}
+
+int yoho_set_partII_mode(yoho_ctx* c, int mode) {
+    if (!c || (mode != 0 && mode != 1)) { set_error("yoho_set_partII_mode: mode must be 0 (fp32 MFMA) or 1 (bf16x3 MFMA for the cone layers)"); return YOHO_EINVAL; }
+    c->partII_mode = mode;
     return 0;
 }
 
@@ -470,8 +483,37 @@ int yoho_group_mean_np(yoho_ctx* c, const float* eqv, int B, float* out, void* s
     return launch_group_mean_np(eqv, B, out, (hipStream_t)stream);
 }
 
+// PartII with the two large cone layers (128->256 @45 g, 256->512 @13 g) on the bf16x3 split MFMA; the g = 0 tail
+// (512->256 conv + the 1x1 MLP) stays on the fp32 kernels, fed through fp32 32-tile hand-over buffers.
+static int partII_pass16(yoho_ctx* c, const float* s0, const float* s1, const float* s2, const float* s3, const int64_t* idx,
+                         int M, float* quat, hipStream_t s) {
+    const int nT16 = (M + 15) / 16, nT = (M + TILE - 1) / TILE;
+    const size_t ch = (size_t)CHUNK_FLOATS * sizeof(float), ch16 = 46080;
+    const size_t n128 = (size_t)nT * 16, n256 = (size_t)nT * 32, n512 = (size_t)nT * 64, n32 = (size_t)nT * 4;
+    const size_t szX = (size_t)nT16 * 16 * ch16, szA0 = (size_t)nT16 * 32 * ch16;
+    int rc;
+    if ((rc = ensure_ws(c, szX + szA0 + (n256 + n512 + n256 + n512 + n128 + n32) * ch, s))) return rc;
+    char* bX = (char*)c->ws.p;                          // 128 ch planes
+    char* bA0 = bX + szX;                               // 256 ch planes (45 slabs valid)
+    float* bH0 = (float*)(bA0 + szA0);                  // 256 raw fp32, 32-tile layout
+    float* bA1 = bH0 + n256 * CHUNK_FLOATS;             // 512 act fp32 (13 slabs valid)
+    float* bF = bA1 + n512 * CHUNK_FLOATS;              // 256 raw (g = 0)
+    float* bF0 = bF + n256 * CHUNK_FLOATS;              // 512 act
+    float* bF1 = bF0 + n512 * CHUNK_FLOATS;             // 128 act
+    float* bQ = bF1 + n128 * CHUNK_FLOATS;              // 32 raw (4 used)
+    if ((rc = launch_pack16_partII(s0, s1, s2, s3, idx, c->dP, c->p2_init_bn_s, c->p2_init_bn_t, M, nT16, bX, s))) return rc;
+    if ((rc = launch_gconv16(c->p2[0], bX, nT16, nullptr, nullptr, bA0, EPI_RAW32 | EPI_ACT, s, 1, bH0, nullptr))) return rc;
+    if ((rc = launch_gconv16(c->p2[1], bA0, nT16, nullptr, nullptr, nullptr, EPI_ACT32, s, 2, nullptr, bA1))) return rc;
+    if ((rc = launch_gconv(conv_args(c->p2[2], bA1, nT, bH0, bF, nullptr, true), -1, EPI_RES | EPI_RAW, s))) return rc;
+    if ((rc = launch_gconv(conv_args(c->p2[3], bF, nT, nullptr, nullptr, bF0, true), -1, EPI_ACT, s))) return rc;
+    if ((rc = launch_gconv(conv_args(c->p2[4], bF0, nT, nullptr, nullptr, bF1, true), -1, EPI_ACT, s))) return rc;
+    if ((rc = launch_gconv(conv_args(c->p2[5], bF1, nT, nullptr, bQ, nullptr, false), 1, EPI_RAW, s))) return rc;
+    return launch_quat_norm(bQ, M, quat, s);
+}
+
 static int partII_pass(yoho_ctx* c, const float* s0, const float* s1, const float* s2, const float* s3, const int64_t* idx,
                        int M, float* quat, hipStream_t s) {
+    if (c->partII_mode == 1) return partII_pass16(c, s0, s1, s2, s3, idx, M, quat, s);
     const int nT = (M + TILE - 1) / TILE;
     const size_t ch = (size_t)CHUNK_FLOATS * sizeof(float);
     const size_t n128 = (size_t)nT * 16, n256 = (size_t)nT * 32, n512 = (size_t)nT * 64, n32 = (size_t)nT * 4;

@@ -37,7 +37,7 @@ struct Layer {
 };
 
 // epilogue flags
-enum { EPI_RES = 1, EPI_RAW = 2, EPI_ACT = 4 };
+enum { EPI_RES = 1, EPI_RAW = 2, EPI_ACT = 4, EPI_RAW32 = 8, EPI_ACT32 = 16 };
 
 struct ConvArgs {
     const float* X;        // activated input, internal layout [tile][cin/8][60 slabs][256]
@@ -76,7 +76,10 @@ int launch_gft(int mode, const float* in, float* out, const float* Fpad, const f
 // bf16x3 variant (gconv16.hip)
 int upload_slot_tables16(const int* slab4_h, const int* unitg_h);
 int gconv16_init();
-int launch_gconv16(const Layer& L, const char* X, int nTiles, const float* res, float* out_raw, char* out_act, int flags, hipStream_t s);
+int launch_gconv16(const Layer& L, const char* X, int nTiles, const float* res, float* out_raw, char* out_act, int flags, hipStream_t s,
+                   int cfg = 0, float* out_raw32 = nullptr, float* out_act32 = nullptr);
+int launch_pack16_partII(const float* s0, const float* s1, const float* s2, const float* s3, const int64_t* pre_idx, const int* P,
+                         const float* bn_s, const float* bn_t, int M, int nTiles16, char* out, hipStream_t s);
 int launch_pack16_partI(const float* x, int B, int nTiles, char* out, hipStream_t s);
 int launch_group_mean_np(const float* eqv, int B, float* out, hipStream_t s);
 int launch_pack_partII(const float* s0, const float* s1, const float* s2, const float* s3, const int64_t* pre_idx,
@@ -111,6 +114,7 @@ struct yoho_ctx {
     yoho::Layer p1[4];           // conv_in, res_in, res_out, conv_out
     yoho::Layer p2[6];           // init, res_in, res_out, fc0, fc1, fc2
     float *p2_init_bn_s = nullptr, *p2_init_bn_t = nullptr;  // BN(128) applied by the PartII pack kernel
+    int partII_mode = 1;         // 0: fp32 MFMA cone kernels, 1: bf16x3 split MFMA for the two large cone layers (default)
     int gconv_mode = 2;          // 0: direct conv fp32 MFMA, 1: direct conv bf16x3 split MFMA, 2: group-Fourier conv fp32 MFMA (default)
     yoho::FourierBasis* fb = nullptr;
     float* dFpad = nullptr;      // F padded to 64 x 64 (device)

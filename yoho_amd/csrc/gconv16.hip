@@ -43,12 +43,15 @@ constexpr int NUNIT = 32;                             // unit slots per configur
 // c_slab4[cfg][tp][unit] = the four slab indices N[ga][t0], N[ga][t1], N[gb][t0], N[gb][t1] packed one per byte
 //                           (a lane picks byte 2*gsel + h with one v_bfe_u32; no divergent control flow)
 // c_unitg[cfg][unit][2]  = output group elements (ga, gb) of the unit, -1 = unused
-__constant__ int c_slab4[1][NTP * NUNIT];
-__constant__ int c_unitg[1][NUNIT * 2];
+// cfg: 0 = all 60 group elements (30 units), 1 = the 45-element 2-hop cone of element 0 (23 units),
+//      2 = its 13-element 1-hop cone (7 units)   [PartII only needs group element 0 of its last feature map]
+constexpr int NCFG16 = 3;
+__constant__ int c_slab4[NCFG16][NTP * NUNIT];
+__constant__ int c_unitg[NCFG16][NUNIT * 2];
 
 int upload_slot_tables16(const int* slab4_h, const int* unitg_h) {
-    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_slab4), slab4_h, sizeof(int) * NTP * NUNIT));
-    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_unitg), unitg_h, sizeof(int) * NUNIT * 2));
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_slab4), slab4_h, sizeof(int) * NCFG16 * NTP * NUNIT));
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_unitg), unitg_h, sizeof(int) * NCFG16 * NUNIT * 2));
     return 0;
 }
 
@@ -115,7 +118,9 @@ struct Conv16Args {
     const float* res;      // raw fp32 residual [tile][cout8][60][16 kp][8 ch]
     float* out_raw;        // same layout (EPI_RAW)
     char* out_act;         // plane layout of the next layer (EPI_ACT)
-    int nTiles, cin8, cout8, nOBgrid;
+    float* out_raw32;      // fp32, 32-keypoint tile layout of gconv.hip (EPI_RAW32): hand-over to the fp32 kernels
+    float* out_act32;      // same layout, relu(v*s + t) (EPI_ACT32)
+    int nTiles, cin8, cout8, nOBgrid, cfg;
 };
 
 template <int UPW, int NOB>
@@ -130,8 +135,11 @@ __global__ __launch_bounds__(256, 1) void gconv16_kernel(Conv16Args a, int flags
     const int v = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot8;
     const int tile = v / a.nOBgrid;
     const int obk = v - tile * a.nOBgrid;
-    const int ob = NOB == 2 ? obk * 2 + (w >> 1) : obk;
-    const int ubase = NOB == 2 ? (w & 1) * UPW : w * UPW;         // first unit slot of this wave
+    // NOB = 2: waves {0,1}/{2,3} own two o-blocks and split the unit slots in halves; NOB = 1: one o-block, the four
+    // waves split the unit slots; NOB = 4: every wave owns an o-block of its own and all unit slots
+    const int ob = NOB == 2 ? obk * 2 + (w >> 1) : (NOB == 4 ? obk * 4 + w : obk);
+    const int ubase = NOB == 2 ? (w & 1) * UPW : (NOB == 4 ? 0 : w * UPW);         // first unit slot of this wave
+    const int cfg = a.cfg;
 
     floatx16 acc[UPW];
 #pragma unroll
@@ -152,7 +160,7 @@ __global__ __launch_bounds__(256, 1) void gconv16_kernel(Conv16Args a, int flags
     int* tab = reinterpret_cast<int*>(smem + LDS16_BYTES) + w * (8 * UPW * 4);
     for (int i = lane; i < 8 * UPW * 4; i += 64) {
         const int cls = i & 3, j = (i >> 2) % UPW, tp = (i >> 2) / UPW;
-        const unsigned packed = (unsigned)c_slab4[0][(tp == NTP ? 0 : tp) * NUNIT + ubase + j];
+        const unsigned packed = (unsigned)c_slab4[cfg][(tp == NTP ? 0 : tp) * NUNIT + ubase + j];
         tab[i] = (int)(((packed >> (8 * cls)) & 0xFFu) << 8);
     }
     // lane class: 2 * (column belongs to the unit's second group element) + (second tap of the pair)
@@ -231,7 +239,7 @@ __global__ __launch_bounds__(256, 1) void gconv16_kernel(Conv16Args a, int flags
 
     // ---- epilogue.  D[i = o][j = col]: lane (col = lane&31, half = lane>>5), reg r -> o = (r&3) + 8*(r>>2) + 4*half
     const int kp = lane & 15, half = lane >> 5, gsel = (lane >> 4) & 1;
-    const int* ug = &c_unitg[0][ubase * 2];
+    const int* ug = &c_unitg[cfg][ubase * 2];
 #pragma unroll
     for (int j = 0; j < UPW; ++j) {
         const int g = gsel ? ug[2 * j + 1] : ug[2 * j];
@@ -247,10 +255,19 @@ __global__ __launch_bounds__(256, 1) void gconv16_kernel(Conv16Args a, int flags
             const size_t roff = slab * (T16 * 8) + kp * 8 + half * 4;                    // fp32 raw layout
             if (flags & EPI_RES) val += *reinterpret_cast<const floatx4*>(a.res + roff);
             if (flags & EPI_RAW) *reinterpret_cast<floatx4*>(a.out_raw + roff) = val;
-            if (flags & EPI_ACT) {
+            // 32-keypoint tile layout [tile32][c8][g][h][kp32][4]: tile32 = tile/2, kp32 = 16*(tile&1) + kp
+            const size_t off32 = (((((size_t)(tile >> 1) * a.cout8 + ob * 4 + q) * G + g) * 2 + half) * TILE + (tile & 1) * 16 + kp) * 4;
+            if (flags & EPI_RAW32) *reinterpret_cast<floatx4*>(a.out_raw32 + off32) = val;
+            if (flags & (EPI_ACT | EPI_ACT32)) {
                 const floatx4 s = *reinterpret_cast<const floatx4*>(a.bn_s + ch);
                 const floatx4 t = *reinterpret_cast<const floatx4*>(a.bn_t + ch);
                 floatx4 y = val * s + t;
+                if (flags & EPI_ACT32) {
+                    floatx4 r;
+                    r.x = fmaxf(y.x, 0.f); r.y = fmaxf(y.y, 0.f); r.z = fmaxf(y.z, 0.f); r.w = fmaxf(y.w, 0.f);
+                    *reinterpret_cast<floatx4*>(a.out_act32 + off32) = r;
+                }
+                if (!(flags & EPI_ACT)) continue;
                 unsigned h[4], m[4], l[4];
                 split3(fmaxf(y.x, 0.f), h[0], m[0], l[0]);
                 split3(fmaxf(y.y, 0.f), h[1], m[1], l[1]);
@@ -281,15 +298,29 @@ static int launch16_t(const Conv16Args& a, int flags, hipStream_t s) {
 int gconv16_init() {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gconv16_kernel<15, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS16_TOTAL));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gconv16_kernel<8, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS16_TOTAL));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gconv16_kernel<12, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS16_TOTAL));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gconv16_kernel<7, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS16_TOTAL));
     return 0;
 }
 
-// layer launch: L.wp16 packed weights; cout_pad multiple of 64 -> NOB = 2, else the single-block variant
-int launch_gconv16(const Layer& L, const char* X, int nTiles, const float* res, float* out_raw, char* out_act, int flags, hipStream_t s) {
+// layer launch: L.wp16 packed weights.  cfg 0 (all 60 outputs): cout_pad multiple of 64 -> NOB = 2, else the
+// single-block variant; cfg 1 (45 outputs, 23 units): <12,2>; cfg 2 (13 outputs, 7 units): <7,4>.
+int launch_gconv16(const Layer& L, const char* X, int nTiles, const float* res, float* out_raw, char* out_act, int flags, hipStream_t s,
+                   int cfg, float* out_raw32, float* out_act32) {
     Conv16Args a;
     a.X = X; a.Wp = reinterpret_cast<const char*>(L.wp16); a.bias = L.bias; a.bn_s = L.bn_s; a.bn_t = L.bn_t;
-    a.res = res; a.out_raw = out_raw; a.out_act = out_act;
-    a.nTiles = nTiles; a.cin8 = L.cin / 8; a.cout8 = L.cout_pad / 8;
+    a.res = res; a.out_raw = out_raw; a.out_act = out_act; a.out_raw32 = out_raw32; a.out_act32 = out_act32;
+    a.nTiles = nTiles; a.cin8 = L.cin / 8; a.cout8 = L.cout_pad / 8; a.cfg = cfg;
+    if (cfg == 1) {
+        if (L.cout_pad % 64) { set_error("gconv16: cone-45 variant needs cout %% 64 == 0"); return YOHO_EINVAL; }
+        a.nOBgrid = L.cout_pad / 64;
+        return launch16_t<12, 2>(a, flags, s);
+    }
+    if (cfg == 2) {
+        if (L.cout_pad % 128) { set_error("gconv16: cone-13 variant needs cout %% 128 == 0"); return YOHO_EINVAL; }
+        a.nOBgrid = L.cout_pad / 128;
+        return launch16_t<7, 4>(a, flags, s);
+    }
     if (L.cout_pad % 64 == 0) { a.nOBgrid = L.cout_pad / 64; return launch16_t<15, 2>(a, flags, s); }
     a.nOBgrid = L.cout_pad / 32;
     return launch16_t<8, 1>(a, flags, s);
@@ -323,6 +354,57 @@ __global__ __launch_bounds__(256) void pack16_partI_kernel(const float* __restri
 
 int launch_pack16_partI(const float* x, int B, int nTiles, char* out, hipStream_t s) {
     hipLaunchKernelGGL(pack16_partI_kernel, dim3(nTiles * 4), dim3(256), 0, s, x, B, out);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// PartII head for the bf16x3 path (utils/network.py:266-269 + Conv_init's BN/ReLU): permute the group axis of
+// before_eqv0 / after_eqv0 by P[pre_idx], concatenate 4 x 32 channels, BN(128) + ReLU, split into bf16 planes.
+// One workgroup per (tile16, c8); c8 >> 2 selects the source tensor.
+__global__ __launch_bounds__(256) void pack16_partII_kernel(const float* __restrict__ s0, const float* __restrict__ s1,
+                                                            const float* __restrict__ s2, const float* __restrict__ s3,
+                                                            const int64_t* __restrict__ pre_idx, const int* __restrict__ P,
+                                                            const float* __restrict__ bn_s, const float* __restrict__ bn_t,
+                                                            int M, char* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) unsigned short lds[CHUNK16_BYTES / 2];
+    const int tile = blockIdx.x >> 4, c8 = blockIdx.x & 15;
+    const int src = c8 >> 2;
+    const float* sp = src == 0 ? s0 : (src == 1 ? s1 : (src == 2 ? s2 : s3));
+    const bool permute = (src == 0) || (src == 2);
+    const int cbase = (c8 & 3) * 8;
+    for (int i = threadIdx.x; i < T16 * 8 * G; i += 256) {
+        const int kp = i / (8 * G);
+        const int r = i - kp * (8 * G);
+        const int cl = r / G, g = r - cl * G;
+        const int m = tile * T16 + kp;
+        float v = 0.f;
+        if (m < M) {
+            int gs = g;
+            if (permute) {
+                long long pi = pre_idx[m];
+                pi = pi < 0 ? 0 : (pi > 59 ? 59 : pi);
+                gs = P[(int)pi * G + g];
+            }
+            const int cc = c8 * 8 + cl;
+            v = sp[(size_t)m * (F * G) + (cbase + cl) * G + gs];
+            v = fmaxf(v * bn_s[cc] + bn_t[cc], 0.f);
+        }
+        unsigned h, mm, l;
+        split3(v, h, mm, l);
+        const int o = (g * T16 + kp) * 8 + cl;
+        lds[o] = (unsigned short)h;
+        lds[PLANE16_BYTES / 2 + o] = (unsigned short)mm;
+        lds[PLANE16_BYTES + o] = (unsigned short)l;
+    }
+    __syncthreads();
+    uintx4* o = reinterpret_cast<uintx4*>(out + ((size_t)tile * 16 + c8) * CHUNK16_BYTES);
+    const uintx4* l = reinterpret_cast<const uintx4*>(lds);
+    for (int i = threadIdx.x; i < CHUNK16_BYTES / 16; i += 256) o[i] = l[i];
+}
+
+int launch_pack16_partII(const float* s0, const float* s1, const float* s2, const float* s3, const int64_t* pre_idx, const int* P,
+                         const float* bn_s, const float* bn_t, int M, int nTiles16, char* out, hipStream_t s) {
+    hipLaunchKernelGGL(pack16_partII_kernel, dim3(nTiles16 * 16), dim3(256), 0, s, s0, s1, s2, s3, pre_idx, P, bn_s, bn_t, M, out);
     HIPCHK(hipGetLastError());
     return 0;
 }

@@ -19,7 +19,7 @@ SYMBOLS = [
     "yoho_last_error", "yoho_version", "yoho_ctx_create", "yoho_ctx_destroy", "yoho_load_partI",
     "yoho_load_partII", "yoho_partI_forward", "yoho_group_mean_np", "yoho_nn_search", "yoho_mutual_nn",
     "yoho_des2r", "yoho_partII_forward", "yoho_hyp_from_quat", "yoho_o_score", "yoho_c_ransac",
-    "yoho_group_gather", "yoho_set_profiling", "yoho_get_kernel_ms", "yoho_set_gconv_mode",
+    "yoho_group_gather", "yoho_set_profiling", "yoho_get_kernel_ms", "yoho_set_gconv_mode", "yoho_set_partII_mode",
 ]
 
 
@@ -78,6 +78,7 @@ def load_library():
     lib.yoho_group_gather.argtypes = [vp, vp, ci, vp, vp, ci, ci, vp, vp, vp, vp]
     lib.yoho_set_profiling.argtypes = [vp, ci]
     lib.yoho_set_gconv_mode.argtypes = [vp, ci]
+    lib.yoho_set_partII_mode.argtypes = [vp, ci]
     lib.yoho_get_kernel_ms.argtypes = [vp, ci, C.POINTER(C.c_float)]
     for s in SYMBOLS[2:]:
         getattr(lib, s).restype = ci
@@ -285,6 +286,10 @@ class Context:
         """'f32' (direct conv, fp32 MFMA), 'bf16x3' (direct conv, fp32-accurate 3-way bf16 split MFMA) or
         'fourier' (group-Fourier domain conv, fp32 MFMA) for the PartI group conv."""
         _check(self._lib.yoho_set_gconv_mode(self._h, {"f32": 0, "bf16x3": 1, "fourier": 2}[mode]))
+
+    def set_partII_mode(self, mode):
+        """'f32' or 'bf16x3' for the two large cone layers of PartII."""
+        _check(self._lib.yoho_set_partII_mode(self._h, {"f32": 0, "bf16x3": 1}[mode]))
 
     # ---- profiling hook (bench.py) ------------------------------------------------------------
     def set_profiling(self, on=True):
