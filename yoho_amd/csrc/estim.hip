@@ -271,56 +271,75 @@ __global__ void pick_T_kernel(const double* __restrict__ T_all, const int* __res
 
 // ---- group-feature gather (one group element) ------------------------------------------------
 // kr = keys @ Rg^T (f64); NN among pts (f32, widened) with sqrt(D2 + 1e-7) in f64; copy feature row.
-constexpr int GG_SPLIT = 16, GG_ROWS = 16, GG_TT = 1024;
+// N-body style: a thread owns GG_KR rotated keys in registers and walks a slice of the cloud that the workgroup
+// streams through LDS (every lane reads the same point: one broadcast LDS read feeds 64 x GG_KR distance
+// evaluations).  The cloud is cut into `nslice` slices across blockIdx.y; a second kernel merges the per-slice
+// winners (distance, then lower index) and copies the feature row.
+constexpr int GG_KR = 2, GG_TT = 2048;
 struct Mat3 { double m[9]; };
 
-__global__ __launch_bounds__(256) void gather_kernel(const double* __restrict__ keys, int K, const float* __restrict__ pts,
-                                                     const float* __restrict__ feat, int n, int g, Mat3 Rg,
-                                                     float* __restrict__ out, int64_t* __restrict__ nn_idx) {
-    __shared__ float tile[GG_TT * 3];
-    __shared__ double rd[GG_ROWS * GG_SPLIT];
-    __shared__ int ri[GG_ROWS * GG_SPLIT];
-    const int r = threadIdx.x % GG_ROWS, sp = threadIdx.x / GG_ROWS;
-    const int row = blockIdx.x * GG_ROWS + r;
-    const int rowc = row < K ? row : K - 1;
-    const double* kk = keys + (size_t)rowc * 3;
-    double kr[3];
+__global__ __launch_bounds__(256) void gather_nn_kernel(const double* __restrict__ keys, int K, const float* __restrict__ pts, int n,
+                                                        Mat3 Rg, int slice_len, double* __restrict__ part_d, int* __restrict__ part_i) {
+    __shared__ double tile[GG_TT * 3];            // cloud points widened to f64 once per tile
+    const int k0 = (blockIdx.x * 256 + threadIdx.x) * GG_KR;
+    double kr[GG_KR][3], best[GG_KR];
+    int besti[GG_KR];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) kr[i] = fma(kk[2], Rg.m[i * 3 + 2], fma(kk[1], Rg.m[i * 3 + 1], kk[0] * Rg.m[i * 3]));
-    double best = __builtin_inf();
-    int besti = 0;
-    for (int t0 = 0; t0 < n; t0 += GG_TT) {
-        const int nt = n - t0 < GG_TT ? n - t0 : GG_TT;
+    for (int q = 0; q < GG_KR; ++q) {
+        const int kc = k0 + q < K ? k0 + q : K - 1;
+        const double* kk = keys + (size_t)kc * 3;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) kr[q][i] = fma(kk[2], Rg.m[i * 3 + 2], fma(kk[1], Rg.m[i * 3 + 1], kk[0] * Rg.m[i * 3]));
+        best[q] = __builtin_inf();
+        besti[q] = 0;
+    }
+    const int s0 = blockIdx.y * slice_len;
+    const int s1 = s0 + slice_len < n ? s0 + slice_len : n;
+    // The reference takes argmin of sqrt(D2 + 1e-7) (first minimum).  sqrt is monotone, so a later candidate can
+    // only win with a smaller D2; the f64 sqrt is evaluated only when two D2 are so close that rounding could map
+    // them to the same distance - then the earlier index must stay.
+    for (int t0 = s0; t0 < s1; t0 += GG_TT) {
+        const int nt = s1 - t0 < GG_TT ? s1 - t0 : GG_TT;
         __syncthreads();
-        for (int i = threadIdx.x; i < nt * 3; i += 256) tile[i] = pts[(size_t)t0 * 3 + i];
+        for (int i = threadIdx.x; i < nt * 3; i += 256) tile[i] = (double)pts[(size_t)t0 * 3 + i];
         __syncthreads();
-        for (int t = sp; t < nt; t += GG_SPLIT) {
-            const double d0 = __dsub_rn(kr[0], (double)tile[t * 3]);
-            const double d1 = __dsub_rn(kr[1], (double)tile[t * 3 + 1]);
-            const double d2 = __dsub_rn(kr[2], (double)tile[t * 3 + 2]);
-            const double s = __dadd_rn(__dadd_rn(__dmul_rn(d0, d0), __dmul_rn(d1, d1)), __dmul_rn(d2, d2));
-            const double d = sqrt(__dadd_rn(s, 1e-7));
-            if (d < best) { best = d; besti = t0 + t; }
+        for (int t = 0; t < nt; ++t) {
+            const double px = tile[t * 3], py = tile[t * 3 + 1], pz = tile[t * 3 + 2];
+#pragma unroll
+            for (int q = 0; q < GG_KR; ++q) {
+                const double d0 = __dsub_rn(kr[q][0], px), d1 = __dsub_rn(kr[q][1], py), d2 = __dsub_rn(kr[q][2], pz);
+                const double s = __dadd_rn(__dadd_rn(__dmul_rn(d0, d0), __dmul_rn(d1, d1)), __dmul_rn(d2, d2));
+                if (s < best[q]) {
+                    if (s < best[q] * (1.0 - 1e-12) || sqrt(__dadd_rn(s, 1e-7)) < sqrt(__dadd_rn(best[q], 1e-7))) { best[q] = s; besti[q] = t0 + t; }
+                }
+            }
         }
     }
-    rd[r * GG_SPLIT + sp] = best;
-    ri[r * GG_SPLIT + sp] = besti;
-    __syncthreads();
-    if (row < K) {
-        double bd = rd[r * GG_SPLIT];
-        int bi = ri[r * GG_SPLIT];
-        for (int k = 1; k < GG_SPLIT; ++k) {
-            const double d = rd[r * GG_SPLIT + k];
-            const int i = ri[r * GG_SPLIT + k];
-            if (d < bd || (d == bd && i < bi)) { bd = d; bi = i; }
+#pragma unroll
+    for (int q = 0; q < GG_KR; ++q)
+        if (k0 + q < K) {
+            part_d[(size_t)blockIdx.y * K + k0 + q] = sqrt(__dadd_rn(best[q], 1e-7));
+            part_i[(size_t)blockIdx.y * K + k0 + q] = besti[q];
         }
-        if (sp == 0 && nn_idx) nn_idx[row] = bi;
-        // 16 threads of this row copy the 32-D feature row (2 channels each)
-        const float* fr = feat + (size_t)bi * F;
-        float* o = out + (size_t)row * F * G + g;
-        o[(size_t)(2 * sp) * G] = fr[2 * sp];
-        o[(size_t)(2 * sp + 1) * G] = fr[2 * sp + 1];
+}
+
+// merge the slices of one key (16 threads per key: each also copies 2 of the 32 feature channels)
+__global__ __launch_bounds__(256) void gather_merge_kernel(const double* __restrict__ part_d, const int* __restrict__ part_i, int K,
+                                                           int nslice, const float* __restrict__ feat, int g,
+                                                           float* __restrict__ out, int64_t* __restrict__ nn_idx) {
+    const int row = blockIdx.x * 16 + (threadIdx.x >> 4), sp = threadIdx.x & 15;
+    if (row >= K) return;
+    double bd = part_d[row];
+    int bi = part_i[row];
+    for (int k = 1; k < nslice; ++k) {                 // slices are in ascending index order: strict < keeps the first minimum
+        const double d = part_d[(size_t)k * K + row];
+        if (d < bd) { bd = d; bi = part_i[(size_t)k * K + row]; }
     }
+    if (sp == 0 && nn_idx) nn_idx[row] = bi;
+    const float* fr = feat + (size_t)bi * F;
+    float* o = out + (size_t)row * F * G + g;
+    o[(size_t)(2 * sp) * G] = fr[2 * sp];
+    o[(size_t)(2 * sp + 1) * G] = fr[2 * sp + 1];
 }
 
 }  // namespace yoho
@@ -386,10 +405,23 @@ int yoho_group_gather(yoho_ctx* c, const double* keys, int K, const float* pts, 
         set_error("yoho_group_gather: bad argument"); return YOHO_EINVAL;
     }
     HIPCHK(hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
     Mat3 R;
     for (int i = 0; i < 9; ++i) R.m[i] = Rg_host[i];
-    hipLaunchKernelGGL(gather_kernel, dim3((K + GG_ROWS - 1) / GG_ROWS), dim3(256), 0, (hipStream_t)stream, keys, K, pts, feat, n, g, R,
-                       out, nn_idx);
+    const int kblocks = (K + 256 * GG_KR - 1) / (256 * GG_KR);
+    int nslice = (2048 + kblocks - 1) / kblocks;                       // aim for ~2048 workgroups
+    const int max_slices = (n + 255) / 256;                             // at least 256 cloud points per slice
+    if (nslice > max_slices) nslice = max_slices;
+    if (nslice < 1) nslice = 1;
+    const int slice_len = ((n + nslice - 1) / nslice + 255) / 256 * 256;
+    nslice = (n + slice_len - 1) / slice_len;
+    int rc;
+    if ((rc = ensure_ws(c, (size_t)nslice * K * (sizeof(double) + sizeof(int)), s))) return rc;
+    double* pd = (double*)c->ws.p;
+    int* pi = (int*)(pd + (size_t)nslice * K);
+    hipLaunchKernelGGL(gather_nn_kernel, dim3(kblocks, nslice), dim3(256), 0, s, keys, K, pts, n, R, slice_len, pd, pi);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(gather_merge_kernel, dim3((K + 15) / 16), dim3(256), 0, s, pd, pi, K, nslice, feat, g, out, nn_idx);
     HIPCHK(hipGetLastError());
     return 0;
 }

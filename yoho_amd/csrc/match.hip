@@ -60,6 +60,10 @@ __global__ __launch_bounds__(256) void nn_kernel(const float* __restrict__ src, 
     const int rowc = row < Ns ? row : Ns - 1;
 #pragma unroll
     for (int k = 0; k < D; ++k) a[k] = src[(size_t)rowc * D + k];
+    // best holds the squared distance.  For the 'L2' form the reference compares sqrt(D2 + 1e-7) (first minimum);
+    // sqrt is monotone, so a later candidate can only win with a smaller D2, and the correctly rounded sqrt
+    // (computed in f64) is evaluated only when the two D2 are close enough to round to the same distance.
+    auto dist_of = [](float d2) -> float { return (float)sqrt((double)__fadd_rn(d2, 1e-7f)); };
     float best = __builtin_inff();
     int besti = 0;
     for (int t0 = 0; t0 < Nt; t0 += NN_TT) {
@@ -69,10 +73,12 @@ __global__ __launch_bounds__(256) void nn_kernel(const float* __restrict__ src, 
         __syncthreads();
         for (int t = sp; t < nt; t += NN_SPLIT) {
             const float d2 = dist2_f32<D>(a, tile + t * D);
-            const float d = SQUARED ? d2 : (float)sqrt((double)__fadd_rn(d2, 1e-7f));   // correctly rounded fp32 sqrt
-            if (d < best) { best = d; besti = t0 + t; }
+            if (d2 < best) {
+                if (SQUARED || d2 < best * (1.0f - 1e-6f) || dist_of(d2) < dist_of(best)) { best = d2; besti = t0 + t; }
+            }
         }
     }
+    if (!SQUARED) best = dist_of(best);
     rd[r * NN_SPLIT + sp] = best;
     ri[r * NN_SPLIT + sp] = besti;
     __syncthreads();
