@@ -82,8 +82,11 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--gconv", choices=["f32", "bf16x3", "fourier"], default=os.environ.get("YOHO_GCONV", "fourier"),
-                    help="PartI group conv: group-Fourier domain (fp32 MFMA), direct fp32 MFMA, or direct fp32-accurate 3-way bf16 split MFMA")
+    ap.add_argument("--gconv", choices=["f32", "bf16x3", "fourier", "fp16x2"], default=os.environ.get("YOHO_GCONV", "fp16x2"),
+                    help="PartI group conv: group-Fourier domain (fp32 MFMA), direct fp32 MFMA, direct 3-way bf16 split MFMA, "
+                         "or direct 2-way fp16 split MFMA")
+    ap.add_argument("--partII", choices=["f32", "bf16x3", "fp16x2"], default=os.environ.get("YOHO_PARTII", "fp16x2"),
+                    help="arithmetic of the two PartII cone layers")
     args = ap.parse_args()
 
     rank, world, local = ydist.init_from_env("nccl" if args.gpus > 1 else None)
@@ -100,6 +103,7 @@ def main():
     ctx.load_partI(sd1)
     ctx.load_partII(sd2)
     ctx.set_gconv_mode(args.gconv)
+    ctx.set_partII_mode(args.partII)
 
     # every rank owns a different synthetic pair (weak scaling: per-GPU work is fixed)
     pr = synth.make_pair(KP, seed=10 + rank)
@@ -150,6 +154,15 @@ def main():
                     "note": "achieved = algorithmic fp32-equivalent FLOP/s; the fp32-accurate bf16 split issues 6.46 bf16 MFMA flops "
                             "per algorithmic flop, so frac <= 0.155 for this formulation"}
             dtype = "bf16x3 split (fp32-accurate, fp32 accumulate)"
+        elif args.gconv == "fp16x2":
+            roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": BF16_MFMA_PEAK, "unit": "TFLOP/s",
+                    "frac": round(achieved / BF16_MFMA_PEAK, 4), "traffic": pmc_traffic("fp16x2"),
+                    "kernel": "gconv16_kernel<15,2,2> + <8,1,2> (4 launches = 4 PartI layers, 2.1725 algorithmic TFLOP per 5000 kp)",
+                    "executed_tflops": round(achieved * BF16X3_EXEC_PER_ALG / 2, 1),
+                    "executed_frac": round(achieved * BF16X3_EXEC_PER_ALG / 2 / BF16_MFMA_PEAK, 4),
+                    "note": "achieved = algorithmic fp32-equivalent FLOP/s; the 2-way fp16 split (x = hi + lo, 3 products, error "
+                            "<= 3*2^-22 per product) issues 3.23 fp16 MFMA flops per algorithmic flop, so frac <= 0.31"}
+            dtype = "fp16x2 split (2^-22-accurate products, fp32 accumulate)"
         else:
             ex = achieved * FOURIER_EXEC_PER_ALG
             roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK, "unit": "TFLOP/s",
@@ -173,7 +186,7 @@ def main():
             "config": {"workload": "one synthetic scene pair per step per GPU: 2 fragments x 5000 keypoints x 60 rotations x 32-D "
                                    "-> PartI group conv + invariant pooling -> mutual NN -> Des2R -> PartII -> YOHO-O (<=1000 hypotheses); "
                                    "random-init weights (seeded), inputs resident in HBM",
-                       "keypoints_per_fragment": KP, "matches": M, "hypotheses": min(1000, M), "gconv": args.gconv,
+                       "keypoints_per_fragment": KP, "matches": M, "hypotheses": min(1000, M), "gconv": args.gconv, "partII": args.partII,
                        "parallelism": f"pairs sharded over {world} GPU(s), no data-path collective"},
             "roofline": roof,
             "roofline_extra": {"launch_ms": [round(float(v), 3) for v in conv_ms[:4]], "head_ms": round(float(conv_ms[4]), 3),

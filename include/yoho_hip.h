@@ -135,10 +135,13 @@ int yoho_group_gather(yoho_ctx* ctx, const double* keys, int K, const float* pts
 
 /* PartI group-conv formulation: 0 = direct 13-tap conv on fp32 MFMA (v_mfma_f32_32x32x2_f32), 1 = direct conv with an
  * fp32-accurate 3-way bf16 split on v_mfma_f32_32x32x16_bf16 (6 products per term), 2 = group-Fourier domain conv
- * (244 instead of 780 slab products per chunk) on fp32 MFMA.  All meet the 1e-4 parity tolerance. */
+ * (244 instead of 780 slab products per chunk) on fp32 MFMA, 3 = direct conv with a 2-way fp16 split on
+ * v_mfma_f32_32x32x16_f16 (3 products per term, error <= 3*2^-22 per product; activations must stay below 4094 in
+ * magnitude, beyond that the result is inf/NaN).  All meet the 1e-4 parity tolerance. */
 int yoho_set_gconv_mode(yoho_ctx* ctx, int mode);
 
-/* PartII cone layers (128->256 @45 group elements, 256->512 @13): 0 = fp32 MFMA, 1 = bf16x3 split MFMA (default). */
+/* PartII cone layers (128->256 @45 group elements, 256->512 @13): 0 = fp32 MFMA, 1 = bf16x3 split MFMA (default),
+ * 2 = fp16x2 split MFMA. */
 int yoho_set_partII_mode(yoho_ctx* ctx, int mode);
 
 /* timing hook for bench.py: average device time (ms) of the last yoho_partI_forward's dominant

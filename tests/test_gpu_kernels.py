@@ -68,22 +68,39 @@ def test_partI_equivariance_at_full_size(ctx, tables):
     assert (n - 1).abs().max().item() < 1e-5
 
 
-@pytest.fixture(scope="module")
-def ctx16(hip, sd1, sd2):
-    """second context running the PartI group conv on the bf16x3 split MFMA path"""
+def _split_ctx(hip, sd1, sd2, mode):
     c = hip.Context()
     c.load_partI(sd1)
     c.load_partII(sd2)
-    c.set_gconv_mode("bf16x3")
-    c.set_partII_mode("bf16x3")
+    c.set_gconv_mode(mode)
+    c.set_partII_mode(mode)
     return c
 
 
-def test_partI_bf16x3_golden_and_vs_f32(ctx, ctx16, gold, sd1, tables):
+@pytest.fixture(scope="module")
+def ctx16(hip, sd1, sd2):
+    """second context running the PartI group conv on the bf16x3 split MFMA path"""
+    return _split_ctx(hip, sd1, sd2, "bf16x3")
+
+
+@pytest.fixture(scope="module")
+def ctxh(hip, sd1, sd2):
+    """third context: fp16x2 split MFMA path"""
+    return _split_ctx(hip, sd1, sd2, "fp16x2")
+
+
+@pytest.fixture
+def ctx_of(ctx, ctx16, ctxh):
+    return {"f32": ctx, "bf16x3": ctx16, "fp16x2": ctxh}
+
+
+@pytest.mark.parametrize("mode,dmax", [("bf16x3", 5e-6), ("fp16x2", 2e-5)])
+def test_partI_split_golden_and_vs_f32(ctx, ctx_of, mode, dmax, gold, sd1, tables):
+    ctx16 = ctx_of[mode]
     g = gold("partI.npz")
     out = ctx16.partI_forward(cu(g["x"]), want_inv=True, want_inv_np=True)
     eqv, inv = out["eqv"].cpu().numpy(), out["inv"].cpu().numpy()
-    print("bf16x3 golden: rel err eqv %.3g inv %.3g" % (rel(eqv, g["eqv"]), rel(inv, g["inv"])))
+    print("%s golden: rel err eqv %.3g inv %.3g" % (mode, rel(eqv, g["eqv"]), rel(inv, g["inv"])))
     assert rel(eqv, g["eqv"]) < TOL and rel(inv, g["inv"]) < TOL
     assert np.array_equal(out["inv_np"].cpu().numpy(), np.mean(eqv, axis=-1))
     for B in (1, 2, 15, 16, 17, 33, 100):
@@ -91,13 +108,21 @@ def test_partI_bf16x3_golden_and_vs_f32(ctx, ctx16, gold, sd1, tables):
         o = ctx16.partI_forward(cu(x))
         e, i = orc.partI_forward(x, sd1, tables.N)
         assert rel(o["eqv"].cpu().numpy(), e) < TOL and rel(o["inv"].cpu().numpy(), i) < TOL, B
+    # input magnitudes far from 1 (tiny values exercise the low planes near the bottom of the 16-bit exponent range)
+    for scale in (1e-3, 30.0):
+        x = synth.unit_features(40, seed=77) * np.float32(scale)
+        o = ctx16.partI_forward(cu(x))
+        e, i = orc.partI_forward(x, sd1, tables.N)
+        r = rel(o["eqv"].cpu().numpy(), e)
+        print("%s input scale %g: rel err %.3g" % (mode, scale, r))
+        assert r < TOL, scale
     # the two arithmetic paths agree to fp32 rounding at full size
     x = cu(synth.unit_features(5000, seed=1))
     e32 = ctx.partI_forward(x)["eqv"]
     e16 = ctx16.partI_forward(x)["eqv"]
     d = (e32 - e16).abs().max().item()
-    print("bf16x3 vs f32 MFMA at 5000 kp: max abs diff %.3g" % d)
-    assert d < 5e-6
+    print("%s vs f32 MFMA at 5000 kp: max abs diff %.3g" % (mode, d))
+    assert d < dmax
     P = torch.from_numpy(tables.P).cuda()
     ei = ctx16.partI_forward(x[:, :, P[17]].contiguous())["eqv"]
     assert (ei - e16[:, :, P[17]]).abs().max().item() < 2e-5
@@ -165,9 +190,9 @@ def test_mutual_match_golden_and_full_size(ctx, gold):
     assert (np.diff(mm[:, 0]) > 0).all() and len(set(mm[:, 1])) == len(mm)
 
 
-@pytest.mark.parametrize("mode", ["f32", "bf16x3"])
-def test_des2r_golden(ctx, ctx16, mode, gold, sd1, tables):
-    ctx = ctx if mode == "f32" else ctx16
+@pytest.mark.parametrize("mode", ["f32", "bf16x3", "fp16x2"])
+def test_des2r_golden(ctx_of, mode, gold, sd1, tables):
+    ctx = ctx_of[mode]
     g = gold("chain.npz")
     pr = synth.make_pair(int(g["K"]), seed=int(g["pair_seed"]))
     e0 = ctx.partI_forward(cu(pr["feat0"]))["eqv"]
@@ -186,9 +211,9 @@ def test_des2r_golden(ctx, ctx16, mode, gold, sd1, tables):
         assert (ctx.des2r(ea, eb).cpu().numpy() == i).all()
 
 
-@pytest.mark.parametrize("mode", ["f32", "bf16x3"])
-def test_partII_hyp_golden(ctx, ctx16, mode, gold, sd1, sd2, tables):
-    ctx = ctx if mode == "f32" else ctx16
+@pytest.mark.parametrize("mode", ["f32", "bf16x3", "fp16x2"])
+def test_partII_hyp_golden(ctx_of, mode, gold, sd1, sd2, tables):
+    ctx = ctx_of[mode]
     g = gold("chain.npz")
     pr = synth.make_pair(int(g["K"]), seed=int(g["pair_seed"]))
     m, dr = g["match"], g["dr_index"]

@@ -33,6 +33,7 @@ static int upload(const void* h, size_t bytes, void** d) {
 static void free_layer(Layer& L) {
     if (L.wp) (void)hipFree(L.wp);
     if (L.wp16) (void)hipFree(L.wp16);
+    if (L.wph) (void)hipFree(L.wph);
     if (L.wpf) (void)hipFree(L.wpf);
     if (L.bias) (void)hipFree(L.bias);
     if (L.bn_s) (void)hipFree(L.bn_s);
@@ -92,6 +93,43 @@ static int build_wp16(Layer& L, const yoho_conv_w& cw) {
     return upload(wp.data(), wp.size() * sizeof(unsigned short), &L.wp16);
 }
 
+static inline unsigned short half_bits(float x) {
+    const _Float16 h = (_Float16)x;       // round to nearest even
+    unsigned short u;
+    std::memcpy(&u, &h, 2);
+    return u;
+}
+
+// 13-tap conv weight -> fp16x2 planes, same fragment order with 2 planes: x * 2^k = hi + lo.  2^k puts max|w| into
+// [2^9, 2^10) so that the lo plane of every weight that matters stays a normal fp16 number.
+static int build_wph(Layer& L, const yoho_conv_w& cw) {
+    const int nob = (L.cout_pad + 63) / 64 * 2;
+    const int c8n = L.cin / 8;
+    float wmax = 0.f;
+    for (size_t i = 0; i < (size_t)L.cout * L.cin * L.ntaps; ++i) wmax = std::fmax(wmax, std::fabs(cw.weight[i]));
+    int ex = 0;
+    if (wmax > 0.f && std::isfinite(wmax)) { (void)std::frexp(wmax, &ex); }      // wmax = f * 2^ex, f in [0.5, 1)
+    const float wscale = std::ldexp(1.f, 10 - ex);
+    L.wph_descale = 1.f / (wscale * H2_ASCALE);
+    std::vector<unsigned short> wp((size_t)nob * c8n * 7 * 2 * 64 * 8, 0);
+    for (int ob = 0; ob < nob; ++ob)
+        for (int c8 = 0; c8 < c8n; ++c8)
+            for (int tp = 0; tp < 7; ++tp) {
+                unsigned short* dst = &wp[(((size_t)ob * c8n + c8) * 7 + tp) * 2 * 512];
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int h = lane >> 5, o = ob * 32 + (lane & 31), tap = 2 * tp + h;
+                    if (o >= L.cout || tap >= L.ntaps) continue;
+                    for (int e = 0; e < 8; ++e) {
+                        const float x = cw.weight[((size_t)o * L.cin + c8 * 8 + e) * L.ntaps + tap] * wscale;
+                        const _Float16 hi = (_Float16)x;
+                        dst[0 * 512 + lane * 8 + e] = half_bits(x);
+                        dst[1 * 512 + lane * 8 + e] = half_bits(x - (float)hi);
+                    }
+                }
+            }
+    return upload(wp.data(), wp.size() * sizeof(unsigned short), &L.wph);
+}
+
 // conv weight (cout,cin,1,ntaps) -> A-fragment order [ob][c8][tap][lane = h*32+i][s]:
 //   value = W[ob*32 + i][c8*8 + 4h + s][tap]
 static int build_layer(Layer& L, const yoho_conv_w& cw, int cin, int cout, int ntaps, const yoho_bn_w* bn_after, const FourierBasis* fb = nullptr) {
@@ -120,6 +158,7 @@ static int build_layer(Layer& L, const yoho_conv_w& cw, int cin, int cout, int n
     int rc;
     if ((rc = upload(wp.data(), wp.size() * sizeof(float), (void**)&L.wp))) return rc;
     if (ntaps == NTAP && (rc = build_wp16(L, cw))) return rc;
+    if (ntaps == NTAP && (rc = build_wph(L, cw))) return rc;
     if (ntaps == NTAP && fb) {
         std::vector<float> wf;
         pack_fourier_weights(*fb, cw.weight, cin, cout, L.cout_pad, wf);
@@ -241,9 +280,10 @@ int yoho_ctx_create(int device, const float* R, const uint8_t* N, const uint8_t*
         }
         if ((rc = upload_slot_tables16(slab4.data(), unitg.data())) || (rc = gconv16_init())) { delete c; return rc; }
     }
-    c->gconv_mode = 2;      // default: group-Fourier conv on fp32 MFMA; YOHO_GCONV=f32 | bf16x3 select the direct-conv kernels
-    if (const char* m = std::getenv("YOHO_PARTII")) c->partII_mode = std::strcmp(m, "f32") == 0 ? 0 : 1;
-    if (const char* m = std::getenv("YOHO_GCONV")) c->gconv_mode = std::strcmp(m, "f32") == 0 ? 0 : (std::strcmp(m, "bf16x3") == 0 ? 1 : 2);
+    c->gconv_mode = 3;      // default: direct conv on the fp16x2 split MFMA; YOHO_GCONV=f32 | bf16x3 | fourier | fp16x2
+    c->partII_mode = 2;     // default: fp16x2 cone layers; YOHO_PARTII=f32 | bf16x3 | fp16x2
+    if (const char* m = std::getenv("YOHO_PARTII")) c->partII_mode = std::strcmp(m, "f32") == 0 ? 0 : (std::strcmp(m, "fp16x2") == 0 ? 2 : 1);
+    if (const char* m = std::getenv("YOHO_GCONV")) c->gconv_mode = std::strcmp(m, "f32") == 0 ? 0 : (std::strcmp(m, "bf16x3") == 0 ? 1 : (std::strcmp(m, "fp16x2") == 0 ? 3 : 2));
     // group-Fourier basis (irreps of the table's group)
     c->fb = new FourierBasis();
     if ((rc = build_fourier(N, P, *c->fb))) { delete c->fb; delete c; return rc; }
@@ -317,13 +357,13 @@ int yoho_load_partII(yoho_ctx* c, const yoho_partII_weights* w) {
 }
 
 int yoho_set_gconv_mode(yoho_ctx* c, int mode) {
-    if (!c || mode < 0 || mode > 2) { set_error("yoho_set_gconv_mode: mode must be 0 (fp32 MFMA), 1 (bf16x3 MFMA) or 2 (group-Fourier fp32 MFMA)"); return YOHO_EINVAL; }
+    if (!c || mode < 0 || mode > 3) { set_error("yoho_set_gconv_mode: mode must be 0 (fp32 MFMA), 1 (bf16x3 MFMA), 2 (group-Fourier fp32 MFMA) or 3 (fp16x2 MFMA)"); return YOHO_EINVAL; }
     c->gconv_mode = mode;
     return 0;
 }
 
 int yoho_set_partII_mode(yoho_ctx* c, int mode) {
-    if (!c || (mode != 0 && mode != 1)) { set_error("yoho_set_partII_mode: mode must be 0 (fp32 MFMA) or 1 (bf16x3 MFMA for the cone layers)"); return YOHO_EINVAL; }
+    if (!c || mode < 0 || mode > 2) { set_error("yoho_set_partII_mode: mode must be 0 (fp32 MFMA), 1 (bf16x3) or 2 (fp16x2 MFMA for the cone layers)"); return YOHO_EINVAL; }
     c->partII_mode = mode;
     return 0;
 }
@@ -359,10 +399,11 @@ int yoho_get_kernel_ms(yoho_ctx* c, int which, float* ms) {
     return 0;
 }
 
-// bf16x3 variant: 16-keypoint tiles, bf16 plane activations, fp32 raw residual / output
-static int partI_pass16(yoho_ctx* c, const float* x, int B, float* eqv, float* inv, float* inv_np, hipStream_t s) {
+// split-precision variants (npl = 3: bf16x3, npl = 2: fp16x2): 16-keypoint tiles, 16-bit plane activations, fp32 raw
+// residual / output
+static int partI_pass16(yoho_ctx* c, const float* x, int B, float* eqv, float* inv, float* inv_np, hipStream_t s, int npl) {
     const int nT = (B + 15) / 16;
-    const size_t chunk = 46080, rawslabs = (size_t)G * 128 * sizeof(float);      // bytes per (tile, c8)
+    const size_t chunk = (size_t)npl * 15360, rawslabs = (size_t)G * 128 * sizeof(float);      // bytes per (tile, c8)
     const size_t szX = (size_t)nT * 4 * chunk, szA = (size_t)nT * 32 * chunk, szA1 = (size_t)nT * 64 * chunk;
     const size_t szH0 = (size_t)nT * 32 * rawslabs, szY = (size_t)nT * 8 * rawslabs;   // Y padded to 64 channels
     int rc;
@@ -375,15 +416,15 @@ static int partI_pass16(yoho_ctx* c, const float* x, int B, float* eqv, float* i
     const bool prof = c->profiling && c->ev_created;
     auto mark = [&](int i) { if (prof) (void)hipEventRecord(c->ev[i], s); };
     mark(0);
-    if ((rc = launch_pack16_partI(x, B, nT, bX, s))) return rc;
+    if ((rc = launch_pack16_partI(x, B, nT, bX, s, npl))) return rc;
     mark(1);
-    if ((rc = launch_gconv16(c->p1[0], bX, nT, nullptr, bH0, bA, EPI_RAW | EPI_ACT, s))) return rc;
+    if ((rc = launch_gconv16(c->p1[0], bX, nT, nullptr, bH0, bA, EPI_RAW | EPI_ACT, s, 0, nullptr, nullptr, npl))) return rc;
     mark(2); mark(3);
-    if ((rc = launch_gconv16(c->p1[1], bA, nT, nullptr, nullptr, bA1, EPI_ACT, s))) return rc;
+    if ((rc = launch_gconv16(c->p1[1], bA, nT, nullptr, nullptr, bA1, EPI_ACT, s, 0, nullptr, nullptr, npl))) return rc;
     mark(4); mark(5);
-    if ((rc = launch_gconv16(c->p1[2], bA1, nT, bH0, nullptr, bA, EPI_RES | EPI_ACT, s))) return rc;
+    if ((rc = launch_gconv16(c->p1[2], bA1, nT, bH0, nullptr, bA, EPI_RES | EPI_ACT, s, 0, nullptr, nullptr, npl))) return rc;
     mark(6); mark(7);
-    if ((rc = launch_gconv16(c->p1[3], bA, nT, nullptr, bY, nullptr, EPI_RAW, s))) return rc;
+    if ((rc = launch_gconv16(c->p1[3], bA, nT, nullptr, bY, nullptr, EPI_RAW, s, 0, nullptr, nullptr, npl))) return rc;
     mark(8);
     if ((rc = launch_finalize_partI(bY, x, B, eqv, inv, inv_np, 1, s))) return rc;
     mark(9);
@@ -431,7 +472,7 @@ static int partI_passF(yoho_ctx* c, const float* x, int B, float* eqv, float* in
 }
 
 static int partI_pass(yoho_ctx* c, const float* x, int B, float* eqv, float* inv, float* inv_np, hipStream_t s) {
-    if (c->gconv_mode == 1) return partI_pass16(c, x, B, eqv, inv, inv_np, s);
+    if (c->gconv_mode == 1 || c->gconv_mode == 3) return partI_pass16(c, x, B, eqv, inv, inv_np, s, c->gconv_mode == 1 ? 3 : 2);
     if (c->gconv_mode == 2) return partI_passF(c, x, B, eqv, inv, inv_np, s);
     const int nT = (B + TILE - 1) / TILE;
     const size_t ch = (size_t)CHUNK_FLOATS * sizeof(float);
@@ -486,9 +527,9 @@ int yoho_group_mean_np(yoho_ctx* c, const float* eqv, int B, float* out, void* s
 // PartII with the two large cone layers (128->256 @45 g, 256->512 @13 g) on the bf16x3 split MFMA; the g = 0 tail
 // (512->256 conv + the 1x1 MLP) stays on the fp32 kernels, fed through fp32 32-tile hand-over buffers.
 static int partII_pass16(yoho_ctx* c, const float* s0, const float* s1, const float* s2, const float* s3, const int64_t* idx,
-                         int M, float* quat, hipStream_t s) {
+                         int M, float* quat, hipStream_t s, int npl) {
     const int nT16 = (M + 15) / 16, nT = (M + TILE - 1) / TILE;
-    const size_t ch = (size_t)CHUNK_FLOATS * sizeof(float), ch16 = 46080;
+    const size_t ch = (size_t)CHUNK_FLOATS * sizeof(float), ch16 = (size_t)npl * 15360;
     const size_t n128 = (size_t)nT * 16, n256 = (size_t)nT * 32, n512 = (size_t)nT * 64, n32 = (size_t)nT * 4;
     const size_t szX = (size_t)nT16 * 16 * ch16, szA0 = (size_t)nT16 * 32 * ch16;
     int rc;
@@ -501,9 +542,9 @@ static int partII_pass16(yoho_ctx* c, const float* s0, const float* s1, const fl
     float* bF0 = bF + n256 * CHUNK_FLOATS;              // 512 act
     float* bF1 = bF0 + n512 * CHUNK_FLOATS;             // 128 act
     float* bQ = bF1 + n128 * CHUNK_FLOATS;              // 32 raw (4 used)
-    if ((rc = launch_pack16_partII(s0, s1, s2, s3, idx, c->dP, c->p2_init_bn_s, c->p2_init_bn_t, M, nT16, bX, s))) return rc;
-    if ((rc = launch_gconv16(c->p2[0], bX, nT16, nullptr, nullptr, bA0, EPI_RAW32 | EPI_ACT, s, 1, bH0, nullptr))) return rc;
-    if ((rc = launch_gconv16(c->p2[1], bA0, nT16, nullptr, nullptr, nullptr, EPI_ACT32, s, 2, nullptr, bA1))) return rc;
+    if ((rc = launch_pack16_partII(s0, s1, s2, s3, idx, c->dP, c->p2_init_bn_s, c->p2_init_bn_t, M, nT16, bX, s, npl))) return rc;
+    if ((rc = launch_gconv16(c->p2[0], bX, nT16, nullptr, nullptr, bA0, EPI_RAW32 | EPI_ACT, s, 1, bH0, nullptr, npl))) return rc;
+    if ((rc = launch_gconv16(c->p2[1], bA0, nT16, nullptr, nullptr, nullptr, EPI_ACT32, s, 2, nullptr, bA1, npl))) return rc;
     if ((rc = launch_gconv(conv_args(c->p2[2], bA1, nT, bH0, bF, nullptr, true), -1, EPI_RES | EPI_RAW, s))) return rc;
     if ((rc = launch_gconv(conv_args(c->p2[3], bF, nT, nullptr, nullptr, bF0, true), -1, EPI_ACT, s))) return rc;
     if ((rc = launch_gconv(conv_args(c->p2[4], bF0, nT, nullptr, nullptr, bF1, true), -1, EPI_ACT, s))) return rc;
@@ -513,7 +554,7 @@ static int partII_pass16(yoho_ctx* c, const float* s0, const float* s1, const fl
 
 static int partII_pass(yoho_ctx* c, const float* s0, const float* s1, const float* s2, const float* s3, const int64_t* idx,
                        int M, float* quat, hipStream_t s) {
-    if (c->partII_mode == 1) return partII_pass16(c, s0, s1, s2, s3, idx, M, quat, s);
+    if (c->partII_mode != 0) return partII_pass16(c, s0, s1, s2, s3, idx, M, quat, s, c->partII_mode == 1 ? 3 : 2);
     const int nT = (M + TILE - 1) / TILE;
     const size_t ch = (size_t)CHUNK_FLOATS * sizeof(float);
     const size_t n128 = (size_t)nT * 16, n256 = (size_t)nT * 32, n512 = (size_t)nT * 64, n32 = (size_t)nT * 4;

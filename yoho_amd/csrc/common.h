@@ -26,10 +26,14 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line);
     } while (0)
 
 // One group-conv (or 1x1) layer as it lives on the device.
+constexpr float H2_ASCALE = 16.f;     // fp16x2 activations are stored as 16 * x (|x| < 4094)
+
 struct Layer {
     int cin = 0, cout = 0, cout_pad = 0, ntaps = 0;
     float* wp = nullptr;      // packed MFMA A-fragments [ob][c8][tap][lane64][4]
     void* wp16 = nullptr;     // bf16x3 planes [ob][c8][tap-pair 7][plane 3][lane64][8] (13-tap layers only)
+    float wph_descale = 1.f;  // 1 / (power-of-two weight scale * H2_ASCALE) of the fp16x2 planes
+    void* wph = nullptr;      // fp16x2 planes [ob][c8][tap-pair 7][plane 2][lane64][8] (13-tap layers only)
     float* wpf = nullptr;     // group-Fourier weights [ob][c8][frag 60][lane64][4] (13-tap layers only)
     float* bias = nullptr;    // [cout_pad]
     float* bn_s = nullptr;    // [cout_pad] scale of the BN that FOLLOWS this conv (applied with ReLU in the epilogue)
@@ -77,10 +81,10 @@ int launch_gft(int mode, const float* in, float* out, const float* Fpad, const f
 int upload_slot_tables16(const int* slab4_h, const int* unitg_h);
 int gconv16_init();
 int launch_gconv16(const Layer& L, const char* X, int nTiles, const float* res, float* out_raw, char* out_act, int flags, hipStream_t s,
-                   int cfg = 0, float* out_raw32 = nullptr, float* out_act32 = nullptr);
+                   int cfg = 0, float* out_raw32 = nullptr, float* out_act32 = nullptr, int npl = 3);
 int launch_pack16_partII(const float* s0, const float* s1, const float* s2, const float* s3, const int64_t* pre_idx, const int* P,
-                         const float* bn_s, const float* bn_t, int M, int nTiles16, char* out, hipStream_t s);
-int launch_pack16_partI(const float* x, int B, int nTiles, char* out, hipStream_t s);
+                         const float* bn_s, const float* bn_t, int M, int nTiles16, char* out, hipStream_t s, int npl = 3);
+int launch_pack16_partI(const float* x, int B, int nTiles, char* out, hipStream_t s, int npl = 3);
 int launch_group_mean_np(const float* eqv, int B, float* out, hipStream_t s);
 int launch_pack_partII(const float* s0, const float* s1, const float* s2, const float* s3, const int64_t* pre_idx,
                        const int* P, const float* bn_s, const float* bn_t, int M, int nTiles, float* out, hipStream_t s);
@@ -114,8 +118,8 @@ struct yoho_ctx {
     yoho::Layer p1[4];           // conv_in, res_in, res_out, conv_out
     yoho::Layer p2[6];           // init, res_in, res_out, fc0, fc1, fc2
     float *p2_init_bn_s = nullptr, *p2_init_bn_t = nullptr;  // BN(128) applied by the PartII pack kernel
-    int partII_mode = 1;         // 0: fp32 MFMA cone kernels, 1: bf16x3 split MFMA for the two large cone layers (default)
-    int gconv_mode = 2;          // 0: direct conv fp32 MFMA, 1: direct conv bf16x3 split MFMA, 2: group-Fourier conv fp32 MFMA (default)
+    int partII_mode = 2;         // cone layers: 0 fp32 MFMA, 1 bf16x3 split MFMA, 2 fp16x2 split MFMA (default)
+    int gconv_mode = 3;          // 0 direct fp32 MFMA, 1 direct bf16x3 split, 2 group-Fourier fp32 MFMA, 3 direct fp16x2 split (default)
     yoho::FourierBasis* fb = nullptr;
     float* dFpad = nullptr;      // F padded to 64 x 64 (device)
     // workspace (grown on demand)

@@ -28,15 +28,18 @@ namespace yoho {
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 halfx8 __attribute__((ext_vector_type(8)));
 typedef unsigned int uintx4 __attribute__((ext_vector_type(4)));
 typedef unsigned int uintx2 __attribute__((ext_vector_type(2)));
 
 constexpr int T16 = 16;                               // keypoints per tile
 constexpr int SLAB16_BYTES = T16 * 8 * 2;             // 256 B: one group element, 8 channels, one plane
 constexpr int PLANE16_BYTES = G * SLAB16_BYTES;       // 15360
-constexpr int CHUNK16_BYTES = 3 * PLANE16_BYTES;      // 46080
-constexpr int LDS16_BYTES = 2 * CHUNK16_BYTES;        // 92160 (+ the per-wave slab-offset tables, LDS16_TOTAL)
-constexpr int LDS16_TOTAL = LDS16_BYTES + 4 * 8 * 15 * 4 * 4;   // 99840
+// NPL = number of 16-bit planes per fp32 operand:
+//   3: bf16 x = h + m + l, six cross products  (any fp32 range)
+//   2: fp16 x = h + l,     three cross products (|x| within fp16 range; error <= 3 * 2^-22 per product)
+constexpr int chunk16_bytes(int npl) { return npl * PLANE16_BYTES; }       // 46080 / 30720
+constexpr int lds16_total(int npl) { return 2 * chunk16_bytes(npl) + 4 * 8 * 15 * 4 * 4; }   // chunks + per-wave slab-offset tables
 constexpr int NTP = 7;                                // tap pairs
 constexpr int NUNIT = 32;                             // unit slots per configuration (30 used for 60 g)
 
@@ -58,8 +61,9 @@ int upload_slot_tables16(const int* slab4_h, const int* unitg_h) {
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
+template <int NPL>
 __device__ __forceinline__ void stage_chunk16(const char* src, char* dst, int w, int lane) {
-    for (int p = w; p < CHUNK16_BYTES / 1024; p += 4) {
+    for (int p = w; p < chunk16_bytes(NPL) / 1024; p += 4) {
         const char* s = src + p * 1024 + lane * 16;
         char* d = dst + p * 1024;                      // wave-uniform; hardware adds lane*16
         __builtin_amdgcn_global_load_lds((gptr_t)s, (lptr_t)d, 16, 0, 0);
@@ -84,6 +88,38 @@ __device__ __forceinline__ void split3(float x, unsigned& h, unsigned& m, unsign
     const float r2 = r1 - __uint_as_float(m << 16);
     l = bf16_rne_bits(r2);
 }
+// fp32 -> (hi, lo) fp16 bit patterns (round-to-nearest-even conversions)
+__device__ __forceinline__ unsigned half_bits(float x) {
+    const _Float16 h = (_Float16)x;
+    unsigned short u;
+    __builtin_memcpy(&u, &h, 2);
+    return u;
+}
+__device__ __forceinline__ void split2h(float x, unsigned& h, unsigned& l) {
+    const _Float16 hh = (_Float16)x;
+    const float r = x - (float)hh;
+    unsigned short u;
+    __builtin_memcpy(&u, &hh, 2);
+    h = u;
+    l = half_bits(r);
+}
+// planes of one fp32 value, plane order = LDS plane order (0 = hi)
+template <int NPL>
+__device__ __forceinline__ void split_planes(float x, unsigned (&p)[3]) {
+    if constexpr (NPL == 3) split3(x, p[0], p[1], p[2]);
+    else { split2h(x * H2_ASCALE, p[0], p[1]); p[2] = 0; }       // exact power-of-two scaling keeps the lo plane out of the fp16 subnormals
+}
+// D += A(plane pa) * B(plane pb) on the MFMA of the plane type
+template <int NPL>
+__device__ __forceinline__ floatx16 mfma16(uintx4 a, uintx4 b, floatx16 c) {
+    if constexpr (NPL == 3) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a), as_bf16x8(b), c, 0, 0, 0);
+    } else {
+        union { uintx4 u; halfx8 h; } ca, cb;
+        ca.u = a; cb.u = b;
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(ca.h, cb.h, c, 0, 0, 0);
+    }
+}
 
 template <int I, int N, typename Fn>
 __device__ __forceinline__ void static_for(Fn&& f) {
@@ -101,11 +137,12 @@ __device__ __forceinline__ void pin_interleave() {
     } else {
         // reads go out behind the first NR MFMAs, so the last one has (NM - NR) MFMAs (>= 190 cycles) to land
         // before the step boundary, where hipcc waits with lgkmcnt(0)
-        static_for<0, NR>([](auto) {
+        static_for<0, (NR < NM ? NR : NM)>([](auto) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         });
-        __builtin_amdgcn_sched_group_barrier(0x008, NM - NR, 0);
+        if constexpr (NR > NM) __builtin_amdgcn_sched_group_barrier(0x100, NR - NM, 0);
+        if constexpr (NM > NR) __builtin_amdgcn_sched_group_barrier(0x008, NM - NR, 0);
     }
 }
 
@@ -121,10 +158,12 @@ struct Conv16Args {
     float* out_raw32;      // fp32, 32-keypoint tile layout of gconv.hip (EPI_RAW32): hand-over to the fp32 kernels
     float* out_act32;      // same layout, relu(v*s + t) (EPI_ACT32)
     int nTiles, cin8, cout8, nOBgrid, cfg;
+    float descale;         // fp16x2: 1 / (weight scale * H2_ASCALE), a power of two; bf16x3: unused
 };
 
-template <int UPW, int NOB>
+template <int UPW, int NOB, int NPL>
 __global__ __launch_bounds__(256, 1) void gconv16_kernel(Conv16Args a, int flags) {
+    constexpr int CHB = chunk16_bytes(NPL);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -147,9 +186,9 @@ __global__ __launch_bounds__(256, 1) void gconv16_kernel(Conv16Args a, int flags
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
 
-    const char* Xt = a.X + (size_t)tile * a.cin8 * CHUNK16_BYTES;
+    const char* Xt = a.X + (size_t)tile * a.cin8 * CHB;
     const int total = a.cin8 * NTP;
-    const uintx4* Wb = reinterpret_cast<const uintx4*>(a.Wp) + (size_t)ob * total * 192 + lane;   // 3 planes x 64 lanes per step
+    const uintx4* Wb = reinterpret_cast<const uintx4*>(a.Wp) + (size_t)ob * total * (64 * NPL) + lane;   // NPL planes x 64 lanes per step
 
     const int laneoff = (lane & 15) * 16;
 
@@ -157,7 +196,7 @@ __global__ __launch_bounds__(256, 1) void gconv16_kernel(Conv16Args a, int flags
     // in a small LDS table [tp 0..7][unit][lane class 4] (tp 7 repeats tp 0 so that "next" never wraps).  They
     // are read one tap pair ahead with ds_read_b32 inside the MFMA pipeline: constant-memory (SMEM) loads
     // share the LGKM counter with LDS reads but return out of order, which would force full lgkmcnt(0) drains.
-    int* tab = reinterpret_cast<int*>(smem + LDS16_BYTES) + w * (8 * UPW * 4);
+    int* tab = reinterpret_cast<int*>(smem + 2 * CHB) + w * (8 * UPW * 4);
     for (int i = lane; i < 8 * UPW * 4; i += 64) {
         const int cls = i & 3, j = (i >> 2) % UPW, tp = (i >> 2) / UPW;
         const unsigned packed = (unsigned)c_slab4[cfg][(tp == NTP ? 0 : tp) * NUNIT + ubase + j];
@@ -167,8 +206,10 @@ __global__ __launch_bounds__(256, 1) void gconv16_kernel(Conv16Args a, int flags
     const int cls = 2 * ((lane >> 4) & 1) + (lane >> 5);
     const int* tabl = tab + cls;
 
-    stage_chunk16(Xt, smem, w, lane);
-    uintx4 wn_h = Wb[0], wn_m = Wb[64], wn_l = Wb[128];
+    stage_chunk16<NPL>(Xt, smem, w, lane);
+    uintx4 wn[3];
+#pragma unroll
+    for (int pl = 0; pl < NPL; ++pl) wn[pl] = Wb[64 * pl];
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -178,34 +219,39 @@ __global__ __launch_bounds__(256, 1) void gconv16_kernel(Conv16Args a, int flags
 
     int it = 0;
     for (int c8 = 0; c8 < a.cin8; ++c8) {
-        if (c8 + 1 < a.cin8) stage_chunk16(Xt + (size_t)(c8 + 1) * CHUNK16_BYTES, smem + ((c8 + 1) & 1) * CHUNK16_BYTES, w, lane);
-        const char* xb = smem + (c8 & 1) * CHUNK16_BYTES + laneoff;
+        if (c8 + 1 < a.cin8) stage_chunk16<NPL>(Xt + (size_t)(c8 + 1) * CHB, smem + ((c8 + 1) & 1) * CHB, w, lane);
+        const char* xb = smem + (c8 & 1) * CHB + laneoff;
         for (int tp = 0; tp < NTP; ++tp) {
-            const bf16x8 a_h = as_bf16x8(wn_h), a_m = as_bf16x8(wn_m), a_l = as_bf16x8(wn_l);
+            uintx4 wa[3];                                            // A planes of this tap pair: [0] = hi .. [NPL-1] = lo
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl) wa[pl] = wn[pl];
             ++it;
             if (it < total) {
-                const uintx4* wp = Wb + (size_t)it * 192;
-                wn_h = wp[0]; wn_m = wp[64]; wn_l = wp[128];
+                const uintx4* wp = Wb + (size_t)it * (64 * NPL);
+#pragma unroll
+                for (int pl = 0; pl < NPL; ++pl) wn[pl] = wp[64 * pl];
             }
             const int* tabn = tabl + (tp + 1) * (UPW * 4);          // offsets of the next tap pair (tp 7 == tp 0)
             int soffn[UPW];
-            uintx4 bh[2][2], bm[2][2], bl[2][2];
-            // LDS reads are issued in the order the MFMAs consume them: h0 h1 l0 l1 m0 m1
+            uintx4 bp[2][2][3];                                      // [buffer][unit of the pair][plane]
+            // LDS reads are issued in the order the MFMAs consume them: hi planes of both units first, then the lower ones
             auto fetch = [&](int j, int buf, bool two) {
                 const char* p0 = xb + soff[j];
                 const char* p1 = two ? xb + soff[j + 1] : p0;
-                bh[buf][0] = *reinterpret_cast<const uintx4*>(p0);
-                if (two) bh[buf][1] = *reinterpret_cast<const uintx4*>(p1);
-                bl[buf][0] = *reinterpret_cast<const uintx4*>(p0 + 2 * PLANE16_BYTES);
-                if (two) bl[buf][1] = *reinterpret_cast<const uintx4*>(p1 + 2 * PLANE16_BYTES);
-                bm[buf][0] = *reinterpret_cast<const uintx4*>(p0 + PLANE16_BYTES);
-                if (two) bm[buf][1] = *reinterpret_cast<const uintx4*>(p1 + PLANE16_BYTES);
+                bp[buf][0][0] = *reinterpret_cast<const uintx4*>(p0);
+                if (two) bp[buf][1][0] = *reinterpret_cast<const uintx4*>(p1);
+                bp[buf][0][NPL - 1] = *reinterpret_cast<const uintx4*>(p0 + (NPL - 1) * PLANE16_BYTES);
+                if (two) bp[buf][1][NPL - 1] = *reinterpret_cast<const uintx4*>(p1 + (NPL - 1) * PLANE16_BYTES);
+                if constexpr (NPL == 3) {
+                    bp[buf][0][1] = *reinterpret_cast<const uintx4*>(p0 + PLANE16_BYTES);
+                    if (two) bp[buf][1][1] = *reinterpret_cast<const uintx4*>(p1 + PLANE16_BYTES);
+                }
             };
             fetch(0, 0, UPW > 1);
-            __builtin_amdgcn_sched_group_barrier(0x100, UPW > 1 ? 6 : 3, 0);      // first pair's planes are read before the pipeline starts
-            // Units are processed two at a time with their MFMAs interleaved (each unit's six products are a
-            // dependent chain on one accumulator).  The planes of the next pair and the slab offsets of the
-            // next tap pair are read from LDS behind the first MFMAs of the current pair.
+            __builtin_amdgcn_sched_group_barrier(0x100, (UPW > 1 ? 2 : 1) * NPL, 0);      // first pair's planes are read before the pipeline starts
+            // Units are processed two at a time with their MFMAs interleaved (each unit's products are a dependent
+            // chain on one accumulator).  The planes of the next pair and the slab offsets of the next tap pair are
+            // read from LDS behind the first MFMAs of the current pair.  Smallest terms are accumulated first.
             static_for<0, (UPW + 1) / 2>([&](auto pc) {
                 constexpr int j = decltype(pc)::value * 2;
                 constexpr int cur = (j >> 1) & 1, nxt = cur ^ 1;
@@ -213,22 +259,17 @@ __global__ __launch_bounds__(256, 1) void gconv16_kernel(Conv16Args a, int flags
                 if constexpr (j + 2 < UPW) fetch(j + 2, nxt, j + 3 < UPW);
                 soffn[j] = tabn[j * 4];
                 if constexpr (two) soffn[j + 1] = tabn[(j + 1) * 4];
-                const bf16x8 h0 = as_bf16x8(bh[cur][0]), m0 = as_bf16x8(bm[cur][0]), l0 = as_bf16x8(bl[cur][0]);
-                const bf16x8 h1 = as_bf16x8(bh[cur][1]), m1 = as_bf16x8(bm[cur][1]), l1 = as_bf16x8(bl[cur][1]);
-                // smallest terms first
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_l, h0, acc[j], 0, 0, 0);
-                if constexpr (two) acc[j + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_l, h1, acc[j + 1], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, l0, acc[j], 0, 0, 0);
-                if constexpr (two) acc[j + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, l1, acc[j + 1], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_m, m0, acc[j], 0, 0, 0);
-                if constexpr (two) acc[j + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_m, m1, acc[j + 1], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_m, h0, acc[j], 0, 0, 0);
-                if constexpr (two) acc[j + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_m, h1, acc[j + 1], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, m0, acc[j], 0, 0, 0);
-                if constexpr (two) acc[j + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, m1, acc[j + 1], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, h0, acc[j], 0, 0, 0);
-                if constexpr (two) acc[j + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, h1, acc[j + 1], 0, 0, 0);
-                pin_interleave<(two ? 12 : 6), (j + 3 < UPW ? 6 : (j + 2 < UPW ? 3 : 0)) + (two ? 2 : 1)>();
+                auto prod = [&](int pa, int pb) {                    // acc += A[pa] * B[pb] for both units of the pair
+                    acc[j] = mfma16<NPL>(wa[pa], bp[cur][0][pb], acc[j]);
+                    if constexpr (two) acc[j + 1] = mfma16<NPL>(wa[pa], bp[cur][1][pb], acc[j + 1]);
+                };
+                if constexpr (NPL == 3) {
+                    prod(2, 0); prod(0, 2); prod(1, 1); prod(1, 0); prod(0, 1); prod(0, 0);      // l.h  h.l  m.m  m.h  h.m  h.h
+                } else {
+                    prod(1, 0); prod(0, 1); prod(0, 0);                                          // l.h  h.l  h.h
+                }
+                constexpr int NPROD = NPL == 3 ? 6 : 3;
+                pin_interleave<(two ? 2 : 1) * NPROD, (j + 3 < UPW ? 2 * NPL : (j + 2 < UPW ? NPL : 0)) + (two ? 2 : 1)>();
             });
 #pragma unroll
             for (int j = 0; j < UPW; ++j) soff[j] = soffn[j];
@@ -250,6 +291,7 @@ __global__ __launch_bounds__(256, 1) void gconv16_kernel(Conv16Args a, int flags
             floatx4 val;
             val.x = acc[j][4 * q + 0]; val.y = acc[j][4 * q + 1];
             val.z = acc[j][4 * q + 2]; val.w = acc[j][4 * q + 3];
+            if constexpr (NPL == 2) val *= a.descale;
             val += *reinterpret_cast<const floatx4*>(a.bias + ch);
             const size_t slab = ((size_t)tile * a.cout8 + ob * 4 + q) * G + g;           // (tile, c8, g)
             const size_t roff = slab * (T16 * 8) + kp * 8 + half * 4;                    // fp32 raw layout
@@ -268,70 +310,83 @@ __global__ __launch_bounds__(256, 1) void gconv16_kernel(Conv16Args a, int flags
                     *reinterpret_cast<floatx4*>(a.out_act32 + off32) = r;
                 }
                 if (!(flags & EPI_ACT)) continue;
-                unsigned h[4], m[4], l[4];
-                split3(fmaxf(y.x, 0.f), h[0], m[0], l[0]);
-                split3(fmaxf(y.y, 0.f), h[1], m[1], l[1]);
-                split3(fmaxf(y.z, 0.f), h[2], m[2], l[2]);
-                split3(fmaxf(y.w, 0.f), h[3], m[3], l[3]);
-                // plane layout: [tile][c8][plane][g][kp][8 ch] bf16
-                char* base = a.out_act + ((size_t)tile * a.cout8 + ob * 4 + q) * CHUNK16_BYTES + (size_t)g * SLAB16_BYTES + kp * 16 + half * 8;
-                uintx2 ph, pm, pl;
-                ph.x = h[0] | (h[1] << 16); ph.y = h[2] | (h[3] << 16);
-                pm.x = m[0] | (m[1] << 16); pm.y = m[2] | (m[3] << 16);
-                pl.x = l[0] | (l[1] << 16); pl.y = l[2] | (l[3] << 16);
-                *reinterpret_cast<uintx2*>(base) = ph;
-                *reinterpret_cast<uintx2*>(base + PLANE16_BYTES) = pm;
-                *reinterpret_cast<uintx2*>(base + 2 * PLANE16_BYTES) = pl;
+                unsigned p0[3], p1[3], p2[3], p3[3];
+                split_planes<NPL>(fmaxf(y.x, 0.f), p0);
+                split_planes<NPL>(fmaxf(y.y, 0.f), p1);
+                split_planes<NPL>(fmaxf(y.z, 0.f), p2);
+                split_planes<NPL>(fmaxf(y.w, 0.f), p3);
+                // plane layout: [tile][c8][plane][g][kp][8 ch], 16-bit elements
+                char* base = a.out_act + ((size_t)tile * a.cout8 + ob * 4 + q) * CHB + (size_t)g * SLAB16_BYTES + kp * 16 + half * 8;
+#pragma unroll
+                for (int pl = 0; pl < NPL; ++pl) {
+                    uintx2 pk;
+                    pk.x = p0[pl] | (p1[pl] << 16); pk.y = p2[pl] | (p3[pl] << 16);
+                    *reinterpret_cast<uintx2*>(base + pl * PLANE16_BYTES) = pk;
+                }
             }
         }
     }
 }
 
-template <int UPW, int NOB>
+template <int UPW, int NOB, int NPL>
 static int launch16_t(const Conv16Args& a, int flags, hipStream_t s) {
     const int grid = a.nTiles * a.nOBgrid;
-    hipLaunchKernelGGL((gconv16_kernel<UPW, NOB>), dim3(grid), dim3(256), LDS16_TOTAL, s, a, flags);
+    hipLaunchKernelGGL((gconv16_kernel<UPW, NOB, NPL>), dim3(grid), dim3(256), lds16_total(NPL), s, a, flags);
     HIPCHK(hipGetLastError());
     return 0;
 }
 
-int gconv16_init() {
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gconv16_kernel<15, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS16_TOTAL));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gconv16_kernel<8, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS16_TOTAL));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gconv16_kernel<12, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS16_TOTAL));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gconv16_kernel<7, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS16_TOTAL));
+template <int UPW, int NOB, int NPL>
+static int init16_t() {
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gconv16_kernel<UPW, NOB, NPL>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               lds16_total(NPL)));
     return 0;
 }
 
-// layer launch: L.wp16 packed weights.  cfg 0 (all 60 outputs): cout_pad multiple of 64 -> NOB = 2, else the
-// single-block variant; cfg 1 (45 outputs, 23 units): <12,2>; cfg 2 (13 outputs, 7 units): <7,4>.
-int launch_gconv16(const Layer& L, const char* X, int nTiles, const float* res, float* out_raw, char* out_act, int flags, hipStream_t s,
-                   int cfg, float* out_raw32, float* out_act32) {
-    Conv16Args a;
-    a.X = X; a.Wp = reinterpret_cast<const char*>(L.wp16); a.bias = L.bias; a.bn_s = L.bn_s; a.bn_t = L.bn_t;
-    a.res = res; a.out_raw = out_raw; a.out_act = out_act; a.out_raw32 = out_raw32; a.out_act32 = out_act32;
-    a.nTiles = nTiles; a.cin8 = L.cin / 8; a.cout8 = L.cout_pad / 8; a.cfg = cfg;
+int gconv16_init() {
+    int rc;
+    if ((rc = init16_t<15, 2, 3>()) || (rc = init16_t<8, 1, 3>()) || (rc = init16_t<12, 2, 3>()) || (rc = init16_t<7, 4, 3>())) return rc;
+    if ((rc = init16_t<15, 2, 2>()) || (rc = init16_t<8, 1, 2>()) || (rc = init16_t<12, 2, 2>()) || (rc = init16_t<7, 4, 2>())) return rc;
+    return 0;
+}
+
+template <int NPL>
+static int launch16_cfg(Conv16Args& a, const Layer& L, int cfg, int flags, hipStream_t s) {
     if (cfg == 1) {
         if (L.cout_pad % 64) { set_error("gconv16: cone-45 variant needs cout %% 64 == 0"); return YOHO_EINVAL; }
         a.nOBgrid = L.cout_pad / 64;
-        return launch16_t<12, 2>(a, flags, s);
+        return launch16_t<12, 2, NPL>(a, flags, s);
     }
     if (cfg == 2) {
         if (L.cout_pad % 128) { set_error("gconv16: cone-13 variant needs cout %% 128 == 0"); return YOHO_EINVAL; }
         a.nOBgrid = L.cout_pad / 128;
-        return launch16_t<7, 4>(a, flags, s);
+        return launch16_t<7, 4, NPL>(a, flags, s);
     }
-    if (L.cout_pad % 64 == 0) { a.nOBgrid = L.cout_pad / 64; return launch16_t<15, 2>(a, flags, s); }
+    if (L.cout_pad % 64 == 0) { a.nOBgrid = L.cout_pad / 64; return launch16_t<15, 2, NPL>(a, flags, s); }
     a.nOBgrid = L.cout_pad / 32;
-    return launch16_t<8, 1>(a, flags, s);
+    return launch16_t<8, 1, NPL>(a, flags, s);
+}
+
+// layer launch.  npl = 3: bf16x3 planes (L.wp16), npl = 2: fp16x2 planes (L.wph).  cfg 0 (all 60 outputs): cout_pad
+// multiple of 64 -> NOB = 2, else the single-block variant; cfg 1 (45 outputs, 23 units): <12,2>; cfg 2 (13 outputs): <7,4>.
+int launch_gconv16(const Layer& L, const char* X, int nTiles, const float* res, float* out_raw, char* out_act, int flags, hipStream_t s,
+                   int cfg, float* out_raw32, float* out_act32, int npl) {
+    Conv16Args a;
+    a.X = X; a.Wp = reinterpret_cast<const char*>(npl == 2 ? L.wph : L.wp16); a.bias = L.bias; a.bn_s = L.bn_s; a.bn_t = L.bn_t;
+    a.res = res; a.out_raw = out_raw; a.out_act = out_act; a.out_raw32 = out_raw32; a.out_act32 = out_act32;
+    a.nTiles = nTiles; a.cin8 = L.cin / 8; a.cout8 = L.cout_pad / 8; a.cfg = cfg; a.nOBgrid = 1;
+    a.descale = L.wph_descale;
+    return npl == 2 ? launch16_cfg<2>(a, L, cfg, flags, s) : launch16_cfg<3>(a, L, cfg, flags, s);
 }
 
 // ---------------------------------------------------------------------------------------------
 // head / tail for the 16-keypoint tile layouts
 // ---------------------------------------------------------------------------------------------
 // x (B,32,60) f32 -> planes [tile][c8 = 4][3][60][16][8] bf16.  One workgroup per (tile, c8).
+template <int NPL>
 __global__ __launch_bounds__(256) void pack16_partI_kernel(const float* __restrict__ x, int B, char* __restrict__ out) {
-    __shared__ __attribute__((aligned(16))) unsigned short lds[CHUNK16_BYTES / 2];
+    constexpr int CHB = chunk16_bytes(NPL);
+    __shared__ __attribute__((aligned(16))) unsigned short lds[CHB / 2];
     const int tile = blockIdx.x >> 2, c8 = blockIdx.x & 3;
     for (int i = threadIdx.x; i < T16 * 8 * G; i += 256) {
         const int kp = i / (8 * G);
@@ -339,21 +394,21 @@ __global__ __launch_bounds__(256) void pack16_partI_kernel(const float* __restri
         const int cl = r / G, g = r - cl * G;
         const int bb = tile * T16 + kp;
         const float v = bb < B ? x[(size_t)bb * (F * G) + (c8 * 8 + cl) * G + g] : 0.f;
-        unsigned h, m, l;
-        split3(v, h, m, l);
+        unsigned pp[3];
+        split_planes<NPL>(v, pp);
         const int o = (g * T16 + kp) * 8 + cl;
-        lds[o] = (unsigned short)h;
-        lds[PLANE16_BYTES / 2 + o] = (unsigned short)m;
-        lds[PLANE16_BYTES + o] = (unsigned short)l;
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) lds[pl * (PLANE16_BYTES / 2) + o] = (unsigned short)pp[pl];
     }
     __syncthreads();
-    uintx4* o = reinterpret_cast<uintx4*>(out + ((size_t)tile * 4 + c8) * CHUNK16_BYTES);
+    uintx4* o = reinterpret_cast<uintx4*>(out + ((size_t)tile * 4 + c8) * CHB);
     const uintx4* l = reinterpret_cast<const uintx4*>(lds);
-    for (int i = threadIdx.x; i < CHUNK16_BYTES / 16; i += 256) o[i] = l[i];
+    for (int i = threadIdx.x; i < CHB / 16; i += 256) o[i] = l[i];
 }
 
-int launch_pack16_partI(const float* x, int B, int nTiles, char* out, hipStream_t s) {
-    hipLaunchKernelGGL(pack16_partI_kernel, dim3(nTiles * 4), dim3(256), 0, s, x, B, out);
+int launch_pack16_partI(const float* x, int B, int nTiles, char* out, hipStream_t s, int npl) {
+    if (npl == 2) hipLaunchKernelGGL(pack16_partI_kernel<2>, dim3(nTiles * 4), dim3(256), 0, s, x, B, out);
+    else hipLaunchKernelGGL(pack16_partI_kernel<3>, dim3(nTiles * 4), dim3(256), 0, s, x, B, out);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -361,12 +416,14 @@ int launch_pack16_partI(const float* x, int B, int nTiles, char* out, hipStream_
 // PartII head for the bf16x3 path (utils/network.py:266-269 + Conv_init's BN/ReLU): permute the group axis of
 // before_eqv0 / after_eqv0 by P[pre_idx], concatenate 4 x 32 channels, BN(128) + ReLU, split into bf16 planes.
 // One workgroup per (tile16, c8); c8 >> 2 selects the source tensor.
+template <int NPL>
 __global__ __launch_bounds__(256) void pack16_partII_kernel(const float* __restrict__ s0, const float* __restrict__ s1,
                                                             const float* __restrict__ s2, const float* __restrict__ s3,
                                                             const int64_t* __restrict__ pre_idx, const int* __restrict__ P,
                                                             const float* __restrict__ bn_s, const float* __restrict__ bn_t,
                                                             int M, char* __restrict__ out) {
-    __shared__ __attribute__((aligned(16))) unsigned short lds[CHUNK16_BYTES / 2];
+    constexpr int CHB = chunk16_bytes(NPL);
+    __shared__ __attribute__((aligned(16))) unsigned short lds[CHB / 2];
     const int tile = blockIdx.x >> 4, c8 = blockIdx.x & 15;
     const int src = c8 >> 2;
     const float* sp = src == 0 ? s0 : (src == 1 ? s1 : (src == 2 ? s2 : s3));
@@ -389,22 +446,22 @@ __global__ __launch_bounds__(256) void pack16_partII_kernel(const float* __restr
             v = sp[(size_t)m * (F * G) + (cbase + cl) * G + gs];
             v = fmaxf(v * bn_s[cc] + bn_t[cc], 0.f);
         }
-        unsigned h, mm, l;
-        split3(v, h, mm, l);
+        unsigned pp[3];
+        split_planes<NPL>(v, pp);
         const int o = (g * T16 + kp) * 8 + cl;
-        lds[o] = (unsigned short)h;
-        lds[PLANE16_BYTES / 2 + o] = (unsigned short)mm;
-        lds[PLANE16_BYTES + o] = (unsigned short)l;
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) lds[pl * (PLANE16_BYTES / 2) + o] = (unsigned short)pp[pl];
     }
     __syncthreads();
-    uintx4* o = reinterpret_cast<uintx4*>(out + ((size_t)tile * 16 + c8) * CHUNK16_BYTES);
+    uintx4* o = reinterpret_cast<uintx4*>(out + ((size_t)tile * 16 + c8) * CHB);
     const uintx4* l = reinterpret_cast<const uintx4*>(lds);
-    for (int i = threadIdx.x; i < CHUNK16_BYTES / 16; i += 256) o[i] = l[i];
+    for (int i = threadIdx.x; i < CHB / 16; i += 256) o[i] = l[i];
 }
 
 int launch_pack16_partII(const float* s0, const float* s1, const float* s2, const float* s3, const int64_t* pre_idx, const int* P,
-                         const float* bn_s, const float* bn_t, int M, int nTiles16, char* out, hipStream_t s) {
-    hipLaunchKernelGGL(pack16_partII_kernel, dim3(nTiles16 * 16), dim3(256), 0, s, s0, s1, s2, s3, pre_idx, P, bn_s, bn_t, M, out);
+                         const float* bn_s, const float* bn_t, int M, int nTiles16, char* out, hipStream_t s, int npl) {
+    if (npl == 2) hipLaunchKernelGGL(pack16_partII_kernel<2>, dim3(nTiles16 * 16), dim3(256), 0, s, s0, s1, s2, s3, pre_idx, P, bn_s, bn_t, M, out);
+    else hipLaunchKernelGGL(pack16_partII_kernel<3>, dim3(nTiles16 * 16), dim3(256), 0, s, s0, s1, s2, s3, pre_idx, P, bn_s, bn_t, M, out);
     HIPCHK(hipGetLastError());
     return 0;
 }
