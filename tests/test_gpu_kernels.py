@@ -128,24 +128,26 @@ def test_partI_split_golden_and_vs_f32(ctx, ctx_of, mode, dmax, gold, sd1, table
     assert (ei - e16[:, :, P[17]]).abs().max().item() < 2e-5
 
 
-def test_partI_group_fourier_mode(hip, ctx, gold, sd1, tables):
-    """mode 'fourier': the conv runs on group-Fourier coefficients (244 instead of 780 slab products)"""
+@pytest.mark.parametrize("fmode", ["fourier", "fgemm"])
+def test_partI_group_fourier_mode(hip, ctx, gold, sd1, tables, fmode):
+    """modes 'fourier' / 'fgemm': the conv runs on group-Fourier coefficients (244 instead of 780 slab products),
+    on fp32 MFMA, or with the two large layers as irrep GEMMs on the fp16x2 split MFMA"""
     c = hip.Context()
     c.load_partI(sd1)
-    c.set_gconv_mode("fourier")
+    c.set_gconv_mode(fmode)
     g = gold("partI.npz")
     out = c.partI_forward(cu(g["x"]), want_inv=True, want_inv_np=True)
     eqv, inv = out["eqv"].cpu().numpy(), out["inv"].cpu().numpy()
-    print("fourier golden: rel err eqv %.3g inv %.3g" % (rel(eqv, g["eqv"]), rel(inv, g["inv"])))
+    print("%s golden: rel err eqv %.3g inv %.3g" % (fmode, rel(eqv, g["eqv"]), rel(inv, g["inv"])))
     assert rel(eqv, g["eqv"]) < TOL and rel(inv, g["inv"]) < TOL
-    for B in (1, 31, 33, 100):
+    for B in (1, 31, 33, 100, 257):
         x = synth.unit_features(B, seed=300 + B)
         o = c.partI_forward(cu(x))
         e, i = orc.partI_forward(x, sd1, tables.N)
         assert rel(o["eqv"].cpu().numpy(), e) < TOL and rel(o["inv"].cpu().numpy(), i) < TOL, B
     x = cu(synth.unit_features(5000, seed=1))
     d = (ctx.partI_forward(x)["eqv"] - c.partI_forward(x)["eqv"]).abs().max().item()
-    print("fourier vs direct f32 MFMA at 5000 kp: max abs diff %.3g" % d)
+    print("%s vs direct f32 MFMA at 5000 kp: max abs diff %.3g" % (fmode, d))
     assert d < 1e-5
 
 

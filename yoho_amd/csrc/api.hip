@@ -34,6 +34,7 @@ static void free_layer(Layer& L) {
     if (L.wp) (void)hipFree(L.wp);
     if (L.wp16) (void)hipFree(L.wp16);
     if (L.wph) (void)hipFree(L.wph);
+    if (L.wpg) (void)hipFree(L.wpg);
     if (L.wpf) (void)hipFree(L.wpf);
     if (L.bias) (void)hipFree(L.bias);
     if (L.bn_s) (void)hipFree(L.bn_s);
@@ -163,6 +164,11 @@ static int build_layer(Layer& L, const yoho_conv_w& cw, int cin, int cout, int n
         std::vector<float> wf;
         pack_fourier_weights(*fb, cw.weight, cin, cout, L.cout_pad, wf);
         if ((rc = upload(wf.data(), wf.size() * sizeof(float), (void**)&L.wpf))) return rc;
+        if (cout % 256 == 0 && cin % 32 == 0) {
+            std::vector<unsigned short> wg;
+            if (pack_fgemm_weights(*fb, cw.weight, cin, cout, wg, &L.wpg_descale)) { set_error("irrep-GEMM weight packing failed"); return YOHO_EINVAL; }
+            if ((rc = upload(wg.data(), wg.size() * sizeof(unsigned short), &L.wpg))) return rc;
+        }
     }
     if ((rc = upload(bias.data(), bias.size() * sizeof(float), (void**)&L.bias))) return rc;
     if (bn_after) {
@@ -283,7 +289,7 @@ int yoho_ctx_create(int device, const float* R, const uint8_t* N, const uint8_t*
     c->gconv_mode = 3;      // default: direct conv on the fp16x2 split MFMA; YOHO_GCONV=f32 | bf16x3 | fourier | fp16x2
     c->partII_mode = 2;     // default: fp16x2 cone layers; YOHO_PARTII=f32 | bf16x3 | fp16x2
     if (const char* m = std::getenv("YOHO_PARTII")) c->partII_mode = std::strcmp(m, "f32") == 0 ? 0 : (std::strcmp(m, "fp16x2") == 0 ? 2 : 1);
-    if (const char* m = std::getenv("YOHO_GCONV")) c->gconv_mode = std::strcmp(m, "f32") == 0 ? 0 : (std::strcmp(m, "bf16x3") == 0 ? 1 : (std::strcmp(m, "fp16x2") == 0 ? 3 : 2));
+    if (const char* m = std::getenv("YOHO_GCONV")) c->gconv_mode = std::strcmp(m, "f32") == 0 ? 0 : (std::strcmp(m, "bf16x3") == 0 ? 1 : (std::strcmp(m, "fp16x2") == 0 ? 3 : (std::strcmp(m, "fgemm") == 0 ? 4 : 2)));
     // group-Fourier basis (irreps of the table's group)
     c->fb = new FourierBasis();
     if ((rc = build_fourier(N, P, *c->fb))) { delete c->fb; delete c; return rc; }
@@ -294,7 +300,7 @@ int yoho_ctx_create(int device, const float* R, const uint8_t* N, const uint8_t*
                 fpad[s * 64 + g] = (float)c->fb->F[s * G + g];
                 fpad[64 * 64 + g * 64 + s] = (float)c->fb->F[s * G + g];
             }
-        if ((rc = upload(fpad.data(), fpad.size() * sizeof(float), (void**)&c->dFpad)) || (rc = gft_init())) { delete c->fb; delete c; return rc; }
+        if ((rc = upload(fpad.data(), fpad.size() * sizeof(float), (void**)&c->dFpad)) || (rc = gft_init()) || (rc = fgemm_init())) { delete c->fb; delete c; return rc; }
     }
     *out = c;
     return 0;
@@ -357,7 +363,7 @@ int yoho_load_partII(yoho_ctx* c, const yoho_partII_weights* w) {
 }
 
 int yoho_set_gconv_mode(yoho_ctx* c, int mode) {
-    if (!c || mode < 0 || mode > 3) { set_error("yoho_set_gconv_mode: mode must be 0 (fp32 MFMA), 1 (bf16x3 MFMA), 2 (group-Fourier fp32 MFMA) or 3 (fp16x2 MFMA)"); return YOHO_EINVAL; }
+    if (!c || mode < 0 || mode > 4) { set_error("yoho_set_gconv_mode: mode must be 0 (fp32 MFMA), 1 (bf16x3 MFMA), 2 (group-Fourier fp32 MFMA), 3 (fp16x2 MFMA) or 4 (group-Fourier irrep GEMMs, fp16x2 MFMA)"); return YOHO_EINVAL; }
     c->gconv_mode = mode;
     return 0;
 }
@@ -471,7 +477,53 @@ static int partI_passF(yoho_ctx* c, const float* x, int B, float* eqv, float* in
     return 0;
 }
 
+// group-Fourier variant with the two large layers (256->512, 512->256) as irrep GEMMs on the fp16x2 split MFMA
+static int partI_passG(yoho_ctx* c, const float* x, int B, float* eqv, float* inv, float* inv_np, hipStream_t s) {
+    const int nT = (B + TILE - 1) / TILE;
+    const int kppad = (B + 255) / 256 * 256;
+    const size_t nX = (size_t)nT * 4, n256 = (size_t)nT * 32, n512 = (size_t)nT * 64;
+    const size_t szP256 = fgemm_planes_bytes(kppad, 256), szP512 = fgemm_planes_bytes(kppad, 512);
+    int rc;
+    if ((rc = ensure_ws(c, (nX * 4 + n256 * 2 + n512) * CHUNK_FLOATS * sizeof(float) + szP256 + szP512, s))) return rc;
+    float* bS = (float*)c->ws.p;                  // packed input, group domain
+    float* bX = bS + nX * CHUNK_FLOATS;           // its Fourier coefficients
+    float* bH0 = bX + nX * CHUNK_FLOATS;          // raw h0 (Fourier), kept for the residual
+    float* bA = bH0 + n256 * CHUNK_FLOATS;        // raw h2, then act(h2)
+    float* bM = bA + n256 * CHUNK_FLOATS;         // raw mid 512
+    float* bY = bM + n512 * CHUNK_FLOATS;         // conv_out raw (Fourier)
+    float* bYs = bY + nX * CHUNK_FLOATS;          // conv_out raw (group domain)
+    char* bP256 = (char*)(bYs + nX * CHUNK_FLOATS);   // act(h0) as GEMM operand planes
+    char* bP512 = bP256 + szP256;                     // act(mid)
+    const bool prof = c->profiling && c->ev_created;
+    auto mark = [&](int i) { if (prof) (void)hipEventRecord(c->ev[i], s); };
+    const Layer* L = c->p1;
+    if (!L[1].wpg || !L[2].wpg) { set_error("irrep-GEMM weights missing"); return YOHO_ENOWEIGHTS; }
+    mark(0);
+    if ((rc = launch_pack_partI(x, B, nT, bS, s))) return rc;
+    if ((rc = launch_gft(0, bS, bX, c->dFpad, nullptr, nullptr, nT, 4, s))) return rc;
+    mark(1);
+    if ((rc = launch_gconvf(L[0], bX, nT, nullptr, bH0, 0, s))) return rc;
+    mark(2);
+    if ((rc = launch_gft_planes(bH0, bP256, kppad, c->dFpad, L[0].bn_s, L[0].bn_t, nT, 32, s))) return rc;
+    mark(3);
+    if ((rc = launch_fgemm(L[1], bP256, kppad, nT, nullptr, bM, 0, s))) return rc;
+    mark(4);
+    if ((rc = launch_gft_planes(bM, bP512, kppad, c->dFpad, L[1].bn_s, L[1].bn_t, nT, 64, s))) return rc;
+    mark(5);
+    if ((rc = launch_fgemm(L[2], bP512, kppad, nT, bH0, bA, EPI_RES, s))) return rc;
+    mark(6);
+    if ((rc = launch_gft(2, bA, bA, c->dFpad, L[2].bn_s, L[2].bn_t, nT, 32, s))) return rc;
+    mark(7);
+    if ((rc = launch_gconvf(L[3], bA, nT, nullptr, bY, 0, s))) return rc;
+    mark(8);
+    if ((rc = launch_gft(1, bY, bYs, c->dFpad, nullptr, nullptr, nT, 4, s))) return rc;
+    if ((rc = launch_finalize_partI(bYs, x, B, eqv, inv, inv_np, 0, s))) return rc;
+    mark(9);
+    return 0;
+}
+
 static int partI_pass(yoho_ctx* c, const float* x, int B, float* eqv, float* inv, float* inv_np, hipStream_t s) {
+    if (c->gconv_mode == 4) return partI_passG(c, x, B, eqv, inv, inv_np, s);
     if (c->gconv_mode == 1 || c->gconv_mode == 3) return partI_pass16(c, x, B, eqv, inv, inv_np, s, c->gconv_mode == 1 ? 3 : 2);
     if (c->gconv_mode == 2) return partI_passF(c, x, B, eqv, inv, inv_np, s);
     const int nT = (B + TILE - 1) / TILE;

@@ -26,6 +26,8 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line);
     } while (0)
 
 // One group-conv (or 1x1) layer as it lives on the device.
+constexpr float HF_ASCALE = 4.f;      // Fourier-coefficient planes of the irrep GEMMs are stored as 4 * x (|x| < 16376)
+constexpr int NIR_ORD = 5;            // irreps of the icosahedral group
 constexpr float H2_ASCALE = 16.f;     // fp16x2 activations are stored as 16 * x (|x| < 4094)
 
 struct Layer {
@@ -34,7 +36,9 @@ struct Layer {
     void* wp16 = nullptr;     // bf16x3 planes [ob][c8][tap-pair 7][plane 3][lane64][8] (13-tap layers only)
     float wph_descale = 1.f;  // 1 / (power-of-two weight scale * H2_ASCALE) of the fp16x2 planes
     void* wph = nullptr;      // fp16x2 planes [ob][c8][tap-pair 7][plane 2][lane64][8] (13-tap layers only)
-    float* wpf = nullptr;     // group-Fourier weights [ob][c8][frag 60][lane64][4] (13-tap layers only)
+    float* wpf = nullptr;
+    void* wpg = nullptr;      // irrep-GEMM A operand: fp16x2 planes of What (gemmf.hip), 13-tap layers with cout % 256 == 0
+    float wpg_descale = 1.f;     // group-Fourier weights [ob][c8][frag 60][lane64][4] (13-tap layers only)
     float* bias = nullptr;    // [cout_pad]
     float* bn_s = nullptr;    // [cout_pad] scale of the BN that FOLLOWS this conv (applied with ReLU in the epilogue)
     float* bn_t = nullptr;    // [cout_pad] shift
@@ -75,6 +79,14 @@ int build_fourier(const uint8_t* N, const uint8_t* P, FourierBasis& fb);
 namespace yoho {
 void pack_fourier_weights(const FourierBasis& fb, const float* W, int cin, int cout, int cout_pad, std::vector<float>& out);
 int gft_init();
+int fgemm_init();
+size_t fgemm_planes_bytes(int kppad, int cin);
+void fgemm_qinfo(int* qi);
+void fgemm_plane_offsets(int kppad, int cin, long long* off);
+int pack_fgemm_weights(const FourierBasis& fb, const float* W, int cin, int cout, std::vector<unsigned short>& out, float* descale);
+int launch_fgemm(const Layer& L, const char* Bplanes, int kppad, int nT32, const float* res, float* out, int flags, hipStream_t s);
+int launch_gft_planes(const float* in, char* planes, int kppad, const float* Fpad, const float* bn_s, const float* bn_t, int nTiles, int C8,
+                      hipStream_t s);
 int launch_gconvf(const Layer& L, const float* X, int nTiles, const float* res, float* out, int flags, hipStream_t s);
 int launch_gft(int mode, const float* in, float* out, const float* Fpad, const float* bn_s, const float* bn_t, int nTiles, int C8, hipStream_t s);
 // bf16x3 variant (gconv16.hip)

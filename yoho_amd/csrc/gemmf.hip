@@ -1,0 +1,331 @@
+// Group-Fourier conv as five dense GEMMs on the fp16x2 split MFMA.
+//
+// On Fourier coefficients the 13-tap icosahedral group conv is block diagonal over the irreps r (d = 1,3,3,4,5):
+//     Yhat(r,i,j)[o, kp] = sum_m sum_c What(r,i,m)[o,c] * Xhat(r,m,j)[c, kp]
+// which for a fixed irrep is ONE plain matrix product
+//     Y[(i,o), (j,kp)] = sum_(m,c) A[(i,o), (m,c)] * B[(m,c), (j,kp)],      M = d*Cout, K = d*Cin, N = d*KPpad
+// (sum_r d^3 = 244 slab products instead of the 780 of the direct 13-tap form).  Both operands are kept as two fp16
+// planes (x * 2^s = hi + lo) and every term is evaluated as lo*hi + hi*lo + hi*hi on v_mfma_f32_32x32x16_f16 with
+// fp32 accumulation (error <= 3 * 2^-22 per product).
+//
+// Blocking: 256 x 256 output tile per workgroup, 128 x 128 per wave (4 x 4 MFMA tiles, 256 accumulator registers),
+// K in stages of 32 = two MFMA sub-steps of 16.  Operands are stored in HBM already in the order the LDS wants them:
+//     pack[tile 256][stage K32][plane 2][sub-step 2][k-group 2][row/col 256][8 x fp16]        (32 KiB per tile and stage)
+// so a stage is two straight 32 KiB LDS-DMA copies.  LDS holds two stages (128 KiB).  A fragment of sub-step
+// s+1 is read into registers while the MFMAs of sub-step s issue; the barrier of a stage sits between its two
+// sub-steps, after which the stage's buffer is refilled with stage + 2.
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <type_traits>
+#include <vector>
+#include <cmath>
+#include <cstring>
+
+#include "common.h"
+
+namespace yoho {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
+typedef _Float16 halfx8 __attribute__((ext_vector_type(8)));
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+constexpr int FG_STAGE = 32768;               // bytes of one operand tile per K32 stage
+constexpr int FG_LDS = 4 * FG_STAGE;          // 2 buffers x (A + B)
+
+// irreps in launch order (heaviest first)
+__constant__ int c_fg_d[NIR_ORD];             // dimension of the t-th irrep in launch order
+__constant__ int c_fg_base[NIR_ORD];          // first coefficient index
+static const int FG_ORD_D[NIR_ORD] = {5, 4, 3, 3, 1};
+static const int FG_ORD_R[NIR_ORD] = {4, 3, 1, 2, 0};
+static const int FG_IR_BASE[5] = {0, 1, 10, 19, 35};
+static const int FG_IR_D[5] = {1, 3, 3, 4, 5};
+
+struct FGemmArgs {
+    const char* A;        // weight planes, all irreps
+    const char* B;        // activation planes, all irreps
+    const float* bias;
+    const float* res;     // fp32 coefficient slabs [tile32][cout8][60][h][kp32][4] or null
+    float* out;           // same layout
+    long long a_off[NIR_ORD], b_off[NIR_ORD];
+    int wg_start[NIR_ORD + 1];
+    int cin, cout, kppad, nT32;
+    float descale;
+};
+
+template <int I, int N, typename Fn>
+__device__ __forceinline__ void sfor(Fn&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        sfor<I + 1, N>(f);
+    }
+}
+
+__device__ __forceinline__ floatx16 mfma_h(uintx4 a, uintx4 b, floatx16 c) {
+    union { uintx4 u; halfx8 h; } ca, cb;
+    ca.u = a; cb.u = b;
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(ca.h, cb.h, c, 0, 0, 0);
+}
+
+struct Frags {
+    uintx4 ah[4], al[4], bh[4], bl[4];
+};
+
+// fragments of sub-step `sub` from the stage at LDS address p (lane offsets already applied)
+template <int SUB>
+__device__ __forceinline__ void read_frags(const char* pa, const char* pb, Frags& f) {
+    // order of use: A lo + B hi, then A hi + B lo
+#pragma unroll
+    for (int t = 0; t < 4; ++t) f.al[t] = *reinterpret_cast<const uintx4*>(pa + (2 + SUB) * 8192 + t * 512);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) f.bh[t] = *reinterpret_cast<const uintx4*>(pb + (0 + SUB) * 8192 + t * 512);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) f.ah[t] = *reinterpret_cast<const uintx4*>(pa + (0 + SUB) * 8192 + t * 512);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) f.bl[t] = *reinterpret_cast<const uintx4*>(pb + (2 + SUB) * 8192 + t * 512);
+}
+
+__device__ __forceinline__ void mma_substep(const Frags& f, floatx16 (&acc)[4][4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = mfma_h(f.al[i], f.bh[j], acc[i][j]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = mfma_h(f.ah[i], f.bl[j], acc[i][j]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = mfma_h(f.ah[i], f.bh[j], acc[i][j]);
+}
+
+// scheduling directive: 48 MFMAs with 16 LDS reads spread behind the first 16 of them
+__device__ __forceinline__ void pin_48_16() {
+    sfor<0, 16>([](auto) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    });
+    __builtin_amdgcn_sched_group_barrier(0x008, 32, 0);
+}
+
+__device__ __forceinline__ void stage_tile(const char* src, char* dst, int w, int lane) {
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        const int blk = p * 4 + w;                     // 32 x 1 KiB
+        __builtin_amdgcn_global_load_lds((gptr_t)(src + blk * 1024 + lane * 16), (lptr_t)(dst + blk * 1024), 16, 0, 0);
+    }
+}
+
+__global__ __launch_bounds__(256, 1) void fgemm_kernel(FGemmArgs a, int flags) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nwg = gridDim.x, b = blockIdx.x;
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = b & 7, slot8 = b >> 3;
+    const int v = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot8;
+    int t = 0;
+#pragma unroll
+    for (int i = 1; i < NIR_ORD; ++i) t += (v >= a.wg_start[i]) ? 1 : 0;
+    const int d = c_fg_d[t], qbase = c_fg_base[t];
+    const int MT = d * a.cout / 256, KS = d * a.cin / 32;
+    const int local = v - a.wg_start[t];
+    const int ntile = local / MT, mtile = local - ntile * MT;
+    const char* Ag = a.A + a.a_off[t] + (size_t)mtile * KS * FG_STAGE;
+    const char* Bg = a.B + a.b_off[t] + (size_t)ntile * KS * FG_STAGE;
+    const int wm = w >> 1, wn = w & 1;
+
+    floatx16 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // LDS: buffer u at u * 64 KiB: A tile, then B tile
+    const int lane_a = (lane >> 5) * 4096 + (wm * 128 + (lane & 31)) * 16;
+    const int lane_b = FG_STAGE + (lane >> 5) * 4096 + (wn * 128 + (lane & 31)) * 16;
+
+    stage_tile(Ag, smem, w, lane);
+    stage_tile(Bg, smem + FG_STAGE, w, lane);
+    if (KS > 1) {
+        stage_tile(Ag + FG_STAGE, smem + 2 * FG_STAGE, w, lane);
+        stage_tile(Bg + FG_STAGE, smem + 3 * FG_STAGE, w, lane);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    Frags P, Q;
+    read_frags<0>(smem + lane_a, smem + lane_b, P);
+    for (int s = 0; s < KS; ++s) {
+        char* cur = smem + (s & 1) * (2 * FG_STAGE);
+        char* nxt = smem + ((s + 1) & 1) * (2 * FG_STAGE);
+        // sub-step 0: MFMAs on P, fragments of sub-step 1 into Q
+        read_frags<1>(cur + lane_a, cur + lane_b, Q);
+        mma_substep(P, acc);
+        pin_48_16();
+        __builtin_amdgcn_sched_barrier(0);
+        // everybody has its sub-step-1 fragments in registers: the buffer is free, and stage s+1 has landed
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
+        // sub-step 1: MFMAs on Q; refill the freed buffer with stage s+2 and read the first fragments of stage s+1 into P.
+        // Past the end both are repeated on the last stage (branch-free, the data is not used).
+        const int s2 = s + 2 < KS ? s + 2 : KS - 1;
+        stage_tile(Ag + (size_t)s2 * FG_STAGE, cur, w, lane);
+        stage_tile(Bg + (size_t)s2 * FG_STAGE, cur + FG_STAGE, w, lane);
+        read_frags<0>(nxt + lane_a, nxt + lane_b, P);
+        mma_substep(Q, acc);
+        sfor<0, 16>([](auto) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        });
+        __builtin_amdgcn_sched_group_barrier(0x008, 32, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // ---- epilogue: D[row][col]: lane (col = lane & 31, half = lane >> 5), reg r -> row = (r & 3) + 8 * (r >> 2) + 4 * half
+    const int half = lane >> 5, kp32 = lane & 31;
+    const int cout8 = a.cout >> 3;
+    const int row0 = mtile * 256 + wm * 128;                 // the 256 rows of a tile share i (cout is a multiple of 256)
+    const int iidx = row0 / a.cout, o0 = row0 - iidx * a.cout;
+    const int col0 = ntile * 256 + wn * 128;
+    const int jidx = col0 / a.kppad, kp0 = col0 - jidx * a.kppad;
+    const int q = qbase + iidx * d + jidx;
+    const bool addb = (d == 1);                              // trivial irrep: coefficient 0 carries sqrt(60) * bias
+#pragma unroll
+    for (int bi = 0; bi < 4; ++bi) {
+        const int tile32 = (kp0 >> 5) + bi;
+        if (tile32 >= a.nT32) continue;
+#pragma unroll
+        for (int ai = 0; ai < 4; ++ai)
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const int o = o0 + ai * 32 + q4 * 8 + half * 4;
+                floatx4 val;
+                val.x = acc[ai][bi][4 * q4 + 0]; val.y = acc[ai][bi][4 * q4 + 1];
+                val.z = acc[ai][bi][4 * q4 + 2]; val.w = acc[ai][bi][4 * q4 + 3];
+                val *= a.descale;
+                if (addb) val += *reinterpret_cast<const floatx4*>(a.bias + o) * 7.745966692414834f;
+                const size_t off = (((((size_t)tile32 * cout8 + (o >> 3)) * G + q) * 2 + half) * TILE + kp32) * 4;
+                if (flags & EPI_RES) val += *reinterpret_cast<const floatx4*>(a.res + off);
+                *reinterpret_cast<floatx4*>(a.out + off) = val;
+            }
+    }
+}
+
+int fgemm_init() {
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&fgemm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, FG_LDS));
+    int dd[NIR_ORD], bb[NIR_ORD];
+    for (int t = 0; t < NIR_ORD; ++t) { dd[t] = FG_ORD_D[t]; bb[t] = FG_IR_BASE[FG_ORD_R[t]]; }
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_fg_d), dd, sizeof(dd)));
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_fg_base), bb, sizeof(bb)));
+    return 0;
+}
+
+// byte offset of the t-th (launch order) irrep inside an operand pack with `rows` rows/cols per irrep-dimension unit
+// and kdim = channels of the contracted side
+static long long pack_off(int t, int rows, int kdim) {
+    long long off = 0;
+    for (int u = 0; u < t; ++u) off += (long long)(FG_ORD_D[u] * rows / 256) * (FG_ORD_D[u] * kdim / 32) * FG_STAGE;
+    return off;
+}
+
+size_t fgemm_planes_bytes(int kppad, int cin) { return (size_t)pack_off(NIR_ORD, kppad, cin); }
+
+// B-operand addressing for the transform kernel: coefficient q = (r, m, j) -> irrep slot
+void fgemm_qinfo(int* qi /* [60][4]: t, m, j, d */) {
+    for (int t = 0; t < NIR_ORD; ++t) {
+        const int r = FG_ORD_R[t], d = FG_IR_D[r];
+        for (int m = 0; m < d; ++m)
+            for (int j = 0; j < d; ++j) {
+                int* p = qi + (FG_IR_BASE[r] + m * d + j) * 4;
+                p[0] = t; p[1] = m; p[2] = j; p[3] = d;
+            }
+    }
+}
+void fgemm_plane_offsets(int kppad, int cin, long long* off /* [NIR_ORD] */) {
+    for (int t = 0; t < NIR_ORD; ++t) off[t] = pack_off(t, kppad, cin);
+}
+
+static inline unsigned short half_bits_h(float x) {
+    const _Float16 h = (_Float16)x;
+    unsigned short u;
+    std::memcpy(&u, &h, 2);
+    return u;
+}
+
+// What(r,i,m)[o][c] = sum_k W[o][c][k] rho_r(n_k)[m][i]  ->  A pack (fp16x2 planes of What * 2^s)
+int pack_fgemm_weights(const FourierBasis& fb, const float* W, int cin, int cout, std::vector<unsigned short>& out, float* descale) {
+    if (cout % 256 || cin % 32) return -1;
+    std::vector<float> what((size_t)60 * cout * cin);
+    std::vector<double> coef(60 * NTAP);
+    for (int r = 0; r < 5; ++r) {
+        const int d = FG_IR_D[r];
+        for (int i = 0; i < d; ++i)
+            for (int m = 0; m < d; ++m)
+                for (int k = 0; k < NTAP; ++k) coef[(FG_IR_BASE[r] + i * d + m) * NTAP + k] = fb.rho[r][fb.n0[k]][m * d + i];
+    }
+    float wmax = 0.f;
+    for (int f = 0; f < 60; ++f)
+        for (int o = 0; o < cout; ++o)
+            for (int c = 0; c < cin; ++c) {
+                const float* wk = W + ((size_t)o * cin + c) * NTAP;
+                double acc = 0.0;
+                for (int k = 0; k < NTAP; ++k) acc += (double)wk[k] * coef[f * NTAP + k];
+                const float v = (float)acc;
+                what[((size_t)f * cout + o) * cin + c] = v;
+                wmax = std::fmax(wmax, std::fabs(v));
+            }
+    int ex = 0;
+    if (wmax > 0.f && std::isfinite(wmax)) (void)std::frexp(wmax, &ex);
+    const float wscale = std::ldexp(1.f, 10 - ex);                 // max |What| * wscale in [2^9, 2^10)
+    *descale = 1.f / (wscale * HF_ASCALE);
+    out.assign((size_t)pack_off(NIR_ORD, cout, cin) / 2, 0);
+    for (int t = 0; t < NIR_ORD; ++t) {
+        const int r = FG_ORD_R[t], d = FG_IR_D[r];
+        const int KS = d * cin / 32;
+        unsigned short* base = out.data() + pack_off(t, cout, cin) / 2;
+        for (int i = 0; i < d; ++i)
+            for (int o = 0; o < cout; ++o) {
+                const int row = i * cout + o, mtile = row >> 8, rr = row & 255;
+                for (int m = 0; m < d; ++m) {
+                    const float* src = &what[((size_t)(FG_IR_BASE[r] + i * d + m) * cout + o) * cin];
+                    for (int c = 0; c < cin; ++c) {
+                        const int k = m * cin + c, ks = k >> 5, sub = (k >> 4) & 1, kg = (k >> 3) & 1, e = k & 7;
+                        const float x = src[c] * wscale;
+                        const _Float16 hi = (_Float16)x;
+                        unsigned short* blk = base + ((size_t)mtile * KS + ks) * (FG_STAGE / 2);
+                        const size_t idx = ((size_t)(sub * 2 + kg) * 256 + rr) * 8 + e;      // within a plane (8192 halfs per plane-substep pair)
+                        blk[0 * 8192 + idx] = half_bits_h(x);
+                        blk[1 * 8192 + idx] = half_bits_h(x - (float)hi);
+                    }
+                }
+            }
+    }
+    return 0;
+}
+
+int launch_fgemm(const Layer& L, const char* Bplanes, int kppad, int nT32, const float* res, float* out, int flags, hipStream_t s) {
+    FGemmArgs a;
+    a.A = reinterpret_cast<const char*>(L.wpg); a.B = Bplanes; a.bias = L.bias; a.res = res; a.out = out;
+    a.cin = L.cin; a.cout = L.cout; a.kppad = kppad; a.nT32 = nT32; a.descale = L.wpg_descale;
+    int tot = 0;
+    for (int t = 0; t < NIR_ORD; ++t) {
+        a.a_off[t] = pack_off(t, L.cout, L.cin);
+        a.b_off[t] = pack_off(t, kppad, L.cin);
+        a.wg_start[t] = tot;
+        tot += (FG_ORD_D[t] * L.cout / 256) * (FG_ORD_D[t] * kppad / 256);
+    }
+    a.wg_start[NIR_ORD] = tot;
+    hipLaunchKernelGGL(fgemm_kernel, dim3(tot), dim3(256), FG_LDS, s, a, flags);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+}  // namespace yoho

@@ -285,7 +285,7 @@ class Context:
     def set_gconv_mode(self, mode):
         """'f32' (direct conv, fp32 MFMA), 'bf16x3' (direct conv, fp32-accurate 3-way bf16 split MFMA),
         'fourier' (group-Fourier domain conv, fp32 MFMA) or 'fp16x2' (direct conv, 2-way fp16 split MFMA) for PartI."""
-        _check(self._lib.yoho_set_gconv_mode(self._h, {"f32": 0, "bf16x3": 1, "fourier": 2, "fp16x2": 3}[mode]))
+        _check(self._lib.yoho_set_gconv_mode(self._h, {"f32": 0, "bf16x3": 1, "fourier": 2, "fp16x2": 3, "fgemm": 4}[mode]))
 
     def set_partII_mode(self, mode):
         """'f32', 'bf16x3' or 'fp16x2' for the two large cone layers of PartII."""
