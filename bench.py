@@ -82,7 +82,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--gconv", choices=["f32", "bf16x3", "fourier", "fp16x2", "fgemm"], default=os.environ.get("YOHO_GCONV", "fp16x2"),
+    ap.add_argument("--gconv", choices=["f32", "bf16x3", "fourier", "fp16x2", "fgemm"], default=os.environ.get("YOHO_GCONV", "fgemm"),
                     help="PartI group conv: group-Fourier domain (fp32 MFMA), direct fp32 MFMA, direct 3-way bf16 split MFMA, "
                          "or direct 2-way fp16 split MFMA")
     ap.add_argument("--partII", choices=["f32", "bf16x3", "fp16x2"], default=os.environ.get("YOHO_PARTII", "fp16x2"),

@@ -137,7 +137,8 @@ int yoho_group_gather(yoho_ctx* ctx, const double* keys, int K, const float* pts
  * fp32-accurate 3-way bf16 split on v_mfma_f32_32x32x16_bf16 (6 products per term), 2 = group-Fourier domain conv
  * (244 instead of 780 slab products per chunk) on fp32 MFMA, 3 = direct conv with a 2-way fp16 split on
  * v_mfma_f32_32x32x16_f16 (3 products per term, error <= 3*2^-22 per product; activations must stay below 4094 in
- * magnitude, beyond that the result is inf/NaN).  All meet the 1e-4 parity tolerance. */
+ * magnitude, beyond that the result is inf/NaN), 4 = group-Fourier domain with the two large layers as five dense
+ * irrep GEMMs on the fp16x2 split MFMA and fp16x2 transform kernels (default).  All meet the 1e-4 parity tolerance. */
 int yoho_set_gconv_mode(yoho_ctx* ctx, int mode);
 
 /* PartII cone layers (128->256 @45 group elements, 256->512 @13): 0 = fp32 MFMA, 1 = bf16x3 split MFMA (default),

@@ -286,7 +286,7 @@ int yoho_ctx_create(int device, const float* R, const uint8_t* N, const uint8_t*
         }
         if ((rc = upload_slot_tables16(slab4.data(), unitg.data())) || (rc = gconv16_init())) { delete c; return rc; }
     }
-    c->gconv_mode = 3;      // default: direct conv on the fp16x2 split MFMA; YOHO_GCONV=f32 | bf16x3 | fourier | fp16x2
+    c->gconv_mode = 4;      // default: group-Fourier irrep GEMMs on the fp16x2 split MFMA; YOHO_GCONV=f32 | bf16x3 | fourier | fp16x2 | fgemm
     c->partII_mode = 2;     // default: fp16x2 cone layers; YOHO_PARTII=f32 | bf16x3 | fp16x2
     if (const char* m = std::getenv("YOHO_PARTII")) c->partII_mode = std::strcmp(m, "f32") == 0 ? 0 : (std::strcmp(m, "fp16x2") == 0 ? 2 : 1);
     if (const char* m = std::getenv("YOHO_GCONV")) c->gconv_mode = std::strcmp(m, "f32") == 0 ? 0 : (std::strcmp(m, "bf16x3") == 0 ? 1 : (std::strcmp(m, "fp16x2") == 0 ? 3 : (std::strcmp(m, "fgemm") == 0 ? 4 : 2)));
@@ -300,7 +300,12 @@ int yoho_ctx_create(int device, const float* R, const uint8_t* N, const uint8_t*
                 fpad[s * 64 + g] = (float)c->fb->F[s * G + g];
                 fpad[64 * 64 + g * 64 + s] = (float)c->fb->F[s * G + g];
             }
-        if ((rc = upload(fpad.data(), fpad.size() * sizeof(float), (void**)&c->dFpad)) || (rc = gft_init()) || (rc = fgemm_init())) { delete c->fb; delete c; return rc; }
+        if ((rc = upload(fpad.data(), fpad.size() * sizeof(float), (void**)&c->dFpad)) || (rc = gft_init()) || (rc = fgemm_init()) || (rc = gft16_init())) { delete c->fb; delete c; return rc; }
+        std::vector<unsigned short> f16;
+        build_gft16_frags(*c->fb, f16);
+        if ((rc = upload(f16.data(), f16.size() * sizeof(unsigned short), &c->dF16))) { delete c->fb; delete c; return rc; }
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->nCU = prop.multiProcessorCount;
     }
     *out = c;
     return 0;
@@ -320,6 +325,7 @@ int yoho_ctx_destroy(yoho_ctx* c) {
     if (c->dN) (void)hipFree(c->dN);
     if (c->dP) (void)hipFree(c->dP);
     if (c->dFpad) (void)hipFree(c->dFpad);
+    if (c->dF16) (void)hipFree(c->dF16);
     delete c->fb;
     if (c->ev_created) for (auto& e : c->ev) (void)hipEventDestroy(e);
     delete c;
@@ -504,15 +510,15 @@ static int partI_passG(yoho_ctx* c, const float* x, int B, float* eqv, float* in
     mark(1);
     if ((rc = launch_gconvf(L[0], bX, nT, nullptr, bH0, 0, s))) return rc;
     mark(2);
-    if ((rc = launch_gft_planes(bH0, bP256, kppad, c->dFpad, L[0].bn_s, L[0].bn_t, nT, 32, s))) return rc;
+    if ((rc = launch_gft16(bH0, nullptr, bP256, kppad, c->dF16, L[0].bn_s, L[0].bn_t, nT, 32, c->nCU, s))) return rc;
     mark(3);
     if ((rc = launch_fgemm(L[1], bP256, kppad, nT, nullptr, bM, 0, s))) return rc;
     mark(4);
-    if ((rc = launch_gft_planes(bM, bP512, kppad, c->dFpad, L[1].bn_s, L[1].bn_t, nT, 64, s))) return rc;
+    if ((rc = launch_gft16(bM, nullptr, bP512, kppad, c->dF16, L[1].bn_s, L[1].bn_t, nT, 64, c->nCU, s))) return rc;
     mark(5);
     if ((rc = launch_fgemm(L[2], bP512, kppad, nT, bH0, bA, EPI_RES, s))) return rc;
     mark(6);
-    if ((rc = launch_gft(2, bA, bA, c->dFpad, L[2].bn_s, L[2].bn_t, nT, 32, s))) return rc;
+    if ((rc = launch_gft16(bA, bA, nullptr, kppad, c->dF16, L[2].bn_s, L[2].bn_t, nT, 32, c->nCU, s))) return rc;
     mark(7);
     if ((rc = launch_gconvf(L[3], bA, nT, nullptr, bY, 0, s))) return rc;
     mark(8);

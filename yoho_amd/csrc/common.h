@@ -85,6 +85,10 @@ void fgemm_qinfo(int* qi);
 void fgemm_plane_offsets(int kppad, int cin, long long* off);
 int pack_fgemm_weights(const FourierBasis& fb, const float* W, int cin, int cout, std::vector<unsigned short>& out, float* descale);
 int launch_fgemm(const Layer& L, const char* Bplanes, int kppad, int nT32, const float* res, float* out, int flags, hipStream_t s);
+void build_gft16_frags(const FourierBasis& fb, std::vector<unsigned short>& out);
+int gft16_init();
+int launch_gft16(const float* in, float* out32, char* planes, int kppad, const void* Ffrag, const float* bn_s, const float* bn_t, int nTiles,
+                 int C8, int nCU, hipStream_t s);
 int launch_gft_planes(const float* in, char* planes, int kppad, const float* Fpad, const float* bn_s, const float* bn_t, int nTiles, int C8,
                       hipStream_t s);
 int launch_gconvf(const Layer& L, const float* X, int nTiles, const float* res, float* out, int flags, hipStream_t s);
@@ -131,9 +135,12 @@ struct yoho_ctx {
     yoho::Layer p2[6];           // init, res_in, res_out, fc0, fc1, fc2
     float *p2_init_bn_s = nullptr, *p2_init_bn_t = nullptr;  // BN(128) applied by the PartII pack kernel
     int partII_mode = 2;         // cone layers: 0 fp32 MFMA, 1 bf16x3 split MFMA, 2 fp16x2 split MFMA (default)
-    int gconv_mode = 3;          // 0 direct fp32 MFMA, 1 direct bf16x3 split, 2 group-Fourier fp32 MFMA, 3 direct fp16x2 split (default)
+    int gconv_mode = 4;          // 0 direct fp32 MFMA, 1 direct bf16x3 split, 2 group-Fourier fp32 MFMA, 3 direct fp16x2 split,
+                                 // 4 group-Fourier irrep GEMMs on the fp16x2 split MFMA (default)
     yoho::FourierBasis* fb = nullptr;
     float* dFpad = nullptr;      // F padded to 64 x 64 (device)
+    void* dF16 = nullptr;        // fp16x2 MFMA fragments of F^T and F (gft16.hip)
+    int nCU = 256;
     // workspace (grown on demand)
     yoho::Workspace ws;
     // profiling

@@ -1,0 +1,297 @@
+// BN + ReLU between two Fourier-domain convs on the fp16x2 split MFMA:
+//     out = F * relu(s * (F^T * in) + t)            F = 60 x 60 group-Fourier matrix (orthogonal)
+// One (32-keypoint tile, 8-channel block) chunk = 60 coefficient slabs x 256 columns (col = h*128 + kp*4 + e) at a time;
+// persistent workgroups walk the chunks with the next chunk's LDS DMA in flight.  Both 64x64x64 (zero padded) products
+// per wave run on v_mfma_f32_32x32x16_f16 with each operand as two fp16 planes (hi + lo, three products per term).
+//   product 1: A = F^T planes (registers, constant), B = coefficients read from the fp32 chunk in LDS; a lane reads 8
+//              coefficients of its two columns (ds_read_b64 per coefficient) and splits them itself.
+//   product 2: A = F planes with its columns permuted to the order in which product 1 leaves the group elements in
+//              the accumulator registers, so the activated values go from registers straight into B fragments.
+// Output: fp16x2 operand planes of the irrep GEMMs (gemmf.hip), gathered to 16-byte units through LDS, or the fp32
+// coefficient chunk again (input of the fp32 Fourier kernel).
+#include <hip/hip_runtime.h>
+#include <type_traits>
+#include <vector>
+#include <cmath>
+#include <cstring>
+
+#include "common.h"
+
+namespace yoho {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float floatx2 __attribute__((ext_vector_type(2)));
+typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
+typedef _Float16 halfx8 __attribute__((ext_vector_type(8)));
+typedef _Float16 halfx2 __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+constexpr int GB = 65536;                       // one chunk buffer: 64 rows x 1 KiB (rows 60..63 stay zero)
+constexpr int G16_LDS = 2 * GB + 1024;          // + per-coefficient output offsets
+constexpr float F_SCALE = 1024.f;               // |F| <= sqrt(5/60): planes of F * 2^10
+
+struct Gft16Args {
+    const float* in;
+    float* out32;
+    char* planes;
+    const uintx4* Ffrag;      // [matrix 2][rb 2][kb 4][plane 2][lane 64] x 16 B
+    const float* bn_s;
+    const float* bn_t;
+    int nChunks, C8;
+    long long qbase[G];       // byte offset of coefficient q inside the operand planes (irrep pack + j and m terms)
+    int qstride[G];           // bytes per 256-column tile of q's irrep (= K stages * 32 KiB)
+};
+
+__device__ __forceinline__ floatx16 mfma_hh(uintx4 a, uintx4 b, floatx16 c) {
+    union { uintx4 u; halfx8 h; } ca, cb;
+    ca.u = a; cb.u = b;
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(ca.h, cb.h, c, 0, 0, 0);
+}
+
+// (x0, x1) -> packed fp16 hi pair and lo pair (round to nearest even)
+__device__ __forceinline__ void split_pair(float x0, float x1, unsigned& hi, unsigned& lo) {
+    floatx2 x;
+    x.x = x0; x.y = x1;
+    const halfx2 h = __builtin_convertvector(x, halfx2);
+    const floatx2 r = x - __builtin_convertvector(h, floatx2);
+    const halfx2 l = __builtin_convertvector(r, halfx2);
+    __builtin_memcpy(&hi, &h, 4);
+    __builtin_memcpy(&lo, &l, 4);
+}
+
+__device__ __forceinline__ void stage_chunk(const float* src, char* dst, int w, int lane) {
+    const char* s = reinterpret_cast<const char*>(src);
+    for (int p = w; p < G; p += 4) __builtin_amdgcn_global_load_lds((gptr_t)(s + p * 1024 + lane * 16), (lptr_t)(dst + p * 1024), 16, 0, 0);
+}
+
+template <bool PLANES>
+__global__ __launch_bounds__(256, 1) void gft16_kernel(Gft16Args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int Lp = lane & 31, kg = lane >> 5;
+
+    // zero rows 60..63 of both buffers (never overwritten), per-coefficient output offsets
+    for (int i = tid; i < 2 * 256; i += 256) {
+        const int bsel = i >> 8, j = i & 255;
+        reinterpret_cast<uintx4*>(smem + bsel * GB + G * 1024)[j] = uintx4{0u, 0u, 0u, 0u};
+    }
+    long long* qb = reinterpret_cast<long long*>(smem + 2 * GB);
+    int* qs = reinterpret_cast<int*>(smem + 2 * GB + 512);
+    if (tid < G) { qb[tid] = a.qbase[tid]; qs[tid] = a.qstride[tid]; }
+
+    uintx4 A1[2][4][2], A2[2][4][2];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+                A1[rb][kb][pl] = a.Ffrag[(((0 * 2 + rb) * 4 + kb) * 2 + pl) * 64 + lane];
+                A2[rb][kb][pl] = a.Ffrag[(((1 * 2 + rb) * 4 + kb) * 2 + pl) * 64 + lane];
+            }
+
+    int chunk = blockIdx.x;
+    if (chunk < a.nChunks) stage_chunk(a.in + (size_t)chunk * CHUNK_FLOATS, smem, w, lane);
+    for (int it = 0; chunk < a.nChunks; chunk += gridDim.x, ++it) {
+        char* cur = smem + (it & 1) * GB;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const int next = chunk + gridDim.x;
+        if (next < a.nChunks) stage_chunk(a.in + (size_t)next * CHUNK_FLOATS, smem + ((it + 1) & 1) * GB, w, lane);
+        const int c8 = chunk % a.C8, tile32 = chunk / a.C8;
+
+        // ---- product 1: group domain = F^T * coefficients (this wave's 64 columns: lane -> columns 64w + 2Lp + {0,1})
+        floatx16 acc[2][2];
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int f = 0; f < 2; ++f)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[rb][f][r] = 0.f;
+        const char* colp = cur + (64 * w + 2 * Lp) * 4 + kg * 8 * 1024;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            floatx2 v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = *reinterpret_cast<const floatx2*>(colp + (kb * 16 + e) * 1024) * HF_ASCALE;
+            uintx4 bh[2], bl[2];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                unsigned h0, l0, h1, l1;
+                split_pair(v[2 * p].x, v[2 * p + 1].x, h0, l0);
+                split_pair(v[2 * p].y, v[2 * p + 1].y, h1, l1);
+                bh[0][p] = h0; bl[0][p] = l0; bh[1][p] = h1; bl[1][p] = l1;
+            }
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int f = 0; f < 2; ++f) acc[rb][f] = mfma_hh(A1[rb][kb][1], bh[f], acc[rb][f]);
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int f = 0; f < 2; ++f) acc[rb][f] = mfma_hh(A1[rb][kb][0], bl[f], acc[rb][f]);
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int f = 0; f < 2; ++f) acc[rb][f] = mfma_hh(A1[rb][kb][0], bh[f], acc[rb][f]);
+        }
+
+        // ---- BN + ReLU in registers, product 2: coefficients = F * activated
+        // column -> channel: col = h*128 + kp*4 + e, channel = c8*8 + h*4 + e; this lane: e = 2*(Lp&1) + f
+        const int ch0 = c8 * 8 + (w >> 1) * 4 + 2 * (Lp & 1);
+        const float dscale1 = 1.f / (F_SCALE * HF_ASCALE);
+        const float s0 = a.bn_s[ch0] * dscale1 * H2_ASCALE, s1 = a.bn_s[ch0 + 1] * dscale1 * H2_ASCALE;
+        const float t0 = a.bn_t[ch0] * H2_ASCALE, t1 = a.bn_t[ch0 + 1] * H2_ASCALE;
+        floatx16 acc2[2][2];
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int f = 0; f < 2; ++f)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc2[rb][f][r] = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            // K block kb of product 2 = registers 8*(kb&1) .. +7 of accumulator row block kb>>1 (the permuted order of A2)
+            uintx4 bh[2], bl[2];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int r = 8 * (kb & 1) + 2 * p;
+                const float y00 = fmaxf(acc[kb >> 1][0][r] * s0 + t0, 0.f), y01 = fmaxf(acc[kb >> 1][0][r + 1] * s0 + t0, 0.f);
+                const float y10 = fmaxf(acc[kb >> 1][1][r] * s1 + t1, 0.f), y11 = fmaxf(acc[kb >> 1][1][r + 1] * s1 + t1, 0.f);
+                unsigned h0, l0, h1, l1;
+                split_pair(y00, y01, h0, l0);
+                split_pair(y10, y11, h1, l1);
+                bh[0][p] = h0; bl[0][p] = l0; bh[1][p] = h1; bl[1][p] = l1;
+            }
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int f = 0; f < 2; ++f) acc2[rb][f] = mfma_hh(A2[rb][kb][1], bh[f], acc2[rb][f]);
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int f = 0; f < 2; ++f) acc2[rb][f] = mfma_hh(A2[rb][kb][0], bl[f], acc2[rb][f]);
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int f = 0; f < 2; ++f) acc2[rb][f] = mfma_hh(A2[rb][kb][0], bh[f], acc2[rb][f]);
+        }
+
+        // ---- output.  acc2[rb][f][r]: coefficient q = 32 rb + (r&3) + 8 (r>>2) + 4 kg, column 64w + 2Lp + f
+        if (PLANES) {
+            const float osc = HF_ASCALE / (F_SCALE * H2_ASCALE);
+            __syncthreads();                                   // every wave is done reading the coefficients of this buffer
+            // staging image [plane][q][kp 32][8 ch] fp16
+            const int kp = (w & 1) * 16 + (Lp >> 1);
+            char* st = cur + kp * 16 + ((w >> 1) * 4 + 2 * (Lp & 1)) * 2;
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int q = 32 * rb + (r & 3) + 8 * (r >> 2) + 4 * kg;
+                    unsigned hi, lo;
+                    split_pair(acc2[rb][0][r] * osc, acc2[rb][1][r] * osc, hi, lo);
+                    if (q < G) {
+                        *reinterpret_cast<unsigned*>(st + q * 512) = hi;
+                        *reinterpret_cast<unsigned*>(st + 30720 + q * 512) = lo;
+                    }
+                }
+            __syncthreads();
+            char* dst0 = a.planes + (size_t)(c8 >> 2) * 32768 + (c8 & 3) * 4096 + (tile32 & 7) * 512;
+            const int nt = tile32 >> 3;
+#pragma unroll
+            for (int i = 0; i < 15; ++i) {
+                const int idx = i * 256 + tid;
+                const int pl = idx >= 1920 ? 1 : 0, rem = idx - pl * 1920;
+                const int q = rem >> 5, kpp = rem & 31;
+                const uintx4 val = *reinterpret_cast<const uintx4*>(cur + idx * 16);
+                *reinterpret_cast<uintx4*>(dst0 + qb[q] + (long long)nt * qs[q] + kpp * 16 + pl * 16384) = val;
+            }
+        } else {
+            const float osc = 1.f / (F_SCALE * H2_ASCALE);
+            float* dst = a.out32 + (size_t)chunk * CHUNK_FLOATS + 64 * w + 2 * Lp;
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int q = 32 * rb + (r & 3) + 8 * (r >> 2) + 4 * kg;
+                    floatx2 o;
+                    o.x = acc2[rb][0][r] * osc; o.y = acc2[rb][1][r] * osc;
+                    if (q < G) *reinterpret_cast<floatx2*>(dst + q * 256) = o;
+                }
+        }
+    }
+}
+
+static inline unsigned short hbits(float x) {
+    const _Float16 h = (_Float16)x;
+    unsigned short u;
+    std::memcpy(&u, &h, 2);
+    return u;
+}
+
+// MFMA A fragments of F^T (natural K order) and of F (K order = accumulator register order of product 1)
+void build_gft16_frags(const FourierBasis& fb, std::vector<unsigned short>& out) {
+    out.assign((size_t)2 * 2 * 4 * 2 * 64 * 8, 0);
+    auto Fv = [&](int q, int g) -> float { return (q < G && g < G) ? (float)fb.F[q * G + g] : 0.f; };
+    for (int mat = 0; mat < 2; ++mat)
+        for (int rb = 0; rb < 2; ++rb)
+            for (int kb = 0; kb < 4; ++kb)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int e = 0; e < 8; ++e) {
+                        const int i = lane & 31, kg = lane >> 5;
+                        float v;
+                        if (mat == 0) {
+                            const int g = 32 * rb + i, q = 16 * kb + 8 * kg + e;
+                            v = Fv(q, g);
+                        } else {
+                            const int q = 32 * rb + i;
+                            const int g = 32 * (kb >> 1) + (e & 3) + 8 * (2 * (kb & 1) + (e >> 2)) + 4 * kg;
+                            v = Fv(q, g);
+                        }
+                        v *= F_SCALE;
+                        const _Float16 hi = (_Float16)v;
+                        const size_t base = ((((size_t)mat * 2 + rb) * 4 + kb) * 2) * 512 + lane * 8 + e;
+                        out[base] = hbits(v);
+                        out[base + 512] = hbits(v - (float)hi);
+                    }
+}
+
+int gft16_init() {
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gft16_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, G16_LDS));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gft16_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, G16_LDS));
+    return 0;
+}
+
+// planes != null: operand planes for the irrep GEMMs (kppad columns per j); else fp32 chunks to out32 (may alias in)
+int launch_gft16(const float* in, float* out32, char* planes, int kppad, const void* Ffrag, const float* bn_s, const float* bn_t, int nTiles,
+                 int C8, int nCU, hipStream_t s) {
+    Gft16Args a;
+    a.in = in; a.out32 = out32; a.planes = planes; a.Ffrag = reinterpret_cast<const uintx4*>(Ffrag); a.bn_s = bn_s; a.bn_t = bn_t;
+    a.nChunks = nTiles * C8; a.C8 = C8;
+    if (planes) {
+        int qi[G * 4];
+        long long off[NIR_ORD];
+        fgemm_qinfo(qi);
+        const int cin = C8 * 8;
+        fgemm_plane_offsets(kppad, cin, off);
+        for (int q = 0; q < G; ++q) {
+            const int t = qi[q * 4], m = qi[q * 4 + 1], j = qi[q * 4 + 2], d = qi[q * 4 + 3];
+            const long long KS = d * cin / 32;
+            a.qstride[q] = (int)(KS * 32768);
+            a.qbase[q] = off[t] + ((long long)j * (kppad / 256) * KS + (long long)m * cin / 32) * 32768;
+        }
+    } else {
+        for (int q = 0; q < G; ++q) { a.qbase[q] = 0; a.qstride[q] = 0; }
+    }
+    const int grid = a.nChunks < nCU ? a.nChunks : nCU;
+    if (grid == 0) return 0;
+    if (planes) hipLaunchKernelGGL(gft16_kernel<true>, dim3(grid), dim3(256), G16_LDS, s, a);
+    else hipLaunchKernelGGL(gft16_kernel<false>, dim3(grid), dim3(256), G16_LDS, s, a);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+}  // namespace yoho
