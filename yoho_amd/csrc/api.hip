@@ -164,7 +164,7 @@ static int build_layer(Layer& L, const yoho_conv_w& cw, int cin, int cout, int n
         std::vector<float> wf;
         pack_fourier_weights(*fb, cw.weight, cin, cout, L.cout_pad, wf);
         if ((rc = upload(wf.data(), wf.size() * sizeof(float), (void**)&L.wpf))) return rc;
-        if (cout % 256 == 0 && cin % 32 == 0) {
+        if ((cout % 256 == 0 || cout == 32) && cin % 32 == 0) {
             std::vector<unsigned short> wg;
             if (pack_fgemm_weights(*fb, cw.weight, cin, cout, wg, &L.wpg_descale)) { set_error("irrep-GEMM weight packing failed"); return YOHO_EINVAL; }
             if ((rc = upload(wg.data(), wg.size() * sizeof(unsigned short), &L.wpg))) return rc;
@@ -483,32 +483,30 @@ static int partI_passF(yoho_ctx* c, const float* x, int B, float* eqv, float* in
     return 0;
 }
 
-// group-Fourier variant with the two large layers (256->512, 512->256) as irrep GEMMs on the fp16x2 split MFMA
+// group-Fourier variant: all four layers as irrep GEMMs on the fp16x2 split MFMA, fp16x2 transform kernels between them
 static int partI_passG(yoho_ctx* c, const float* x, int B, float* eqv, float* inv, float* inv_np, hipStream_t s) {
     const int nT = (B + TILE - 1) / TILE;
     const int kppad = (B + 255) / 256 * 256;
     const size_t nX = (size_t)nT * 4, n256 = (size_t)nT * 32, n512 = (size_t)nT * 64;
-    const size_t szP256 = fgemm_planes_bytes(kppad, 256), szP512 = fgemm_planes_bytes(kppad, 512);
+    const size_t szP32 = fgemm_planes_bytes(kppad, 32), szP256 = fgemm_planes_bytes(kppad, 256), szP512 = fgemm_planes_bytes(kppad, 512);
     int rc;
-    if ((rc = ensure_ws(c, (nX * 4 + n256 * 2 + n512) * CHUNK_FLOATS * sizeof(float) + szP256 + szP512, s))) return rc;
-    float* bS = (float*)c->ws.p;                  // packed input, group domain
-    float* bX = bS + nX * CHUNK_FLOATS;           // its Fourier coefficients
-    float* bH0 = bX + nX * CHUNK_FLOATS;          // raw h0 (Fourier), kept for the residual
-    float* bA = bH0 + n256 * CHUNK_FLOATS;        // raw h2, then act(h2)
+    if ((rc = ensure_ws(c, (nX * 2 + n256 * 2 + n512) * CHUNK_FLOATS * sizeof(float) + szP32 + szP256 + szP512, s))) return rc;
+    float* bH0 = (float*)c->ws.p;                 // raw h0 (Fourier), kept for the residual
+    float* bA = bH0 + n256 * CHUNK_FLOATS;        // raw h2
     float* bM = bA + n256 * CHUNK_FLOATS;         // raw mid 512
     float* bY = bM + n512 * CHUNK_FLOATS;         // conv_out raw (Fourier)
-    float* bYs = bY + nX * CHUNK_FLOATS;          // conv_out raw (group domain)
-    char* bP256 = (char*)(bYs + nX * CHUNK_FLOATS);   // act(h0) as GEMM operand planes
+    float* bYs = bY + nX * CHUNK_FLOATS;          // conv_out raw (group domain), (B,32,60)
+    char* bP32 = (char*)(bYs + nX * CHUNK_FLOATS);    // input coefficients as GEMM operand planes
+    char* bP256 = bP32 + szP32;                       // act(h0), later act(h2)
     char* bP512 = bP256 + szP256;                     // act(mid)
     const bool prof = c->profiling && c->ev_created;
     auto mark = [&](int i) { if (prof) (void)hipEventRecord(c->ev[i], s); };
     const Layer* L = c->p1;
-    if (!L[1].wpg || !L[2].wpg) { set_error("irrep-GEMM weights missing"); return YOHO_ENOWEIGHTS; }
+    for (int i = 0; i < 4; ++i) if (!L[i].wpg) { set_error("irrep-GEMM weights missing"); return YOHO_ENOWEIGHTS; }
     mark(0);
-    if ((rc = launch_pack_partI(x, B, nT, bS, s))) return rc;
-    if ((rc = launch_gft(0, bS, bX, c->dFpad, nullptr, nullptr, nT, 4, s))) return rc;
+    if ((rc = launch_head16(x, B, nT, bP32, kppad, c->dF16, s))) return rc;
     mark(1);
-    if ((rc = launch_gconvf(L[0], bX, nT, nullptr, bH0, 0, s))) return rc;
+    if ((rc = launch_fgemm(L[0], bP32, kppad, nT, nullptr, bH0, 0, s))) return rc;
     mark(2);
     if ((rc = launch_gft16(bH0, nullptr, bP256, kppad, c->dF16, L[0].bn_s, L[0].bn_t, nT, 32, c->nCU, s))) return rc;
     mark(3);
@@ -518,12 +516,12 @@ static int partI_passG(yoho_ctx* c, const float* x, int B, float* eqv, float* in
     mark(5);
     if ((rc = launch_fgemm(L[2], bP512, kppad, nT, bH0, bA, EPI_RES, s))) return rc;
     mark(6);
-    if ((rc = launch_gft16(bA, bA, nullptr, kppad, c->dF16, L[2].bn_s, L[2].bn_t, nT, 32, c->nCU, s))) return rc;
+    if ((rc = launch_gft16(bA, nullptr, bP256, kppad, c->dF16, L[2].bn_s, L[2].bn_t, nT, 32, c->nCU, s))) return rc;
     mark(7);
-    if ((rc = launch_gconvf(L[3], bA, nT, nullptr, bY, 0, s))) return rc;
+    if ((rc = launch_fgemm(L[3], bP256, kppad, nT, nullptr, bY, 0, s))) return rc;
     mark(8);
-    if ((rc = launch_gft(1, bY, bYs, c->dFpad, nullptr, nullptr, nT, 4, s))) return rc;
-    if ((rc = launch_finalize_partI(bYs, x, B, eqv, inv, inv_np, 0, s))) return rc;
+    if ((rc = launch_gft16(bY, bYs, nullptr, kppad, c->dF16, nullptr, nullptr, nT, 4, c->nCU, s, B))) return rc;
+    if ((rc = launch_finalize_partI(bYs, x, B, eqv, inv, inv_np, 2, s))) return rc;
     mark(9);
     return 0;
 }

@@ -88,7 +88,8 @@ int launch_fgemm(const Layer& L, const char* Bplanes, int kppad, int nT32, const
 void build_gft16_frags(const FourierBasis& fb, std::vector<unsigned short>& out);
 int gft16_init();
 int launch_gft16(const float* in, float* out32, char* planes, int kppad, const void* Ffrag, const float* bn_s, const float* bn_t, int nTiles,
-                 int C8, int nCU, hipStream_t s);
+                 int C8, int nCU, hipStream_t s, int B = 0);
+int launch_head16(const float* x, int B, int nTiles, char* planes, int kppad, const void* Ffrag, hipStream_t s);
 int launch_gft_planes(const float* in, char* planes, int kppad, const float* Fpad, const float* bn_s, const float* bn_t, int nTiles, int C8,
                       hipStream_t s);
 int launch_gconvf(const Layer& L, const float* X, int nTiles, const float* res, float* out, int flags, hipStream_t s);

@@ -20,6 +20,7 @@
 #include <vector>
 #include <cmath>
 #include <cstring>
+#include <cstdlib>
 
 #include "common.h"
 
@@ -50,7 +51,7 @@ struct FGemmArgs {
     const float* res;     // fp32 coefficient slabs [tile32][cout8][60][h][kp32][4] or null
     float* out;           // same layout
     long long a_off[NIR_ORD], b_off[NIR_ORD];
-    int wg_start[NIR_ORD + 1];
+    int NT[NIR_ORD], MT[NIR_ORD], rot[NIR_ORD];
     int cin, cout, kppad, nT32;
     float descale;
 };
@@ -73,42 +74,30 @@ struct Frags {
     uintx4 ah[4], al[4], bh[4], bl[4];
 };
 
-// fragments of sub-step `sub` from the stage at LDS address p (lane offsets already applied)
+// one fragment read of sub-step SUB from the stage at LDS address pa / pb (lane offsets already applied).
+// Read order = order of use: A lo, B hi (first 16 products), then A hi, B lo.
+template <int SUB, int R>
+__device__ __forceinline__ void read_frag(const char* pa, const char* pb, Frags& f) {
+    constexpr int t = R & 3;
+    if constexpr (R < 4) f.al[t] = *reinterpret_cast<const uintx4*>(pa + (2 + SUB) * 8192 + t * 512);
+    else if constexpr (R < 8) f.bh[t] = *reinterpret_cast<const uintx4*>(pb + (0 + SUB) * 8192 + t * 512);
+    else if constexpr (R < 12) f.ah[t] = *reinterpret_cast<const uintx4*>(pa + (0 + SUB) * 8192 + t * 512);
+    else f.bl[t] = *reinterpret_cast<const uintx4*>(pb + (2 + SUB) * 8192 + t * 512);
+}
+
 template <int SUB>
 __device__ __forceinline__ void read_frags(const char* pa, const char* pb, Frags& f) {
-    // order of use: A lo + B hi, then A hi + B lo
-#pragma unroll
-    for (int t = 0; t < 4; ++t) f.al[t] = *reinterpret_cast<const uintx4*>(pa + (2 + SUB) * 8192 + t * 512);
-#pragma unroll
-    for (int t = 0; t < 4; ++t) f.bh[t] = *reinterpret_cast<const uintx4*>(pb + (0 + SUB) * 8192 + t * 512);
-#pragma unroll
-    for (int t = 0; t < 4; ++t) f.ah[t] = *reinterpret_cast<const uintx4*>(pa + (0 + SUB) * 8192 + t * 512);
-#pragma unroll
-    for (int t = 0; t < 4; ++t) f.bl[t] = *reinterpret_cast<const uintx4*>(pb + (2 + SUB) * 8192 + t * 512);
+    sfor<0, 16>([&](auto rc) { read_frag<SUB, decltype(rc)::value>(pa, pb, f); });
 }
 
-__device__ __forceinline__ void mma_substep(const Frags& f, floatx16 (&acc)[4][4]) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = mfma_h(f.al[i], f.bh[j], acc[i][j]);
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = mfma_h(f.ah[i], f.bl[j], acc[i][j]);
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = mfma_h(f.ah[i], f.bh[j], acc[i][j]);
-}
-
-// scheduling directive: 48 MFMAs with 16 LDS reads spread behind the first 16 of them
-__device__ __forceinline__ void pin_48_16() {
-    sfor<0, 16>([](auto) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-    });
-    __builtin_amdgcn_sched_group_barrier(0x008, 32, 0);
+// 1 KiB of the LDS DMA of a stage: unit U of 16 per wave (8 of the A tile, 8 of the B tile)
+template <int U>
+__device__ __forceinline__ void stage_unit(const char* srcA, const char* srcB, char* dst, int w, int lane) {
+    constexpr int p = U & 7;
+    const int blk = p * 4 + w;
+    const char* src = (U < 8 ? srcA : srcB) + blk * 1024 + lane * 16;
+    char* d = dst + (U < 8 ? 0 : FG_STAGE) + blk * 1024;
+    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)d, 16, 0, 0);
 }
 
 __device__ __forceinline__ void stage_tile(const char* src, char* dst, int w, int lane) {
@@ -119,20 +108,56 @@ __device__ __forceinline__ void stage_tile(const char* src, char* dst, int w, in
     }
 }
 
+// One K16 sub-step: 48 MFMAs on fragment set `f` (every accumulator gets lo*hi, hi*lo, hi*hi, 16 MFMAs apart), with
+// the 16 fragment reads of the next sub-step (and, if DMA, the 16 LDS-DMA units of a later stage) issued one per MFMA
+// behind the first 16.  sched_barrier pins the order: left alone the scheduler puts dependent MFMAs back to back.
+template <int RSUB, bool DMA, int DBG = 0>
+__device__ __forceinline__ void substep(const Frags& f, floatx16 (&acc)[4][4], const char* ra, const char* rb, Frags& nf,
+                                        const char* srcA, const char* srcB, char* dmadst, int w, int lane) {
+    sfor<0, 16>([&](auto gc) {
+        constexpr int g = decltype(gc)::value;
+        acc[g >> 2][g & 3] = mfma_h(f.al[g >> 2], f.bh[g & 3], acc[g >> 2][g & 3]);
+        if constexpr (!(DBG & 1)) read_frag<RSUB, g>(ra, rb, nf);
+        if constexpr (DMA && !(DBG & 2)) stage_unit<g>(srcA, srcB, dmadst, w, lane);
+        __builtin_amdgcn_sched_barrier(0);
+    });
+    sfor<0, 16>([&](auto gc) {
+        constexpr int g = decltype(gc)::value;
+        acc[g >> 2][g & 3] = mfma_h(f.ah[g >> 2], f.bl[g & 3], acc[g >> 2][g & 3]);
+    });
+    __builtin_amdgcn_sched_barrier(0);
+    sfor<0, 16>([&](auto gc) {
+        constexpr int g = decltype(gc)::value;
+        acc[g >> 2][g & 3] = mfma_h(f.ah[g >> 2], f.bh[g & 3], acc[g >> 2][g & 3]);
+    });
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int DBG>
 __global__ __launch_bounds__(256, 1) void fgemm_kernel(FGemmArgs a, int flags) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nwg = gridDim.x, b = blockIdx.x;
-    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = b & 7, slot8 = b >> 3;
-    const int v = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot8;
-    int t = 0;
+    // Work map.  Workgroup b runs on XCD b & 7.  A column tile (irrep t, ntile) and its MT[t] row tiles stay on one XCD
+    // (the B panel is then read from HBM once and served from that XCD's L2 to the other row tiles); the column tiles
+    // of every irrep are dealt round-robin over the XCDs so that all eight get the same mix of long and short K loops.
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    int t = -1, local = 0, r = 0;
+    {
+        int start = 0;
 #pragma unroll
-    for (int i = 1; i < NIR_ORD; ++i) t += (v >= a.wg_start[i]) ? 1 : 0;
+        for (int u = 0; u < NIR_ORD; ++u) {
+            const int ru = (xcd + a.rot[u]) & 7;
+            const int cnt = a.NT[u] > ru ? ((a.NT[u] - 1 - ru) / 8 + 1) * a.MT[u] : 0;
+            if (t < 0 && slot < start + cnt) { t = u; local = slot - start; r = ru; }
+            start += cnt;
+        }
+    }
+    if (t < 0) return;
     const int d = c_fg_d[t], qbase = c_fg_base[t];
-    const int MT = d * a.cout / 256, KS = d * a.cin / 32;
-    const int local = v - a.wg_start[t];
-    const int ntile = local / MT, mtile = local - ntile * MT;
+    const int MT = a.MT[t], KS = d * a.cin / 32;
+    const int cg = local / MT, mtile = local - cg * MT;
+    const int ntile = r + 8 * cg;
     const char* Ag = a.A + a.a_off[t] + (size_t)mtile * KS * FG_STAGE;
     const char* Bg = a.B + a.b_off[t] + (size_t)ntile * KS * FG_STAGE;
     const int wm = w >> 1, wn = w & 1;
@@ -158,55 +183,58 @@ __global__ __launch_bounds__(256, 1) void fgemm_kernel(FGemmArgs a, int flags) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
+    if ((mtile * 256 + wm * 128) >= d * a.cout) {
+        // all 128 rows of this wave are padding (small cout): only keep the LDS DMA and the barriers going
+        for (int s = 0; s < KS; ++s) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            const int s2 = s + 2 < KS ? s + 2 : KS - 1;
+            char* cur = smem + (s & 1) * (2 * FG_STAGE);
+            stage_tile(Ag + (size_t)s2 * FG_STAGE, cur, w, lane);
+            stage_tile(Bg + (size_t)s2 * FG_STAGE, cur + FG_STAGE, w, lane);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return;
+    }
     Frags P, Q;
     read_frags<0>(smem + lane_a, smem + lane_b, P);
+    if constexpr (DBG & 1) read_frags<1>(smem + lane_a, smem + lane_b, Q);
     for (int s = 0; s < KS; ++s) {
         char* cur = smem + (s & 1) * (2 * FG_STAGE);
         char* nxt = smem + ((s + 1) & 1) * (2 * FG_STAGE);
         // sub-step 0: MFMAs on P, fragments of sub-step 1 into Q
-        read_frags<1>(cur + lane_a, cur + lane_b, Q);
-        mma_substep(P, acc);
-        pin_48_16();
-        __builtin_amdgcn_sched_barrier(0);
+        substep<1, false, DBG>(P, acc, cur + lane_a, cur + lane_b, Q, nullptr, nullptr, nullptr, w, lane);
         // everybody has its sub-step-1 fragments in registers: the buffer is free, and stage s+1 has landed
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __syncthreads();
+        if constexpr (!(DBG & 4)) __syncthreads();
         __builtin_amdgcn_sched_barrier(0);
         // sub-step 1: MFMAs on Q; refill the freed buffer with stage s+2 and read the first fragments of stage s+1 into P.
         // Past the end both are repeated on the last stage (branch-free, the data is not used).
         const int s2 = s + 2 < KS ? s + 2 : KS - 1;
-        stage_tile(Ag + (size_t)s2 * FG_STAGE, cur, w, lane);
-        stage_tile(Bg + (size_t)s2 * FG_STAGE, cur + FG_STAGE, w, lane);
-        read_frags<0>(nxt + lane_a, nxt + lane_b, P);
-        mma_substep(Q, acc);
-        sfor<0, 16>([](auto) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-        });
-        __builtin_amdgcn_sched_group_barrier(0x008, 32, 0);
-        __builtin_amdgcn_sched_barrier(0);
+        substep<0, true, DBG>(Q, acc, nxt + lane_a, nxt + lane_b, P, Ag + (size_t)s2 * FG_STAGE, Bg + (size_t)s2 * FG_STAGE, cur, w, lane);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     // ---- epilogue: D[row][col]: lane (col = lane & 31, half = lane >> 5), reg r -> row = (r & 3) + 8 * (r >> 2) + 4 * half
     const int half = lane >> 5, kp32 = lane & 31;
     const int cout8 = a.cout >> 3;
-    const int row0 = mtile * 256 + wm * 128;                 // the 256 rows of a tile share i (cout is a multiple of 256)
-    const int iidx = row0 / a.cout, o0 = row0 - iidx * a.cout;
     const int col0 = ntile * 256 + wn * 128;
     const int jidx = col0 / a.kppad, kp0 = col0 - jidx * a.kppad;
-    const int q = qbase + iidx * d + jidx;
     const bool addb = (d == 1);                              // trivial irrep: coefficient 0 carries sqrt(60) * bias
 #pragma unroll
     for (int bi = 0; bi < 4; ++bi) {
         const int tile32 = (kp0 >> 5) + bi;
         if (tile32 >= a.nT32) continue;
 #pragma unroll
-        for (int ai = 0; ai < 4; ++ai)
+        for (int ai = 0; ai < 4; ++ai) {
+            // the 32 rows of an MFMA tile share i (cout is a multiple of 32)
+            const int rowb = mtile * 256 + wm * 128 + ai * 32;
+            const int iidx = rowb / a.cout, o0 = rowb - iidx * a.cout;
+            if (iidx >= d) continue;
+            const int q = qbase + iidx * d + jidx;
 #pragma unroll
             for (int q4 = 0; q4 < 4; ++q4) {
-                const int o = o0 + ai * 32 + q4 * 8 + half * 4;
+                const int o = o0 + q4 * 8 + half * 4;
                 floatx4 val;
                 val.x = acc[ai][bi][4 * q4 + 0]; val.y = acc[ai][bi][4 * q4 + 1];
                 val.z = acc[ai][bi][4 * q4 + 2]; val.w = acc[ai][bi][4 * q4 + 3];
@@ -216,11 +244,16 @@ __global__ __launch_bounds__(256, 1) void fgemm_kernel(FGemmArgs a, int flags) {
                 if (flags & EPI_RES) val += *reinterpret_cast<const floatx4*>(a.res + off);
                 *reinterpret_cast<floatx4*>(a.out + off) = val;
             }
+        }
     }
 }
 
 int fgemm_init() {
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&fgemm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, FG_LDS));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&fgemm_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, FG_LDS));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&fgemm_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, FG_LDS));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&fgemm_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, FG_LDS));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&fgemm_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, FG_LDS));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&fgemm_kernel<7>), hipFuncAttributeMaxDynamicSharedMemorySize, FG_LDS));
     int dd[NIR_ORD], bb[NIR_ORD];
     for (int t = 0; t < NIR_ORD; ++t) { dd[t] = FG_ORD_D[t]; bb[t] = FG_IR_BASE[FG_ORD_R[t]]; }
     HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_fg_d), dd, sizeof(dd)));
@@ -232,7 +265,7 @@ int fgemm_init() {
 // and kdim = channels of the contracted side
 static long long pack_off(int t, int rows, int kdim) {
     long long off = 0;
-    for (int u = 0; u < t; ++u) off += (long long)(FG_ORD_D[u] * rows / 256) * (FG_ORD_D[u] * kdim / 32) * FG_STAGE;
+    for (int u = 0; u < t; ++u) off += (long long)((FG_ORD_D[u] * rows + 255) / 256) * (FG_ORD_D[u] * kdim / 32) * FG_STAGE;
     return off;
 }
 
@@ -262,7 +295,7 @@ static inline unsigned short half_bits_h(float x) {
 
 // What(r,i,m)[o][c] = sum_k W[o][c][k] rho_r(n_k)[m][i]  ->  A pack (fp16x2 planes of What * 2^s)
 int pack_fgemm_weights(const FourierBasis& fb, const float* W, int cin, int cout, std::vector<unsigned short>& out, float* descale) {
-    if (cout % 256 || cin % 32) return -1;
+    if ((cout % 256 && cout != 32) || cin % 32) return -1;     // row tiles must not straddle i unless the whole irrep fits one tile
     std::vector<float> what((size_t)60 * cout * cin);
     std::vector<double> coef(60 * NTAP);
     for (int r = 0; r < 5; ++r) {
@@ -315,15 +348,31 @@ int launch_fgemm(const Layer& L, const char* Bplanes, int kppad, int nT32, const
     FGemmArgs a;
     a.A = reinterpret_cast<const char*>(L.wpg); a.B = Bplanes; a.bias = L.bias; a.res = res; a.out = out;
     a.cin = L.cin; a.cout = L.cout; a.kppad = kppad; a.nT32 = nT32; a.descale = L.wpg_descale;
-    int tot = 0;
+    static const int ROT[NIR_ORD] = {0, 0, 4, 4, 2};
     for (int t = 0; t < NIR_ORD; ++t) {
         a.a_off[t] = pack_off(t, L.cout, L.cin);
         a.b_off[t] = pack_off(t, kppad, L.cin);
-        a.wg_start[t] = tot;
-        tot += (FG_ORD_D[t] * L.cout / 256) * (FG_ORD_D[t] * kppad / 256);
+        a.MT[t] = (FG_ORD_D[t] * L.cout + 255) / 256;
+        a.NT[t] = FG_ORD_D[t] * kppad / 256;
+        a.rot[t] = ROT[t];
     }
-    a.wg_start[NIR_ORD] = tot;
-    hipLaunchKernelGGL(fgemm_kernel, dim3(tot), dim3(256), FG_LDS, s, a, flags);
+    int tot = 0;
+    for (int x = 0; x < 8; ++x) {
+        int n = 0;
+        for (int t = 0; t < NIR_ORD; ++t) {
+            const int r = (x + a.rot[t]) & 7;
+            if (a.NT[t] > r) n += ((a.NT[t] - 1 - r) / 8 + 1) * a.MT[t];
+        }
+        tot = n > tot ? n : tot;
+    }
+    tot *= 8;
+    int dbg = 0;
+    if (const char* e = std::getenv("YOHO_FG_DEBUG")) dbg = std::atoi(e);
+    if (dbg == 1) hipLaunchKernelGGL(fgemm_kernel<1>, dim3(tot), dim3(256), FG_LDS, s, a, flags);
+    else if (dbg == 2) hipLaunchKernelGGL(fgemm_kernel<2>, dim3(tot), dim3(256), FG_LDS, s, a, flags);
+    else if (dbg == 3) hipLaunchKernelGGL(fgemm_kernel<3>, dim3(tot), dim3(256), FG_LDS, s, a, flags);
+    else if (dbg == 7) hipLaunchKernelGGL(fgemm_kernel<7>, dim3(tot), dim3(256), FG_LDS, s, a, flags);
+    else hipLaunchKernelGGL(fgemm_kernel<0>, dim3(tot), dim3(256), FG_LDS, s, a, flags);
     HIPCHK(hipGetLastError());
     return 0;
 }

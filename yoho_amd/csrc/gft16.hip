@@ -21,6 +21,7 @@ namespace yoho {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef float floatx2 __attribute__((ext_vector_type(2)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
 typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
 typedef _Float16 halfx8 __attribute__((ext_vector_type(8)));
 typedef _Float16 halfx2 __attribute__((ext_vector_type(2)));
@@ -38,7 +39,7 @@ struct Gft16Args {
     const uintx4* Ffrag;      // [matrix 2][rb 2][kb 4][plane 2][lane 64] x 16 B
     const float* bn_s;
     const float* bn_t;
-    int nChunks, C8;
+    int nChunks, C8, B;
     long long qbase[G];       // byte offset of coefficient q inside the operand planes (irrep pack + j and m terms)
     int qstride[G];           // bytes per 256-column tile of q's irrep (= K stages * 32 KiB)
 };
@@ -65,8 +66,11 @@ __device__ __forceinline__ void stage_chunk(const float* src, char* dst, int w, 
     for (int p = w; p < G; p += 4) __builtin_amdgcn_global_load_lds((gptr_t)(s + p * 1024 + lane * 16), (lptr_t)(dst + p * 1024), 16, 0, 0);
 }
 
-template <bool PLANES>
+enum { G16_ACT32 = 0, G16_ACTP = 1, G16_INV = 2 };
+
+template <int MODE>
 __global__ __launch_bounds__(256, 1) void gft16_kernel(Gft16Args a) {
+    constexpr bool PLANES = MODE == G16_ACTP;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -136,6 +140,30 @@ __global__ __launch_bounds__(256, 1) void gft16_kernel(Gft16Args a) {
             for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
                 for (int f = 0; f < 2; ++f) acc[rb][f] = mfma_hh(A1[rb][kb][0], bh[f], acc[rb][f]);
+        }
+
+        if constexpr (MODE == G16_INV) {
+            // group-domain values straight out: y[kp][c][g] (B,32,60), 4 consecutive group elements per store
+            const float osc = 1.f / (F_SCALE * HF_ASCALE);
+            const int kpg = tile32 * TILE + (w & 1) * 16 + (Lp >> 1);
+            if (kpg < a.B) {
+#pragma unroll
+                for (int f = 0; f < 2; ++f) {
+                    const int c = c8 * 8 + (w >> 1) * 4 + 2 * (Lp & 1) + f;
+                    float* dst = a.out32 + ((size_t)kpg * F + c) * G;
+#pragma unroll
+                    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                        for (int t4 = 0; t4 < 4; ++t4) {
+                            const int g0 = 32 * rb + 8 * t4 + 4 * kg;
+                            floatx4 o;
+                            o.x = acc[rb][f][4 * t4] * osc; o.y = acc[rb][f][4 * t4 + 1] * osc;
+                            o.z = acc[rb][f][4 * t4 + 2] * osc; o.w = acc[rb][f][4 * t4 + 3] * osc;
+                            if (g0 < G) *reinterpret_cast<floatx4*>(dst + g0) = o;
+                        }
+                }
+            }
+            continue;
         }
 
         // ---- BN + ReLU in registers, product 2: coefficients = F * activated
@@ -232,11 +260,11 @@ static inline unsigned short hbits(float x) {
     return u;
 }
 
-// MFMA A fragments of F^T (natural K order) and of F (K order = accumulator register order of product 1)
+// MFMA A fragments of F^T (natural K order), of F (K order = accumulator register order of product 1) and of F (natural K order)
 void build_gft16_frags(const FourierBasis& fb, std::vector<unsigned short>& out) {
-    out.assign((size_t)2 * 2 * 4 * 2 * 64 * 8, 0);
+    out.assign((size_t)3 * 2 * 4 * 2 * 64 * 8, 0);
     auto Fv = [&](int q, int g) -> float { return (q < G && g < G) ? (float)fb.F[q * G + g] : 0.f; };
-    for (int mat = 0; mat < 2; ++mat)
+    for (int mat = 0; mat < 3; ++mat)
         for (int rb = 0; rb < 2; ++rb)
             for (int kb = 0; kb < 4; ++kb)
                 for (int lane = 0; lane < 64; ++lane)
@@ -246,9 +274,12 @@ void build_gft16_frags(const FourierBasis& fb, std::vector<unsigned short>& out)
                         if (mat == 0) {
                             const int g = 32 * rb + i, q = 16 * kb + 8 * kg + e;
                             v = Fv(q, g);
-                        } else {
+                        } else if (mat == 1) {
                             const int q = 32 * rb + i;
                             const int g = 32 * (kb >> 1) + (e & 3) + 8 * (2 * (kb & 1) + (e >> 2)) + 4 * kg;
+                            v = Fv(q, g);
+                        } else {
+                            const int q = 32 * rb + i, g = 16 * kb + 8 * kg + e;      // F, natural K order (head kernel)
                             v = Fv(q, g);
                         }
                         v *= F_SCALE;
@@ -260,36 +291,141 @@ void build_gft16_frags(const FourierBasis& fb, std::vector<unsigned short>& out)
 }
 
 int gft16_init() {
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gft16_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, G16_LDS));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gft16_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, G16_LDS));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gft16_kernel<G16_ACT32>), hipFuncAttributeMaxDynamicSharedMemorySize, G16_LDS));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gft16_kernel<G16_ACTP>), hipFuncAttributeMaxDynamicSharedMemorySize, G16_LDS));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gft16_kernel<G16_INV>), hipFuncAttributeMaxDynamicSharedMemorySize, G16_LDS));
     return 0;
 }
 
-// planes != null: operand planes for the irrep GEMMs (kppad columns per j); else fp32 chunks to out32 (may alias in)
+static void fill_qtables(int kppad, int cin, long long* qbase, int* qstride) {
+    int qi[G * 4];
+    long long off[NIR_ORD];
+    fgemm_qinfo(qi);
+    fgemm_plane_offsets(kppad, cin, off);
+    for (int q = 0; q < G; ++q) {
+        const int t = qi[q * 4], m = qi[q * 4 + 1], j = qi[q * 4 + 2], d = qi[q * 4 + 3];
+        const long long KS = d * cin / 32;
+        qstride[q] = (int)(KS * 32768);
+        qbase[q] = off[t] + ((long long)j * (kppad / 256) * KS + (long long)m * cin / 32) * 32768;
+    }
+}
+
+// planes != null: BN + ReLU, operand planes for the irrep GEMMs (kppad columns per j);
+// else bn_s != null: BN + ReLU, fp32 chunks to out32 (may alias in);
+// else: inverse transform only, out32 = group-domain values (B,32,60) (C8 must be 4)
 int launch_gft16(const float* in, float* out32, char* planes, int kppad, const void* Ffrag, const float* bn_s, const float* bn_t, int nTiles,
-                 int C8, int nCU, hipStream_t s) {
+                 int C8, int nCU, hipStream_t s, int B) {
     Gft16Args a;
+    a.B = B;
     a.in = in; a.out32 = out32; a.planes = planes; a.Ffrag = reinterpret_cast<const uintx4*>(Ffrag); a.bn_s = bn_s; a.bn_t = bn_t;
     a.nChunks = nTiles * C8; a.C8 = C8;
     if (planes) {
-        int qi[G * 4];
-        long long off[NIR_ORD];
-        fgemm_qinfo(qi);
-        const int cin = C8 * 8;
-        fgemm_plane_offsets(kppad, cin, off);
-        for (int q = 0; q < G; ++q) {
-            const int t = qi[q * 4], m = qi[q * 4 + 1], j = qi[q * 4 + 2], d = qi[q * 4 + 3];
-            const long long KS = d * cin / 32;
-            a.qstride[q] = (int)(KS * 32768);
-            a.qbase[q] = off[t] + ((long long)j * (kppad / 256) * KS + (long long)m * cin / 32) * 32768;
-        }
+        fill_qtables(kppad, C8 * 8, a.qbase, a.qstride);
     } else {
         for (int q = 0; q < G; ++q) { a.qbase[q] = 0; a.qstride[q] = 0; }
     }
     const int grid = a.nChunks < nCU ? a.nChunks : nCU;
     if (grid == 0) return 0;
-    if (planes) hipLaunchKernelGGL(gft16_kernel<true>, dim3(grid), dim3(256), G16_LDS, s, a);
-    else hipLaunchKernelGGL(gft16_kernel<false>, dim3(grid), dim3(256), G16_LDS, s, a);
+    if (planes) hipLaunchKernelGGL(gft16_kernel<G16_ACTP>, dim3(grid), dim3(256), G16_LDS, s, a);
+    else if (bn_s) hipLaunchKernelGGL(gft16_kernel<G16_ACT32>, dim3(grid), dim3(256), G16_LDS, s, a);
+    else hipLaunchKernelGGL(gft16_kernel<G16_INV>, dim3(grid), dim3(256), G16_LDS, s, a);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// head: x (B,32,60) fp32 -> Fourier coefficients as operand planes of the first irrep GEMM (cin = 32).
+// One wave per (32-keypoint tile, 8-channel block): MFMA column = keypoint, eight column blocks = the eight channels,
+// so a lane ends up with the 8 channels of one (coefficient, keypoint) = one 16-byte unit of each plane.  The group
+// axis is contiguous in x, i.e. K-contiguous per column: B fragments are two 16-byte global loads.
+// ---------------------------------------------------------------------------------------------------------------
+struct Head16Args {
+    const float* x;
+    char* planes;
+    const uintx4* Ffrag;
+    int B, nTiles;
+    long long qbase[G];
+    int qstride[G];
+};
+
+__global__ __launch_bounds__(256, 1) void head16_kernel(Head16Args a) {
+    __shared__ long long qb[G];
+    __shared__ int qs[G];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);       // = 8-channel block
+    const int Lp = lane & 31, kg = lane >> 5;
+    if (tid < G) { qb[tid] = a.qbase[tid]; qs[tid] = a.qstride[tid]; }
+    __syncthreads();
+    const int tile32 = blockIdx.x;
+    const int kp = tile32 * TILE + Lp;
+    uintx4 A[2][4][2];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) A[rb][kb][pl] = a.Ffrag[(((2 * 2 + rb) * 4 + kb) * 2 + pl) * 64 + lane];
+
+    floatx16 acc[8][2];
+#pragma unroll
+    for (int f = 0; f < 8; ++f) {
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[f][rb][r] = 0.f;
+        const float* xp = a.x + ((size_t)kp * F + (8 * w + f)) * G + 8 * kg;
+        floatx4 v[4][2];
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            const bool ok = kp < a.B;
+            v[kb][0] = ok ? *reinterpret_cast<const floatx4*>(xp + 16 * kb) : floatx4{0.f, 0.f, 0.f, 0.f};
+            v[kb][1] = (ok && (16 * kb + 8 * kg + 4) < G) ? *reinterpret_cast<const floatx4*>(xp + 16 * kb + 4) : floatx4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            uintx4 bh, bl;
+            unsigned h, l;
+            split_pair(v[kb][0].x * H2_ASCALE, v[kb][0].y * H2_ASCALE, h, l); bh.x = h; bl.x = l;
+            split_pair(v[kb][0].z * H2_ASCALE, v[kb][0].w * H2_ASCALE, h, l); bh.y = h; bl.y = l;
+            split_pair(v[kb][1].x * H2_ASCALE, v[kb][1].y * H2_ASCALE, h, l); bh.z = h; bl.z = l;
+            split_pair(v[kb][1].z * H2_ASCALE, v[kb][1].w * H2_ASCALE, h, l); bh.w = h; bl.w = l;
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) acc[f][rb] = mfma_hh(A[rb][kb][1], bh, acc[f][rb]);
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) acc[f][rb] = mfma_hh(A[rb][kb][0], bl, acc[f][rb]);
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) acc[f][rb] = mfma_hh(A[rb][kb][0], bh, acc[f][rb]);
+        }
+    }
+    // acc[f][rb][r]: coefficient q = 32 rb + (r&3) + 8 (r>>2) + 4 kg of (keypoint Lp, channel 8w + f)
+    const float osc = HF_ASCALE / (F_SCALE * H2_ASCALE);
+    char* dst0 = a.planes + (w & 3) * 4096 + ((tile32 & 7) * 32 + Lp) * 16;         // cin = 32: K stage 0 of every m
+    const int nt = tile32 >> 3;
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int q = 32 * rb + (r & 3) + 8 * (r >> 2) + 4 * kg;
+            uintx4 ph, pl;
+            unsigned h, l;
+            split_pair(acc[0][rb][r] * osc, acc[1][rb][r] * osc, h, l); ph.x = h; pl.x = l;
+            split_pair(acc[2][rb][r] * osc, acc[3][rb][r] * osc, h, l); ph.y = h; pl.y = l;
+            split_pair(acc[4][rb][r] * osc, acc[5][rb][r] * osc, h, l); ph.z = h; pl.z = l;
+            split_pair(acc[6][rb][r] * osc, acc[7][rb][r] * osc, h, l); ph.w = h; pl.w = l;
+            if (q < G) {
+                char* d = dst0 + qb[q] + (long long)nt * qs[q];
+                *reinterpret_cast<uintx4*>(d) = ph;
+                *reinterpret_cast<uintx4*>(d + 16384) = pl;
+            }
+        }
+}
+
+int launch_head16(const float* x, int B, int nTiles, char* planes, int kppad, const void* Ffrag, hipStream_t s) {
+    Head16Args a;
+    a.x = x; a.planes = planes; a.Ffrag = reinterpret_cast<const uintx4*>(Ffrag); a.B = B; a.nTiles = nTiles;
+    fill_qtables(kppad, 32, a.qbase, a.qstride);
+    if (nTiles == 0) return 0;
+    hipLaunchKernelGGL(head16_kernel, dim3(nTiles), dim3(256), 0, s, a);
     HIPCHK(hipGetLastError());
     return 0;
 }

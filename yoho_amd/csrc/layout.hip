@@ -73,12 +73,13 @@ __global__ __launch_bounds__(64) void finalize_partI_kernel(const float* __restr
     __shared__ float rn[G];
     const int b = blockIdx.x;
     const int lane = threadIdx.x;
-    const int tw = layout16 ? 16 : TILE;
+    const int tw = layout16 == 1 ? 16 : TILE;
     const int tile = b / tw, kp = b - tile * tw;
     const float* xb = x + (size_t)b * (F * G);
     for (int i = lane; i < F * G; i += 64) {
         const int c = i / G, g = i - c * G;
-        e[i] = y[layout16 ? iidx16(tile, 4, c, g, kp) : iidx(tile, 4, c, g, kp)] + xb[i];
+        // layout16: 0 = fp32 32-keypoint tile layout, 1 = 16-keypoint tile layout, 2 = plain (B,32,60)
+        e[i] = y[layout16 == 2 ? (size_t)b * (F * G) + i : (layout16 ? iidx16(tile, 4, c, g, kp) : iidx(tile, 4, c, g, kp))] + xb[i];
     }
     __syncthreads();
     if (lane < G) {
