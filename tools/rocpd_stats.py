@@ -3,11 +3,18 @@
 
     python tools/rocpd_stats.py gpurun_out/prof/bench_results.db > profiles/r01_kernel_stats.md
 """
+import glob
+import os
 import sqlite3
 import sys
 
 
 def main(path):
+    if os.path.isdir(path):
+        found = glob.glob(os.path.join(path, "**", "*.db"), recursive=True)
+        if not found:
+            raise SystemExit("no .db under " + path)
+        path = found[0]
     db = sqlite3.connect(path)
     rows = db.execute(
         "select name, count(*), sum(duration), avg(duration), min(duration), max(duration), "
@@ -20,13 +27,14 @@ def main(path):
         name = r[0] if len(r[0]) < 90 else r[0][:87] + "..."
         print(f"| `{name}` | {r[1]} | {r[2] / 1e6:.3f} | {r[3] / 1e3:.1f} | {r[4] / 1e3:.1f} | {r[5] / 1e3:.1f} | "
               f"{100 * r[2] / tot:.1f} | {r[6]} | {r[7]} | {r[8]} | {r[9]} | {r[10]} | {r[11]} |")
-    # per-launch listing for the group-conv kernel (the 4 PartI layers differ in shape)
-    print("\nPer-launch durations of gconv_kernel<15,false> by grid size (one PartI pass = 4 launches):\n")
-    print("| grid (threads) | calls | avg us |")
-    print("|---|---|---|")
-    for g, n, a in db.execute("select grid_x, count(*), avg(duration) from kernels where name like '%gconv_kernel<15%' "
-                              "group by grid_x order by grid_x"):
-        print(f"| {g} | {n} | {a / 1e3:.1f} |")
+    # per-launch listing by grid size (the layers of one pass share a kernel but differ in shape)
+    print("\nPer-launch durations by kernel and grid size:\n")
+    print("| kernel | grid (threads) | calls | avg us |")
+    print("|---|---|---|---|")
+    for nm, g, n, a in db.execute("select name, grid_x, count(*), avg(duration) from kernels group by name, grid_x "
+                                  "having sum(duration) > 0 order by name, grid_x"):
+        nm = nm if len(nm) < 70 else nm[:67] + "..."
+        print(f"| `{nm}` | {g} | {n} | {a / 1e3:.1f} |")
 
 
 if __name__ == "__main__":

@@ -563,7 +563,7 @@ int yoho_partI_forward(yoho_ctx* c, const float* x, int B, float* eqv, float* in
     if (!c->has_partI) { set_error("yoho_partI_forward: PartI weights not loaded"); return YOHO_ENOWEIGHTS; }
     HIPCHK(hipSetDevice(c->device));
     hipStream_t s = (hipStream_t)stream;
-    const int MAXB = 8192;                       // bounds the workspace to ~2.2 GB
+    const int MAXB = 16384;                      // bounds the workspace to ~4.5 GB
     for (int b0 = 0; b0 < B; b0 += MAXB) {
         const int nb = B - b0 < MAXB ? B - b0 : MAXB;
         int rc = partI_pass(c, x + (size_t)b0 * F * G, nb, eqv + (size_t)b0 * F * G, inv ? inv + (size_t)b0 * F : nullptr,
@@ -588,11 +588,13 @@ static int partII_pass16(yoho_ctx* c, const float* s0, const float* s1, const fl
     const size_t ch = (size_t)CHUNK_FLOATS * sizeof(float), ch16 = (size_t)npl * 15360;
     const size_t n128 = (size_t)nT * 16, n256 = (size_t)nT * 32, n512 = (size_t)nT * 64, n32 = (size_t)nT * 4;
     const size_t szX = (size_t)nT16 * 16 * ch16, szA0 = (size_t)nT16 * 32 * ch16;
+    const size_t szA1p = npl == 2 ? (size_t)nT16 * 64 * ch16 : 0;      // fp16x2: 13-cone activation planes for cone1_kernel
     int rc;
-    if ((rc = ensure_ws(c, szX + szA0 + (n256 + n512 + n256 + n512 + n128 + n32) * ch, s))) return rc;
+    if ((rc = ensure_ws(c, szX + szA0 + szA1p + (n256 + n512 + n256 + n512 + n128 + n32) * ch, s))) return rc;
     char* bX = (char*)c->ws.p;                          // 128 ch planes
     char* bA0 = bX + szX;                               // 256 ch planes (45 slabs valid)
-    float* bH0 = (float*)(bA0 + szA0);                  // 256 raw fp32, 32-tile layout
+    char* bA1p = bA0 + szA0;                            // 512 ch planes (13 slabs valid)
+    float* bH0 = (float*)(bA1p + szA1p);                // 256 raw fp32, 32-tile layout
     float* bA1 = bH0 + n256 * CHUNK_FLOATS;             // 512 act fp32 (13 slabs valid)
     float* bF = bA1 + n512 * CHUNK_FLOATS;              // 256 raw (g = 0)
     float* bF0 = bF + n256 * CHUNK_FLOATS;              // 512 act
@@ -600,8 +602,15 @@ static int partII_pass16(yoho_ctx* c, const float* s0, const float* s1, const fl
     float* bQ = bF1 + n128 * CHUNK_FLOATS;              // 32 raw (4 used)
     if ((rc = launch_pack16_partII(s0, s1, s2, s3, idx, c->dP, c->p2_init_bn_s, c->p2_init_bn_t, M, nT16, bX, s, npl))) return rc;
     if ((rc = launch_gconv16(c->p2[0], bX, nT16, nullptr, nullptr, bA0, EPI_RAW32 | EPI_ACT, s, 1, bH0, nullptr, npl))) return rc;
-    if ((rc = launch_gconv16(c->p2[1], bA0, nT16, nullptr, nullptr, nullptr, EPI_ACT32, s, 2, nullptr, bA1, npl))) return rc;
-    if ((rc = launch_gconv(conv_args(c->p2[2], bA1, nT, bH0, bF, nullptr, true), -1, EPI_RES | EPI_RAW, s))) return rc;
+    if (npl == 2) {
+        int n0[NTAP];
+        for (int k = 0; k < NTAP; ++k) n0[k] = c->hN[k];
+        if ((rc = launch_gconv16(c->p2[1], bA0, nT16, nullptr, nullptr, bA1p, EPI_ACT, s, 2, nullptr, nullptr, npl))) return rc;
+        if ((rc = launch_cone1(c->p2[2], bA1p, nT, nT16, bH0, bF, n0, s))) return rc;
+    } else {
+        if ((rc = launch_gconv16(c->p2[1], bA0, nT16, nullptr, nullptr, nullptr, EPI_ACT32, s, 2, nullptr, bA1, npl))) return rc;
+        if ((rc = launch_gconv(conv_args(c->p2[2], bA1, nT, bH0, bF, nullptr, true), -1, EPI_RES | EPI_RAW, s))) return rc;
+    }
     if ((rc = launch_gconv(conv_args(c->p2[3], bF, nT, nullptr, nullptr, bF0, true), -1, EPI_ACT, s))) return rc;
     if ((rc = launch_gconv(conv_args(c->p2[4], bF0, nT, nullptr, nullptr, bF1, true), -1, EPI_ACT, s))) return rc;
     if ((rc = launch_gconv(conv_args(c->p2[5], bF1, nT, nullptr, bQ, nullptr, false), 1, EPI_RAW, s))) return rc;

@@ -90,14 +90,21 @@ __device__ __forceinline__ void read_frags(const char* pa, const char* pb, Frags
     sfor<0, 16>([&](auto rc) { read_frag<SUB, decltype(rc)::value>(pa, pb, f); });
 }
 
-// 1 KiB of the LDS DMA of a stage: unit U of 16 per wave (8 of the A tile, 8 of the B tile)
+// 1 KiB of the LDS DMA of a stage: unit U of 16 per wave (8 of the A tile, 8 of the B tile).  srcA / srcB are wave
+// uniform (scalar base + per-lane 32-bit offset addressing, no 64-bit vector adds between the MFMAs)
 template <int U>
-__device__ __forceinline__ void stage_unit(const char* srcA, const char* srcB, char* dst, int w, int lane) {
+__device__ __forceinline__ void stage_unit(const char* srcA, const char* srcB, char* dst, int w, int lane16) {
     constexpr int p = U & 7;
     const int blk = p * 4 + w;
-    const char* src = (U < 8 ? srcA : srcB) + blk * 1024 + lane * 16;
+    const char* src = (U < 8 ? srcA : srcB) + blk * 1024;
     char* d = dst + (U < 8 ? 0 : FG_STAGE) + blk * 1024;
-    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)d, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr_t)(src + lane16), (lptr_t)d, 16, 0, 0);
+}
+
+__device__ __forceinline__ const char* uniform_ptr(const char* p) {
+    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return reinterpret_cast<const char*>(((unsigned long long)hi << 32) | lo);
 }
 
 __device__ __forceinline__ void stage_tile(const char* src, char* dst, int w, int lane) {
@@ -113,17 +120,20 @@ __device__ __forceinline__ void stage_tile(const char* src, char* dst, int w, in
 // behind the first 16.  sched_barrier pins the order: left alone the scheduler puts dependent MFMAs back to back.
 template <int RSUB, bool DMA, int DBG = 0>
 __device__ __forceinline__ void substep(const Frags& f, floatx16 (&acc)[4][4], const char* ra, const char* rb, Frags& nf,
-                                        const char* srcA, const char* srcB, char* dmadst, int w, int lane) {
+                                        const char* srcA, const char* srcB, char* dmadst, int w, int lane16) {
     sfor<0, 16>([&](auto gc) {
         constexpr int g = decltype(gc)::value;
         acc[g >> 2][g & 3] = mfma_h(f.al[g >> 2], f.bh[g & 3], acc[g >> 2][g & 3]);
         if constexpr (!(DBG & 1)) read_frag<RSUB, g>(ra, rb, nf);
-        if constexpr (DMA && !(DBG & 2)) stage_unit<g>(srcA, srcB, dmadst, w, lane);
         __builtin_amdgcn_sched_barrier(0);
     });
     sfor<0, 16>([&](auto gc) {
         constexpr int g = decltype(gc)::value;
         acc[g >> 2][g & 3] = mfma_h(f.ah[g >> 2], f.bl[g & 3], acc[g >> 2][g & 3]);
+        if constexpr (DMA && !(DBG & 2)) {
+            stage_unit<g>(srcA, srcB, dmadst, w, lane16);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     });
     __builtin_amdgcn_sched_barrier(0);
     sfor<0, 16>([&](auto gc) {
@@ -161,6 +171,7 @@ __global__ __launch_bounds__(256, 1) void fgemm_kernel(FGemmArgs a, int flags) {
     const char* Ag = a.A + a.a_off[t] + (size_t)mtile * KS * FG_STAGE;
     const char* Bg = a.B + a.b_off[t] + (size_t)ntile * KS * FG_STAGE;
     const int wm = w >> 1, wn = w & 1;
+    const int lane16 = lane * 16;
 
     floatx16 acc[4][4];
 #pragma unroll
@@ -203,7 +214,7 @@ __global__ __launch_bounds__(256, 1) void fgemm_kernel(FGemmArgs a, int flags) {
         char* cur = smem + (s & 1) * (2 * FG_STAGE);
         char* nxt = smem + ((s + 1) & 1) * (2 * FG_STAGE);
         // sub-step 0: MFMAs on P, fragments of sub-step 1 into Q
-        substep<1, false, DBG>(P, acc, cur + lane_a, cur + lane_b, Q, nullptr, nullptr, nullptr, w, lane);
+        substep<1, false, DBG>(P, acc, cur + lane_a, cur + lane_b, Q, nullptr, nullptr, nullptr, w, lane16);
         // everybody has its sub-step-1 fragments in registers: the buffer is free, and stage s+1 has landed
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         if constexpr (!(DBG & 4)) __syncthreads();
@@ -211,7 +222,8 @@ __global__ __launch_bounds__(256, 1) void fgemm_kernel(FGemmArgs a, int flags) {
         // sub-step 1: MFMAs on Q; refill the freed buffer with stage s+2 and read the first fragments of stage s+1 into P.
         // Past the end both are repeated on the last stage (branch-free, the data is not used).
         const int s2 = s + 2 < KS ? s + 2 : KS - 1;
-        substep<0, true, DBG>(Q, acc, nxt + lane_a, nxt + lane_b, P, Ag + (size_t)s2 * FG_STAGE, Bg + (size_t)s2 * FG_STAGE, cur, w, lane);
+        substep<0, true, DBG>(Q, acc, nxt + lane_a, nxt + lane_b, P, uniform_ptr(Ag + (size_t)s2 * FG_STAGE), uniform_ptr(Bg + (size_t)s2 * FG_STAGE),
+                              cur, w, lane16);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 

@@ -18,8 +18,12 @@ def run_pair(ctx, feat0, feat1, keys0, keys1, inlier_dist=0.09, max_iter=1000, o
     Returns PairResult with device tensors (trans is a (3,4) f64 host array, eye(4) rows if no
     hypothesis has an inlier, as tests/estimator.py:327-336)."""
     if eqv is None:
-        o0 = ctx.partI_forward(feat0, want_inv=False, want_inv_np=True)
-        o1 = ctx.partI_forward(feat1, want_inv=False, want_inv_np=True)
+        # both fragments in one descriptor batch (tests/extractor.py:51-59 batches keypoints the same way): larger
+        # launches fill the chip better than two half-size passes
+        n0 = feat0.shape[0]
+        o = ctx.partI_forward(torch.cat([feat0, feat1]), want_inv=False, want_inv_np=True)
+        o0 = {k: (v[:n0] if v is not None else None) for k, v in o.items()}
+        o1 = {k: (v[n0:] if v is not None else None) for k, v in o.items()}
     else:
         o0, o1 = eqv
     # tests/matcher.py:35-48
