@@ -211,9 +211,9 @@ __global__ __launch_bounds__(256, 1) void gft16_kernel(Gft16Args a) {
         if (PLANES) {
             const float osc = HF_ASCALE / (F_SCALE * H2_ASCALE);
             __syncthreads();                                   // every wave is done reading the coefficients of this buffer
-            // staging image [plane][q][kp 32][8 ch] fp16
+            // staging image [plane][q][h][kp 32][4 ch] fp16: the 32 lanes of a half-wave write 128 contiguous bytes
             const int kp = (w & 1) * 16 + (Lp >> 1);
-            char* st = cur + kp * 16 + ((w >> 1) * 4 + 2 * (Lp & 1)) * 2;
+            char* st = cur + (w >> 1) * 256 + kp * 8 + (Lp & 1) * 4;
 #pragma unroll
             for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
@@ -231,11 +231,13 @@ __global__ __launch_bounds__(256, 1) void gft16_kernel(Gft16Args a) {
             const int nt = tile32 >> 3;
 #pragma unroll
             for (int i = 0; i < 15; ++i) {
-                const int idx = i * 256 + tid;
+                const int idx = i * 256 + tid;                 // (plane, q, kp): 16 bytes = channels 0-3 (h = 0) | 4-7 (h = 1)
                 const int pl = idx >= 1920 ? 1 : 0, rem = idx - pl * 1920;
                 const int q = rem >> 5, kpp = rem & 31;
-                const uintx4 val = *reinterpret_cast<const uintx4*>(cur + idx * 16);
-                *reinterpret_cast<uintx4*>(dst0 + qb[q] + (long long)nt * qs[q] + kpp * 16 + pl * 16384) = val;
+                const char* sp = cur + pl * 30720 + q * 512 + kpp * 8;
+                const uint2 c03 = *reinterpret_cast<const uint2*>(sp);
+                const uint2 c47 = *reinterpret_cast<const uint2*>(sp + 256);
+                *reinterpret_cast<uintx4*>(dst0 + qb[q] + (long long)nt * qs[q] + kpp * 16 + pl * 16384) = uintx4{c03.x, c03.y, c47.x, c47.y};
             }
         } else {
             const float osc = 1.f / (F_SCALE * H2_ASCALE);
