@@ -358,7 +358,7 @@ int yoho_load_partII(yoho_ctx* c, const yoho_partII_weights* w) {
     if (c->p2_init_bn_t) { (void)hipFree(c->p2_init_bn_t); c->p2_init_bn_t = nullptr; }
     if ((rc = upload(s.data(), 128 * sizeof(float), (void**)&c->p2_init_bn_s))) return rc;
     if ((rc = upload(t.data(), 128 * sizeof(float), (void**)&c->p2_init_bn_t))) return rc;
-    if ((rc = build_layer(c->p2[0], w->init, 128, 256, NTAP, &w->res_in_bn))) return rc;
+    if ((rc = build_layer(c->p2[0], w->init, 128, 256, NTAP, &w->res_in_bn, c->fb))) return rc;      // + irrep-GEMM weights
     if ((rc = build_layer(c->p2[1], w->res_in, 256, 512, NTAP, &w->res_out_bn))) return rc;
     if ((rc = build_layer(c->p2[2], w->res_out, 512, 256, NTAP, nullptr))) return rc;
     if ((rc = build_layer(c->p2[3], w->fc0, 256, 512, 1, &w->fc0_bn))) return rc;
@@ -600,8 +600,24 @@ static int partII_pass16(yoho_ctx* c, const float* s0, const float* s1, const fl
     float* bF0 = bF + n256 * CHUNK_FLOATS;              // 512 act
     float* bF1 = bF0 + n512 * CHUNK_FLOATS;             // 128 act
     float* bQ = bF1 + n128 * CHUNK_FLOATS;              // 32 raw (4 used)
-    if ((rc = launch_pack16_partII(s0, s1, s2, s3, idx, c->dP, c->p2_init_bn_s, c->p2_init_bn_t, M, nT16, bX, s, npl))) return rc;
-    if ((rc = launch_gconv16(c->p2[0], bX, nT16, nullptr, nullptr, bA0, EPI_RAW32 | EPI_ACT, s, 1, bH0, nullptr, npl))) return rc;
+    if (npl == 2 && c->p2[0].wpg && !std::getenv("YOHO_PARTII_L0_DIRECT")) {
+        // first layer (128 -> 256) in the group-Fourier domain: all 60 outputs cost 244/780 of a full direct layer, i.e.
+        // less than half of the 45-element cone the direct kernel computes
+        const int kppad = (M + 255) / 256 * 256;
+        const size_t szP = fgemm_planes_bytes(kppad, 128);
+        if ((rc = ensure_ws(c, szX + szA0 + szA1p + (n256 + n512 + n256 + n512 + n128 + n32) * ch + szP + n256 * ch, s))) return rc;
+        // ensure_ws may have moved the workspace
+        bX = (char*)c->ws.p; bA0 = bX + szX; bA1p = bA0 + szA0; bH0 = (float*)(bA1p + szA1p); bA1 = bH0 + n256 * CHUNK_FLOATS;
+        bF = bA1 + n512 * CHUNK_FLOATS; bF0 = bF + n256 * CHUNK_FLOATS; bF1 = bF0 + n512 * CHUNK_FLOATS; bQ = bF1 + n128 * CHUNK_FLOATS;
+        char* bP = (char*)(bQ + n32 * CHUNK_FLOATS);
+        float* bC = (float*)(bP + szP);                 // raw Fourier coefficients of the first layer
+        if ((rc = launch_head2(s0, s1, s2, s3, idx, c->dP, c->p2_init_bn_s, c->p2_init_bn_t, M, nT, bP, kppad, c->dF16, s))) return rc;
+        if ((rc = launch_fgemm(c->p2[0], bP, kppad, nT, nullptr, bC, 0, s))) return rc;
+        if ((rc = launch_gft16_invp(bC, bH0, bA0, nT16, c->dF16, c->p2[0].bn_s, c->p2[0].bn_t, nT, 32, c->nCU, s))) return rc;
+    } else {
+        if ((rc = launch_pack16_partII(s0, s1, s2, s3, idx, c->dP, c->p2_init_bn_s, c->p2_init_bn_t, M, nT16, bX, s, npl))) return rc;
+        if ((rc = launch_gconv16(c->p2[0], bX, nT16, nullptr, nullptr, bA0, EPI_RAW32 | EPI_ACT, s, 1, bH0, nullptr, npl))) return rc;
+    }
     if (npl == 2) {
         int n0[NTAP];
         for (int k = 0; k < NTAP; ++k) n0[k] = c->hN[k];

@@ -40,6 +40,8 @@ struct Gft16Args {
     const float* bn_s;
     const float* bn_t;
     int nChunks, C8, B;
+    float* res0;              // G16_INVP: raw group-domain values at group element 0, fp32 [tile32][C8][60][h][kp32][4] (slab 0 only)
+    int nTiles16;             // G16_INVP: activated values as direct-conv planes [tile16][C8][plane][60][16][8] into `planes`
     long long qbase[G];       // byte offset of coefficient q inside the operand planes (irrep pack + j and m terms)
     int qstride[G];           // bytes per 256-column tile of q's irrep (= K stages * 32 KiB)
 };
@@ -66,7 +68,7 @@ __device__ __forceinline__ void stage_chunk(const float* src, char* dst, int w, 
     for (int p = w; p < G; p += 4) __builtin_amdgcn_global_load_lds((gptr_t)(s + p * 1024 + lane * 16), (lptr_t)(dst + p * 1024), 16, 0, 0);
 }
 
-enum { G16_ACT32 = 0, G16_ACTP = 1, G16_INV = 2 };
+enum { G16_ACT32 = 0, G16_ACTP = 1, G16_INV = 2, G16_INVP = 3 };
 
 template <int MODE>
 __global__ __launch_bounds__(256, 1) void gft16_kernel(Gft16Args a) {
@@ -162,6 +164,49 @@ __global__ __launch_bounds__(256, 1) void gft16_kernel(Gft16Args a) {
                             if (g0 < G) *reinterpret_cast<floatx4*>(dst + g0) = o;
                         }
                 }
+            }
+            continue;
+        }
+
+        if constexpr (MODE == G16_INVP) {
+            // inverse transform + BN + ReLU, output in the group domain for the direct cone kernels (PartII)
+            const int ch0 = c8 * 8 + (w >> 1) * 4 + 2 * (Lp & 1);
+            const float d1 = 1.f / (F_SCALE * HF_ASCALE);
+            const float s0 = a.bn_s[ch0] * d1 * H2_ASCALE, s1 = a.bn_s[ch0 + 1] * d1 * H2_ASCALE;
+            const float t0 = a.bn_t[ch0] * H2_ASCALE, t1 = a.bn_t[ch0 + 1] * H2_ASCALE;
+            const int kp = (w & 1) * 16 + (Lp >> 1);
+            if (kg == 0) {                                     // group element 0 = accumulator row 0 of the lanes with kg = 0
+                floatx2 o;
+                o.x = acc[0][0][0] * d1; o.y = acc[0][1][0] * d1;
+                *reinterpret_cast<floatx2*>(a.res0 + (((((size_t)tile32 * a.C8 + c8) * G + 0) * 2 + (w >> 1)) * TILE + kp) * 4 + 2 * (Lp & 1)) = o;
+            }
+            __syncthreads();                                   // every wave is done reading the coefficients of this buffer
+            char* st = cur + (w >> 1) * 256 + kp * 8 + (Lp & 1) * 4;     // staging image [plane][g][h][kp 32][4 ch] fp16
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int g = 32 * rb + (r & 3) + 8 * (r >> 2) + 4 * kg;
+                    unsigned hi, lo;
+                    split_pair(fmaxf(acc[rb][0][r] * s0 + t0, 0.f), fmaxf(acc[rb][1][r] * s1 + t1, 0.f), hi, lo);
+                    if (g < G) {
+                        *reinterpret_cast<unsigned*>(st + g * 512) = hi;
+                        *reinterpret_cast<unsigned*>(st + 30720 + g * 512) = lo;
+                    }
+                }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 15; ++i) {
+                const int idx = i * 256 + tid;                 // (plane, g, kp)
+                const int pl = idx >= 1920 ? 1 : 0, rem = idx - pl * 1920;
+                const int g = rem >> 5, kpp = rem & 31;
+                const int t16 = 2 * tile32 + (kpp >> 4);
+                const char* sp = cur + pl * 30720 + g * 512 + kpp * 8;
+                const uint2 c03 = *reinterpret_cast<const uint2*>(sp);
+                const uint2 c47 = *reinterpret_cast<const uint2*>(sp + 256);
+                if (t16 < a.nTiles16)
+                    *reinterpret_cast<uintx4*>(a.planes + (((size_t)t16 * a.C8 + c8) * 2 + pl) * 15360 + g * 256 + (kpp & 15) * 16) =
+                        uintx4{c03.x, c03.y, c47.x, c47.y};
             }
             continue;
         }
@@ -296,6 +341,7 @@ int gft16_init() {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gft16_kernel<G16_ACT32>), hipFuncAttributeMaxDynamicSharedMemorySize, G16_LDS));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gft16_kernel<G16_ACTP>), hipFuncAttributeMaxDynamicSharedMemorySize, G16_LDS));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gft16_kernel<G16_INV>), hipFuncAttributeMaxDynamicSharedMemorySize, G16_LDS));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gft16_kernel<G16_INVP>), hipFuncAttributeMaxDynamicSharedMemorySize, G16_LDS));
     return 0;
 }
 
@@ -318,7 +364,7 @@ static void fill_qtables(int kppad, int cin, long long* qbase, int* qstride) {
 int launch_gft16(const float* in, float* out32, char* planes, int kppad, const void* Ffrag, const float* bn_s, const float* bn_t, int nTiles,
                  int C8, int nCU, hipStream_t s, int B) {
     Gft16Args a;
-    a.B = B;
+    a.B = B; a.res0 = nullptr; a.nTiles16 = 0;
     a.in = in; a.out32 = out32; a.planes = planes; a.Ffrag = reinterpret_cast<const uintx4*>(Ffrag); a.bn_s = bn_s; a.bn_t = bn_t;
     a.nChunks = nTiles * C8; a.C8 = C8;
     if (planes) {
@@ -428,6 +474,156 @@ int launch_head16(const float* x, int B, int nTiles, char* planes, int kppad, co
     fill_qtables(kppad, 32, a.qbase, a.qstride);
     if (nTiles == 0) return 0;
     hipLaunchKernelGGL(head16_kernel, dim3(nTiles), dim3(256), 0, s, a);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// PartII: fp32 coefficients (C8 * 8 channels) -> inverse transform; raw values at group element 0 -> res0 (fp32 tile layout),
+// relu(bn) of all 60 group elements -> fp16x2 planes of the direct cone kernels
+int launch_gft16_invp(const float* in, float* res0, char* planes16, int nTiles16, const void* Ffrag, const float* bn_s, const float* bn_t,
+                      int nTiles, int C8, int nCU, hipStream_t s) {
+    Gft16Args a;
+    a.in = in; a.out32 = nullptr; a.planes = planes16; a.Ffrag = reinterpret_cast<const uintx4*>(Ffrag); a.bn_s = bn_s; a.bn_t = bn_t;
+    a.nChunks = nTiles * C8; a.C8 = C8; a.B = 0; a.res0 = res0; a.nTiles16 = nTiles16;
+    for (int q = 0; q < G; ++q) { a.qbase[q] = 0; a.qstride[q] = 0; }
+    const int grid = a.nChunks < nCU ? a.nChunks : nCU;
+    if (grid == 0) return 0;
+    hipLaunchKernelGGL(gft16_kernel<G16_INVP>, dim3(grid), dim3(256), G16_LDS, s, a);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// PartII head (utils/network.py:266-269 + Conv_init's BN/ReLU :16-17): per match, the group axis of before_eqv0 /
+// after_eqv0 is permuted by P[pre_idx], the four 32-channel sources are concatenated, BN(128) + ReLU, then the forward
+// transform -> operand planes of the first irrep GEMM (cin = 128).  Same scheme as head16_kernel; a wave takes the
+// 8-channel blocks w, w+4, w+8, w+12 = one block of each source.  Permuted sources are gathered element-wise.
+// ---------------------------------------------------------------------------------------------------------------
+struct Head2Args {
+    const float* src[4];
+    const int64_t* pre_idx;
+    const int* P;
+    const float* bn_s;
+    const float* bn_t;
+    char* planes;
+    const uintx4* Ffrag;
+    int M;
+    long long qbase[G];
+    int qstride[G];
+};
+
+__global__ __launch_bounds__(256, 1) void head2_kernel(Head2Args a) {
+    __shared__ long long qb[G];
+    __shared__ int qs[G];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int Lp = lane & 31, kg = lane >> 5;
+    if (tid < G) { qb[tid] = a.qbase[tid]; qs[tid] = a.qstride[tid]; }
+    __syncthreads();
+    const int tile32 = blockIdx.x;
+    const int m = tile32 * TILE + Lp;
+    const bool ok = m < a.M;
+    uintx4 A[2][4][2];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) A[rb][kb][pl] = a.Ffrag[(((2 * 2 + rb) * 4 + kb) * 2 + pl) * 64 + lane];
+    // source group element of this lane's K slots (g' = 16 kb + 8 kg + e) under the match's permutation
+    int gsrc[4][8];
+    {
+        long long pi = ok ? a.pre_idx[m] : 0;
+        pi = pi < 0 ? 0 : (pi > 59 ? 59 : pi);
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int gp = 16 * kb + 8 * kg + e;
+                gsrc[kb][e] = gp < G ? a.P[(int)pi * G + gp] : 0;
+            }
+    }
+    const int nt = tile32 >> 3;
+    const float osc = HF_ASCALE / (F_SCALE * H2_ASCALE);
+    for (int sidx = 0; sidx < 4; ++sidx) {
+        const int cblk = sidx * 4 + w;                     // 8-channel block of the concatenated 128 channels
+        const float* sp = a.src[sidx] + (size_t)m * (F * G) + (size_t)(w * 8) * G;
+        const bool permute = (sidx == 0) || (sidx == 2);
+        floatx16 acc[8][2];
+#pragma unroll
+        for (int f = 0; f < 8; ++f) {
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[f][rb][r] = 0.f;
+            const float bs = a.bn_s[cblk * 8 + f] * H2_ASCALE, bt = a.bn_t[cblk * 8 + f] * H2_ASCALE;
+            const float* xp = sp + f * G;
+            float v[4][8];
+            if (permute) {
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[kb][e] = ok ? xp[gsrc[kb][e]] : 0.f;
+            } else {
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) {
+                    const floatx4 lo4 = ok ? *reinterpret_cast<const floatx4*>(xp + 16 * kb + 8 * kg) : floatx4{0.f, 0.f, 0.f, 0.f};
+                    const floatx4 hi4 = (ok && (16 * kb + 8 * kg + 4) < G) ? *reinterpret_cast<const floatx4*>(xp + 16 * kb + 8 * kg + 4)
+                                                                           : floatx4{0.f, 0.f, 0.f, 0.f};
+                    v[kb][0] = lo4.x; v[kb][1] = lo4.y; v[kb][2] = lo4.z; v[kb][3] = lo4.w;
+                    v[kb][4] = hi4.x; v[kb][5] = hi4.y; v[kb][6] = hi4.z; v[kb][7] = hi4.w;
+                }
+            }
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {
+                uintx4 bh, bl;
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const bool v0 = ok && (16 * kb + 8 * kg + 2 * p) < G, v1 = ok && (16 * kb + 8 * kg + 2 * p + 1) < G;
+                    const float y0 = v0 ? fmaxf(v[kb][2 * p] * bs + bt, 0.f) : 0.f;
+                    const float y1 = v1 ? fmaxf(v[kb][2 * p + 1] * bs + bt, 0.f) : 0.f;
+                    unsigned h, l;
+                    split_pair(y0, y1, h, l);
+                    bh[p] = h; bl[p] = l;
+                }
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb) acc[f][rb] = mfma_hh(A[rb][kb][1], bh, acc[f][rb]);
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb) acc[f][rb] = mfma_hh(A[rb][kb][0], bl, acc[f][rb]);
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb) acc[f][rb] = mfma_hh(A[rb][kb][0], bh, acc[f][rb]);
+            }
+        }
+        // cin = 128: K index = m_coef * 128 + channel -> stage (k >> 5) = 4 m_coef + (cblk >> 2), slot (cblk & 3)
+        char* dst0 = a.planes + (size_t)(cblk >> 2) * 32768 + (cblk & 3) * 4096 + ((tile32 & 7) * 32 + Lp) * 16;
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int q = 32 * rb + (r & 3) + 8 * (r >> 2) + 4 * kg;
+                uintx4 ph, pl;
+                unsigned h, l;
+                split_pair(acc[0][rb][r] * osc, acc[1][rb][r] * osc, h, l); ph.x = h; pl.x = l;
+                split_pair(acc[2][rb][r] * osc, acc[3][rb][r] * osc, h, l); ph.y = h; pl.y = l;
+                split_pair(acc[4][rb][r] * osc, acc[5][rb][r] * osc, h, l); ph.z = h; pl.z = l;
+                split_pair(acc[6][rb][r] * osc, acc[7][rb][r] * osc, h, l); ph.w = h; pl.w = l;
+                if (q < G) {
+                    char* d = dst0 + qb[q] + (long long)nt * qs[q];
+                    *reinterpret_cast<uintx4*>(d) = ph;
+                    *reinterpret_cast<uintx4*>(d + 16384) = pl;
+                }
+            }
+    }
+}
+
+int launch_head2(const float* s0, const float* s1, const float* s2, const float* s3, const int64_t* pre_idx, const int* P, const float* bn_s,
+                 const float* bn_t, int M, int nTiles, char* planes, int kppad, const void* Ffrag, hipStream_t s) {
+    Head2Args a;
+    a.src[0] = s0; a.src[1] = s1; a.src[2] = s2; a.src[3] = s3;
+    a.pre_idx = pre_idx; a.P = P; a.bn_s = bn_s; a.bn_t = bn_t; a.planes = planes; a.Ffrag = reinterpret_cast<const uintx4*>(Ffrag); a.M = M;
+    fill_qtables(kppad, 128, a.qbase, a.qstride);
+    if (nTiles == 0) return 0;
+    hipLaunchKernelGGL(head2_kernel, dim3(nTiles), dim3(256), 0, s, a);
     HIPCHK(hipGetLastError());
     return 0;
 }
