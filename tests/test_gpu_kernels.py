@@ -239,6 +239,43 @@ def test_partII_hyp_golden(ctx_of, mode, gold, sd1, sd2, tables):
     assert rel(T2, g["trans_pre"]) < TOL
 
 
+@pytest.mark.parametrize("M", [1, 17, 40, 100])
+def test_partII_ragged_match_counts(ctx, ctxh, sd2, tables, M):
+    """odd tile counts (16- and 32-match tiles, 256-column GEMM padding): default fp16x2 / Fourier first layer vs oracle and fp32"""
+    rs = np.random.RandomState(500 + M)
+    mk = lambda sd: synth.unit_features(M, seed=sd)
+    a, b, c_, d = mk(1), mk(2), mk(3), mk(4)
+    dr = rs.randint(0, 60, size=M).astype(np.int64)
+    args = [cu(x) for x in (a, b, c_, d)]
+    q = ctxh.partII_forward(*args, cu(dr)).cpu().numpy()
+    q32 = ctx.partII_forward(*args, cu(dr)).cpu().numpy()
+    qo = orc.partII_forward(a, b, c_, d, dr, sd2, tables.N, tables.P)
+    assert q.shape == (M, 4) and np.isfinite(q).all()
+    assert rel(q, qo) < TOL and rel(q32, qo) < TOL, (rel(q, qo), rel(q32, qo))
+
+
+def test_partII_zero_matches(ctxh):
+    e = torch.empty((0, 32, 60), dtype=torch.float32, device="cuda")
+    q = ctxh.partII_forward(e, e, e, e, torch.empty((0,), dtype=torch.int64, device="cuda"))
+    assert tuple(q.shape) == (0, 4)
+
+
+def test_partI_large_batch_is_chunked_consistently(hip, sd1):
+    """more keypoints than one pass takes (16384): same rows as separate calls, in the default arithmetic mode"""
+    c = hip.Context()
+    c.load_partI(sd1)
+    B = 16384 + 300
+    x = cu(synth.unit_features(B, seed=9))
+    full = c.partI_forward(x, want_inv=True, want_inv_np=True)
+    for lo, hi in ((0, 64), (16384 - 32, 16384 + 64), (B - 50, B)):
+        part = c.partI_forward(x[lo:hi].contiguous(), want_inv=True, want_inv_np=True)
+        for k in ("eqv", "inv", "inv_np"):
+            d = (full[k][lo:hi] - part[k]).abs().max().item()
+            assert d < 2e-6, (k, lo, d)
+    n = torch.linalg.norm(full["eqv"], dim=1)
+    assert (n - 1).abs().max().item() < 1e-5
+
+
 def test_quat2mat_bitexact(ctx, gold):
     g = gold("quat.npz")
     M = g["q"].shape[0]

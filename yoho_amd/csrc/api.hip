@@ -663,11 +663,12 @@ static int partII_pass(yoho_ctx* c, const float* s0, const float* s1, const floa
 
 int yoho_partII_forward(yoho_ctx* c, const float* before_eqv0, const float* before_eqv1, const float* after_eqv0,
                         const float* after_eqv1, const int64_t* pre_idx, int M, float* quat, void* stream) {
-    if (!c || !before_eqv0 || !before_eqv1 || !after_eqv0 || !after_eqv1 || !pre_idx || !quat || M < 0) {
+    if (!c || M < 0) { set_error("yoho_partII_forward: bad argument"); return YOHO_EINVAL; }
+    if (!c->has_partII) { set_error("yoho_partII_forward: PartII weights not loaded"); return YOHO_ENOWEIGHTS; }
+    if (M == 0) return 0;                                  // empty match set: nothing to do (pointers may be null)
+    if (!before_eqv0 || !before_eqv1 || !after_eqv0 || !after_eqv1 || !pre_idx || !quat) {
         set_error("yoho_partII_forward: bad argument"); return YOHO_EINVAL;
     }
-    if (!c->has_partII) { set_error("yoho_partII_forward: PartII weights not loaded"); return YOHO_ENOWEIGHTS; }
-    if (M == 0) return 0;
     HIPCHK(hipSetDevice(c->device));
     hipStream_t s = (hipStream_t)stream;
     const int MAXM = 8192;
