@@ -108,7 +108,113 @@ int launch_nn(const float* src, int Ns, const float* tgt, int Nt, int D, int dis
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// D = 32, large problems: the same arithmetic, blocked for the LDS return path and for load balance.
+//   * a thread owns TWO source rows, so every target row read from LDS (8 x ds_read_b128) feeds two distance
+//     evaluations (the single-row kernel is bound by the LDS return bandwidth, not by its packed fp32 math);
+//   * the targets are cut into segments over blockIdx.y so that there are a few workgroups per CU whatever Ns is; the
+//     per-segment winners meet in a packed (distance bits << 32 | index) key with atomicMin — distances are
+//     non-negative, so the integer order is (distance, then lowest index) = the reference's first minimum.
+// ---------------------------------------------------------------------------------------------------------------
+template <bool SQUARED>
+__global__ __launch_bounds__(256) void nn32seg_kernel(const float* __restrict__ src, int Ns, const float* __restrict__ tgt, int Nt,
+                                                      unsigned long long* __restrict__ keys, int segLen) {
+    constexpr int D = 32;
+    __shared__ __attribute__((aligned(16))) float tile[NN_TT * D];
+    __shared__ float rd[32 * NN_SPLIT];
+    __shared__ int ri[32 * NN_SPLIT];
+    const int r = threadIdx.x % 16, sp = threadIdx.x / 16;
+    const int row0 = blockIdx.x * 32 + r, row1 = row0 + 16;
+    float a0[D], a1[D];
+    {
+        const int rc0 = row0 < Ns ? row0 : Ns - 1, rc1 = row1 < Ns ? row1 : Ns - 1;
+#pragma unroll
+        for (int k = 0; k < D; ++k) { a0[k] = src[(size_t)rc0 * D + k]; a1[k] = src[(size_t)rc1 * D + k]; }
+    }
+    auto dist_of = [](float d2) -> float { return (float)sqrt((double)__fadd_rn(d2, 1e-7f)); };
+    float best0 = __builtin_inff(), best1 = __builtin_inff();
+    int bi0 = 0, bi1 = 0;
+    const int tlo = blockIdx.y * segLen;
+    const int thi = tlo + segLen < Nt ? tlo + segLen : Nt;
+    for (int t0 = tlo; t0 < thi; t0 += NN_TT) {
+        const int nt = thi - t0 < NN_TT ? thi - t0 : NN_TT;
+        __syncthreads();
+        {
+            const float4* g4 = reinterpret_cast<const float4*>(tgt + (size_t)t0 * D);      // rows are 128 B: 16-byte aligned
+            float4* t4 = reinterpret_cast<float4*>(tile);
+            for (int i = threadIdx.x; i < nt * (D / 4); i += 256) t4[i] = g4[i];
+        }
+        __syncthreads();
+        for (int t = sp; t < nt; t += NN_SPLIT) {
+            float b[D];
+#pragma unroll
+            for (int k = 0; k < D / 4; ++k) {
+                const float4 v = reinterpret_cast<const float4*>(tile + t * D)[k];
+                b[4 * k] = v.x; b[4 * k + 1] = v.y; b[4 * k + 2] = v.z; b[4 * k + 3] = v.w;
+            }
+            const float d0 = dist2_f32<D>(a0, b), d1 = dist2_f32<D>(a1, b);
+            if (d0 < best0) {
+                if (SQUARED || d0 < best0 * (1.0f - 1e-6f) || dist_of(d0) < dist_of(best0)) { best0 = d0; bi0 = t0 + t; }
+            }
+            if (d1 < best1) {
+                if (SQUARED || d1 < best1 * (1.0f - 1e-6f) || dist_of(d1) < dist_of(best1)) { best1 = d1; bi1 = t0 + t; }
+            }
+        }
+    }
+    if (!SQUARED) { best0 = dist_of(best0); best1 = dist_of(best1); }
+    rd[r * NN_SPLIT + sp] = best0; ri[r * NN_SPLIT + sp] = bi0;
+    rd[(r + 16) * NN_SPLIT + sp] = best1; ri[(r + 16) * NN_SPLIT + sp] = bi1;
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        const int rr = threadIdx.x, row = blockIdx.x * 32 + rr;
+        if (row < Ns && tlo < thi) {
+            float bd = rd[rr * NN_SPLIT];
+            int bi = ri[rr * NN_SPLIT];
+            for (int k = 1; k < NN_SPLIT; ++k) {
+                const float d = rd[rr * NN_SPLIT + k];
+                const int i = ri[rr * NN_SPLIT + k];
+                if (d < bd || (d == bd && i < bi)) { bd = d; bi = i; }
+            }
+            const unsigned long long key = ((unsigned long long)__float_as_uint(bd) << 32) | (unsigned)bi;
+            atomicMin(keys + row, key);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void nn_unpack_kernel(const unsigned long long* __restrict__ keys, int Ns, int64_t* __restrict__ idx,
+                                                        float* __restrict__ dist) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= Ns) return;
+    const unsigned long long k = keys[i];
+    idx[i] = (int64_t)(k & 0xFFFFFFFFull);
+    if (dist) dist[i] = __uint_as_float((unsigned)(k >> 32));
+}
+
+// keys must hold Ns words; they are (re)initialised here
+int launch_nn32seg(const float* src, int Ns, const float* tgt, int Nt, bool squared, unsigned long long* keys, int nCU, hipStream_t s) {
+    const int rb = (Ns + 31) / 32;
+    int nseg = (4 * nCU + rb - 1) / rb;
+    const int maxseg = (Nt + 63) / 64;
+    nseg = nseg < 1 ? 1 : (nseg > maxseg ? maxseg : nseg);
+    int segLen = (Nt + nseg - 1) / nseg;
+    segLen = (segLen + 15) / 16 * 16;
+    nseg = (Nt + segLen - 1) / segLen;
+    HIPCHK(hipMemsetAsync(keys, 0xFF, sizeof(unsigned long long) * (size_t)Ns, s));
+    if (squared) hipLaunchKernelGGL(nn32seg_kernel<true>, dim3(rb, nseg), dim3(256), 0, s, src, Ns, tgt, Nt, keys, segLen);
+    else hipLaunchKernelGGL(nn32seg_kernel<false>, dim3(rb, nseg), dim3(256), 0, s, src, Ns, tgt, Nt, keys, segLen);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int launch_nn_unpack(const unsigned long long* keys, int Ns, int64_t* idx, float* dist, hipStream_t s) {
+    hipLaunchKernelGGL(nn_unpack_kernel, dim3((Ns + 255) / 256), dim3(256), 0, s, keys, Ns, idx, dist);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 // keep i with back[fwd[i]] == i, ascending i (tests/matcher.py:42-47).  Single workgroup scan.
+// PACKED: fwd / back hold (distance bits << 32 | index) keys of the segmented search.
+template <bool PACKED>
 __global__ __launch_bounds__(1024) void mutual_compact_kernel(const int64_t* __restrict__ fwd, const int64_t* __restrict__ back,
                                                               int Na, int64_t* __restrict__ pairs, int* __restrict__ M_out) {
     __shared__ int wsum[16];
@@ -120,7 +226,11 @@ __global__ __launch_bounds__(1024) void mutual_compact_kernel(const int64_t* __r
         const int i = i0 + tid;
         bool keep = false;
         int64_t j = 0;
-        if (i < Na) { j = fwd[i]; keep = back[j] == (int64_t)i; }
+        if (i < Na) {
+            j = PACKED ? (fwd[i] & 0xFFFFFFFFll) : fwd[i];
+            const int64_t bk = PACKED ? (back[j] & 0xFFFFFFFFll) : back[j];
+            keep = bk == (int64_t)i;
+        }
         const unsigned long long m = __ballot(keep);
         const int before = __popcll(m & ((1ull << lane) - 1ull));
         if (lane == 0) wsum[wv] = __popcll(m);
@@ -135,8 +245,9 @@ __global__ __launch_bounds__(1024) void mutual_compact_kernel(const int64_t* __r
     if (tid == 0) *M_out = base;
 }
 
-int launch_mutual_compact(const int64_t* fwd, const int64_t* back, int Na, int64_t* pairs, int* M_out, hipStream_t s) {
-    hipLaunchKernelGGL(mutual_compact_kernel, dim3(1), dim3(1024), 0, s, fwd, back, Na, pairs, M_out);
+int launch_mutual_compact(const int64_t* fwd, const int64_t* back, int Na, int64_t* pairs, int* M_out, hipStream_t s, bool packed = false) {
+    if (packed) hipLaunchKernelGGL(mutual_compact_kernel<true>, dim3(1), dim3(1024), 0, s, fwd, back, Na, pairs, M_out);
+    else hipLaunchKernelGGL(mutual_compact_kernel<false>, dim3(1), dim3(1024), 0, s, fwd, back, Na, pairs, M_out);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -190,6 +301,13 @@ int yoho_nn_search(yoho_ctx* c, const float* src, int Ns, const float* tgt, int 
     if (!c || !src || !tgt || !idx || Ns < 0 || Nt < 1) { set_error("yoho_nn_search: bad argument"); return YOHO_EINVAL; }
     if (Ns == 0) return 0;
     HIPCHK(hipSetDevice(c->device));
+    if (D == 32 && (size_t)Ns * Nt >= (1u << 20) && (dist_type == YOHO_DIST_L2 || dist_type == YOHO_DIST_SQUARE_L2)) {
+        int rc;
+        if ((rc = ensure_ws(c, sizeof(unsigned long long) * (size_t)Ns, (hipStream_t)stream))) return rc;
+        unsigned long long* keys = (unsigned long long*)c->ws.p;
+        if ((rc = launch_nn32seg(src, Ns, tgt, Nt, dist_type == YOHO_DIST_SQUARE_L2, keys, c->nCU, (hipStream_t)stream))) return rc;
+        return launch_nn_unpack(keys, Ns, idx, dist, (hipStream_t)stream);
+    }
     return launch_nn(src, Ns, tgt, Nt, D, dist_type, idx, dist, (hipStream_t)stream);
 }
 
@@ -203,6 +321,12 @@ int yoho_mutual_nn(yoho_ctx* c, const float* a, int Na, const float* b, int Nb, 
     if ((rc = ensure_ws(c, need, s))) return rc;
     int64_t* fwd = (int64_t*)c->ws.p;
     int64_t* back = fwd + Na;
+    if ((size_t)Na * Nb >= (1u << 20)) {
+        // segmented search: the workspace words are the packed keys, the compaction reads the index half
+        if ((rc = launch_nn32seg(a, Na, b, Nb, false, (unsigned long long*)fwd, c->nCU, s))) return rc;
+        if ((rc = launch_nn32seg(b, Nb, a, Na, false, (unsigned long long*)back, c->nCU, s))) return rc;
+        return launch_mutual_compact(fwd, back, Na, pairs, M_out, s, true);
+    }
     if ((rc = launch_nn(a, Na, b, Nb, 32, YOHO_DIST_L2, fwd, nullptr, s))) return rc;     // NN of every a-row in b  (KNN(feats1, feats0))
     if ((rc = launch_nn(b, Nb, a, Na, 32, YOHO_DIST_L2, back, nullptr, s))) return rc;    // NN of every b-row in a  (KNN(feats0, feats1))
     return launch_mutual_compact(fwd, back, Na, pairs, M_out, s);
