@@ -109,6 +109,18 @@ int yoho_partII_forward(yoho_ctx* ctx, const float* before_eqv0, const float* be
                         const float* after_eqv0, const float* after_eqv1, const int64_t* pre_idx,
                         int M, float* quat, void* stream);
 
+/* HBM-resident variants for a caller that holds the full descriptor arrays and a match list: the rows are addressed in
+ * place through index arrays instead of being gathered first.  i* point at the first index, consecutive indices are
+ * `istride` elements apart (2 for the columns of an (M,2) int64 match array).
+ *   yoho_des2r_indexed:          d1 = e1[i1[m]], d2 = e2[i2[m]]
+ *   yoho_partII_forward_indexed: before_eqv0 = s0[i0[m]], before_eqv1 = s1[i1[m]], after_eqv0 = s2[i2[m]], after_eqv1 = s3[i3[m]];
+ *                                default PartII arithmetic mode only (YOHO_EINVAL otherwise) */
+int yoho_des2r_indexed(yoho_ctx* ctx, const float* e1, const int64_t* i1, const float* e2, const int64_t* i2, int istride, int M,
+                       int64_t* idx, float* cor, void* stream);
+int yoho_partII_forward_indexed(yoho_ctx* ctx, const float* s0, const int64_t* i0, const float* s1, const int64_t* i1, const float* s2,
+                                const int64_t* i2, const float* s3, const int64_t* i3, int istride, const int64_t* pre_idx, int M,
+                                float* quat, void* stream);
+
 /* T[m] = [R | t], R = quat2mat_f32(quat[m]) * Rgroup_f32[idx[m]] (f64), t = k0[m] - R k1[m] */
 int yoho_hyp_from_quat(yoho_ctx* ctx, const float* quat, const int64_t* idx, const double* k0,
                        const double* k1, int M, double* T, void* stream);

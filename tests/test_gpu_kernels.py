@@ -276,6 +276,22 @@ def test_partI_large_batch_is_chunked_consistently(hip, sd1):
     assert (n - 1).abs().max().item() < 1e-5
 
 
+def test_matched_variants_equal_gathered(ctxh, tables):
+    """row-indexed Des2R / PartII (HBM-resident pipeline) == the same calls on gathered rows"""
+    K, M = 300, 130
+    rs = np.random.RandomState(11)
+    f0, f1 = cu(synth.unit_features(K, seed=21)), cu(synth.unit_features(K, seed=22))
+    e0, e1 = cu(synth.unit_features(K, seed=23)), cu(synth.unit_features(K, seed=24))
+    match = torch.from_numpy(np.stack([rs.permutation(K)[:M], rs.permutation(K)[:M]], 1).astype(np.int64)).cuda()
+    m0, m1 = match[:, 0], match[:, 1]
+    dr_g = ctxh.des2r(e1[m1].contiguous(), e0[m0].contiguous())
+    dr_m = ctxh.des2r_matched(e1, e0, match)
+    assert torch.equal(dr_g, dr_m)
+    q_g = ctxh.partII_forward(f1[m1].contiguous(), f0[m0].contiguous(), e1[m1].contiguous(), e0[m0].contiguous(), dr_g)
+    q_m = ctxh.partII_forward_matched(f0, f1, e0, e1, match, dr_g)
+    assert torch.equal(q_g, q_m)
+
+
 def test_quat2mat_bitexact(ctx, gold):
     g = gold("quat.npz")
     M = g["q"].shape[0]

@@ -28,20 +28,19 @@ for it in range(N + 2):
         acc.clear()
     torch.cuda.synchronize()
     t = time.perf_counter()
-    o0 = ctx.partI_forward(f0, want_inv=False, want_inv_np=True)
-    o1 = ctx.partI_forward(f1, want_inv=False, want_inv_np=True)
-    t = lap("partI x2", t)
+    o = ctx.partI_forward(torch.cat([f0, f1]), want_inv=False, want_inv_np=True)
+    o0 = {k: v[:KP] for k, v in o.items()}
+    o1 = {k: v[KP:] for k, v in o.items()}
+    t = lap("partI (both fragments)", t)
     match = ctx.mutual_nn(o0["inv_np"], o1["inv_np"])
     t = lap("mutual_nn", t)
     M = match.shape[0]
     m0, m1 = match[:, 0], match[:, 1]
-    y0, y1 = o0["eqv"][m0], o1["eqv"][m1]
-    g0, g1 = f0[m0], f1[m1]
     k0m, k1m = k0[m0].contiguous(), k1[m1].contiguous()
-    t = lap("torch gathers", t)
-    dr = ctx.des2r(y1, y0)
+    t = lap("key gathers", t)
+    dr = ctx.des2r_matched(o1["eqv"], o0["eqv"], match)
     t = lap("des2r", t)
-    q = ctx.partII_forward(g1, g0, y1, y0, dr)
+    q = ctx.partII_forward_matched(f0, f1, o0["eqv"], o1["eqv"], match, dr)
     t = lap("partII", t)
     T = ctx.hyp_from_quat(q, dr, k0m, k1m)
     t = lap("hyp_from_quat", t)

@@ -582,8 +582,12 @@ int yoho_group_mean_np(yoho_ctx* c, const float* eqv, int B, float* out, void* s
 
 // PartII with the two large cone layers (128->256 @45 g, 256->512 @13 g) on the bf16x3 split MFMA; the g = 0 tail
 // (512->256 conv + the 1x1 MLP) stays on the fp32 kernels, fed through fp32 32-tile hand-over buffers.
+static bool partII_fourier_head(const yoho_ctx* c) {
+    return c->partII_mode == 2 && c->p2[0].wpg && !std::getenv("YOHO_PARTII_L0_DIRECT");
+}
+
 static int partII_pass16(yoho_ctx* c, const float* s0, const float* s1, const float* s2, const float* s3, const int64_t* idx,
-                         int M, float* quat, hipStream_t s, int npl) {
+                         int M, float* quat, hipStream_t s, int npl, const int64_t* const* ridx = nullptr, int istride = 1) {
     const int nT16 = (M + 15) / 16, nT = (M + TILE - 1) / TILE;
     const size_t ch = (size_t)CHUNK_FLOATS * sizeof(float), ch16 = (size_t)npl * 15360;
     const size_t n128 = (size_t)nT * 16, n256 = (size_t)nT * 32, n512 = (size_t)nT * 64, n32 = (size_t)nT * 4;
@@ -600,7 +604,8 @@ static int partII_pass16(yoho_ctx* c, const float* s0, const float* s1, const fl
     float* bF0 = bF + n256 * CHUNK_FLOATS;              // 512 act
     float* bF1 = bF0 + n512 * CHUNK_FLOATS;             // 128 act
     float* bQ = bF1 + n128 * CHUNK_FLOATS;              // 32 raw (4 used)
-    if (npl == 2 && c->p2[0].wpg && !std::getenv("YOHO_PARTII_L0_DIRECT")) {
+    if (ridx && !partII_fourier_head(c)) { set_error("indexed PartII needs the default (fp16x2, Fourier first layer) mode"); return YOHO_EINVAL; }
+    if (npl == 2 && partII_fourier_head(c)) {
         // first layer (128 -> 256) in the group-Fourier domain: all 60 outputs cost 244/780 of a full direct layer, i.e.
         // less than half of the 45-element cone the direct kernel computes
         const int kppad = (M + 255) / 256 * 256;
@@ -611,7 +616,7 @@ static int partII_pass16(yoho_ctx* c, const float* s0, const float* s1, const fl
         bF = bA1 + n512 * CHUNK_FLOATS; bF0 = bF + n256 * CHUNK_FLOATS; bF1 = bF0 + n512 * CHUNK_FLOATS; bQ = bF1 + n128 * CHUNK_FLOATS;
         char* bP = (char*)(bQ + n32 * CHUNK_FLOATS);
         float* bC = (float*)(bP + szP);                 // raw Fourier coefficients of the first layer
-        if ((rc = launch_head2(s0, s1, s2, s3, idx, c->dP, c->p2_init_bn_s, c->p2_init_bn_t, M, nT, bP, kppad, c->dF16, s))) return rc;
+        if ((rc = launch_head2(s0, s1, s2, s3, idx, c->dP, c->p2_init_bn_s, c->p2_init_bn_t, M, nT, bP, kppad, c->dF16, s, ridx, istride))) return rc;
         if ((rc = launch_fgemm(c->p2[0], bP, kppad, nT, nullptr, bC, 0, s))) return rc;
         if ((rc = launch_gft16_invp(bC, bH0, bA0, nT16, c->dF16, c->p2[0].bn_s, c->p2[0].bn_t, nT, 32, c->nCU, s))) return rc;
     } else {
@@ -677,6 +682,29 @@ int yoho_partII_forward(yoho_ctx* c, const float* before_eqv0, const float* befo
         const size_t o = (size_t)m0 * F * G;
         int rc = partII_pass(c, before_eqv0 + o, before_eqv1 + o, after_eqv0 + o, after_eqv1 + o, pre_idx + m0, nm,
                              quat + (size_t)m0 * 4, s);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+int yoho_partII_forward_indexed(yoho_ctx* c, const float* s0, const int64_t* i0, const float* s1, const int64_t* i1, const float* s2,
+                                const int64_t* i2, const float* s3, const int64_t* i3, int istride, const int64_t* pre_idx, int M,
+                                float* quat, void* stream) {
+    if (!c || M < 0 || istride < 1) { set_error("yoho_partII_forward_indexed: bad argument"); return YOHO_EINVAL; }
+    if (!c->has_partII) { set_error("yoho_partII_forward_indexed: PartII weights not loaded"); return YOHO_ENOWEIGHTS; }
+    if (M == 0) return 0;
+    if (!s0 || !s1 || !s2 || !s3 || !i0 || !i1 || !i2 || !i3 || !pre_idx || !quat) {
+        set_error("yoho_partII_forward_indexed: bad argument"); return YOHO_EINVAL;
+    }
+    if (!partII_fourier_head(c)) { set_error("yoho_partII_forward_indexed: needs the default PartII mode (fp16x2, Fourier first layer)"); return YOHO_EINVAL; }
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    const int MAXM = 8192;
+    for (int m0 = 0; m0 < M; m0 += MAXM) {
+        const int nm = M - m0 < MAXM ? M - m0 : MAXM;
+        const size_t io = (size_t)m0 * istride;
+        const int64_t* ridx[4] = {i0 + io, i1 + io, i2 + io, i3 + io};
+        int rc = partII_pass16(c, s0, s1, s2, s3, pre_idx + m0, nm, quat + (size_t)m0 * 4, s, 2, ridx, istride);
         if (rc) return rc;
     }
     return 0;

@@ -93,7 +93,8 @@ int launch_gft16(const float* in, float* out32, char* planes, int kppad, const v
 int launch_gft16_invp(const float* in, float* res0, char* planes16, int nTiles16, const void* Ffrag, const float* bn_s, const float* bn_t,
                       int nTiles, int C8, int nCU, hipStream_t s);
 int launch_head2(const float* s0, const float* s1, const float* s2, const float* s3, const int64_t* pre_idx, const int* P, const float* bn_s,
-                 const float* bn_t, int M, int nTiles, char* planes, int kppad, const void* Ffrag, hipStream_t s);
+                 const float* bn_t, int M, int nTiles, char* planes, int kppad, const void* Ffrag, hipStream_t s,
+                 const int64_t* const* ridx = nullptr, int istride = 1);
 int launch_head16(const float* x, int B, int nTiles, char* planes, int kppad, const void* Ffrag, hipStream_t s);
 int launch_gft_planes(const float* in, char* planes, int kppad, const float* Fpad, const float* bn_s, const float* bn_t, int nTiles, int C8,
                       hipStream_t s);

@@ -501,6 +501,8 @@ int launch_gft16_invp(const float* in, float* res0, char* planes16, int nTiles16
 // ---------------------------------------------------------------------------------------------------------------
 struct Head2Args {
     const float* src[4];
+    const int64_t* ridx[4];   // optional row indices into src[s] (null: row = match number), istride elements apart
+    int istride;
     const int64_t* pre_idx;
     const int* P;
     const float* bn_s;
@@ -547,7 +549,8 @@ __global__ __launch_bounds__(256, 1) void head2_kernel(Head2Args a) {
     const float osc = HF_ASCALE / (F_SCALE * H2_ASCALE);
     for (int sidx = 0; sidx < 4; ++sidx) {
         const int cblk = sidx * 4 + w;                     // 8-channel block of the concatenated 128 channels
-        const float* sp = a.src[sidx] + (size_t)m * (F * G) + (size_t)(w * 8) * G;
+        const size_t srow = (ok && a.ridx[sidx]) ? (size_t)a.ridx[sidx][(size_t)m * a.istride] : (size_t)m;
+        const float* sp = a.src[sidx] + srow * (F * G) + (size_t)(w * 8) * G;
         const bool permute = (sidx == 0) || (sidx == 2);
         floatx16 acc[8][2];
 #pragma unroll
@@ -617,9 +620,12 @@ __global__ __launch_bounds__(256, 1) void head2_kernel(Head2Args a) {
 }
 
 int launch_head2(const float* s0, const float* s1, const float* s2, const float* s3, const int64_t* pre_idx, const int* P, const float* bn_s,
-                 const float* bn_t, int M, int nTiles, char* planes, int kppad, const void* Ffrag, hipStream_t s) {
+                 const float* bn_t, int M, int nTiles, char* planes, int kppad, const void* Ffrag, hipStream_t s, const int64_t* const* ridx,
+                 int istride) {
     Head2Args a;
     a.src[0] = s0; a.src[1] = s1; a.src[2] = s2; a.src[3] = s3;
+    for (int i = 0; i < 4; ++i) a.ridx[i] = ridx ? ridx[i] : nullptr;
+    a.istride = istride;
     a.pre_idx = pre_idx; a.P = P; a.bn_s = bn_s; a.bn_t = bn_t; a.planes = planes; a.Ffrag = reinterpret_cast<const uintx4*>(Ffrag); a.M = M;
     fill_qtables(kppad, 128, a.qbase, a.qstride);
     if (nTiles == 0) return 0;

@@ -253,28 +253,66 @@ int launch_mutual_compact(const int64_t* fwd, const int64_t* back, int Na, int64
 }
 
 // cor[m, a] = sum_g sum_f d1[m, f, P[a, g]] * d2[m, f, g];  idx[m] = argmax_a (first maximum).
-// One 64-lane workgroup per match; lane a < 60 owns one candidate rotation.
-__global__ __launch_bounds__(64) void des2r_kernel(const float* __restrict__ d1, const float* __restrict__ d2, const int* __restrict__ P,
-                                                   int M, int64_t* __restrict__ idx, float* __restrict__ cor) {
-    __shared__ float s1[F * G];
-    __shared__ float s2[F * G];
+// One wave per match.  The double sum is a gather of the 60 x 60 Gram matrix C = D1^T D2 (contraction over the 32
+// channels): cor[a] = sum_g C[P[a,g]][g].  C is computed on the fp32 MFMA (64 x v_mfma_f32_32x32x2_f32, exact fp32
+// products, fp32 accumulation) from the two descriptors staged in LDS with rows padded to 64 zeros, written back to LDS
+// (row stride 65: the gather's rows are a permutation, so stride 64 would put all lanes on one bank) and every lane
+// a < 60 adds its 60 entries in the order g = 0..59.  Optional row indices address the descriptors in place.
+typedef float floatx16m __attribute__((ext_vector_type(16)));
+constexpr int D2R_S = 64;        // padded group axis of the staged descriptors
+constexpr int D2R_C = 65;        // row stride of the Gram matrix
+
+__global__ __launch_bounds__(64) void des2r_kernel(const float* __restrict__ e1, const int64_t* __restrict__ i1, const float* __restrict__ e2,
+                                                   const int64_t* __restrict__ i2, int istride, const int* __restrict__ P, int M,
+                                                   int64_t* __restrict__ idx, float* __restrict__ cor) {
+    __shared__ __attribute__((aligned(16))) float s1[F * D2R_S];
+    __shared__ __attribute__((aligned(16))) float s2[F * D2R_S];
+    __shared__ float Cl[64 * D2R_C];
     const int m = blockIdx.x, lane = threadIdx.x;
-    const float4* p1 = reinterpret_cast<const float4*>(d1 + (size_t)m * F * G);
-    const float4* p2 = reinterpret_cast<const float4*>(d2 + (size_t)m * F * G);
-    for (int i = lane; i < F * G / 4; i += 64) {
-        reinterpret_cast<float4*>(s1)[i] = p1[i];
-        reinterpret_cast<float4*>(s2)[i] = p2[i];
+    const size_t r1 = i1 ? (size_t)i1[(size_t)m * istride] : (size_t)m, r2 = i2 ? (size_t)i2[(size_t)m * istride] : (size_t)m;
+    const float4* p1 = reinterpret_cast<const float4*>(e1 + r1 * F * G);
+    const float4* p2 = reinterpret_cast<const float4*>(e2 + r2 * F * G);
+    for (int i = lane; i < F * (D2R_S / 4); i += 64) {
+        const int f = i >> 4, g4 = i & 15;                   // 15 float4 of data + 1 of zeros per row
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        reinterpret_cast<float4*>(s1)[i] = g4 < 15 ? p1[f * 15 + g4] : z;
+        reinterpret_cast<float4*>(s2)[i] = g4 < 15 ? p2[f * 15 + g4] : z;
     }
     __syncthreads();
-    const int a = lane < G ? lane : G - 1;
-    float acc = 0.f;
-    for (int g = 0; g < G; ++g) {
-        const int pg = P[a * G + g];
-#pragma unroll 8
-        for (int f = 0; f < F; ++f) acc = fmaf(s1[f * G + pg], s2[f * G + g], acc);
+    floatx16m acc[2][2];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[rb][cb][r] = 0.f;
+    const int li = lane & 31, lk = lane >> 5;
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+        const int f = 2 * kk + lk;
+        const float a0 = s1[f * D2R_S + li], a1 = s1[f * D2R_S + 32 + li];
+        const float b0 = s2[f * D2R_S + li], b1 = s2[f * D2R_S + 32 + li];
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
     }
-    if (cor && lane < G) cor[(size_t)m * G + lane] = acc;
-    float bv = lane < G ? acc : -__builtin_inff();
+    // D[row g'][col g]: lane (col = lane & 31, half = lane >> 5), reg r -> row = (r & 3) + 8 (r >> 2) + 4 half
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = 32 * rb + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                Cl[row * D2R_C + 32 * cb + li] = acc[rb][cb][r];
+            }
+    __syncthreads();
+    const int a = lane < G ? lane : G - 1;
+    float sum = 0.f;
+    for (int g = 0; g < G; ++g) sum += Cl[P[a * G + g] * D2R_C + g];
+    if (cor && lane < G) cor[(size_t)m * G + lane] = sum;
+    float bv = lane < G ? sum : -__builtin_inff();
     int bi = lane;
     for (int o = 32; o >= 1; o >>= 1) {
         const float ov = __shfl_xor(bv, o);
@@ -284,8 +322,9 @@ __global__ __launch_bounds__(64) void des2r_kernel(const float* __restrict__ d1,
     if (lane == 0) idx[m] = bi;
 }
 
-int launch_des2r(const float* d1, const float* d2, const int* P, int M, int64_t* idx, float* cor, hipStream_t s) {
-    hipLaunchKernelGGL(des2r_kernel, dim3(M), dim3(64), 0, s, d1, d2, P, M, idx, cor);
+int launch_des2r(const float* e1, const int64_t* i1, const float* e2, const int64_t* i2, int istride, const int* P, int M, int64_t* idx,
+                 float* cor, hipStream_t s) {
+    hipLaunchKernelGGL(des2r_kernel, dim3(M), dim3(64), 0, s, e1, i1, e2, i2, istride, P, M, idx, cor);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -336,7 +375,15 @@ int yoho_des2r(yoho_ctx* c, const float* d1, const float* d2, int M, int64_t* id
     if (!c || !d1 || !d2 || !idx || M < 0) { set_error("yoho_des2r: bad argument"); return YOHO_EINVAL; }
     if (M == 0) return 0;
     HIPCHK(hipSetDevice(c->device));
-    return launch_des2r(d1, d2, c->dP, M, idx, cor, (hipStream_t)stream);
+    return launch_des2r(d1, nullptr, d2, nullptr, 1, c->dP, M, idx, cor, (hipStream_t)stream);
+}
+
+int yoho_des2r_indexed(yoho_ctx* c, const float* e1, const int64_t* i1, const float* e2, const int64_t* i2, int istride, int M,
+                       int64_t* idx, float* cor, void* stream) {
+    if (!c || !e1 || !e2 || !i1 || !i2 || !idx || M < 0 || istride < 1) { set_error("yoho_des2r_indexed: bad argument"); return YOHO_EINVAL; }
+    if (M == 0) return 0;
+    HIPCHK(hipSetDevice(c->device));
+    return launch_des2r(e1, i1, e2, i2, istride, c->dP, M, idx, cor, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -18,7 +18,7 @@ _lib = None
 SYMBOLS = [
     "yoho_last_error", "yoho_version", "yoho_ctx_create", "yoho_ctx_destroy", "yoho_load_partI",
     "yoho_load_partII", "yoho_partI_forward", "yoho_group_mean_np", "yoho_nn_search", "yoho_mutual_nn",
-    "yoho_des2r", "yoho_partII_forward", "yoho_hyp_from_quat", "yoho_o_score", "yoho_c_ransac",
+    "yoho_des2r", "yoho_des2r_indexed", "yoho_partII_forward", "yoho_partII_forward_indexed", "yoho_hyp_from_quat", "yoho_o_score", "yoho_c_ransac",
     "yoho_group_gather", "yoho_set_profiling", "yoho_get_kernel_ms", "yoho_set_gconv_mode", "yoho_set_partII_mode",
 ]
 
@@ -71,6 +71,8 @@ def load_library():
     lib.yoho_nn_search.argtypes = [vp, vp, ci, vp, ci, ci, ci, vp, vp, vp]
     lib.yoho_mutual_nn.argtypes = [vp, vp, ci, vp, ci, vp, vp, vp]
     lib.yoho_des2r.argtypes = [vp, vp, vp, ci, vp, vp, vp]
+    lib.yoho_des2r_indexed.argtypes = [vp, vp, vp, vp, vp, ci, ci, vp, vp, vp]
+    lib.yoho_partII_forward_indexed.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, vp, ci, vp, vp]
     lib.yoho_partII_forward.argtypes = [vp, vp, vp, vp, vp, vp, ci, vp, vp]
     lib.yoho_hyp_from_quat.argtypes = [vp, vp, vp, vp, vp, ci, vp, vp]
     lib.yoho_o_score.argtypes = [vp, vp, vp, ci, vp, vp, ci, C.c_double, vp, vp, vp, vp]
@@ -228,6 +230,27 @@ class Context:
         _check(self._lib.yoho_des2r(self._h, _dev(d1, torch.float32, "d1"), _dev(d2, torch.float32, "d2"), M,
                                     C.c_void_p(idx.data_ptr()), C.c_void_p(cor.data_ptr()) if want_cor else None, _stream()))
         return (idx, cor) if want_cor else idx
+
+    def des2r_matched(self, e1, e2, match):
+        """Des2R(e1[match[:,1]], e2[match[:,0]]) with the rows read in place (match (M,2) int64 cuda, contiguous)."""
+        M = match.shape[0]
+        idx = torch.empty((M,), dtype=torch.int64, device=e1.device)
+        mp = _dev(match, torch.int64, "match")
+        _check(self._lib.yoho_des2r_indexed(self._h, _dev(e1, torch.float32, "e1"), C.c_void_p(match.data_ptr() + 8),
+                                            _dev(e2, torch.float32, "e2"), mp, 2, M, C.c_void_p(idx.data_ptr()), None, _stream()))
+        return idx
+
+    def partII_forward_matched(self, feat0, feat1, eqv0, eqv1, match, pre_idx):
+        """partII_forward(feat1[m1], feat0[m0], eqv1[m1], eqv0[m0], pre_idx) with m0, m1 = match[:,0], match[:,1], rows read
+        in place.  Default PartII arithmetic mode only (raises RuntimeError otherwise)."""
+        M = match.shape[0]
+        quat = torch.empty((M, 4), dtype=torch.float32, device=feat0.device)
+        m0p, m1p = C.c_void_p(_dev(match, torch.int64, "match").value), C.c_void_p(match.data_ptr() + 8)
+        _check(self._lib.yoho_partII_forward_indexed(
+            self._h, _dev(feat1, torch.float32, "feat1"), m1p, _dev(feat0, torch.float32, "feat0"), m0p,
+            _dev(eqv1, torch.float32, "eqv1"), m1p, _dev(eqv0, torch.float32, "eqv0"), m0p, 2,
+            _dev(pre_idx, torch.int64, "pre_idx"), M, C.c_void_p(quat.data_ptr()), _stream()))
+        return quat
 
     def partII_forward(self, before_eqv0, before_eqv1, after_eqv0, after_eqv1, pre_idx):
         M = before_eqv0.shape[0]

@@ -36,12 +36,13 @@ def run_pair(ctx, feat0, feat1, keys0, keys1, inlier_dist=0.09, max_iter=1000, o
         r.best_h, r.best_count, r.trans, r.order = 0, 0, np.eye(4), None
         return r
     m0, m1 = match[:, 0], match[:, 1]
-    y0, y1 = o0["eqv"][m0], o1["eqv"][m1]
-    f0, f1 = feat0[m0], feat1[m1]
-    # tests/extractor.py:97-99: Batch_Des2R_torch(feats1, feats0)
-    r.dr_index = ctx.des2r(y1, y0)
+    # tests/extractor.py:97-99: Batch_Des2R_torch(feats1, feats0); rows addressed in place through the match list
+    r.dr_index = ctx.des2r_matched(o1["eqv"], o0["eqv"], match)
     # tests/extractor.py:125-138 batch_create (0<->1 exchange) + utils/network.py:259-278
-    r.quat = ctx.partII_forward(f1, f0, y1, y0, r.dr_index)
+    try:
+        r.quat = ctx.partII_forward_matched(feat0, feat1, o0["eqv"], o1["eqv"], match, r.dr_index)
+    except RuntimeError:                                   # non-default PartII arithmetic mode: gather first
+        r.quat = ctx.partII_forward(feat1[m1], feat0[m0], o1["eqv"][m1], o0["eqv"][m0], r.dr_index)
     k0m, k1m = keys0[m0].contiguous(), keys1[m1].contiguous()
     r.trans_pre = ctx.hyp_from_quat(r.quat, r.dr_index, k0m, k1m)
     # tests/estimator.py:321-336
