@@ -1,0 +1,88 @@
+"""FCGF backbone oracle (oracle/fcgf_oracle.py): the sparse (transposed) convolution restated from MinkowskiEngine's sources
+is pinned against torch's dense conv3d / conv_transpose3d on densified inputs; structural checks of the U-Net."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.nn.functional as TF
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle"))
+import fcgf_oracle as fo  # noqa: E402
+from yoho_amd import weights as W  # noqa: E402
+
+
+def _cloud(n, grid, seed):
+    rs = np.random.RandomState(seed)
+    c = np.unique(rs.randint(0, grid, size=(n, 3)), axis=0).astype(np.int32)
+    rs.shuffle(c)
+    return c
+
+
+def _dense(coords, feat, grid):
+    d = np.zeros((feat.shape[1], grid, grid, grid), dtype=np.float32)       # [c][x][y][z]
+    d[:, coords[:, 0], coords[:, 1], coords[:, 2]] = feat.T
+    return torch.from_numpy(d)[None]
+
+
+def _wt(Wk, K):
+    # ME kernel index k = a + K*b + K*K*c (x fastest)  ->  torch [co][ci][a][b][c] on a tensor indexed [x][y][z]
+    return torch.from_numpy(np.ascontiguousarray(Wk.reshape(K, K, K, Wk.shape[1], Wk.shape[2]).transpose(4, 3, 2, 1, 0)))
+
+
+def test_conv_matches_dense_conv3d():
+    rs = np.random.RandomState(0)
+    grid, K = 12, 3
+    c = _cloud(500, grid, 1)
+    x = rs.randn(len(c), 5).astype(np.float32)
+    Wk = rs.randn(K ** 3, 5, 7).astype(np.float32)
+    out = fo.conv(x, c, c, Wk, K, 1)
+    ref = TF.conv3d(_dense(c, x, grid), _wt(Wk, K), padding=K // 2)[0].numpy()
+    assert np.allclose(out, ref[:, c[:, 0], c[:, 1], c[:, 2]].T, atol=2e-5)
+    # kernel size 5 (conv1 family)
+    W5 = rs.randn(125, 5, 3).astype(np.float32)
+    out = fo.conv(x, c, c, W5, 5, 1)
+    ref = TF.conv3d(_dense(c, x, grid), _wt(W5, 5), padding=2)[0].numpy()
+    assert np.allclose(out, ref[:, c[:, 0], c[:, 1], c[:, 2]].T, atol=5e-5)
+
+
+def test_strided_and_transposed_conv_match_dense():
+    rs = np.random.RandomState(2)
+    grid = 12
+    c1 = _cloud(400, grid, 3)
+    c2 = fo.stride_coords(c1, 2)
+    assert (c2 % 2 == 0).all() and len(np.unique(c2, axis=0)) == len(c2)
+    assert set(map(tuple, c2.tolist())) == set(map(tuple, (c1 // 2 * 2).tolist()))
+    x = rs.randn(len(c1), 4).astype(np.float32)
+    Wk = rs.randn(27, 4, 6).astype(np.float32)
+    out = fo.conv(x, c1, c2, Wk, 3, 1)                                   # stride-2 convolution, offsets on the input stride
+    ref = TF.conv3d(_dense(c1, x, grid), _wt(Wk, 3), padding=1, stride=2)[0].numpy()
+    j = c2 // 2
+    assert np.allclose(out, ref[:, j[:, 0], j[:, 1], j[:, 2]].T, atol=2e-5)
+    # transposed: coarse (stride 2) -> the existing fine map, offsets on the fine stride
+    y = rs.randn(len(c2), 6).astype(np.float32)
+    Wt = rs.randn(27, 6, 3).astype(np.float32)
+    up = fo.conv(y, c2, c1, Wt, 3, 1, transpose=True)
+    dy = _dense(c2 // 2, y, grid // 2)
+    wt = torch.from_numpy(np.ascontiguousarray(Wt.reshape(3, 3, 3, 6, 3).transpose(3, 4, 2, 1, 0)))    # [ci][co][a][b][c]
+    ref = TF.conv_transpose3d(dy, wt, stride=2, padding=1, output_padding=1)[0].numpy()
+    assert np.allclose(up, ref[:, c1[:, 0], c1[:, 1], c1[:, 2]].T, atol=2e-5)
+
+
+def test_quantize_first_occurrence_and_unet_shapes():
+    rs = np.random.RandomState(4)
+    pc = rs.rand(3000, 3) * 0.6
+    sel, coords = fo.voxelize(pc, 0.025)
+    assert (np.diff(sel) > 0).all() and len(np.unique(coords, axis=0)) == len(coords)
+    q = np.floor(pc / 0.025).astype(np.int32)
+    first = {}
+    for i, t in enumerate(map(tuple, q.tolist())):
+        first.setdefault(t, i)
+    assert sorted(first.values()) == sel.tolist()
+    sd = W.synth_state_dict(W.FCGF_SPEC, 3)
+    sel2, F = fo.extract_features(pc[:1200], 0.025, sd)
+    assert F.shape == (len(sel2), 32) and np.isfinite(F).all()
+    assert np.allclose(np.linalg.norm(F, axis=1), 1, atol=1e-5)
+    # translation by whole multiples of the coarsest stride leaves the features unchanged (all maps shift together)
+    _, F2 = fo.extract_features(pc[:1200] + 8 * 0.025 * np.array([1.0, -2.0, 3.0]), 0.025, sd)
+    assert F2.shape == F.shape and np.abs(F - F2).max() < 1e-5

@@ -52,6 +52,34 @@ PARTII_SPEC = (
 )
 
 
+def fcgf_spec(channels=(None, 32, 64, 128, 256), tr_channels=(None, 64, 64, 64, 128), out_channels=32, conv1_kernel_size=7,
+              in_channels=1):
+    """state_dict keys / shapes of the FCGF backbone ResUNet2 family (reference fcgf_model/resunet.py:21-139; defaults =
+    ResUNetBN2C :200-203 with the 3DMatch settings).  MinkowskiConvolution kernels are (K^3, Cin, Cout), (Cin, Cout) for
+    kernel size 1; MinkowskiBatchNorm wraps BatchNorm1d as `.bn`."""
+    C, T = channels, tr_channels
+
+    def bnk(prefix, c):
+        return _bn(prefix + ".bn", c)
+
+    def blk(prefix, c):
+        return ([(f"{prefix}.conv1.kernel", (27, c, c))] + bnk(f"{prefix}.norm1", c)
+                + [(f"{prefix}.conv2.kernel", (27, c, c))] + bnk(f"{prefix}.norm2", c))
+
+    spec = [("conv1.kernel", (conv1_kernel_size ** 3, in_channels, C[1]))] + bnk("norm1", C[1]) + blk("block1", C[1])
+    spec += [("conv2.kernel", (27, C[1], C[2]))] + bnk("norm2", C[2]) + blk("block2", C[2])
+    spec += [("conv3.kernel", (27, C[2], C[3]))] + bnk("norm3", C[3]) + blk("block3", C[3])
+    spec += [("conv4.kernel", (27, C[3], C[4]))] + bnk("norm4", C[4]) + blk("block4", C[4])
+    spec += [("conv4_tr.kernel", (27, C[4], T[4]))] + bnk("norm4_tr", T[4]) + blk("block4_tr", T[4])
+    spec += [("conv3_tr.kernel", (27, C[3] + T[4], T[3]))] + bnk("norm3_tr", T[3]) + blk("block3_tr", T[3])
+    spec += [("conv2_tr.kernel", (27, C[2] + T[3], T[2]))] + bnk("norm2_tr", T[2]) + blk("block2_tr", T[2])
+    spec += [("conv1_tr.kernel", (C[1] + T[2], T[1])), ("final.kernel", (T[1], out_channels)), ("final.bias", (1, out_channels))]
+    return spec
+
+
+FCGF_SPEC = fcgf_spec()
+
+
 def _splitmix64(x):
     x = (x + np.uint64(0x9E3779B97F4A7C15)) & _M64
     z = x
@@ -87,6 +115,9 @@ def synth_state_dict(spec, seed=0):
         elif len(shape) == 4:                       # conv weight
             fan_in = shape[1] * shape[3]
             v = (u * 2.0 - 1.0) * np.float32(np.sqrt(3.0 / fan_in))
+        elif name.endswith(".kernel"):              # sparse conv kernel (K, Cin, Cout) / (Cin, Cout); ~1/3 of a region is occupied
+            fan_in = shape[0] * shape[1] / 3.0 if len(shape) == 3 else shape[0]
+            v = (u * 2.0 - 1.0) * np.float32(np.sqrt(3.0 / max(fan_in, 1.0)))
         elif name.endswith(".weight"):              # BN gamma
             v = 0.5 + u
         else:                                        # conv bias / BN beta
