@@ -145,6 +145,28 @@ int yoho_c_ransac(yoho_ctx* ctx, const double* k0, const double* k1, int M, cons
 int yoho_group_gather(yoho_ctx* ctx, const double* keys, int K, const float* pts, const float* feat,
                       int n, int g, const double* Rg_host, float* out, int64_t* nn_idx, void* stream);
 
+/* ---- FCGF backbone (reference fcgf_model/resunet.py ResUNet2 family, simple_yoho/fcgf_feat.py) ------------------------
+ * Sparse 3-D ResUNet forward pass, fp32.  channels / tr_channels = CHANNELS / TR_CHANNELS of the model class (index 0
+ * unused), e.g. ResUNetBN2C: {0,32,64,128,256} / {0,64,64,64,128}.  tensors: host pointers to the state_dict entries in
+ * the model's registration order with the num_batches_tracked entries left out (conv1.kernel, norm1.bn.{weight,bias,
+ * running_mean,running_var}, block1.conv1.kernel, ...; yoho_amd.weights.fcgf_spec()). */
+typedef struct yoho_fcgf_config {
+    int channels[5];
+    int tr_channels[5];
+    int out_channels;
+    int conv1_kernel_size;
+    int in_channels;          /* 1: the input feature is a column of ones (fcgf_feat.py:41) */
+    int normalize_feature;
+} yoho_fcgf_config;
+int yoho_load_fcgf(yoho_ctx* ctx, const yoho_fcgf_config* cfg, const float* const* tensors, int ntensors);
+/* fcgf_feat.py:33-43: voxel = floor(p / voxel_size); sel = index of the first point of every voxel, ascending;
+ * coords = their integer voxel coordinates.  pts (n,3) f64, sel (n) i64, coords (n,3) i32 device buffers sized for n;
+ * *count (host) receives the number of voxels (the call synchronises the stream). */
+int yoho_fcgf_voxelize(yoho_ctx* ctx, const double* pts, int n, double voxel_size, int64_t* sel, int32_t* coords, int* count,
+                       void* stream);
+/* resunet.py:141-190 + the final normalisation of fcgf_feat.py:48.  coords (n,3) i32 distinct voxels, out (n,out_channels). */
+int yoho_fcgf_forward(yoho_ctx* ctx, const int32_t* coords, int n, float* out, void* stream);
+
 /* PartI group-conv formulation: 0 = direct 13-tap conv on fp32 MFMA (v_mfma_f32_32x32x2_f32), 1 = direct conv with an
  * fp32-accurate 3-way bf16 split on v_mfma_f32_32x32x16_bf16 (6 products per term), 2 = group-Fourier domain conv
  * (244 instead of 780 slab products per chunk) on fp32 MFMA, 3 = direct conv with a 2-way fp16 split on

@@ -1,0 +1,69 @@
+"""FCGF backbone on the GPU (csrc/sparse.hip through the C ABI) against oracle/fcgf_oracle.py."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle"))
+import fcgf_oracle as fo  # noqa: E402
+from yoho_amd import synth, weights as W  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def rel(a, b):
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+@pytest.fixture(scope="module")
+def fsd():
+    return W.synth_state_dict(W.FCGF_SPEC, 3)
+
+
+@pytest.fixture(scope="module")
+def fctx(hip, fsd):
+    c = hip.Context()
+    c.load_fcgf(fsd)
+    return c
+
+
+def test_voxelize_first_occurrence(fctx):
+    pc = synth.surface_cloud(20000, seed=5)
+    sel, coords = fctx.fcgf_voxelize(torch.from_numpy(pc).cuda(), 0.025)
+    s0, c0 = fo.voxelize(pc, 0.025)
+    assert np.array_equal(sel.cpu().numpy(), s0) and np.array_equal(coords.cpu().numpy(), c0)
+    # negative coordinates, duplicates only, a single point
+    pc2 = np.concatenate([pc[:50] - 3.0, pc[:50] - 3.0])
+    sel, coords = fctx.fcgf_voxelize(torch.from_numpy(pc2).cuda(), 0.025)
+    s0, c0 = fo.voxelize(pc2, 0.025)
+    assert np.array_equal(sel.cpu().numpy(), s0) and np.array_equal(coords.cpu().numpy(), c0)
+    sel, coords = fctx.fcgf_voxelize(torch.from_numpy(pc[:1].copy()).cuda(), 0.025)
+    assert sel.tolist() == [0]
+
+
+@pytest.mark.parametrize("n,seed", [(1500, 1), (6000, 2)])
+def test_backbone_vs_oracle(fctx, fsd, n, seed):
+    pc = synth.surface_cloud(n, seed=seed)
+    _, coords = fo.voxelize(pc, 0.025)
+    F0 = fo.extract_features(pc, 0.025, fsd)[1]
+    F = fctx.fcgf_forward(torch.from_numpy(coords).cuda()).cpu().numpy()
+    assert F.shape == F0.shape and np.isfinite(F).all()
+    print("fcgf backbone n=%d voxels=%d: rel err %.3g" % (n, len(coords), rel(F, F0)))
+    assert rel(F, F0) < TOL
+    assert np.allclose(np.linalg.norm(F, axis=1), 1, atol=1e-5)
+
+
+def test_backbone_row_order_and_translation(fctx):
+    pc = synth.surface_cloud(4000, seed=7)
+    _, coords = fo.voxelize(pc, 0.025)
+    c = torch.from_numpy(coords).cuda()
+    F = fctx.fcgf_forward(c)
+    perm = torch.randperm(len(coords), generator=torch.Generator().manual_seed(0)).cuda()
+    Fp = fctx.fcgf_forward(c[perm].contiguous())
+    assert (Fp - F[perm]).abs().max().item() < 2e-5        # rows follow the input order, values do not depend on it
+    shift = torch.tensor([16, -8, 24], dtype=torch.int32, device="cuda")
+    Fs = fctx.fcgf_forward((c + shift).contiguous())
+    assert (Fs - F).abs().max().item() < 2e-5              # multiples of the coarsest stride: all maps shift together

@@ -326,6 +326,7 @@ int yoho_ctx_destroy(yoho_ctx* c) {
     if (c->dP) (void)hipFree(c->dP);
     if (c->dFpad) (void)hipFree(c->dFpad);
     if (c->dF16) (void)hipFree(c->dF16);
+    if (c->fcgf) fcgf_free(c->fcgf);
     delete c->fb;
     if (c->ev_created) for (auto& e : c->ev) (void)hipEventDestroy(e);
     delete c;
@@ -708,6 +709,35 @@ int yoho_partII_forward_indexed(yoho_ctx* c, const float* s0, const int64_t* i0,
         if (rc) return rc;
     }
     return 0;
+}
+
+int yoho_load_fcgf(yoho_ctx* c, const yoho_fcgf_config* cfg, const float* const* tensors, int ntensors) {
+    if (!c || !cfg || !tensors) { set_error("yoho_load_fcgf: null argument"); return YOHO_EINVAL; }
+    for (int i = 0; i < ntensors; ++i) if (!tensors[i]) { set_error("yoho_load_fcgf: null tensor %d", i); return YOHO_EINVAL; }
+    HIPCHK(hipSetDevice(c->device));
+    FcgfNet* n = nullptr;
+    int rc = fcgf_load(&n, cfg, tensors, ntensors);
+    if (rc) return rc;
+    if (c->fcgf) fcgf_free(c->fcgf);
+    c->fcgf = n;
+    return 0;
+}
+
+int yoho_fcgf_voxelize(yoho_ctx* c, const double* pts, int n, double voxel_size, int64_t* sel, int32_t* coords, int* count, void* stream) {
+    if (!c || !count || n < 0 || !(voxel_size > 0)) { set_error("yoho_fcgf_voxelize: bad argument"); return YOHO_EINVAL; }
+    if (n == 0) { *count = 0; return 0; }
+    if (!pts || !sel || !coords) { set_error("yoho_fcgf_voxelize: bad argument"); return YOHO_EINVAL; }
+    HIPCHK(hipSetDevice(c->device));
+    return fcgf_voxelize(c, pts, n, voxel_size, sel, coords, count, (hipStream_t)stream);
+}
+
+int yoho_fcgf_forward(yoho_ctx* c, const int32_t* coords, int n, float* out, void* stream) {
+    if (!c || n < 0) { set_error("yoho_fcgf_forward: bad argument"); return YOHO_EINVAL; }
+    if (!c->fcgf) { set_error("yoho_fcgf_forward: backbone weights not loaded"); return YOHO_ENOWEIGHTS; }
+    if (n == 0) return 0;
+    if (!coords || !out) { set_error("yoho_fcgf_forward: bad argument"); return YOHO_EINVAL; }
+    HIPCHK(hipSetDevice(c->device));
+    return fcgf_forward(c, c->fcgf, coords, n, out, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -86,6 +86,11 @@ void fgemm_plane_offsets(int kppad, int cin, long long* off);
 int pack_fgemm_weights(const FourierBasis& fb, const float* W, int cin, int cout, std::vector<unsigned short>& out, float* descale);
 int launch_fgemm(const Layer& L, const char* Bplanes, int kppad, int nT32, const float* res, float* out, int flags, hipStream_t s);
 void build_gft16_frags(const FourierBasis& fb, std::vector<unsigned short>& out);
+struct FcgfNet;
+int fcgf_load(FcgfNet** out, const yoho_fcgf_config* cfg, const float* const* t, int ntensors);
+void fcgf_free(FcgfNet* n);
+int fcgf_forward(yoho_ctx* ctx, const FcgfNet* net, const int* coords0, int n0, float* out, hipStream_t s);
+int fcgf_voxelize(yoho_ctx* ctx, const double* pts, int n, double voxel, int64_t* sel, int* coords, int* count_host, hipStream_t s);
 int launch_cone1(const Layer& L, const char* X, int nTiles32, int nTiles16, const float* res, float* out, const int* n0, hipStream_t s);
 int gft16_init();
 int launch_gft16(const float* in, float* out32, char* planes, int kppad, const void* Ffrag, const float* bn_s, const float* bn_t, int nTiles,
@@ -147,6 +152,7 @@ struct yoho_ctx {
     yoho::FourierBasis* fb = nullptr;
     float* dFpad = nullptr;      // F padded to 64 x 64 (device)
     void* dF16 = nullptr;        // fp16x2 MFMA fragments of F^T and F (gft16.hip)
+    yoho::FcgfNet* fcgf = nullptr;   // FCGF backbone weights (sparse.hip)
     int nCU = 256;
     // workspace (grown on demand)
     yoho::Workspace ws;

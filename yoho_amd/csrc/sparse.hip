@@ -1,0 +1,540 @@
+// FCGF backbone: sparse 3-D ResUNet forward pass on a voxelised cloud, fp32.
+// Reference: fcgf_model/resunet.py:10-190 (ResUNet2 family), residual_block.py:9-52, simple_yoho/fcgf_feat.py:33-49, written
+// against MinkowskiEngine 0.5.x; the sparse-tensor semantics implemented here are those listed in oracle/fcgf_oracle.py.
+//
+//   coordinate maps   open-addressing hash tables (64-bit packed voxel key -> row); a coarser map is built by inserting the
+//                     quantised coordinates with atomicMin of the source row, so its rows come out in first-occurrence order
+//                     (the CPU coordinate manager's order), compacted by a single-workgroup scan;
+//   kernel maps       map[k][n] = input row at coord(n) + offset(k) (or coord(n) - offset(k) for a transposed conv), -1 if the
+//                     voxel is empty: output-stationary, so a convolution needs no atomics and sums in kernel-index order;
+//   convolution       one wave = 32 output rows x all output channels on v_mfma_f32_32x32x2_f32: A = gathered input rows
+//                     (a lane reads 16 consecutive channels of its row straight from global memory, no LDS, no barriers),
+//                     B = W[k] read through L1/L2, accumulators = Cout/32 x 16 registers; BN / residual / ReLU / channel
+//                     concatenation (write at a column offset of a wider buffer) in the epilogue.
+#include <hip/hip_runtime.h>
+#include <vector>
+#include <cstring>
+
+#include "common.h"
+
+namespace yoho {
+
+typedef unsigned long long u64;
+typedef float floatx16s __attribute__((ext_vector_type(16)));
+constexpr u64 HEMPTY = ~0ull;
+
+__device__ __forceinline__ u64 pack_key(int x, int y, int z) {
+    return ((u64)(unsigned)(x + (1 << 20)) << 42) | ((u64)(unsigned)(y + (1 << 20)) << 21) | (u64)(unsigned)(z + (1 << 20));
+}
+__device__ __forceinline__ unsigned hslot(u64 key, unsigned mask) { return (unsigned)((key * 0x9E3779B97F4A7C15ull) >> 33) & mask; }
+__device__ __forceinline__ int floor_to(int c, int ts) {            // floor(c / ts) * ts  (src/coordinate_map.hpp:58-76)
+    if (ts <= 1) return c;
+    int q = c / ts;
+    if ((c % ts) != 0 && c < 0) --q;
+    return q * ts;
+}
+
+__global__ void hash_clear_kernel(u64* keys, int* vals, unsigned cap) {
+    const unsigned i = blockIdx.x * 256 + threadIdx.x;
+    if (i < cap) { keys[i] = HEMPTY; vals[i] = 0x7FFFFFFF; }
+}
+
+// voxel of point i: from integer coordinates (quantised to `ts`) or from f64 points (floor(p / voxel), fcgf_feat.py:34)
+struct CoordSrc {
+    const int* coords;       // (n,3) or null
+    const double* pts;       // (n,3) or null
+    double voxel;
+    int ts;
+};
+__device__ __forceinline__ void voxel_of(const CoordSrc& s, int i, int& x, int& y, int& z) {
+    if (s.pts) {
+        x = (int)floor(s.pts[3 * (size_t)i] / s.voxel);
+        y = (int)floor(s.pts[3 * (size_t)i + 1] / s.voxel);
+        z = (int)floor(s.pts[3 * (size_t)i + 2] / s.voxel);
+    } else {
+        x = floor_to(s.coords[3 * (size_t)i], s.ts);
+        y = floor_to(s.coords[3 * (size_t)i + 1], s.ts);
+        z = floor_to(s.coords[3 * (size_t)i + 2], s.ts);
+    }
+}
+
+// slot value = smallest source row with that voxel
+__global__ void hash_insert_min_kernel(CoordSrc src, int n, u64* keys, int* vals, unsigned mask) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    int x, y, z;
+    voxel_of(src, i, x, y, z);
+    const u64 key = pack_key(x, y, z);
+    unsigned s = hslot(key, mask);
+    for (;;) {
+        const u64 old = atomicCAS(&keys[s], HEMPTY, key);
+        if (old == HEMPTY || old == key) { atomicMin(&vals[s], i); return; }
+        s = (s + 1) & mask;
+    }
+}
+
+__device__ __forceinline__ int hash_find_slot(const u64* keys, unsigned mask, u64 key) {
+    unsigned s = hslot(key, mask);
+    for (;;) {
+        const u64 k = keys[s];
+        if (k == key) return (int)s;
+        if (k == HEMPTY) return -1;
+        s = (s + 1) & mask;
+    }
+}
+
+// first occurrences in source order -> new rows: single workgroup scan (order = the CPU coordinate manager's)
+__global__ __launch_bounds__(1024) void first_compact_kernel(CoordSrc src, int n, const u64* keys, int* vals, unsigned mask,
+                                                             int* out_coords, int64_t* sel, int* count) {
+    __shared__ int wsum[16];
+    __shared__ int base;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) base = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < n; i0 += 1024) {
+        const int i = i0 + tid;
+        bool keep = false;
+        int x = 0, y = 0, z = 0, slot = -1;
+        if (i < n) {
+            voxel_of(src, i, x, y, z);
+            slot = hash_find_slot(keys, mask, pack_key(x, y, z));
+            keep = vals[slot] == i;
+        }
+        const unsigned long long m = __ballot(keep);
+        const int before = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) wsum[wv] = __popcll(m);
+        __syncthreads();
+        int off = base;
+        for (int k = 0; k < wv; ++k) off += wsum[k];
+        if (keep) {
+            const int r = off + before;
+            out_coords[3 * (size_t)r] = x; out_coords[3 * (size_t)r + 1] = y; out_coords[3 * (size_t)r + 2] = z;
+            if (sel) sel[r] = i;
+        }
+        __syncthreads();
+        if (tid == 0) { int t = 0; for (int k = 0; k < 16; ++k) t += wsum[k]; base += t; }
+        __syncthreads();
+    }
+    if (tid == 0) *count = base;
+}
+
+// table value := row of the compacted map
+__global__ void hash_set_rows_kernel(const int* coords, int n, const u64* keys, int* vals, unsigned mask) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= n) return;
+    const int slot = hash_find_slot(keys, mask, pack_key(coords[3 * (size_t)r], coords[3 * (size_t)r + 1], coords[3 * (size_t)r + 2]));
+    vals[slot] = r;
+}
+
+// map[k][n] = row of (coord(n) + sign * offset(k) * ts) in the table, -1 if absent; kernel index with x fastest
+__global__ void build_map_kernel(const int* out_coords, int nout, const u64* keys, const int* vals, unsigned mask, int ksize, int ts,
+                                 int sign, int* map) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    const int k = blockIdx.y;
+    if (n >= nout) return;
+    const int h = ksize / 2;
+    const int ox = (k % ksize - h) * ts * sign, oy = ((k / ksize) % ksize - h) * ts * sign, oz = (k / (ksize * ksize) - h) * ts * sign;
+    const int slot = hash_find_slot(keys, mask, pack_key(out_coords[3 * (size_t)n] + ox, out_coords[3 * (size_t)n + 1] + oy,
+                                                          out_coords[3 * (size_t)n + 2] + oz));
+    map[(size_t)k * nout + n] = slot < 0 ? -1 : vals[slot];
+}
+
+struct SpConvArgs {
+    const float* in; int ldin, cin;
+    const int* map;          // [K][nout] or null (K = 1, identity)
+    int K, nout;
+    const float* W;          // (K, cin, cout)
+    int cout;
+    float* out; int ldout, ocoff;
+    const float* aff_s;      // per output channel affine (BN folded) or null
+    const float* aff_t;      // shift / bias or null
+    const float* res; int ldres, rcoff;    // residual added after the affine, or null
+    int relu;
+};
+
+template <int NCB>
+__global__ __launch_bounds__(256) void spconv_kernel(SpConvArgs a) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int li = lane & 31, h = lane >> 5;
+    const int rbase = (blockIdx.x * 4 + w) * 32;
+    if (rbase >= a.nout) return;
+    const int row = rbase + li;
+    const bool valid = row < a.nout;
+    floatx16s acc[NCB];
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[cb][r] = 0.f;
+    const int nchunk = a.cin / 32;
+    for (int k = 0; k < a.K; ++k) {
+        const int src = valid ? (a.map ? a.map[(size_t)k * a.nout + row] : row) : -1;
+        if (__ballot(src >= 0) == 0ull) continue;
+        const float* ip = a.in + (size_t)(src < 0 ? 0 : src) * a.ldin + h * 16;
+        const float* wk = a.W + (size_t)k * a.cin * a.cout + li;
+        for (int cc = 0; cc < nchunk; ++cc) {
+            float av[16];
+            if (src >= 0) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 v = *reinterpret_cast<const float4*>(ip + cc * 32 + 4 * q);
+                    av[4 * q] = v.x; av[4 * q + 1] = v.y; av[4 * q + 2] = v.z; av[4 * q + 3] = v.w;
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) av[q] = 0.f;
+            }
+            const float* wp = wk + (size_t)(cc * 32 + h * 16) * a.cout;
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) {
+#pragma unroll
+                for (int cb = 0; cb < NCB; ++cb) {
+                    const float bv = wp[(size_t)kk * a.cout + cb * 32];
+                    acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], bv, acc[cb], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // D[i = row][j = channel]: lane (j = lane & 31, half = lane >> 5), reg r -> row = (r & 3) + 8 (r >> 2) + 4 half
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) {
+        const int co = cb * 32 + li;
+        const float s = a.aff_s ? a.aff_s[co] : 1.f, t = a.aff_t ? a.aff_t[co] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int orow = rbase + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (orow < a.nout) {
+                float v = acc[cb][r] * s + t;
+                if (a.res) v += a.res[(size_t)orow * a.ldres + a.rcoff + co];
+                if (a.relu) v = fmaxf(v, 0.f);
+                a.out[(size_t)orow * a.ldout + a.ocoff + co] = v;
+            }
+        }
+    }
+}
+
+// Cin < 32 (the first convolution: one input channel, 5^3 / 7^3 offsets): plain fp32, one thread per (row, channel)
+__global__ __launch_bounds__(256) void spconv_small_kernel(SpConvArgs a) {
+    const int co = threadIdx.x % a.cout, rl = threadIdx.x / a.cout;
+    const int rows_per = 256 / a.cout;
+    const int row = blockIdx.x * rows_per + rl;
+    if (rl >= rows_per || row >= a.nout) return;
+    float acc = 0.f;
+    for (int k = 0; k < a.K; ++k) {
+        const int src = a.map ? a.map[(size_t)k * a.nout + row] : row;
+        if (src < 0) continue;
+        const float* ip = a.in + (size_t)src * a.ldin;
+        const float* wk = a.W + (size_t)k * a.cin * a.cout + co;
+        for (int c = 0; c < a.cin; ++c) acc = fmaf(ip[c], wk[(size_t)c * a.cout], acc);
+    }
+    float v = acc * (a.aff_s ? a.aff_s[co] : 1.f) + (a.aff_t ? a.aff_t[co] : 0.f);
+    if (a.res) v += a.res[(size_t)row * a.ldres + a.rcoff + co];
+    if (a.relu) v = fmaxf(v, 0.f);
+    a.out[(size_t)row * a.ldout + a.ocoff + co] = v;
+}
+
+static int launch_spconv(const SpConvArgs& a, hipStream_t s) {
+    if (a.nout == 0) return 0;
+    if (a.cin % 32 == 0 && a.cout % 32 == 0 && a.cout <= 256 && a.ldin % 4 == 0) {
+        const dim3 grid((a.nout + 127) / 128), blk(256);
+        switch (a.cout / 32) {
+            case 1: hipLaunchKernelGGL(spconv_kernel<1>, grid, blk, 0, s, a); break;
+            case 2: hipLaunchKernelGGL(spconv_kernel<2>, grid, blk, 0, s, a); break;
+            case 3: hipLaunchKernelGGL(spconv_kernel<3>, grid, blk, 0, s, a); break;
+            case 4: hipLaunchKernelGGL(spconv_kernel<4>, grid, blk, 0, s, a); break;
+            case 5: hipLaunchKernelGGL(spconv_kernel<5>, grid, blk, 0, s, a); break;
+            case 6: hipLaunchKernelGGL(spconv_kernel<6>, grid, blk, 0, s, a); break;
+            case 7: hipLaunchKernelGGL(spconv_kernel<7>, grid, blk, 0, s, a); break;
+            default: hipLaunchKernelGGL(spconv_kernel<8>, grid, blk, 0, s, a); break;
+        }
+    } else {
+        if (a.cout > 256 || a.cout < 1) { set_error("sparse conv: unsupported channel count %d", a.cout); return YOHO_EINVAL; }
+        const int rows_per = 256 / a.cout;
+        hipLaunchKernelGGL(spconv_small_kernel, dim3((a.nout + rows_per - 1) / rows_per), dim3(256), 0, s, a);
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+__global__ void fill_ones_kernel(float* p, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = 1.f;
+}
+
+// rows /= |row| (resunet.py:183-187), then once more (fcgf_feat.py:48) - one wave per row
+__global__ __launch_bounds__(256) void row_normalize_kernel(const float* in, int n, int c, float* out, int twice) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= n) return;
+    float v = lane < c ? in[(size_t)row * c + lane] : 0.f;
+    for (int pass = 0; pass < (twice ? 2 : 1); ++pass) {
+        float s = v * v;
+        for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+        v = v / sqrtf(s);
+    }
+    if (lane < c) out[(size_t)row * c + lane] = v;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------------
+struct BnAff { float* s = nullptr; float* t = nullptr; };
+
+struct FcgfNet {
+    int C[5] = {0, 32, 64, 128, 256}, T[5] = {0, 64, 64, 64, 128};
+    int out_ch = 32, k1 = 7, in_ch = 1, normalize = 1;
+    // kernels in spec order
+    float* conv[4] = {nullptr, nullptr, nullptr, nullptr};      // conv1..conv4
+    BnAff norm[4];
+    float* bconv[4][2] = {};                                     // block1..4 conv1/conv2
+    BnAff bnorm[4][2];
+    float* conv_tr[3] = {nullptr, nullptr, nullptr};             // conv4_tr, conv3_tr, conv2_tr
+    BnAff norm_tr[3];
+    float* bconv_tr[3][2] = {};                                  // block4_tr, block3_tr, block2_tr
+    BnAff bnorm_tr[3][2];
+    float* conv1_tr = nullptr;
+    float* final_k = nullptr;
+    float* final_b = nullptr;
+    std::vector<void*> owned;
+};
+
+static int up(FcgfNet* n, const float* h, size_t cnt, float** d) {
+    HIPCHK(hipMalloc((void**)d, cnt * sizeof(float)));
+    n->owned.push_back(*d);
+    HIPCHK(hipMemcpy(*d, h, cnt * sizeof(float), hipMemcpyHostToDevice));
+    return 0;
+}
+
+static int up_bn(FcgfNet* n, const float* const* p, int c, BnAff* o) {      // p: weight, bias, running_mean, running_var
+    std::vector<float> s(c), t(c);
+    for (int i = 0; i < c; ++i) {
+        const float sc = p[0][i] / std::sqrt(p[3][i] + 1e-5f);
+        s[i] = sc; t[i] = p[1][i] - p[2][i] * sc;
+    }
+    int rc;
+    if ((rc = up(n, s.data(), c, &o->s)) || (rc = up(n, t.data(), c, &o->t))) return rc;
+    return 0;
+}
+
+void fcgf_free(FcgfNet* n) {
+    if (!n) return;
+    for (void* p : n->owned) (void)hipFree(p);
+    delete n;
+}
+
+// tensors: host pointers in the order of yoho_amd.weights.fcgf_spec() with the num_batches_tracked entries left out
+int fcgf_load(FcgfNet** out, const yoho_fcgf_config* cfg, const float* const* t, int ntensors) {
+    FcgfNet* n = new FcgfNet();
+    for (int i = 1; i < 5; ++i) { n->C[i] = cfg->channels[i]; n->T[i] = cfg->tr_channels[i]; }
+    n->out_ch = cfg->out_channels; n->k1 = cfg->conv1_kernel_size; n->in_ch = cfg->in_channels; n->normalize = cfg->normalize_feature;
+    const int expect = 4 * (1 + 4 + 2 * (1 + 4)) + 3 * (1 + 4 + 2 * (1 + 4)) + 3;
+    if (ntensors != expect) { fcgf_free(n); set_error("yoho_load_fcgf: expected %d tensors, got %d", expect, ntensors); return YOHO_EINVAL; }
+    if (n->k1 % 2 == 0 || n->out_ch > 64 || n->in_ch > 31) { fcgf_free(n); set_error("yoho_load_fcgf: unsupported configuration"); return YOHO_EINVAL; }
+    int ti = 0, rc = 0;
+    auto fail = [&](int r) { fcgf_free(n); return r; };
+    const int* C = n->C; const int* T = n->T;
+    const int cin_enc[4] = {n->in_ch, C[1], C[2], C[3]};
+    for (int l = 0; l < 4 && !rc; ++l) {
+        const int kv = l == 0 ? n->k1 * n->k1 * n->k1 : 27, co = C[l + 1];
+        if ((rc = up(n, t[ti], (size_t)kv * cin_enc[l] * co, &n->conv[l]))) break; ti += 1;
+        if ((rc = up_bn(n, t + ti, co, &n->norm[l]))) break; ti += 4;
+        for (int j = 0; j < 2 && !rc; ++j) {
+            if ((rc = up(n, t[ti], (size_t)27 * co * co, &n->bconv[l][j]))) break; ti += 1;
+            if ((rc = up_bn(n, t + ti, co, &n->bnorm[l][j]))) break; ti += 4;
+        }
+    }
+    if (rc) return fail(rc);
+    const int cin_tr[3] = {C[4], C[3] + T[4], C[2] + T[3]}, cout_tr[3] = {T[4], T[3], T[2]};
+    for (int l = 0; l < 3 && !rc; ++l) {
+        if ((rc = up(n, t[ti], (size_t)27 * cin_tr[l] * cout_tr[l], &n->conv_tr[l]))) break; ti += 1;
+        if ((rc = up_bn(n, t + ti, cout_tr[l], &n->norm_tr[l]))) break; ti += 4;
+        for (int j = 0; j < 2 && !rc; ++j) {
+            if ((rc = up(n, t[ti], (size_t)27 * cout_tr[l] * cout_tr[l], &n->bconv_tr[l][j]))) break; ti += 1;
+            if ((rc = up_bn(n, t + ti, cout_tr[l], &n->bnorm_tr[l][j]))) break; ti += 4;
+        }
+    }
+    if (rc) return fail(rc);
+    if ((rc = up(n, t[ti++], (size_t)(C[1] + T[2]) * T[1], &n->conv1_tr)) || (rc = up(n, t[ti++], (size_t)T[1] * n->out_ch, &n->final_k)) ||
+        (rc = up(n, t[ti++], n->out_ch, &n->final_b))) return fail(rc);
+    *out = n;
+    return 0;
+}
+
+struct Level {
+    int n = 0, ts = 1;
+    int* coords = nullptr;
+    u64* keys = nullptr;
+    int* vals = nullptr;
+    unsigned mask = 0;
+};
+
+static unsigned table_cap(int n) {
+    unsigned c = 64;
+    while (c < 2u * (unsigned)(n > 0 ? n : 1)) c <<= 1;
+    return c;
+}
+
+// bump allocator over the context workspace
+struct Arena {
+    char* p; size_t off = 0, cap;
+    template <typename Tp> Tp* take(size_t cnt) {
+        off = (off + 255) & ~(size_t)255;
+        Tp* r = reinterpret_cast<Tp*>(p + off);
+        off += cnt * sizeof(Tp);
+        return r;
+    }
+};
+
+static int build_table(const CoordSrc& src, int n, Level& L, hipStream_t s) {
+    const unsigned cap = L.mask + 1;
+    hipLaunchKernelGGL(hash_clear_kernel, dim3((cap + 255) / 256), dim3(256), 0, s, L.keys, L.vals, cap);
+    if (n > 0) hipLaunchKernelGGL(hash_insert_min_kernel, dim3((n + 255) / 256), dim3(256), 0, s, src, n, L.keys, L.vals, L.mask);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+size_t fcgf_workspace_bytes(const FcgfNet* net, int n0) {
+    // generous bound: every level sized like level 0
+    const size_t N = (size_t)n0 + 256;
+    const int k1 = net->k1 * net->k1 * net->k1;
+    size_t b = 0;
+    b += 4 * (N * 3 * 4 + (size_t)table_cap(n0) * 12) + 4096;                 // coords + tables
+    b += ((size_t)k1 + 27 * 10) * N * 4;                                      // kernel maps
+    const int* C = net->C; const int* T = net->T;
+    size_t feat = 1 + 2 * C[1] + (T[2] + C[1]) + 2 * T[2] + T[1] + net->out_ch;
+    feat += 2 * C[2] + (T[3] + C[2]) + 2 * T[3] + 2 * C[3] + (T[4] + C[3]) + 2 * T[4] + 3 * C[4];
+    b += feat * N * 4 + 64 * 256;
+    return b;
+}
+
+// coords0: (n0,3) int32 device, distinct voxels; out: (n0, out_ch)
+int fcgf_forward(yoho_ctx* ctx, const FcgfNet* net, const int* coords0, int n0, float* out, hipStream_t s) {
+    if (n0 == 0) return 0;
+    int rc;
+    if ((rc = ensure_ws(ctx, fcgf_workspace_bytes(net, n0), s))) return rc;
+    Arena ar{(char*)ctx->ws.p, 0, ctx->ws.bytes};
+    const int* C = net->C; const int* T = net->T;
+    Level L[4];
+    int* dcount = ar.take<int>(4);
+    // ---- coordinate maps
+    L[0].n = n0; L[0].ts = 1; L[0].coords = const_cast<int*>(coords0);
+    for (int l = 0; l < 4; ++l) {
+        L[l].ts = 1 << l;
+        const int nprev = l == 0 ? n0 : L[l - 1].n;
+        L[l].mask = table_cap(nprev) - 1;
+        L[l].keys = ar.take<u64>(L[l].mask + 1);
+        L[l].vals = ar.take<int>(L[l].mask + 1);
+        if (l == 0) {
+            CoordSrc src{coords0, nullptr, 1.0, 1};
+            if ((rc = build_table(src, n0, L[0], s))) return rc;
+            // distinct input voxels: value = row (atomicMin of the single source row)
+        } else {
+            CoordSrc src{L[l - 1].coords, nullptr, 1.0, L[l].ts};
+            if ((rc = build_table(src, nprev, L[l], s))) return rc;
+            L[l].coords = ar.take<int>((size_t)nprev * 3);
+            hipLaunchKernelGGL(first_compact_kernel, dim3(1), dim3(1024), 0, s, src, nprev, L[l].keys, L[l].vals, L[l].mask, L[l].coords,
+                               (int64_t*)nullptr, dcount + l);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipMemcpyAsync(&L[l].n, dcount + l, sizeof(int), hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+            hipLaunchKernelGGL(hash_set_rows_kernel, dim3((L[l].n + 255) / 256), dim3(256), 0, s, L[l].coords, L[l].n, L[l].keys, L[l].vals,
+                               L[l].mask);
+            HIPCHK(hipGetLastError());
+        }
+    }
+    // ---- kernel maps
+    auto make_map = [&](const Level& outL, const Level& inL, int ksize, int ts, int sign) -> int* {
+        const int kv = ksize * ksize * ksize;
+        int* m = ar.take<int>((size_t)kv * outL.n);
+        if (outL.n > 0)
+            hipLaunchKernelGGL(build_map_kernel, dim3((outL.n + 255) / 256, kv), dim3(256), 0, s, outL.coords, outL.n, inL.keys, inL.vals,
+                               inL.mask, ksize, ts, sign, m);
+        return m;
+    };
+    int* M1 = make_map(L[0], L[0], net->k1, 1, +1);
+    int* Msame[4]; int* Mdown[3]; int* Mup[3];
+    for (int l = 0; l < 4; ++l) Msame[l] = make_map(L[l], L[l], 3, L[l].ts, +1);
+    for (int l = 0; l < 3; ++l) {
+        Mdown[l] = make_map(L[l + 1], L[l], 3, L[l].ts, +1);           // strided conv: offsets on the input (finer) stride
+        Mup[l] = make_map(L[l], L[l + 1], 3, L[l].ts, -1);             // transposed: coarse row at coord(fine) - offset
+    }
+    HIPCHK(hipGetLastError());
+    // ---- features
+    float* ones = ar.take<float>((size_t)n0 * net->in_ch);
+    hipLaunchKernelGGL(fill_ones_kernel, dim3((n0 * net->in_ch + 255) / 256), dim3(256), 0, s, ones, n0 * net->in_ch);
+    float* x[4]; float* tmp[4]; float* cat[3]; float* enc3;
+    const int catw[3] = {T[2] + C[1], T[3] + C[2], T[4] + C[3]}, catoff[3] = {T[2], T[3], T[4]};
+    for (int l = 0; l < 4; ++l) {
+        x[l] = ar.take<float>((size_t)L[l].n * C[l + 1]);
+        tmp[l] = ar.take<float>((size_t)L[l].n * C[l + 1]);
+        if (l < 3) cat[l] = ar.take<float>((size_t)L[l].n * catw[l]);
+    }
+    enc3 = ar.take<float>((size_t)L[3].n * C[4]);
+    if (ar.off > ar.cap) { set_error("fcgf_forward: workspace estimate too small (%zu > %zu)", ar.off, ar.cap); return YOHO_ENOMEM; }
+
+    auto conv = [&](const float* in, int ldin, int cin, const int* map, int K, int nout, const float* W, int cout, float* o, int ldout,
+                    int ocoff, const BnAff* bn, const float* bias, const float* res, int ldres, int rcoff, int relu) -> int {
+        SpConvArgs a;
+        a.in = in; a.ldin = ldin; a.cin = cin; a.map = map; a.K = K; a.nout = nout; a.W = W; a.cout = cout;
+        a.out = o; a.ldout = ldout; a.ocoff = ocoff; a.aff_s = bn ? bn->s : nullptr; a.aff_t = bn ? bn->t : bias;
+        a.res = res; a.ldres = ldres; a.rcoff = rcoff; a.relu = relu;
+        return launch_spconv(a, s);
+    };
+    // BasicBlockBN: out = relu(bn2(conv2(relu(bn1(conv1(x))))) + x), written at column `ocoff` of `o`
+    auto block = [&](int l, const float* xin, int c, float* const* Wc, const BnAff* bnc, float* scratch, float* o, int ldout, int ocoff) -> int {
+        int r;
+        if ((r = conv(xin, c, c, Msame[l], 27, L[l].n, Wc[0], c, scratch, c, 0, &bnc[0], nullptr, nullptr, 0, 0, 1))) return r;
+        return conv(scratch, c, c, Msame[l], 27, L[l].n, Wc[1], c, o, ldout, ocoff, &bnc[1], nullptr, xin, c, 0, 1);
+    };
+
+    // encoder (resunet.py:142-160).  The block outputs land in the decoder's concatenation buffers (right-hand columns).
+    const int k1v = net->k1 * net->k1 * net->k1;
+    if ((rc = conv(ones, net->in_ch, net->in_ch, M1, k1v, n0, net->conv[0], C[1], x[0], C[1], 0, &net->norm[0], nullptr, nullptr, 0, 0, 0))) return rc;
+    if ((rc = block(0, x[0], C[1], net->bconv[0], net->bnorm[0], tmp[0], cat[0], catw[0], catoff[0]))) return rc;
+    for (int l = 1; l < 4; ++l) {
+        const float* in = cat[l - 1] + catoff[l - 1];
+        if ((rc = conv(in, catw[l - 1], C[l], Mdown[l - 1], 27, L[l].n, net->conv[l], C[l + 1], x[l], C[l + 1], 0, &net->norm[l], nullptr, nullptr,
+                       0, 0, 0))) return rc;
+        float* o = l < 3 ? cat[l] : enc3;
+        if ((rc = block(l, x[l], C[l + 1], net->bconv[l], net->bnorm[l], tmp[l], o, l < 3 ? catw[l] : C[4], l < 3 ? catoff[l] : 0))) return rc;
+    }
+    // decoder (resunet.py:162-181): conv_tr -> norm -> block -> left-hand columns of the concatenation buffer
+    const float* din = enc3; int dld = C[4], dcin = C[4];
+    for (int j = 0; j < 3; ++j) {
+        const int l = 2 - j;                       // output level of conv{4,3,2}_tr
+        const int co = j == 0 ? T[4] : (j == 1 ? T[3] : T[2]);
+        float* u = ar.take<float>((size_t)L[l].n * co);
+        float* sc = ar.take<float>((size_t)L[l].n * co);
+        if (ar.off > ar.cap) { set_error("fcgf_forward: workspace estimate too small"); return YOHO_ENOMEM; }
+        if ((rc = conv(din, dld, dcin, Mup[l], 27, L[l].n, net->conv_tr[j], co, u, co, 0, &net->norm_tr[j], nullptr, nullptr, 0, 0, 0))) return rc;
+        if ((rc = block(l, u, co, net->bconv_tr[j], net->bnorm_tr[j], sc, cat[l], catw[l], 0))) return rc;
+        din = cat[l]; dld = catw[l]; dcin = catw[l];
+    }
+    float* f1 = ar.take<float>((size_t)n0 * T[1]);
+    float* f2 = ar.take<float>((size_t)n0 * net->out_ch);
+    if (ar.off > ar.cap) { set_error("fcgf_forward: workspace estimate too small"); return YOHO_ENOMEM; }
+    if ((rc = conv(cat[0], catw[0], catw[0], nullptr, 1, n0, net->conv1_tr, T[1], f1, T[1], 0, nullptr, nullptr, nullptr, 0, 0, 1))) return rc;
+    if ((rc = conv(f1, T[1], T[1], nullptr, 1, n0, net->final_k, net->out_ch, f2, net->out_ch, 0, nullptr, net->final_b, nullptr, 0, 0, 0))) return rc;
+    hipLaunchKernelGGL(row_normalize_kernel, dim3((n0 + 3) / 4), dim3(256), 0, s, f2, n0, net->out_ch, out, net->normalize ? 1 : 0);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// voxelisation (fcgf_feat.py:33-43): first point of every voxel in input order -> sel (ascending), integer coordinates
+int fcgf_voxelize(yoho_ctx* ctx, const double* pts, int n, double voxel, int64_t* sel, int* coords, int* count_host, hipStream_t s) {
+    if (n == 0) { *count_host = 0; return 0; }
+    int rc;
+    const unsigned cap = table_cap(n);
+    if ((rc = ensure_ws(ctx, (size_t)cap * 12 + 1024, s))) return rc;
+    Arena ar{(char*)ctx->ws.p, 0, ctx->ws.bytes};
+    Level L;
+    L.mask = cap - 1; L.keys = ar.take<u64>(cap); L.vals = ar.take<int>(cap);
+    int* dcount = ar.take<int>(1);
+    CoordSrc src{nullptr, pts, voxel, 1};
+    if ((rc = build_table(src, n, L, s))) return rc;
+    hipLaunchKernelGGL(first_compact_kernel, dim3(1), dim3(1024), 0, s, src, n, L.keys, L.vals, L.mask, coords, sel, dcount);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(count_host, dcount, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return 0;
+}
+
+}  // namespace yoho

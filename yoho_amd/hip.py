@@ -18,6 +18,7 @@ _lib = None
 SYMBOLS = [
     "yoho_last_error", "yoho_version", "yoho_ctx_create", "yoho_ctx_destroy", "yoho_load_partI",
     "yoho_load_partII", "yoho_partI_forward", "yoho_group_mean_np", "yoho_nn_search", "yoho_mutual_nn",
+    "yoho_load_fcgf", "yoho_fcgf_voxelize", "yoho_fcgf_forward",
     "yoho_des2r", "yoho_des2r_indexed", "yoho_partII_forward", "yoho_partII_forward_indexed", "yoho_hyp_from_quat", "yoho_o_score", "yoho_c_ransac",
     "yoho_group_gather", "yoho_set_profiling", "yoho_get_kernel_ms", "yoho_set_gconv_mode", "yoho_set_partII_mode",
 ]
@@ -44,6 +45,11 @@ class PartIIWeights(C.Structure):
 
 def lib_path():
     return _LIB_PATH
+
+
+class FcgfConfig(C.Structure):
+    _fields_ = [("channels", C.c_int * 5), ("tr_channels", C.c_int * 5), ("out_channels", C.c_int),
+                ("conv1_kernel_size", C.c_int), ("in_channels", C.c_int), ("normalize_feature", C.c_int)]
 
 
 def load_library():
@@ -78,6 +84,9 @@ def load_library():
     lib.yoho_o_score.argtypes = [vp, vp, vp, ci, vp, vp, ci, C.c_double, vp, vp, vp, vp]
     lib.yoho_c_ransac.argtypes = [vp, vp, vp, ci, vp, vp, ci, C.c_double, vp, vp, vp, vp, vp, vp]
     lib.yoho_group_gather.argtypes = [vp, vp, ci, vp, vp, ci, ci, vp, vp, vp, vp]
+    lib.yoho_load_fcgf.argtypes = [vp, C.POINTER(FcgfConfig), C.POINTER(vp), ci]
+    lib.yoho_fcgf_voxelize.argtypes = [vp, vp, ci, C.c_double, vp, vp, C.POINTER(ci), vp]
+    lib.yoho_fcgf_forward.argtypes = [vp, vp, ci, vp, vp]
     lib.yoho_set_profiling.argtypes = [vp, ci]
     lib.yoho_set_gconv_mode.argtypes = [vp, ci]
     lib.yoho_set_partII_mode.argtypes = [vp, ci]
@@ -177,6 +186,38 @@ class Context:
                           self._conv(sd, f + "0", keep), self._bn(sd, f + "1", keep),
                           self._conv(sd, f + "3", keep), self._bn(sd, f + "4", keep), self._conv(sd, f + "6", keep))
         _check(self._lib.yoho_load_partII(self._h, C.byref(w)))
+
+    # ---- FCGF backbone ------------------------------------------------------------------------
+    def load_fcgf(self, sd, channels=(0, 32, 64, 128, 256), tr_channels=(0, 64, 64, 64, 128), out_channels=32, conv1_kernel_size=7,
+                  in_channels=1, normalize_feature=True):
+        """sd: FCGF backbone state_dict (torch tensors or ndarrays); architecture parameters as in fcgf_model/resunet.py."""
+        sd = _weights.to_numpy_state_dict(sd)
+        spec = _weights.fcgf_spec(tuple(channels), tuple(tr_channels), out_channels, conv1_kernel_size, in_channels)
+        _weights.check_state_dict(sd, spec, strict=False)
+        names = [n for n, _ in spec if not n.endswith("num_batches_tracked")]
+        arrs = [np.ascontiguousarray(sd[n], dtype=np.float32) for n in names]
+        ptrs = (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+        cfg = FcgfConfig((C.c_int * 5)(*[int(v or 0) for v in channels]), (C.c_int * 5)(*[int(v or 0) for v in tr_channels]),
+                         int(out_channels), int(conv1_kernel_size), int(in_channels), int(bool(normalize_feature)))
+        _check(self._lib.yoho_load_fcgf(self._h, C.byref(cfg), ptrs, len(arrs)))
+        self._fcgf_out = int(out_channels)
+
+    def fcgf_voxelize(self, pts, voxel_size):
+        """pts (n,3) f64 cuda -> (sel (m,) int64 ascending, coords (m,3) int32): first point of every voxel (fcgf_feat.py:33-43)."""
+        n = pts.shape[0]
+        sel = torch.empty((n,), dtype=torch.int64, device=pts.device)
+        coords = torch.empty((n, 3), dtype=torch.int32, device=pts.device)
+        cnt = C.c_int(0)
+        _check(self._lib.yoho_fcgf_voxelize(self._h, _dev(pts, torch.float64, "pts"), n, float(voxel_size), C.c_void_p(sel.data_ptr()),
+                                            C.c_void_p(coords.data_ptr()), C.byref(cnt), _stream()))
+        return sel[:cnt.value], coords[:cnt.value]
+
+    def fcgf_forward(self, coords):
+        """coords (n,3) int32 cuda, distinct voxels -> (n, out_channels) f32 unit rows."""
+        n = coords.shape[0]
+        out = torch.empty((n, getattr(self, "_fcgf_out", 32)), dtype=torch.float32, device=coords.device)
+        _check(self._lib.yoho_fcgf_forward(self._h, _dev(coords, torch.int32, "coords"), n, C.c_void_p(out.data_ptr()), _stream()))
+        return out
 
     # ---- descriptor path -------------------------------------------------------------------
     def partI_forward(self, x, want_inv=True, want_inv_np=False):

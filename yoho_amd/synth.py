@@ -197,3 +197,23 @@ def write_scene_files(scene, root, cache_scene_dir=None):
         os.makedirs(f"{cache_scene_dir}/FCGF_Input_Group_feature", exist_ok=True)
         for k in range(n):
             np.save(f"{cache_scene_dir}/FCGF_Input_Group_feature/{k}.npy", scene["feats"][k])
+
+
+def surface_cloud(n, seed=0, extent=1.2):
+    """n points (f64) on a few random planes / a sphere inside a cube of side `extent` metres: a stand-in for an indoor
+    scan (surface-like occupancy, ~1/3 of a voxel neighbourhood filled) for the FCGF backbone tests and benches."""
+    rs = np.random.RandomState(seed)
+    parts = []
+    for _ in range(4):
+        o = rs.rand(3) * extent
+        u, v = rs.randn(3), rs.randn(3)
+        u /= np.linalg.norm(u)
+        v -= u * (u @ v)
+        v /= np.linalg.norm(v)
+        ab = (rs.rand(n // 5, 2) - 0.5) * extent
+        parts.append(o + ab[:, :1] * u + ab[:, 1:] * v)
+    d = rs.randn(n - 4 * (n // 5), 3)
+    parts.append(extent * 0.5 + 0.3 * extent * d / np.linalg.norm(d, axis=1, keepdims=True))
+    pc = np.concatenate(parts) + rs.randn(n, 3) * 0.002
+    rs.shuffle(pc)
+    return np.ascontiguousarray(pc.astype(np.float64))
