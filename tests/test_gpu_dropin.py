@@ -171,7 +171,40 @@ def test_yoho_extractor_with_stub_backbone(sd1, tables):
     e, i = orc.partI_forward(feats, sd1, tables.N)
     assert np.array_equal(kpts, pc[kidx]) and rel(eqv.numpy(), e) < 1e-4 and rel(inv.numpy(), i) < 1e-4
     with pytest.raises(NotImplementedError):
-        yoho_extractor(yoho_ckpt=sd1).run(pc)
+        yoho_extractor(fcgf_ckpt=None, yoho_ckpt=sd1).run(pc)
+
+
+def test_fcgf_extractor_dropin_and_full_yoho_extractor(sd1, tables):
+    """simple_yoho/fcgf_feat.py + yoho_extract.py with the HIP backbone: checkpoint dict in the FCGF format"""
+    import fcgf_oracle as fo
+    from yoho_amd.fcgf_feat import fcgf_extractor
+    from yoho_amd.yoho_extract import yoho_extractor
+    fsd = W.synth_state_dict(W.FCGF_SPEC, 3)
+    ck = {"config": {"model": "ResUNetBN2C", "model_n_out": 32, "normalize_feature": True, "conv1_kernel_size": 7},
+          "state_dict": {k: torch.from_numpy(np.array(v)) for k, v in fsd.items()}}
+    pc = synth.surface_cloud(2500, seed=3)
+    fx = fcgf_extractor(ck)
+    ds, feat = fx.run(pc, voxel_size=0.025)
+    sel, F0 = fo.extract_features(pc, 0.025, fsd)
+    assert np.array_equal(ds, pc[sel]) and not feat.is_cuda and rel(feat.numpy(), F0) < 1e-4
+    # full extractor = the same parts chained over the 60 rotations (reference simple_yoho/yoho_extract.py:41-60)
+    ex = yoho_extractor(fcgf_ckpt=ck, yoho_ckpt=sd1)
+    np.random.seed(7)
+    kpts, inv, eqv = ex.run(pc, voxel_size=0.025, nkpts=64)
+    np.random.seed(7)
+    kidx = np.random.permutation(len(pc))[0:64]
+    assert np.array_equal(kpts, pc[kidx]) and tuple(eqv.shape) == (64, 32, 60)
+    feats = np.empty((64, 32, 60), np.float32)
+    for g in (0, 17, 59):                                    # oracle on three of the sixty rotations
+        pcg = pc @ tables.R64[g].T
+        selg, Fg = fo.extract_features(pcg, 0.025, fsd)
+        j = np.argmin(orc.pdist_l2((pc[kidx] @ tables.R64[g].T).astype(np.float32), pcg[selg].astype(np.float32), squared=True), 1)
+        feats[:, :, g] = Fg[j]
+    got = ex._last_group_feats.cpu().numpy()
+    for g in (0, 17, 59):
+        assert rel(got[:, :, g], feats[:, :, g]) < 1e-4, g
+    e, i = orc.partI_forward(got, sd1, tables.N)
+    assert rel(eqv.numpy(), e) < 1e-4 and rel(inv.numpy(), i) < 1e-4
 
 
 @pytest.mark.parametrize("part,it,seedv", [("PartI", 100, 5), ("PartII", 1000, 6)])

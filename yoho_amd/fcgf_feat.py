@@ -1,0 +1,66 @@
+"""Drop-in for simple_yoho/fcgf_feat.py: the FCGF sparse-conv backbone on the HIP library (csrc/sparse.hip).
+
+    ext = fcgf_extractor('model/Backbone/best_val_checkpoint.pth')
+    ds_points, feats = ext.run(pc, voxel_size=0.025)          # (n,3) ndarray, (n,32) cpu Tensor, unit rows
+
+Same class / method names and return values as the reference (`fcgf_extractor.extract_features` returns
+``(sel, F.cpu())`` with ``sel`` a LongTensor so that ``run`` can do ``pc[inds.numpy()]``, simple_yoho/fcgf_feat.py:33-54).
+The checkpoint is the FCGF format the reference reads (:18-29): ``{'config': <namespace with model, model_n_out,
+normalize_feature, conv1_kernel_size>, 'state_dict': ...}``; a dict with the same keys (or ``state_dict`` + explicit
+arguments) is accepted as well, so that no MinkowskiEngine / easydict is needed to unpickle anything.
+"""
+import numpy as np
+import torch
+
+from . import hip
+
+# CHANNELS / TR_CHANNELS of the model classes (fcgf_model/resunet.py:14-16, 193-246); IN variants share the BN layout only
+# for NORM_TYPE - instance-norm blocks are not supported.
+MODEL_CHANNELS = {
+    "ResUNet2": ((0, 32, 64, 128, 256), (0, 32, 64, 64, 128)),
+    "ResUNetBN2": ((0, 32, 64, 128, 256), (0, 32, 64, 64, 128)),
+    "ResUNetBN2B": ((0, 32, 64, 128, 256), (0, 64, 64, 64, 64)),
+    "ResUNetBN2C": ((0, 32, 64, 128, 256), (0, 64, 64, 64, 128)),
+    "ResUNetBN2D": ((0, 32, 64, 128, 256), (0, 64, 64, 128, 128)),
+    "ResUNetBN2E": ((0, 128, 128, 128, 256), (0, 64, 128, 128, 128)),
+}
+
+
+def _cfg_get(cfg, key, default=None):
+    if isinstance(cfg, dict):
+        return cfg.get(key, default)
+    return getattr(cfg, key, default)
+
+
+class fcgf_extractor():
+    def __init__(self, pth='model/Backbone/best_val_checkpoint.pth', ctx=None):
+        self.pth_fn = pth
+        self.device = "cuda"
+        self.ctx = ctx if ctx is not None else hip.get_context()
+        self._load_model()
+
+    def _load_model(self):
+        checkpoint = self.pth_fn if isinstance(self.pth_fn, dict) else torch.load(self.pth_fn, map_location="cpu", weights_only=False)
+        config = checkpoint['config']
+        name = _cfg_get(config, 'model', 'ResUNetBN2C')
+        if name not in MODEL_CHANNELS:
+            raise ValueError(f"FCGF model {name} is not supported (BN ResUNet2 family only)")
+        ch, tr = MODEL_CHANNELS[name]
+        if name == "ResUNet2":
+            raise ValueError("ResUNet2 has no normalisation layers (NORM_TYPE None); use a BN variant")
+        self.ctx.load_fcgf(checkpoint['state_dict'], channels=ch, tr_channels=tr,
+                           out_channels=int(_cfg_get(config, 'model_n_out', 32)),
+                           conv1_kernel_size=int(_cfg_get(config, 'conv1_kernel_size', 7)), in_channels=1,
+                           normalize_feature=bool(_cfg_get(config, 'normalize_feature', True)))
+
+    def extract_features(self, pc, voxel_size):
+        pts = torch.from_numpy(np.ascontiguousarray(np.asarray(pc, dtype=np.float64))).cuda()
+        sel, coords = self.ctx.fcgf_voxelize(pts, voxel_size)
+        F = self.ctx.fcgf_forward(coords)
+        return sel.cpu(), F.cpu()
+
+    def run(self, pc, voxel_size=0.025):
+        # get features. inds is the indexes in the input pc (indexes of down-sampled keypoints)
+        inds, feat = self.extract_features(pc, voxel_size)
+        # downsampled-kpts, feat w l2 normalization
+        return pc[inds.numpy()], feat

@@ -3,10 +3,10 @@
     extractor = yoho_extractor(fcgf_ckpt, yoho_ckpt, fcgf=my_backbone)
     kpts, feat_inv, feat_eqv = extractor.run(pc, voxel_size=0.025, nkpts=5000)
 
-The FCGF sparse-conv backbone (simple_yoho/fcgf_feat.py on MinkowskiEngine, CUDA-only) is out of
-scope for this path: pass any object with ``run(pc, voxel_size) ->
-(ds_points (n,3), unit-norm feats (n,32))`` as ``fcgf``.  Everything after the backbone - the 60-fold
-NN feature transfer and the PartI group conv - runs on the HIP library.
+The FCGF sparse-conv backbone (simple_yoho/fcgf_feat.py on MinkowskiEngine) is ``yoho_amd.fcgf_feat.fcgf_extractor``
+(csrc/sparse.hip), built from ``fcgf_ckpt`` as the reference does (:20); any object with ``run(pc, voxel_size) ->
+(ds_points (n,3), unit-norm feats (n,32))`` can be passed as ``fcgf`` instead.  The 60-fold NN feature transfer and
+the PartI group conv run on the HIP library too.
 
 Differences from the reference (all deliberate):
   * no argparse at import time (simple_yoho/yoho_extract.py:11-13 breaks under pytest / other argv);
@@ -27,8 +27,11 @@ class yoho_extractor():
                  fcgf=None, so3_dir=None):
         self.ctx = hip.get_context(so3_dir=so3_dir)
         self.grs = self.ctx.tables.R64
-        self.fcgf = fcgf
         self.fcgf_ckpt = fcgf_ckpt
+        if fcgf is None and fcgf_ckpt is not None:
+            from .fcgf_feat import fcgf_extractor
+            fcgf = fcgf_extractor(fcgf_ckpt, ctx=self.ctx)
+        self.fcgf = fcgf
         self.yoho_ckpt = yoho_ckpt
         self._load_model()
         self.bs = 500
@@ -48,8 +51,7 @@ class yoho_extractor():
 
     def extract_features(self, pc, voxel_size, nkpts=5000):
         if self.fcgf is None:
-            raise NotImplementedError("no FCGF backbone: pass fcgf=<object with run(pc, voxel_size)> "
-                                      "(the MinkowskiEngine backbone is outside this path's scope)")
+            raise NotImplementedError("no FCGF backbone: pass fcgf_ckpt=<FCGF checkpoint> or fcgf=<object with run(pc, voxel_size)>")
         kpts_index = np.random.permutation(len(pc))[0:nkpts]
         kpts = pc[kpts_index]
         kpts_f = torch.empty((kpts.shape[0], 32, 60), dtype=torch.float32, device="cuda")
@@ -58,6 +60,7 @@ class yoho_extractor():
             pci = transform_points(pc.copy(), self.grs[i])
             pci_ds, pci_f = self.fcgf.run(pci, voxel_size)
             kpts_f[:, :, i] = self._feature_transfer_xyz(kptsi, pci_ds, pci_f)
+        self._last_group_feats = kpts_f                     # (n,32,60) group features, kept for inspection
         out = self.ctx.partI_forward(kpts_f.contiguous(), want_inv=True)
         # output: n*32; n*32*60 (cpu tensors, as the reference)
         return kpts, out["inv"].cpu(), out["eqv"].cpu()
