@@ -4,7 +4,7 @@
 //
 //   coordinate maps   open-addressing hash tables (64-bit packed voxel key -> row); a coarser map is built by inserting the
 //                     quantised coordinates with atomicMin of the source row, so its rows come out in first-occurrence order
-//                     (the CPU coordinate manager's order), compacted by a single-workgroup scan;
+//                     (the CPU coordinate manager's order), compacted by a block-count / scan / scatter pass;
 //   kernel maps       map[k][n] = input row at coord(n) + offset(k) (or coord(n) - offset(k) for a transposed conv), -1 if the
 //                     voxel is empty: output-stationary, so a convolution needs no atomics and sums in kernel-index order;
 //   convolution       one wave = 32 output rows x all output channels on v_mfma_f32_32x32x2_f32: A = gathered input rows
@@ -83,39 +83,81 @@ __device__ __forceinline__ int hash_find_slot(const u64* keys, unsigned mask, u6
     }
 }
 
-// first occurrences in source order -> new rows: single workgroup scan (order = the CPU coordinate manager's)
-__global__ __launch_bounds__(1024) void first_compact_kernel(CoordSrc src, int n, const u64* keys, int* vals, unsigned mask,
-                                                             int* out_coords, int64_t* sel, int* count) {
+// first occurrences in source order -> new rows (order = the CPU coordinate manager's).  Three phases: per-block counts,
+// single-workgroup scan of the block counts, per-block ballot scan + scatter.
+__device__ __forceinline__ bool is_first(const CoordSrc& src, int i, int n, const u64* keys, const int* vals, unsigned mask, int& x, int& y,
+                                         int& z) {
+    if (i >= n) return false;
+    voxel_of(src, i, x, y, z);
+    const int slot = hash_find_slot(keys, mask, pack_key(x, y, z));
+    return vals[slot] == i;
+}
+
+__global__ __launch_bounds__(1024) void first_count_kernel(CoordSrc src, int n, const u64* keys, const int* vals, unsigned mask, int* bsum) {
     __shared__ int wsum[16];
-    __shared__ int base;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    if (tid == 0) base = 0;
+    int x, y, z;
+    const bool keep = is_first(src, blockIdx.x * 1024 + tid, n, keys, vals, mask, x, y, z);
+    const unsigned long long m = __ballot(keep);
+    if (lane == 0) wsum[wv] = __popcll(m);
     __syncthreads();
-    for (int i0 = 0; i0 < n; i0 += 1024) {
-        const int i = i0 + tid;
-        bool keep = false;
-        int x = 0, y = 0, z = 0, slot = -1;
-        if (i < n) {
-            voxel_of(src, i, x, y, z);
-            slot = hash_find_slot(keys, mask, pack_key(x, y, z));
-            keep = vals[slot] == i;
-        }
-        const unsigned long long m = __ballot(keep);
-        const int before = __popcll(m & ((1ull << lane) - 1ull));
-        if (lane == 0) wsum[wv] = __popcll(m);
+    if (tid == 0) { int t = 0; for (int k = 0; k < 16; ++k) t += wsum[k]; bsum[blockIdx.x] = t; }
+}
+
+// exclusive scan of nb block counts in place, total -> *count
+__global__ __launch_bounds__(1024) void block_scan_kernel(int* bsum, int nb, int* count) {
+    __shared__ int sh[1024];
+    __shared__ int carry;
+    const int tid = threadIdx.x;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (int b0 = 0; b0 < nb; b0 += 1024) {
+        const int i = b0 + tid;
+        const int v = i < nb ? bsum[i] : 0;
+        sh[tid] = v;
         __syncthreads();
-        int off = base;
-        for (int k = 0; k < wv; ++k) off += wsum[k];
-        if (keep) {
-            const int r = off + before;
-            out_coords[3 * (size_t)r] = x; out_coords[3 * (size_t)r + 1] = y; out_coords[3 * (size_t)r + 2] = z;
-            if (sel) sel[r] = i;
+        for (int o = 1; o < 1024; o <<= 1) {
+            const int t = tid >= o ? sh[tid - o] : 0;
+            __syncthreads();
+            sh[tid] += t;
+            __syncthreads();
         }
+        if (i < nb) bsum[i] = carry + sh[tid] - v;
         __syncthreads();
-        if (tid == 0) { int t = 0; for (int k = 0; k < 16; ++k) t += wsum[k]; base += t; }
+        if (tid == 0) carry += sh[1023];
         __syncthreads();
     }
-    if (tid == 0) *count = base;
+    if (tid == 0) *count = carry;
+}
+
+__global__ __launch_bounds__(1024) void first_scatter_kernel(CoordSrc src, int n, const u64* keys, const int* vals, unsigned mask,
+                                                             const int* bsum, int* out_coords, int64_t* sel) {
+    __shared__ int wsum[16];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int i = blockIdx.x * 1024 + tid;
+    int x = 0, y = 0, z = 0;
+    const bool keep = is_first(src, i, n, keys, vals, mask, x, y, z);
+    const unsigned long long m = __ballot(keep);
+    const int before = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) wsum[wv] = __popcll(m);
+    __syncthreads();
+    int off = bsum[blockIdx.x];
+    for (int k = 0; k < wv; ++k) off += wsum[k];
+    if (keep) {
+        const int r = off + before;
+        out_coords[3 * (size_t)r] = x; out_coords[3 * (size_t)r + 1] = y; out_coords[3 * (size_t)r + 2] = z;
+        if (sel) sel[r] = i;
+    }
+}
+
+static int launch_first_compact(const CoordSrc& src, int n, const u64* keys, const int* vals, unsigned mask, int* bsum, int* out_coords,
+                                int64_t* sel, int* count, hipStream_t s) {
+    const int nb = (n + 1023) / 1024;
+    hipLaunchKernelGGL(first_count_kernel, dim3(nb), dim3(1024), 0, s, src, n, keys, vals, mask, bsum);
+    hipLaunchKernelGGL(block_scan_kernel, dim3(1), dim3(1024), 0, s, bsum, nb, count);
+    hipLaunchKernelGGL(first_scatter_kernel, dim3(nb), dim3(1024), 0, s, src, n, keys, vals, mask, bsum, out_coords, sel);
+    HIPCHK(hipGetLastError());
+    return 0;
 }
 
 // table value := row of the compacted map
@@ -158,6 +200,7 @@ __global__ __launch_bounds__(256) void spconv_kernel(SpConvArgs a) {
     const int li = lane & 31, h = lane >> 5;
     const int rbase = (blockIdx.x * 4 + w) * 32;
     if (rbase >= a.nout) return;
+    const int cb0 = blockIdx.y * NCB;                      // this workgroup's first 32-channel output block
     const int row = rbase + li;
     const bool valid = row < a.nout;
     floatx16s acc[NCB];
@@ -170,7 +213,7 @@ __global__ __launch_bounds__(256) void spconv_kernel(SpConvArgs a) {
         const int src = valid ? (a.map ? a.map[(size_t)k * a.nout + row] : row) : -1;
         if (__ballot(src >= 0) == 0ull) continue;
         const float* ip = a.in + (size_t)(src < 0 ? 0 : src) * a.ldin + h * 16;
-        const float* wk = a.W + (size_t)k * a.cin * a.cout + li;
+        const float* wk = a.W + (size_t)k * a.cin * a.cout + cb0 * 32 + li;
         for (int cc = 0; cc < nchunk; ++cc) {
             float av[16];
             if (src >= 0) {
@@ -197,7 +240,7 @@ __global__ __launch_bounds__(256) void spconv_kernel(SpConvArgs a) {
     // D[i = row][j = channel]: lane (j = lane & 31, half = lane >> 5), reg r -> row = (r & 3) + 8 (r >> 2) + 4 half
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb) {
-        const int co = cb * 32 + li;
+        const int co = (cb0 + cb) * 32 + li;
         const float s = a.aff_s ? a.aff_s[co] : 1.f, t = a.aff_t ? a.aff_t[co] : 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -219,12 +262,21 @@ __global__ __launch_bounds__(256) void spconv_small_kernel(SpConvArgs a) {
     const int row = blockIdx.x * rows_per + rl;
     if (rl >= rows_per || row >= a.nout) return;
     float acc = 0.f;
-    for (int k = 0; k < a.K; ++k) {
-        const int src = a.map ? a.map[(size_t)k * a.nout + row] : row;
-        if (src < 0) continue;
-        const float* ip = a.in + (size_t)src * a.ldin;
-        const float* wk = a.W + (size_t)k * a.cin * a.cout + co;
-        for (int c = 0; c < a.cin; ++c) acc = fmaf(ip[c], wk[(size_t)c * a.cout], acc);
+    constexpr int UB = 7;                                  // offsets per batch: independent map / feature loads in flight
+    for (int k0 = 0; k0 < a.K; k0 += UB) {
+        int src[UB];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) src[u] = (k0 + u < a.K) ? (a.map ? a.map[(size_t)(k0 + u) * a.nout + row] : row) : -1;
+        for (int c = 0; c < a.cin; ++c) {
+            float xv[UB], wv[UB];
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                xv[u] = src[u] >= 0 ? a.in[(size_t)src[u] * a.ldin + c] : 0.f;
+                wv[u] = (k0 + u < a.K) ? a.W[((size_t)(k0 + u) * a.cin + c) * a.cout + co] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < UB; ++u) acc = fmaf(xv[u], wv[u], acc);
+        }
     }
     float v = acc * (a.aff_s ? a.aff_s[co] : 1.f) + (a.aff_t ? a.aff_t[co] : 0.f);
     if (a.res) v += a.res[(size_t)row * a.ldres + a.rcoff + co];
@@ -235,16 +287,18 @@ __global__ __launch_bounds__(256) void spconv_small_kernel(SpConvArgs a) {
 static int launch_spconv(const SpConvArgs& a, hipStream_t s) {
     if (a.nout == 0) return 0;
     if (a.cin % 32 == 0 && a.cout % 32 == 0 && a.cout <= 256 && a.ldin % 4 == 0) {
-        const dim3 grid((a.nout + 127) / 128), blk(256);
-        switch (a.cout / 32) {
+        // Output channel blocks per wave: as many as keep >= ~2048 waves in flight (a wave re-gathers its input rows for
+        // every group of channel blocks, so fewer groups = less gather traffic; the coarse levels have few rows and
+        // many channels and need the extra parallelism)
+        const int ncbt = a.cout / 32, rowtiles = (a.nout + 31) / 32;
+        int ncb = 1;
+        for (int c = 2; c <= 4; c *= 2)
+            if (ncbt % c == 0 && (long long)rowtiles * (ncbt / c) >= 2048) ncb = c;
+        const dim3 grid((a.nout + 127) / 128, ncbt / ncb), blk(256);
+        switch (ncb) {
             case 1: hipLaunchKernelGGL(spconv_kernel<1>, grid, blk, 0, s, a); break;
             case 2: hipLaunchKernelGGL(spconv_kernel<2>, grid, blk, 0, s, a); break;
-            case 3: hipLaunchKernelGGL(spconv_kernel<3>, grid, blk, 0, s, a); break;
-            case 4: hipLaunchKernelGGL(spconv_kernel<4>, grid, blk, 0, s, a); break;
-            case 5: hipLaunchKernelGGL(spconv_kernel<5>, grid, blk, 0, s, a); break;
-            case 6: hipLaunchKernelGGL(spconv_kernel<6>, grid, blk, 0, s, a); break;
-            case 7: hipLaunchKernelGGL(spconv_kernel<7>, grid, blk, 0, s, a); break;
-            default: hipLaunchKernelGGL(spconv_kernel<8>, grid, blk, 0, s, a); break;
+            default: hipLaunchKernelGGL(spconv_kernel<4>, grid, blk, 0, s, a); break;
         }
     } else {
         if (a.cout > 256 || a.cout < 1) { set_error("sparse conv: unsupported channel count %d", a.cout); return YOHO_EINVAL; }
@@ -430,9 +484,8 @@ int fcgf_forward(yoho_ctx* ctx, const FcgfNet* net, const int* coords0, int n0, 
             CoordSrc src{L[l - 1].coords, nullptr, 1.0, L[l].ts};
             if ((rc = build_table(src, nprev, L[l], s))) return rc;
             L[l].coords = ar.take<int>((size_t)nprev * 3);
-            hipLaunchKernelGGL(first_compact_kernel, dim3(1), dim3(1024), 0, s, src, nprev, L[l].keys, L[l].vals, L[l].mask, L[l].coords,
-                               (int64_t*)nullptr, dcount + l);
-            HIPCHK(hipGetLastError());
+            int* bsum = ar.take<int>((size_t)(nprev + 1023) / 1024 + 1);
+            if ((rc = launch_first_compact(src, nprev, L[l].keys, L[l].vals, L[l].mask, bsum, L[l].coords, nullptr, dcount + l, s))) return rc;
             HIPCHK(hipMemcpyAsync(&L[l].n, dcount + l, sizeof(int), hipMemcpyDeviceToHost, s));
             HIPCHK(hipStreamSynchronize(s));
             hipLaunchKernelGGL(hash_set_rows_kernel, dim3((L[l].n + 255) / 256), dim3(256), 0, s, L[l].coords, L[l].n, L[l].keys, L[l].vals,
@@ -523,15 +576,15 @@ int fcgf_voxelize(yoho_ctx* ctx, const double* pts, int n, double voxel, int64_t
     if (n == 0) { *count_host = 0; return 0; }
     int rc;
     const unsigned cap = table_cap(n);
-    if ((rc = ensure_ws(ctx, (size_t)cap * 12 + 1024, s))) return rc;
+    if ((rc = ensure_ws(ctx, (size_t)cap * 12 + (size_t)n / 256 + 8192, s))) return rc;
     Arena ar{(char*)ctx->ws.p, 0, ctx->ws.bytes};
     Level L;
     L.mask = cap - 1; L.keys = ar.take<u64>(cap); L.vals = ar.take<int>(cap);
     int* dcount = ar.take<int>(1);
     CoordSrc src{nullptr, pts, voxel, 1};
     if ((rc = build_table(src, n, L, s))) return rc;
-    hipLaunchKernelGGL(first_compact_kernel, dim3(1), dim3(1024), 0, s, src, n, L.keys, L.vals, L.mask, coords, sel, dcount);
-    HIPCHK(hipGetLastError());
+    int* bsum = ar.take<int>((size_t)(n + 1023) / 1024 + 1);
+    if ((rc = launch_first_compact(src, n, L.keys, L.vals, L.mask, bsum, coords, sel, dcount, s))) return rc;
     HIPCHK(hipMemcpyAsync(count_host, dcount, sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     return 0;
