@@ -194,48 +194,84 @@ struct SpConvArgs {
     int relu;
 };
 
-template <int NCB>
+constexpr int SP_MAXK = 27;
+
+// NCB = 32-channel output blocks per wave.  SPLIT = false: every wave of the workgroup owns its own 32 output rows.
+// SPLIT = true (coarse levels: few rows, many channels): the four waves share one 32-row tile and split the
+// (kernel offset, channel chunk) loop four ways; the partial sums meet in LDS and are added in wave order.
+// The input rows of the whole kernel region are looked up once (K <= 27 indices per row, kept in LDS); the gathered
+// A values and the weight fragment of step i+1 are loaded while the MFMAs of step i issue (register ping-pong).
+template <int NCB, bool SPLIT>
 __global__ __launch_bounds__(256) void spconv_kernel(SpConvArgs a) {
+    __shared__ int srcl[4][SP_MAXK * 32];
+    __shared__ float red[SPLIT ? 3 * NCB * 16 * 64 : 1];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int li = lane & 31, h = lane >> 5;
-    const int rbase = (blockIdx.x * 4 + w) * 32;
-    if (rbase >= a.nout) return;
+    const int rbase = SPLIT ? blockIdx.x * 32 : (blockIdx.x * 4 + w) * 32;
+    if (!SPLIT && rbase >= a.nout) return;
     const int cb0 = blockIdx.y * NCB;                      // this workgroup's first 32-channel output block
     const int row = rbase + li;
     const bool valid = row < a.nout;
+    int* sl = srcl[w];
+    for (int k = h; k < a.K; k += 2) sl[k * 32 + li] = valid ? (a.map ? a.map[(size_t)k * a.nout + row] : row) : -1;
+    __builtin_amdgcn_wave_barrier();
+
     floatx16s acc[NCB];
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[cb][r] = 0.f;
     const int nchunk = a.cin / 32;
-    for (int k = 0; k < a.K; ++k) {
-        const int src = valid ? (a.map ? a.map[(size_t)k * a.nout + row] : row) : -1;
-        if (__ballot(src >= 0) == 0ull) continue;
-        const float* ip = a.in + (size_t)(src < 0 ? 0 : src) * a.ldin + h * 16;
-        const float* wk = a.W + (size_t)k * a.cin * a.cout + cb0 * 32 + li;
-        for (int cc = 0; cc < nchunk; ++cc) {
-            float av[16];
-            if (src >= 0) {
+    const int total = a.K * nchunk;
+    const int it0 = SPLIT ? (total * w) / 4 : 0, it1 = SPLIT ? (total * (w + 1)) / 4 : total;
+
+    auto issue = [&](int it, float (&av)[16], float (&bv)[16 * NCB]) {
+        const int k = it / nchunk, cc = it - k * nchunk;
+        const int src = sl[k * 32 + li];
+        const float* ip = a.in + (size_t)(src < 0 ? 0 : src) * a.ldin + cc * 32 + h * 16;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float4 v = *reinterpret_cast<const float4*>(ip + cc * 32 + 4 * q);
-                    av[4 * q] = v.x; av[4 * q + 1] = v.y; av[4 * q + 2] = v.z; av[4 * q + 3] = v.w;
-                }
-            } else {
-#pragma unroll
-                for (int q = 0; q < 16; ++q) av[q] = 0.f;
-            }
-            const float* wp = wk + (size_t)(cc * 32 + h * 16) * a.cout;
-#pragma unroll
-            for (int kk = 0; kk < 16; ++kk) {
-#pragma unroll
-                for (int cb = 0; cb < NCB; ++cb) {
-                    const float bv = wp[(size_t)kk * a.cout + cb * 32];
-                    acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], bv, acc[cb], 0, 0, 0);
-                }
-            }
+        for (int q = 0; q < 4; ++q) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (src >= 0) v = *reinterpret_cast<const float4*>(ip + 4 * q);
+            av[4 * q] = v.x; av[4 * q + 1] = v.y; av[4 * q + 2] = v.z; av[4 * q + 3] = v.w;
         }
+        const float* wp = a.W + ((size_t)k * a.cin + cc * 32 + h * 16) * a.cout + cb0 * 32 + li;
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk)
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) bv[kk * NCB + cb] = wp[(size_t)kk * a.cout + cb * 32];
+    };
+    auto mma = [&](const float (&av)[16], const float (&bv)[16 * NCB]) {
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk)
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], bv[kk * NCB + cb], acc[cb], 0, 0, 0);
+    };
+    float a0[16], a1[16], b0[16 * NCB], b1[16 * NCB];
+    if (it0 < it1) issue(it0, a0, b0);
+    for (int it = it0; it < it1; it += 2) {
+        if (it + 1 < it1) issue(it + 1, a1, b1);
+        mma(a0, b0);
+        if (it + 1 < it1) {
+            if (it + 2 < it1) issue(it + 2, a0, b0);
+            mma(a1, b1);
+        }
+    }
+    if (SPLIT) {
+        if (w > 0) {
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) red[(((w - 1) * NCB + cb) * 16 + r) * 64 + lane] = acc[cb][r];
+        }
+        __syncthreads();
+        if (w > 0) return;
+#pragma unroll
+        for (int ww = 0; ww < 3; ++ww)
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[cb][r] += red[((ww * NCB + cb) * 16 + r) * 64 + lane];
     }
     // D[i = row][j = channel]: lane (j = lane & 31, half = lane >> 5), reg r -> row = (r & 3) + 8 (r >> 2) + 4 half
 #pragma unroll
@@ -286,19 +322,21 @@ __global__ __launch_bounds__(256) void spconv_small_kernel(SpConvArgs a) {
 
 static int launch_spconv(const SpConvArgs& a, hipStream_t s) {
     if (a.nout == 0) return 0;
-    if (a.cin % 32 == 0 && a.cout % 32 == 0 && a.cout <= 256 && a.ldin % 4 == 0) {
-        // Output channel blocks per wave: as many as keep >= ~2048 waves in flight (a wave re-gathers its input rows for
-        // every group of channel blocks, so fewer groups = less gather traffic; the coarse levels have few rows and
-        // many channels and need the extra parallelism)
+    if (a.cin % 32 == 0 && a.cout % 32 == 0 && a.cout <= 256 && a.ldin % 4 == 0 && a.K <= SP_MAXK) {
+        // Two 32-channel output blocks per wave where possible (halves the gather traffic).  Levels with fewer than ~1024
+        // (row tile, channel group) units run the split variant: one unit per workgroup, the K loop over its 4 waves.
         const int ncbt = a.cout / 32, rowtiles = (a.nout + 31) / 32;
-        int ncb = 1;
-        for (int c = 2; c <= 4; c *= 2)
-            if (ncbt % c == 0 && (long long)rowtiles * (ncbt / c) >= 2048) ncb = c;
-        const dim3 grid((a.nout + 127) / 128, ncbt / ncb), blk(256);
-        switch (ncb) {
-            case 1: hipLaunchKernelGGL(spconv_kernel<1>, grid, blk, 0, s, a); break;
-            case 2: hipLaunchKernelGGL(spconv_kernel<2>, grid, blk, 0, s, a); break;
-            default: hipLaunchKernelGGL(spconv_kernel<4>, grid, blk, 0, s, a); break;
+        const int ncb = (ncbt % 2 == 0 && (long long)rowtiles * (ncbt / 2) >= 1024) ? 2 : 1;
+        const bool split = (long long)rowtiles * (ncbt / ncb) < 1024;
+        const dim3 blk(256);
+        if (split) {
+            const dim3 grid(rowtiles, ncbt / ncb);
+            if (ncb == 2) hipLaunchKernelGGL((spconv_kernel<2, true>), grid, blk, 0, s, a);
+            else hipLaunchKernelGGL((spconv_kernel<1, true>), grid, blk, 0, s, a);
+        } else {
+            const dim3 grid((a.nout + 127) / 128, ncbt / ncb);
+            if (ncb == 2) hipLaunchKernelGGL((spconv_kernel<2, false>), grid, blk, 0, s, a);
+            else hipLaunchKernelGGL((spconv_kernel<1, false>), grid, blk, 0, s, a);
         }
     } else {
         if (a.cout > 256 || a.cout < 1) { set_error("sparse conv: unsupported channel count %d", a.cout); return YOHO_EINVAL; }
