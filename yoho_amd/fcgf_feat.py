@@ -53,10 +53,14 @@ class fcgf_extractor():
                            conv1_kernel_size=int(_cfg_get(config, 'conv1_kernel_size', 7)), in_channels=1,
                            normalize_feature=bool(_cfg_get(config, 'normalize_feature', True)))
 
+    def extract_features_dev(self, pts, voxel_size):
+        """HBM-resident variant: pts (n,3) f64 cuda -> (sel int64 cuda, F (m,32) f32 cuda); no host copies."""
+        sel, coords = self.ctx.fcgf_voxelize(pts, voxel_size)
+        return sel, self.ctx.fcgf_forward(coords)
+
     def extract_features(self, pc, voxel_size):
         pts = torch.from_numpy(np.ascontiguousarray(np.asarray(pc, dtype=np.float64))).cuda()
-        sel, coords = self.ctx.fcgf_voxelize(pts, voxel_size)
-        F = self.ctx.fcgf_forward(coords)
+        sel, F = self.extract_features_dev(pts, voxel_size)
         return sel.cpu(), F.cpu()
 
     def run(self, pc, voxel_size=0.025):

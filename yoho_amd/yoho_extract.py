@@ -55,6 +55,21 @@ class yoho_extractor():
         kpts_index = np.random.permutation(len(pc))[0:nkpts]
         kpts = pc[kpts_index]
         kpts_f = torch.empty((kpts.shape[0], 32, 60), dtype=torch.float32, device="cuda")
+        if hasattr(self.fcgf, "extract_features_dev"):
+            # HBM-resident path: the cloud is uploaded once; rotation (f64), voxelisation, backbone and the NN feature
+            # transfer of all 60 group elements run on the device (same operations as the loop below)
+            pc_d = torch.from_numpy(np.ascontiguousarray(np.asarray(pc, dtype=np.float64))).cuda()
+            kp_d = pc_d[torch.from_numpy(kpts_index).cuda()]
+            for i in range(self.grs.shape[0]):
+                Rt = torch.from_numpy(np.ascontiguousarray(self.grs[i].T)).cuda()
+                pci = pc_d @ Rt
+                sel, pci_f = self.fcgf.extract_features_dev(pci, voxel_size)
+                q = (kp_d @ Rt).to(torch.float32).contiguous()
+                _, idx = self.ctx.nn_search(q, pci[sel].to(torch.float32).contiguous(), want_dist=False, squared=True)
+                kpts_f[:, :, i] = pci_f[idx]
+            self._last_group_feats = kpts_f
+            out = self.ctx.partI_forward(kpts_f.contiguous(), want_inv=True)
+            return kpts, out["inv"].cpu(), out["eqv"].cpu()
         for i in range(self.grs.shape[0]):
             kptsi = transform_points(kpts.copy(), self.grs[i])
             pci = transform_points(pc.copy(), self.grs[i])
