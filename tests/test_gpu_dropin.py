@@ -252,3 +252,32 @@ def test_evaluator_fmr_and_registration_recall(gold, tmp_path, sd1, sd2, part, i
     _, ref = RR_cal.read_pre_trajectory(str(ref_log))
     assert rel(mine, ref) < 1e-4
     assert "Mean_Registration_Recall" in (tmp_path / "results.log").read_text()
+
+
+def test_testset_create_from_point_clouds(tmp_path, tables):
+    """YOHO_testset.py drop-in: fragment point clouds + keypoints -> FCGF_Input_Group_feature/{id}.npy; three of the
+    sixty group elements are checked against the oracle chain (voxelise, backbone, f64 NN gather)."""
+    import fcgf_oracle as fo
+    from yoho_amd.YOHO_testset import testset_create
+    fsd = W.synth_state_dict(W.FCGF_SPEC, 3)
+    ck = {"config": {"model": "ResUNetBN2C", "model_n_out": 32, "normalize_feature": True, "conv1_kernel_size": 7}, "state_dict": fsd}
+    clouds = {"0": synth.surface_cloud(2200, seed=11), "1": synth.surface_cloud(1800, seed=12)}
+    rs = np.random.RandomState(0)
+    kps = {k: v[rs.permutation(len(v))[:40]] for k, v in clouds.items()}
+
+    class DS:
+        pc_ids = ["0", "1"]
+        get_pc = staticmethod(lambda i: clouds[i])
+        get_kps = staticmethod(lambda i: kps[i])
+
+    cfg = types.SimpleNamespace(model=ck, voxel_size=0.025, dataset="synth", output_dir=str(tmp_path), origin_dir=str(tmp_path),
+                                datasets={"wholesetname": "synth", "room": DS()})
+    testset_create(cfg).batch_feature_extraction()
+    for pid in ("0", "1"):
+        got = np.load(f"{tmp_path}/Testset/synth/room/FCGF_Input_Group_feature/{pid}.npy")
+        assert got.shape == (40, 32, 60) and got.dtype == np.float32
+        for g in (0, 23, 59):
+            pcg = clouds[pid] @ tables.R64[g].T
+            sel, Fg = fo.extract_features(pcg, 0.025, fsd)
+            ref = orc.group_gather_one(kps[pid], pcg[sel].astype(np.float32), Fg, tables.R64[g])[0]
+            assert rel(got[:, :, g], ref) < 1e-4, (pid, g)
