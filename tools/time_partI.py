@@ -19,4 +19,4 @@ for _ in range(5):
     ms.append([ctx.kernel_ms(i) for i in range(7)])
 ms = np.array(ms).mean(0)
 print(mode, "B=%d" % B, "conv launches", np.round(ms[:4], 3), "head %.3f tail %.3f transforms %.3f total %.3f" % (ms[4], ms[5], ms[6], ms.sum()),
-      "dbg=" + os.environ.get("YOHO_FG_DEBUG", "0"))
+      )

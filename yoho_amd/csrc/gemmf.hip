@@ -118,19 +118,19 @@ __device__ __forceinline__ void stage_tile(const char* src, char* dst, int w, in
 // One K16 sub-step: 48 MFMAs on fragment set `f` (every accumulator gets lo*hi, hi*lo, hi*hi, 16 MFMAs apart), with
 // the 16 fragment reads of the next sub-step (and, if DMA, the 16 LDS-DMA units of a later stage) issued one per MFMA
 // behind the first 16.  sched_barrier pins the order: left alone the scheduler puts dependent MFMAs back to back.
-template <int RSUB, bool DMA, int DBG = 0>
+template <int RSUB, bool DMA>
 __device__ __forceinline__ void substep(const Frags& f, floatx16 (&acc)[4][4], const char* ra, const char* rb, Frags& nf,
                                         const char* srcA, const char* srcB, char* dmadst, int w, int lane16) {
     sfor<0, 16>([&](auto gc) {
         constexpr int g = decltype(gc)::value;
         acc[g >> 2][g & 3] = mfma_h(f.al[g >> 2], f.bh[g & 3], acc[g >> 2][g & 3]);
-        if constexpr (!(DBG & 1)) read_frag<RSUB, g>(ra, rb, nf);
+        read_frag<RSUB, g>(ra, rb, nf);
         __builtin_amdgcn_sched_barrier(0);
     });
     sfor<0, 16>([&](auto gc) {
         constexpr int g = decltype(gc)::value;
         acc[g >> 2][g & 3] = mfma_h(f.ah[g >> 2], f.bl[g & 3], acc[g >> 2][g & 3]);
-        if constexpr (DMA && !(DBG & 2)) {
+        if constexpr (DMA) {
             stage_unit<g>(srcA, srcB, dmadst, w, lane16);
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -143,7 +143,6 @@ __device__ __forceinline__ void substep(const Frags& f, floatx16 (&acc)[4][4], c
     __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int DBG>
 __global__ __launch_bounds__(256, 1) void fgemm_kernel(FGemmArgs a, int flags) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -209,20 +208,19 @@ __global__ __launch_bounds__(256, 1) void fgemm_kernel(FGemmArgs a, int flags) {
     }
     Frags P, Q;
     read_frags<0>(smem + lane_a, smem + lane_b, P);
-    if constexpr (DBG & 1) read_frags<1>(smem + lane_a, smem + lane_b, Q);
     for (int s = 0; s < KS; ++s) {
         char* cur = smem + (s & 1) * (2 * FG_STAGE);
         char* nxt = smem + ((s + 1) & 1) * (2 * FG_STAGE);
         // sub-step 0: MFMAs on P, fragments of sub-step 1 into Q
-        substep<1, false, DBG>(P, acc, cur + lane_a, cur + lane_b, Q, nullptr, nullptr, nullptr, w, lane16);
+        substep<1, false>(P, acc, cur + lane_a, cur + lane_b, Q, nullptr, nullptr, nullptr, w, lane16);
         // everybody has its sub-step-1 fragments in registers: the buffer is free, and stage s+1 has landed
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        if constexpr (!(DBG & 4)) __syncthreads();
+        __syncthreads();
         __builtin_amdgcn_sched_barrier(0);
         // sub-step 1: MFMAs on Q; refill the freed buffer with stage s+2 and read the first fragments of stage s+1 into P.
         // Past the end both are repeated on the last stage (branch-free, the data is not used).
         const int s2 = s + 2 < KS ? s + 2 : KS - 1;
-        substep<0, true, DBG>(Q, acc, nxt + lane_a, nxt + lane_b, P, uniform_ptr(Ag + (size_t)s2 * FG_STAGE), uniform_ptr(Bg + (size_t)s2 * FG_STAGE),
+        substep<0, true>(Q, acc, nxt + lane_a, nxt + lane_b, P, uniform_ptr(Ag + (size_t)s2 * FG_STAGE), uniform_ptr(Bg + (size_t)s2 * FG_STAGE),
                               cur, w, lane16);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -261,11 +259,7 @@ __global__ __launch_bounds__(256, 1) void fgemm_kernel(FGemmArgs a, int flags) {
 }
 
 int fgemm_init() {
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&fgemm_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, FG_LDS));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&fgemm_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, FG_LDS));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&fgemm_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, FG_LDS));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&fgemm_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, FG_LDS));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&fgemm_kernel<7>), hipFuncAttributeMaxDynamicSharedMemorySize, FG_LDS));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&fgemm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, FG_LDS));
     int dd[NIR_ORD], bb[NIR_ORD];
     for (int t = 0; t < NIR_ORD; ++t) { dd[t] = FG_ORD_D[t]; bb[t] = FG_IR_BASE[FG_ORD_R[t]]; }
     HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_fg_d), dd, sizeof(dd)));
@@ -378,13 +372,7 @@ int launch_fgemm(const Layer& L, const char* Bplanes, int kppad, int nT32, const
         tot = n > tot ? n : tot;
     }
     tot *= 8;
-    int dbg = 0;
-    if (const char* e = std::getenv("YOHO_FG_DEBUG")) dbg = std::atoi(e);
-    if (dbg == 1) hipLaunchKernelGGL(fgemm_kernel<1>, dim3(tot), dim3(256), FG_LDS, s, a, flags);
-    else if (dbg == 2) hipLaunchKernelGGL(fgemm_kernel<2>, dim3(tot), dim3(256), FG_LDS, s, a, flags);
-    else if (dbg == 3) hipLaunchKernelGGL(fgemm_kernel<3>, dim3(tot), dim3(256), FG_LDS, s, a, flags);
-    else if (dbg == 7) hipLaunchKernelGGL(fgemm_kernel<7>, dim3(tot), dim3(256), FG_LDS, s, a, flags);
-    else hipLaunchKernelGGL(fgemm_kernel<0>, dim3(tot), dim3(256), FG_LDS, s, a, flags);
+    hipLaunchKernelGGL(fgemm_kernel, dim3(tot), dim3(256), FG_LDS, s, a, flags);
     HIPCHK(hipGetLastError());
     return 0;
 }
