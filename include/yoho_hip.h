@@ -166,6 +166,10 @@ int yoho_fcgf_voxelize(yoho_ctx* ctx, const double* pts, int n, double voxel_siz
                        void* stream);
 /* resunet.py:141-190 + the final normalisation of fcgf_feat.py:48.  coords (n,3) i32 distinct voxels, out (n,out_channels). */
 int yoho_fcgf_forward(yoho_ctx* ctx, const int32_t* coords, int n, float* out, void* stream);
+/* several clouds in one pass (the 60 rotated copies of a fragment, or the reference's DataLoader batch, YOHO_testset.py:172-180):
+ * coords = the clouds' voxel rows one after the other, offsets (host, nb+1 entries, offsets[0] = 0) their row ranges,
+ * nb <= 64.  Same result per cloud as nb separate yoho_fcgf_forward calls. */
+int yoho_fcgf_forward_batch(yoho_ctx* ctx, const int32_t* coords, const int32_t* offsets, int nb, float* out, void* stream);
 
 /* PartI group-conv formulation: 0 = direct 13-tap conv on fp32 MFMA (v_mfma_f32_32x32x2_f32), 1 = direct conv with an
  * fp32-accurate 3-way bf16 split on v_mfma_f32_32x32x16_bf16 (6 products per term), 2 = group-Fourier domain conv

@@ -67,3 +67,14 @@ def test_backbone_row_order_and_translation(fctx):
     shift = torch.tensor([16, -8, 24], dtype=torch.int32, device="cuda")
     Fs = fctx.fcgf_forward((c + shift).contiguous())
     assert (Fs - F).abs().max().item() < 2e-5              # multiples of the coarsest stride: all maps shift together
+
+
+def test_batched_clouds_equal_separate_passes(fctx):
+    clouds = [torch.from_numpy(fo.voxelize(synth.surface_cloud(n, seed=sd), 0.025)[1]).cuda() for n, sd in ((3000, 1), (500, 2), (4500, 3))]
+    sep = [fctx.fcgf_forward(c) for c in clouds]
+    bat = fctx.fcgf_forward_batch(clouds)
+    for a, b in zip(sep, bat):
+        assert a.shape == b.shape and (a - b).abs().max().item() < 2e-5
+    # identical clouds in one batch must not see each other (cloud index is part of the voxel key)
+    two = fctx.fcgf_forward_batch([clouds[0], clouds[0]])
+    assert (two[0] - sep[0]).abs().max().item() < 2e-5 and torch.equal(two[0], two[1])

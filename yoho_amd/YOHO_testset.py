@@ -42,11 +42,12 @@ class testset_create():
         pc_d = torch.from_numpy(np.ascontiguousarray(np.asarray(pc, dtype=np.float64))).cuda()
         k_d = torch.from_numpy(np.ascontiguousarray(np.asarray(keys, dtype=np.float64))).cuda()
         out = torch.empty((k_d.shape[0], 32, 60), dtype=torch.float32, device="cuda")
-        for g_id in range(60):
-            xyz0 = pc_d @ torch.from_numpy(np.ascontiguousarray(self.Rgroup[g_id].T)).cuda()
-            sel, feat = self.fcgf.extract_features_dev(xyz0, self.config.voxel_size)
-            pts = xyz0[sel].to(torch.float32).contiguous()          # 'dspcd0' (.float(), YOHO_testset.py:92)
-            self.ctx.group_gather(k_d, pts, feat, g_id, out)         # keys @ R_g^T, f64 NN, feature row -> out[:, :, g]
+        nb = 6                                                       # rotated copies per backbone pass
+        for g0 in range(0, 60, nb):
+            xyzs = [pc_d @ torch.from_numpy(np.ascontiguousarray(self.Rgroup[g].T)).cuda() for g in range(g0, g0 + nb)]
+            for j, (sel, feat) in enumerate(self.fcgf.extract_features_dev_batch(xyzs, self.config.voxel_size)):
+                pts = xyzs[j][sel].to(torch.float32).contiguous()    # 'dspcd0' (.float(), YOHO_testset.py:92)
+                self.ctx.group_gather(k_d, pts, feat, g0 + j, out)   # keys @ R_g^T, f64 NN, feature row -> out[:, :, g]
         return out
 
     def Feature_extracting(self):

@@ -737,7 +737,19 @@ int yoho_fcgf_forward(yoho_ctx* c, const int32_t* coords, int n, float* out, voi
     if (n == 0) return 0;
     if (!coords || !out) { set_error("yoho_fcgf_forward: bad argument"); return YOHO_EINVAL; }
     HIPCHK(hipSetDevice(c->device));
-    return fcgf_forward(c, c->fcgf, coords, n, out, (hipStream_t)stream);
+    return fcgf_forward(c, c->fcgf, coords, n, nullptr, 1, out, (hipStream_t)stream);
+}
+
+int yoho_fcgf_forward_batch(yoho_ctx* c, const int32_t* coords, const int32_t* offsets, int nb, float* out, void* stream) {
+    if (!c || !offsets || nb < 1 || nb > 64) { set_error("yoho_fcgf_forward_batch: bad argument (1..64 clouds)"); return YOHO_EINVAL; }
+    if (!c->fcgf) { set_error("yoho_fcgf_forward_batch: backbone weights not loaded"); return YOHO_ENOWEIGHTS; }
+    if (offsets[0] != 0) { set_error("yoho_fcgf_forward_batch: offsets[0] must be 0"); return YOHO_EINVAL; }
+    for (int b = 0; b < nb; ++b) if (offsets[b + 1] < offsets[b]) { set_error("yoho_fcgf_forward_batch: offsets must be non-decreasing"); return YOHO_EINVAL; }
+    const int n = offsets[nb];
+    if (n == 0) return 0;
+    if (!coords || !out) { set_error("yoho_fcgf_forward_batch: bad argument"); return YOHO_EINVAL; }
+    HIPCHK(hipSetDevice(c->device));
+    return fcgf_forward(c, c->fcgf, coords, n, offsets, nb, out, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -14,6 +14,8 @@
 #include <hip/hip_runtime.h>
 #include <vector>
 #include <cstring>
+#include <cmath>
+#include <cstdlib>
 
 #include "common.h"
 
@@ -23,8 +25,10 @@ typedef unsigned long long u64;
 typedef float floatx16s __attribute__((ext_vector_type(16)));
 constexpr u64 HEMPTY = ~0ull;
 
-__device__ __forceinline__ u64 pack_key(int x, int y, int z) {
-    return ((u64)(unsigned)(x + (1 << 20)) << 42) | ((u64)(unsigned)(y + (1 << 20)) << 21) | (u64)(unsigned)(z + (1 << 20));
+// 19 bits per axis (|voxel index| < 2^18) + 7 bits of cloud (batch) index
+__device__ __forceinline__ u64 pack_key(int x, int y, int z, int b) {
+    return ((u64)(unsigned)b << 57) | ((u64)(unsigned)((x + (1 << 18)) & 0x7FFFF) << 38) | ((u64)(unsigned)((y + (1 << 18)) & 0x7FFFF) << 19) |
+           (u64)(unsigned)((z + (1 << 18)) & 0x7FFFF);
 }
 __device__ __forceinline__ unsigned hslot(u64 key, unsigned mask) { return (unsigned)((key * 0x9E3779B97F4A7C15ull) >> 33) & mask; }
 __device__ __forceinline__ int floor_to(int c, int ts) {            // floor(c / ts) * ts  (src/coordinate_map.hpp:58-76)
@@ -41,20 +45,20 @@ __global__ void hash_clear_kernel(u64* keys, int* vals, unsigned cap) {
 
 // voxel of point i: from integer coordinates (quantised to `ts`) or from f64 points (floor(p / voxel), fcgf_feat.py:34)
 struct CoordSrc {
-    const int* coords;       // (n,3) or null
+    const int* coords;       // (n,4) rows (x, y, z, cloud) or null
     const double* pts;       // (n,3) or null
     double voxel;
     int ts;
 };
-__device__ __forceinline__ void voxel_of(const CoordSrc& s, int i, int& x, int& y, int& z) {
+__device__ __forceinline__ void voxel_of(const CoordSrc& s, int i, int& x, int& y, int& z, int& b) {
     if (s.pts) {
         x = (int)floor(s.pts[3 * (size_t)i] / s.voxel);
         y = (int)floor(s.pts[3 * (size_t)i + 1] / s.voxel);
         z = (int)floor(s.pts[3 * (size_t)i + 2] / s.voxel);
+        b = 0;
     } else {
-        x = floor_to(s.coords[3 * (size_t)i], s.ts);
-        y = floor_to(s.coords[3 * (size_t)i + 1], s.ts);
-        z = floor_to(s.coords[3 * (size_t)i + 2], s.ts);
+        const int4 c = reinterpret_cast<const int4*>(s.coords)[i];
+        x = floor_to(c.x, s.ts); y = floor_to(c.y, s.ts); z = floor_to(c.z, s.ts); b = c.w;
     }
 }
 
@@ -62,9 +66,9 @@ __device__ __forceinline__ void voxel_of(const CoordSrc& s, int i, int& x, int& 
 __global__ void hash_insert_min_kernel(CoordSrc src, int n, u64* keys, int* vals, unsigned mask) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    int x, y, z;
-    voxel_of(src, i, x, y, z);
-    const u64 key = pack_key(x, y, z);
+    int x, y, z, b;
+    voxel_of(src, i, x, y, z, b);
+    const u64 key = pack_key(x, y, z, b);
     unsigned s = hslot(key, mask);
     for (;;) {
         const u64 old = atomicCAS(&keys[s], HEMPTY, key);
@@ -86,18 +90,18 @@ __device__ __forceinline__ int hash_find_slot(const u64* keys, unsigned mask, u6
 // first occurrences in source order -> new rows (order = the CPU coordinate manager's).  Three phases: per-block counts,
 // single-workgroup scan of the block counts, per-block ballot scan + scatter.
 __device__ __forceinline__ bool is_first(const CoordSrc& src, int i, int n, const u64* keys, const int* vals, unsigned mask, int& x, int& y,
-                                         int& z) {
+                                         int& z, int& b) {
     if (i >= n) return false;
-    voxel_of(src, i, x, y, z);
-    const int slot = hash_find_slot(keys, mask, pack_key(x, y, z));
+    voxel_of(src, i, x, y, z, b);
+    const int slot = hash_find_slot(keys, mask, pack_key(x, y, z, b));
     return vals[slot] == i;
 }
 
 __global__ __launch_bounds__(1024) void first_count_kernel(CoordSrc src, int n, const u64* keys, const int* vals, unsigned mask, int* bsum) {
     __shared__ int wsum[16];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    int x, y, z;
-    const bool keep = is_first(src, blockIdx.x * 1024 + tid, n, keys, vals, mask, x, y, z);
+    int x, y, z, b;
+    const bool keep = is_first(src, blockIdx.x * 1024 + tid, n, keys, vals, mask, x, y, z, b);
     const unsigned long long m = __ballot(keep);
     if (lane == 0) wsum[wv] = __popcll(m);
     __syncthreads();
@@ -130,13 +134,14 @@ __global__ __launch_bounds__(1024) void block_scan_kernel(int* bsum, int nb, int
     if (tid == 0) *count = carry;
 }
 
+// out_coords rows: ocs = 3 (x, y, z: the caller's voxelisation output) or 4 (x, y, z, cloud: internal coordinate maps)
 __global__ __launch_bounds__(1024) void first_scatter_kernel(CoordSrc src, int n, const u64* keys, const int* vals, unsigned mask,
-                                                             const int* bsum, int* out_coords, int64_t* sel) {
+                                                             const int* bsum, int* out_coords, int ocs, int64_t* sel) {
     __shared__ int wsum[16];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int i = blockIdx.x * 1024 + tid;
-    int x = 0, y = 0, z = 0;
-    const bool keep = is_first(src, i, n, keys, vals, mask, x, y, z);
+    int x = 0, y = 0, z = 0, b = 0;
+    const bool keep = is_first(src, i, n, keys, vals, mask, x, y, z, b);
     const unsigned long long m = __ballot(keep);
     const int before = __popcll(m & ((1ull << lane) - 1ull));
     if (lane == 0) wsum[wv] = __popcll(m);
@@ -145,17 +150,18 @@ __global__ __launch_bounds__(1024) void first_scatter_kernel(CoordSrc src, int n
     for (int k = 0; k < wv; ++k) off += wsum[k];
     if (keep) {
         const int r = off + before;
-        out_coords[3 * (size_t)r] = x; out_coords[3 * (size_t)r + 1] = y; out_coords[3 * (size_t)r + 2] = z;
+        out_coords[ocs * (size_t)r] = x; out_coords[ocs * (size_t)r + 1] = y; out_coords[ocs * (size_t)r + 2] = z;
+        if (ocs == 4) out_coords[4 * (size_t)r + 3] = b;
         if (sel) sel[r] = i;
     }
 }
 
 static int launch_first_compact(const CoordSrc& src, int n, const u64* keys, const int* vals, unsigned mask, int* bsum, int* out_coords,
-                                int64_t* sel, int* count, hipStream_t s) {
+                                int ocs, int64_t* sel, int* count, hipStream_t s) {
     const int nb = (n + 1023) / 1024;
     hipLaunchKernelGGL(first_count_kernel, dim3(nb), dim3(1024), 0, s, src, n, keys, vals, mask, bsum);
     hipLaunchKernelGGL(block_scan_kernel, dim3(1), dim3(1024), 0, s, bsum, nb, count);
-    hipLaunchKernelGGL(first_scatter_kernel, dim3(nb), dim3(1024), 0, s, src, n, keys, vals, mask, bsum, out_coords, sel);
+    hipLaunchKernelGGL(first_scatter_kernel, dim3(nb), dim3(1024), 0, s, src, n, keys, vals, mask, bsum, out_coords, ocs, sel);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -164,7 +170,8 @@ static int launch_first_compact(const CoordSrc& src, int n, const u64* keys, con
 __global__ void hash_set_rows_kernel(const int* coords, int n, const u64* keys, int* vals, unsigned mask) {
     const int r = blockIdx.x * 256 + threadIdx.x;
     if (r >= n) return;
-    const int slot = hash_find_slot(keys, mask, pack_key(coords[3 * (size_t)r], coords[3 * (size_t)r + 1], coords[3 * (size_t)r + 2]));
+    const int4 c = reinterpret_cast<const int4*>(coords)[r];
+    const int slot = hash_find_slot(keys, mask, pack_key(c.x, c.y, c.z, c.w));
     vals[slot] = r;
 }
 
@@ -176,9 +183,18 @@ __global__ void build_map_kernel(const int* out_coords, int nout, const u64* key
     if (n >= nout) return;
     const int h = ksize / 2;
     const int ox = (k % ksize - h) * ts * sign, oy = ((k / ksize) % ksize - h) * ts * sign, oz = (k / (ksize * ksize) - h) * ts * sign;
-    const int slot = hash_find_slot(keys, mask, pack_key(out_coords[3 * (size_t)n] + ox, out_coords[3 * (size_t)n + 1] + oy,
-                                                          out_coords[3 * (size_t)n + 2] + oz));
+    const int4 c = reinterpret_cast<const int4*>(out_coords)[n];
+    const int slot = hash_find_slot(keys, mask, pack_key(c.x + ox, c.y + oy, c.z + oz, c.w));
     map[(size_t)k * nout + n] = slot < 0 ? -1 : vals[slot];
+}
+
+// (n,3) voxel rows of `nb` concatenated clouds (row ranges off[0..nb]) -> (n,4) rows with the cloud index
+__global__ void coords4_kernel(const int* c3, int n, const int* off, int nb, int* c4) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    int b = 0;
+    while (b + 1 < nb && i >= off[b + 1]) ++b;
+    reinterpret_cast<int4*>(c4)[i] = make_int4(c3[3 * (size_t)i], c3[3 * (size_t)i + 1], c3[3 * (size_t)i + 2], b);
 }
 
 struct SpConvArgs {
@@ -186,6 +202,8 @@ struct SpConvArgs {
     const int* map;          // [K][nout] or null (K = 1, identity)
     int K, nout;
     const float* W;          // (K, cin, cout)
+    const void* Wh;          // fp16x2 planes of W * 2^s in MFMA B-fragment order (null: fp32 MFMA path), see pack_w16
+    float descale;           // 1 / (2^s * SP_ASCALE)
     int cout;
     float* out; int ldout, ocoff;
     const float* aff_s;      // per output channel affine (BN folded) or null
@@ -291,6 +309,137 @@ __global__ __launch_bounds__(256) void spconv_kernel(SpConvArgs a) {
     }
 }
 
+// fp16x2 split variant (same decomposition as spconv_kernel): every product as lo*hi + hi*lo + hi*hi on
+// v_mfma_f32_32x32x16_f16 with fp32 accumulation (3 MFMAs at 16x the fp32-MFMA rate, error <= 3 * 2^-22 per product).
+// The gathered fp32 rows are split in registers (x * 16 = hi + lo; activations must stay below 4094); the weights are
+// split once at load time and stored in B-fragment order
+//     Wh[k][chunk32][K16 step 2][plane 2][cout block][lane = 32 kg + j][8]  =  W[k][32 chunk + 16 step + 8 kg + e][32 cb + j]
+// so a fragment is one 16-byte load per lane.
+typedef unsigned uintx4s __attribute__((ext_vector_type(4)));
+typedef _Float16 halfx8s __attribute__((ext_vector_type(8)));
+typedef _Float16 halfx2s __attribute__((ext_vector_type(2)));
+typedef float floatx2s __attribute__((ext_vector_type(2)));
+constexpr float SP_ASCALE = 16.f;
+
+__device__ __forceinline__ floatx16s mfma_sp16(uintx4s a, uintx4s b, floatx16s c) {
+    union { uintx4s u; halfx8s h; } ca, cb;
+    ca.u = a; cb.u = b;
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(ca.h, cb.h, c, 0, 0, 0);
+}
+__device__ __forceinline__ void split_pair_sp(float x0, float x1, unsigned& hi, unsigned& lo) {
+    floatx2s x;
+    x.x = x0 * SP_ASCALE; x.y = x1 * SP_ASCALE;
+    const halfx2s h = __builtin_convertvector(x, halfx2s);
+    const floatx2s r = x - __builtin_convertvector(h, floatx2s);
+    const halfx2s l = __builtin_convertvector(r, halfx2s);
+    __builtin_memcpy(&hi, &h, 4);
+    __builtin_memcpy(&lo, &l, 4);
+}
+
+template <int NCB, bool SPLIT>
+__global__ __launch_bounds__(256) void spconv16_kernel(SpConvArgs a) {
+    __shared__ int srcl[4][SP_MAXK * 32];
+    __shared__ float red[SPLIT ? 3 * NCB * 16 * 64 : 1];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int li = lane & 31, h = lane >> 5;
+    const int rbase = SPLIT ? blockIdx.x * 32 : (blockIdx.x * 4 + w) * 32;
+    if (!SPLIT && rbase >= a.nout) return;
+    const int cb0 = blockIdx.y * NCB;
+    const int row = rbase + li;
+    const bool valid = row < a.nout;
+    int* sl = srcl[w];
+    for (int k = h; k < a.K; k += 2) sl[k * 32 + li] = valid ? (a.map ? a.map[(size_t)k * a.nout + row] : row) : -1;
+    __builtin_amdgcn_wave_barrier();
+
+    floatx16s acc[NCB];
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[cb][r] = 0.f;
+    const int nchunk = a.cin / 32, ncbt = a.cout / 32;
+    const int total = a.K * nchunk;
+    const int it0 = SPLIT ? (total * w) / 4 : 0, it1 = SPLIT ? (total * (w + 1)) / 4 : total;
+    const uintx4s* Wh = reinterpret_cast<const uintx4s*>(a.Wh);
+
+    auto issue = [&](int it, float (&av)[16], uintx4s (&bv)[4 * NCB]) {
+        const int k = it / nchunk, cc = it - k * nchunk;
+        const int src = sl[k * 32 + li];
+        // K16 step s uses channels 32 cc + 16 s + 8 h + e: two 32-byte runs of this lane's input row
+        const float* ip = a.in + (size_t)(src < 0 ? 0 : src) * a.ldin + cc * 32 + h * 8;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (src >= 0) v = *reinterpret_cast<const float4*>(ip + (q >> 1) * 16 + (q & 1) * 4);
+            av[4 * q] = v.x; av[4 * q + 1] = v.y; av[4 * q + 2] = v.z; av[4 * q + 3] = v.w;
+        }
+        const uintx4s* wp = Wh + ((size_t)it * 4 * ncbt + cb0) * 64 + lane;        // [it][step][plane][cb][lane]
+#pragma unroll
+        for (int sp = 0; sp < 4; ++sp)
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) bv[sp * NCB + cb] = wp[((size_t)sp * ncbt + cb) * 64];
+    };
+    auto mma = [&](const float (&av)[16], const uintx4s (&bv)[4 * NCB]) {
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            uintx4s ah, al;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                unsigned hh, ll;
+                split_pair_sp(av[8 * st + 2 * p], av[8 * st + 2 * p + 1], hh, ll);
+                ah[p] = hh; al[p] = ll;
+            }
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) acc[cb] = mfma_sp16(al, bv[(2 * st + 0) * NCB + cb], acc[cb]);
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) acc[cb] = mfma_sp16(ah, bv[(2 * st + 1) * NCB + cb], acc[cb]);
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) acc[cb] = mfma_sp16(ah, bv[(2 * st + 0) * NCB + cb], acc[cb]);
+        }
+    };
+    float a0[16], a1[16];
+    uintx4s b0[4 * NCB], b1[4 * NCB];
+    if (it0 < it1) issue(it0, a0, b0);
+    for (int it = it0; it < it1; it += 2) {
+        if (it + 1 < it1) issue(it + 1, a1, b1);
+        mma(a0, b0);
+        if (it + 1 < it1) {
+            if (it + 2 < it1) issue(it + 2, a0, b0);
+            mma(a1, b1);
+        }
+    }
+    if (SPLIT) {
+        if (w > 0) {
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) red[(((w - 1) * NCB + cb) * 16 + r) * 64 + lane] = acc[cb][r];
+        }
+        __syncthreads();
+        if (w > 0) return;
+#pragma unroll
+        for (int ww = 0; ww < 3; ++ww)
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[cb][r] += red[((ww * NCB + cb) * 16 + r) * 64 + lane];
+    }
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) {
+        const int co = (cb0 + cb) * 32 + li;
+        const float s = (a.aff_s ? a.aff_s[co] : 1.f) * a.descale, t = a.aff_t ? a.aff_t[co] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int orow = rbase + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (orow < a.nout) {
+                float v = acc[cb][r] * s + t;
+                if (a.res) v += a.res[(size_t)orow * a.ldres + a.rcoff + co];
+                if (a.relu) v = fmaxf(v, 0.f);
+                a.out[(size_t)orow * a.ldout + a.ocoff + co] = v;
+            }
+        }
+    }
+}
+
 // Cin < 32 (the first convolution: one input channel, 5^3 / 7^3 offsets): plain fp32, one thread per (row, channel)
 __global__ __launch_bounds__(256) void spconv_small_kernel(SpConvArgs a) {
     const int co = threadIdx.x % a.cout, rl = threadIdx.x / a.cout;
@@ -331,11 +480,15 @@ static int launch_spconv(const SpConvArgs& a, hipStream_t s) {
         const dim3 blk(256);
         if (split) {
             const dim3 grid(rowtiles, ncbt / ncb);
-            if (ncb == 2) hipLaunchKernelGGL((spconv_kernel<2, true>), grid, blk, 0, s, a);
+            if (a.Wh && ncb == 2) hipLaunchKernelGGL((spconv16_kernel<2, true>), grid, blk, 0, s, a);
+            else if (a.Wh) hipLaunchKernelGGL((spconv16_kernel<1, true>), grid, blk, 0, s, a);
+            else if (ncb == 2) hipLaunchKernelGGL((spconv_kernel<2, true>), grid, blk, 0, s, a);
             else hipLaunchKernelGGL((spconv_kernel<1, true>), grid, blk, 0, s, a);
         } else {
             const dim3 grid((a.nout + 127) / 128, ncbt / ncb);
-            if (ncb == 2) hipLaunchKernelGGL((spconv_kernel<2, false>), grid, blk, 0, s, a);
+            if (a.Wh && ncb == 2) hipLaunchKernelGGL((spconv16_kernel<2, false>), grid, blk, 0, s, a);
+            else if (a.Wh) hipLaunchKernelGGL((spconv16_kernel<1, false>), grid, blk, 0, s, a);
+            else if (ncb == 2) hipLaunchKernelGGL((spconv_kernel<2, false>), grid, blk, 0, s, a);
             else hipLaunchKernelGGL((spconv_kernel<1, false>), grid, blk, 0, s, a);
         }
     } else {
@@ -369,21 +522,22 @@ __global__ __launch_bounds__(256) void row_normalize_kernel(const float* in, int
 // host side
 // ---------------------------------------------------------------------------------------------------------------
 struct BnAff { float* s = nullptr; float* t = nullptr; };
+struct ConvW { float* w = nullptr; void* wh = nullptr; float descale = 1.f; };      // fp32 kernel, fp16x2 planes (or null)
 
 struct FcgfNet {
     int C[5] = {0, 32, 64, 128, 256}, T[5] = {0, 64, 64, 64, 128};
     int out_ch = 32, k1 = 7, in_ch = 1, normalize = 1;
     // kernels in spec order
-    float* conv[4] = {nullptr, nullptr, nullptr, nullptr};      // conv1..conv4
+    ConvW conv[4];                                               // conv1..conv4
     BnAff norm[4];
-    float* bconv[4][2] = {};                                     // block1..4 conv1/conv2
+    ConvW bconv[4][2];                                           // block1..4 conv1/conv2
     BnAff bnorm[4][2];
-    float* conv_tr[3] = {nullptr, nullptr, nullptr};             // conv4_tr, conv3_tr, conv2_tr
+    ConvW conv_tr[3];                                            // conv4_tr, conv3_tr, conv2_tr
     BnAff norm_tr[3];
-    float* bconv_tr[3][2] = {};                                  // block4_tr, block3_tr, block2_tr
+    ConvW bconv_tr[3][2];                                        // block4_tr, block3_tr, block2_tr
     BnAff bnorm_tr[3][2];
-    float* conv1_tr = nullptr;
-    float* final_k = nullptr;
+    ConvW conv1_tr;
+    ConvW final_k;
     float* final_b = nullptr;
     std::vector<void*> owned;
 };
@@ -392,6 +546,46 @@ static int up(FcgfNet* n, const float* h, size_t cnt, float** d) {
     HIPCHK(hipMalloc((void**)d, cnt * sizeof(float)));
     n->owned.push_back(*d);
     HIPCHK(hipMemcpy(*d, h, cnt * sizeof(float), hipMemcpyHostToDevice));
+    return 0;
+}
+
+static inline unsigned short f16bits(float x) {
+    const _Float16 hh = (_Float16)x;
+    unsigned short u;
+    std::memcpy(&u, &hh, 2);
+    return u;
+}
+
+// kernel (K, cin, cout) fp32 -> device copy + (if the shape fits the MFMA path) fp16x2 planes in B-fragment order
+static int up_conv(FcgfNet* n, const float* h, int K, int cin, int cout, ConvW* o, bool use16) {
+    int rc;
+    if ((rc = up(n, h, (size_t)K * cin * cout, &o->w))) return rc;
+    if (!use16 || cin % 32 || cout % 32 || K > 27) return 0;
+    float wmax = 0.f;
+    for (size_t i = 0; i < (size_t)K * cin * cout; ++i) wmax = std::fmax(wmax, std::fabs(h[i]));
+    int ex = 0;
+    if (wmax > 0.f && std::isfinite(wmax)) (void)std::frexp(wmax, &ex);
+    const float wscale = std::ldexp(1.f, 10 - ex);
+    o->descale = 1.f / (wscale * 16.f);
+    const int nch = cin / 32, ncbt = cout / 32;
+    std::vector<unsigned short> pl((size_t)K * cin * cout * 2);
+    for (int k = 0; k < K; ++k)
+        for (int cc = 0; cc < nch; ++cc)
+            for (int st = 0; st < 2; ++st)
+                for (int cb = 0; cb < ncbt; ++cb)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int e = 0; e < 8; ++e) {
+                            const int c = cc * 32 + st * 16 + (lane >> 5) * 8 + e, co = cb * 32 + (lane & 31);
+                            const float x = h[((size_t)k * cin + c) * cout + co] * wscale;
+                            const _Float16 hi = (_Float16)x;
+                            const size_t it = (size_t)k * nch + cc;
+                            const size_t base = (((it * 2 + st) * 2) * ncbt) * 512;              // plane 0 of (it, st)
+                            pl[base + ((size_t)0 * ncbt + cb) * 512 + lane * 8 + e] = f16bits(x);
+                            pl[base + ((size_t)1 * ncbt + cb) * 512 + lane * 8 + e] = f16bits(x - (float)hi);
+                        }
+    HIPCHK(hipMalloc(&o->wh, pl.size() * 2));
+    n->owned.push_back(o->wh);
+    HIPCHK(hipMemcpy(o->wh, pl.data(), pl.size() * 2, hipMemcpyHostToDevice));
     return 0;
 }
 
@@ -422,30 +616,35 @@ int fcgf_load(FcgfNet** out, const yoho_fcgf_config* cfg, const float* const* t,
     if (n->k1 % 2 == 0 || n->out_ch > 64 || n->in_ch > 31) { fcgf_free(n); set_error("yoho_load_fcgf: unsupported configuration"); return YOHO_EINVAL; }
     int ti = 0, rc = 0;
     auto fail = [&](int r) { fcgf_free(n); return r; };
+    const char* am = std::getenv("YOHO_FCGF");
+    const bool use16 = !(am && std::strcmp(am, "f32") == 0);      // default: fp16x2 split MFMA; YOHO_FCGF=f32 keeps the fp32 MFMA kernels
     const int* C = n->C; const int* T = n->T;
     const int cin_enc[4] = {n->in_ch, C[1], C[2], C[3]};
     for (int l = 0; l < 4 && !rc; ++l) {
         const int kv = l == 0 ? n->k1 * n->k1 * n->k1 : 27, co = C[l + 1];
-        if ((rc = up(n, t[ti], (size_t)kv * cin_enc[l] * co, &n->conv[l]))) break; ti += 1;
+        if ((rc = up_conv(n, t[ti], kv, cin_enc[l], co, &n->conv[l], use16))) break; ti += 1;
         if ((rc = up_bn(n, t + ti, co, &n->norm[l]))) break; ti += 4;
         for (int j = 0; j < 2 && !rc; ++j) {
-            if ((rc = up(n, t[ti], (size_t)27 * co * co, &n->bconv[l][j]))) break; ti += 1;
+            if ((rc = up_conv(n, t[ti], 27, co, co, &n->bconv[l][j], use16))) break; ti += 1;
             if ((rc = up_bn(n, t + ti, co, &n->bnorm[l][j]))) break; ti += 4;
         }
     }
     if (rc) return fail(rc);
     const int cin_tr[3] = {C[4], C[3] + T[4], C[2] + T[3]}, cout_tr[3] = {T[4], T[3], T[2]};
     for (int l = 0; l < 3 && !rc; ++l) {
-        if ((rc = up(n, t[ti], (size_t)27 * cin_tr[l] * cout_tr[l], &n->conv_tr[l]))) break; ti += 1;
+        if ((rc = up_conv(n, t[ti], 27, cin_tr[l], cout_tr[l], &n->conv_tr[l], use16))) break; ti += 1;
         if ((rc = up_bn(n, t + ti, cout_tr[l], &n->norm_tr[l]))) break; ti += 4;
         for (int j = 0; j < 2 && !rc; ++j) {
-            if ((rc = up(n, t[ti], (size_t)27 * cout_tr[l] * cout_tr[l], &n->bconv_tr[l][j]))) break; ti += 1;
+            if ((rc = up_conv(n, t[ti], 27, cout_tr[l], cout_tr[l], &n->bconv_tr[l][j], use16))) break; ti += 1;
             if ((rc = up_bn(n, t + ti, cout_tr[l], &n->bnorm_tr[l][j]))) break; ti += 4;
         }
     }
     if (rc) return fail(rc);
-    if ((rc = up(n, t[ti++], (size_t)(C[1] + T[2]) * T[1], &n->conv1_tr)) || (rc = up(n, t[ti++], (size_t)T[1] * n->out_ch, &n->final_k)) ||
-        (rc = up(n, t[ti++], n->out_ch, &n->final_b))) return fail(rc);
+    if ((rc = up_conv(n, t[ti], 1, C[1] + T[2], T[1], &n->conv1_tr, use16))) return fail(rc);
+    ti += 1;
+    if ((rc = up_conv(n, t[ti], 1, T[1], n->out_ch, &n->final_k, use16))) return fail(rc);
+    ti += 1;
+    if ((rc = up(n, t[ti++], n->out_ch, &n->final_b))) return fail(rc);
     *out = n;
     return 0;
 }
@@ -488,7 +687,7 @@ size_t fcgf_workspace_bytes(const FcgfNet* net, int n0) {
     const size_t N = (size_t)n0 + 256;
     const int k1 = net->k1 * net->k1 * net->k1;
     size_t b = 0;
-    b += 4 * (N * 3 * 4 + (size_t)table_cap(n0) * 12) + 4096;                 // coords + tables
+    b += 4 * (N * 4 * 4 + (size_t)table_cap(n0) * 12) + 8192;                 // coords + tables
     b += ((size_t)k1 + 27 * 10) * N * 4;                                      // kernel maps
     const int* C = net->C; const int* T = net->T;
     size_t feat = 1 + 2 * C[1] + (T[2] + C[1]) + 2 * T[2] + T[1] + net->out_ch;
@@ -497,8 +696,10 @@ size_t fcgf_workspace_bytes(const FcgfNet* net, int n0) {
     return b;
 }
 
-// coords0: (n0,3) int32 device, distinct voxels; out: (n0, out_ch)
-int fcgf_forward(yoho_ctx* ctx, const FcgfNet* net, const int* coords0, int n0, float* out, hipStream_t s) {
+// coords0: (n0,3) int32 device, the distinct voxels of nb clouds stored one after the other (host row offsets off[0..nb],
+// null = one cloud); out: (n0, out_ch).  The clouds share every launch (cloud index = 4th key component).
+int fcgf_forward(yoho_ctx* ctx, const FcgfNet* net, const int* coords0, int n0, const int* off_host, int nb, float* out, hipStream_t s) {
+    if (nb < 1 || nb > 64) { set_error("fcgf_forward: 1..64 clouds per call"); return YOHO_EINVAL; }
     if (n0 == 0) return 0;
     int rc;
     if ((rc = ensure_ws(ctx, fcgf_workspace_bytes(net, n0), s))) return rc;
@@ -507,7 +708,15 @@ int fcgf_forward(yoho_ctx* ctx, const FcgfNet* net, const int* coords0, int n0, 
     Level L[4];
     int* dcount = ar.take<int>(4);
     // ---- coordinate maps
-    L[0].n = n0; L[0].ts = 1; L[0].coords = const_cast<int*>(coords0);
+    L[0].n = n0; L[0].ts = 1; L[0].coords = ar.take<int>((size_t)n0 * 4);
+    {
+        int* doff = ar.take<int>(66);
+        int hoff[66] = {0, n0};
+        if (off_host) for (int b = 0; b <= nb; ++b) hoff[b] = off_host[b];
+        HIPCHK(hipMemcpyAsync(doff, hoff, sizeof(int) * (nb + 1), hipMemcpyHostToDevice, s));
+        HIPCHK(hipStreamSynchronize(s));                     // hoff lives on this stack frame
+        hipLaunchKernelGGL(coords4_kernel, dim3((n0 + 255) / 256), dim3(256), 0, s, coords0, n0, doff, nb, L[0].coords);
+    }
     for (int l = 0; l < 4; ++l) {
         L[l].ts = 1 << l;
         const int nprev = l == 0 ? n0 : L[l - 1].n;
@@ -515,15 +724,15 @@ int fcgf_forward(yoho_ctx* ctx, const FcgfNet* net, const int* coords0, int n0, 
         L[l].keys = ar.take<u64>(L[l].mask + 1);
         L[l].vals = ar.take<int>(L[l].mask + 1);
         if (l == 0) {
-            CoordSrc src{coords0, nullptr, 1.0, 1};
+            CoordSrc src{L[0].coords, nullptr, 1.0, 1};
             if ((rc = build_table(src, n0, L[0], s))) return rc;
             // distinct input voxels: value = row (atomicMin of the single source row)
         } else {
             CoordSrc src{L[l - 1].coords, nullptr, 1.0, L[l].ts};
             if ((rc = build_table(src, nprev, L[l], s))) return rc;
-            L[l].coords = ar.take<int>((size_t)nprev * 3);
+            L[l].coords = ar.take<int>((size_t)nprev * 4);
             int* bsum = ar.take<int>((size_t)(nprev + 1023) / 1024 + 1);
-            if ((rc = launch_first_compact(src, nprev, L[l].keys, L[l].vals, L[l].mask, bsum, L[l].coords, nullptr, dcount + l, s))) return rc;
+            if ((rc = launch_first_compact(src, nprev, L[l].keys, L[l].vals, L[l].mask, bsum, L[l].coords, 4, nullptr, dcount + l, s))) return rc;
             HIPCHK(hipMemcpyAsync(&L[l].n, dcount + l, sizeof(int), hipMemcpyDeviceToHost, s));
             HIPCHK(hipStreamSynchronize(s));
             hipLaunchKernelGGL(hash_set_rows_kernel, dim3((L[l].n + 255) / 256), dim3(256), 0, s, L[l].coords, L[l].n, L[l].keys, L[l].vals,
@@ -561,16 +770,16 @@ int fcgf_forward(yoho_ctx* ctx, const FcgfNet* net, const int* coords0, int n0, 
     enc3 = ar.take<float>((size_t)L[3].n * C[4]);
     if (ar.off > ar.cap) { set_error("fcgf_forward: workspace estimate too small (%zu > %zu)", ar.off, ar.cap); return YOHO_ENOMEM; }
 
-    auto conv = [&](const float* in, int ldin, int cin, const int* map, int K, int nout, const float* W, int cout, float* o, int ldout,
+    auto conv = [&](const float* in, int ldin, int cin, const int* map, int K, int nout, const ConvW& W, int cout, float* o, int ldout,
                     int ocoff, const BnAff* bn, const float* bias, const float* res, int ldres, int rcoff, int relu) -> int {
         SpConvArgs a;
-        a.in = in; a.ldin = ldin; a.cin = cin; a.map = map; a.K = K; a.nout = nout; a.W = W; a.cout = cout;
+        a.in = in; a.ldin = ldin; a.cin = cin; a.map = map; a.K = K; a.nout = nout; a.W = W.w; a.Wh = W.wh; a.descale = W.descale; a.cout = cout;
         a.out = o; a.ldout = ldout; a.ocoff = ocoff; a.aff_s = bn ? bn->s : nullptr; a.aff_t = bn ? bn->t : bias;
         a.res = res; a.ldres = ldres; a.rcoff = rcoff; a.relu = relu;
         return launch_spconv(a, s);
     };
     // BasicBlockBN: out = relu(bn2(conv2(relu(bn1(conv1(x))))) + x), written at column `ocoff` of `o`
-    auto block = [&](int l, const float* xin, int c, float* const* Wc, const BnAff* bnc, float* scratch, float* o, int ldout, int ocoff) -> int {
+    auto block = [&](int l, const float* xin, int c, const ConvW* Wc, const BnAff* bnc, float* scratch, float* o, int ldout, int ocoff) -> int {
         int r;
         if ((r = conv(xin, c, c, Msame[l], 27, L[l].n, Wc[0], c, scratch, c, 0, &bnc[0], nullptr, nullptr, 0, 0, 1))) return r;
         return conv(scratch, c, c, Msame[l], 27, L[l].n, Wc[1], c, o, ldout, ocoff, &bnc[1], nullptr, xin, c, 0, 1);
@@ -622,7 +831,7 @@ int fcgf_voxelize(yoho_ctx* ctx, const double* pts, int n, double voxel, int64_t
     CoordSrc src{nullptr, pts, voxel, 1};
     if ((rc = build_table(src, n, L, s))) return rc;
     int* bsum = ar.take<int>((size_t)(n + 1023) / 1024 + 1);
-    if ((rc = launch_first_compact(src, n, L.keys, L.vals, L.mask, bsum, coords, sel, dcount, s))) return rc;
+    if ((rc = launch_first_compact(src, n, L.keys, L.vals, L.mask, bsum, coords, 3, sel, dcount, s))) return rc;
     HIPCHK(hipMemcpyAsync(count_host, dcount, sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     return 0;

@@ -58,6 +58,12 @@ class fcgf_extractor():
         sel, coords = self.ctx.fcgf_voxelize(pts, voxel_size)
         return sel, self.ctx.fcgf_forward(coords)
 
+    def extract_features_dev_batch(self, pts_list, voxel_size):
+        """several clouds (f64 cuda) in one backbone pass -> list of (sel, F)."""
+        vox = [self.ctx.fcgf_voxelize(p, voxel_size) for p in pts_list]
+        feats = self.ctx.fcgf_forward_batch([c for _, c in vox])
+        return [(sel, f) for (sel, _), f in zip(vox, feats)]
+
     def extract_features(self, pc, voxel_size):
         pts = torch.from_numpy(np.ascontiguousarray(np.asarray(pc, dtype=np.float64))).cuda()
         sel, F = self.extract_features_dev(pts, voxel_size)

@@ -18,7 +18,7 @@ _lib = None
 SYMBOLS = [
     "yoho_last_error", "yoho_version", "yoho_ctx_create", "yoho_ctx_destroy", "yoho_load_partI",
     "yoho_load_partII", "yoho_partI_forward", "yoho_group_mean_np", "yoho_nn_search", "yoho_mutual_nn",
-    "yoho_load_fcgf", "yoho_fcgf_voxelize", "yoho_fcgf_forward",
+    "yoho_load_fcgf", "yoho_fcgf_voxelize", "yoho_fcgf_forward", "yoho_fcgf_forward_batch",
     "yoho_des2r", "yoho_des2r_indexed", "yoho_partII_forward", "yoho_partII_forward_indexed", "yoho_hyp_from_quat", "yoho_o_score", "yoho_c_ransac",
     "yoho_group_gather", "yoho_set_profiling", "yoho_get_kernel_ms", "yoho_set_gconv_mode", "yoho_set_partII_mode",
 ]
@@ -87,6 +87,7 @@ def load_library():
     lib.yoho_load_fcgf.argtypes = [vp, C.POINTER(FcgfConfig), C.POINTER(vp), ci]
     lib.yoho_fcgf_voxelize.argtypes = [vp, vp, ci, C.c_double, vp, vp, C.POINTER(ci), vp]
     lib.yoho_fcgf_forward.argtypes = [vp, vp, ci, vp, vp]
+    lib.yoho_fcgf_forward_batch.argtypes = [vp, vp, vp, ci, vp, vp]
     lib.yoho_set_profiling.argtypes = [vp, ci]
     lib.yoho_set_gconv_mode.argtypes = [vp, ci]
     lib.yoho_set_partII_mode.argtypes = [vp, ci]
@@ -218,6 +219,17 @@ class Context:
         out = torch.empty((n, getattr(self, "_fcgf_out", 32)), dtype=torch.float32, device=coords.device)
         _check(self._lib.yoho_fcgf_forward(self._h, _dev(coords, torch.int32, "coords"), n, C.c_void_p(out.data_ptr()), _stream()))
         return out
+
+    def fcgf_forward_batch(self, coords_list):
+        """several clouds ((n_b,3) int32 cuda each) in one pass -> list of (n_b, out_channels) feature tensors."""
+        nb = len(coords_list)
+        off = np.zeros(nb + 1, dtype=np.int32)
+        off[1:] = np.cumsum([c.shape[0] for c in coords_list])
+        allc = torch.cat(coords_list).contiguous()
+        out = torch.empty((int(off[-1]), getattr(self, "_fcgf_out", 32)), dtype=torch.float32, device=allc.device)
+        _check(self._lib.yoho_fcgf_forward_batch(self._h, _dev(allc, torch.int32, "coords"), off.ctypes.data_as(C.c_void_p), nb,
+                                                 C.c_void_p(out.data_ptr()), _stream()))
+        return [out[int(off[b]):int(off[b + 1])] for b in range(nb)]
 
     # ---- descriptor path -------------------------------------------------------------------
     def partI_forward(self, x, want_inv=True, want_inv_np=False):

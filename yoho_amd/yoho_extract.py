@@ -35,6 +35,7 @@ class yoho_extractor():
         self.yoho_ckpt = yoho_ckpt
         self._load_model()
         self.bs = 500
+        self.rot_batch = 6             # rotated copies of the cloud per backbone pass (HBM-resident path)
 
     def _load_model(self):
         sd = self.yoho_ckpt if isinstance(self.yoho_ckpt, dict) else W.load_checkpoint(self.yoho_ckpt)[0]
@@ -60,13 +61,14 @@ class yoho_extractor():
             # transfer of all 60 group elements run on the device (same operations as the loop below)
             pc_d = torch.from_numpy(np.ascontiguousarray(np.asarray(pc, dtype=np.float64))).cuda()
             kp_d = pc_d[torch.from_numpy(kpts_index).cuda()]
-            for i in range(self.grs.shape[0]):
-                Rt = torch.from_numpy(np.ascontiguousarray(self.grs[i].T)).cuda()
-                pci = pc_d @ Rt
-                sel, pci_f = self.fcgf.extract_features_dev(pci, voxel_size)
-                q = (kp_d @ Rt).to(torch.float32).contiguous()
-                _, idx = self.ctx.nn_search(q, pci[sel].to(torch.float32).contiguous(), want_dist=False, squared=True)
-                kpts_f[:, :, i] = pci_f[idx]
+            G, nb = self.grs.shape[0], self.rot_batch
+            for i0 in range(0, G, nb):
+                Rts = [torch.from_numpy(np.ascontiguousarray(self.grs[i].T)).cuda() for i in range(i0, min(i0 + nb, G))]
+                pcs = [pc_d @ Rt for Rt in Rts]
+                for j, (pci, (sel, pci_f)) in enumerate(zip(pcs, self.fcgf.extract_features_dev_batch(pcs, voxel_size))):
+                    q = (kp_d @ Rts[j]).to(torch.float32).contiguous()
+                    _, idx = self.ctx.nn_search(q, pci[sel].to(torch.float32).contiguous(), want_dist=False, squared=True)
+                    kpts_f[:, :, i0 + j] = pci_f[idx]
             self._last_group_feats = kpts_f
             out = self.ctx.partI_forward(kpts_f.contiguous(), want_inv=True)
             return kpts, out["inv"].cpu(), out["eqv"].cpu()
