@@ -116,10 +116,9 @@ int launch_nn(const float* src, int Ns, const float* tgt, int Nt, int D, int dis
 //     per-segment winners meet in a packed (distance bits << 32 | index) key with atomicMin — distances are
 //     non-negative, so the integer order is (distance, then lowest index) = the reference's first minimum.
 // ---------------------------------------------------------------------------------------------------------------
-template <bool SQUARED>
+template <int D, bool SQUARED>
 __global__ __launch_bounds__(256) void nn32seg_kernel(const float* __restrict__ src, int Ns, const float* __restrict__ tgt, int Nt,
                                                       unsigned long long* __restrict__ keys, int segLen) {
-    constexpr int D = 32;
     __shared__ __attribute__((aligned(16))) float tile[NN_TT * D];
     __shared__ float rd[32 * NN_SPLIT];
     __shared__ int ri[32 * NN_SPLIT];
@@ -139,18 +138,25 @@ __global__ __launch_bounds__(256) void nn32seg_kernel(const float* __restrict__ 
     for (int t0 = tlo; t0 < thi; t0 += NN_TT) {
         const int nt = thi - t0 < NN_TT ? thi - t0 : NN_TT;
         __syncthreads();
-        {
-            const float4* g4 = reinterpret_cast<const float4*>(tgt + (size_t)t0 * D);      // rows are 128 B: 16-byte aligned
+        if ((nt * D) % 4 == 0) {
+            const float4* g4 = reinterpret_cast<const float4*>(tgt + (size_t)t0 * D);      // t0 is a multiple of 16 rows: 16-byte aligned
             float4* t4 = reinterpret_cast<float4*>(tile);
-            for (int i = threadIdx.x; i < nt * (D / 4); i += 256) t4[i] = g4[i];
+            for (int i = threadIdx.x; i < nt * D / 4; i += 256) t4[i] = g4[i];
+        } else {
+            for (int i = threadIdx.x; i < nt * D; i += 256) tile[i] = tgt[(size_t)t0 * D + i];
         }
         __syncthreads();
         for (int t = sp; t < nt; t += NN_SPLIT) {
             float b[D];
+            if constexpr (D % 4 == 0) {
 #pragma unroll
-            for (int k = 0; k < D / 4; ++k) {
-                const float4 v = reinterpret_cast<const float4*>(tile + t * D)[k];
-                b[4 * k] = v.x; b[4 * k + 1] = v.y; b[4 * k + 2] = v.z; b[4 * k + 3] = v.w;
+                for (int k = 0; k < D / 4; ++k) {
+                    const float4 v = reinterpret_cast<const float4*>(tile + t * D)[k];
+                    b[4 * k] = v.x; b[4 * k + 1] = v.y; b[4 * k + 2] = v.z; b[4 * k + 3] = v.w;
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < D; ++k) b[k] = tile[t * D + k];
             }
             const float d0 = dist2_f32<D>(a0, b), d1 = dist2_f32<D>(a1, b);
             if (d0 < best0) {
@@ -191,7 +197,8 @@ __global__ __launch_bounds__(256) void nn_unpack_kernel(const unsigned long long
 }
 
 // keys must hold Ns words; they are (re)initialised here
-int launch_nn32seg(const float* src, int Ns, const float* tgt, int Nt, bool squared, unsigned long long* keys, int nCU, hipStream_t s) {
+int launch_nn32seg(const float* src, int Ns, const float* tgt, int Nt, bool squared, unsigned long long* keys, int nCU, hipStream_t s,
+                   int D = 32) {
     const int rb = (Ns + 31) / 32;
     int nseg = (4 * nCU + rb - 1) / rb;
     const int maxseg = (Nt + 63) / 64;
@@ -200,8 +207,10 @@ int launch_nn32seg(const float* src, int Ns, const float* tgt, int Nt, bool squa
     segLen = (segLen + 15) / 16 * 16;
     nseg = (Nt + segLen - 1) / segLen;
     HIPCHK(hipMemsetAsync(keys, 0xFF, sizeof(unsigned long long) * (size_t)Ns, s));
-    if (squared) hipLaunchKernelGGL(nn32seg_kernel<true>, dim3(rb, nseg), dim3(256), 0, s, src, Ns, tgt, Nt, keys, segLen);
-    else hipLaunchKernelGGL(nn32seg_kernel<false>, dim3(rb, nseg), dim3(256), 0, s, src, Ns, tgt, Nt, keys, segLen);
+    if (D == 3 && squared) hipLaunchKernelGGL((nn32seg_kernel<3, true>), dim3(rb, nseg), dim3(256), 0, s, src, Ns, tgt, Nt, keys, segLen);
+    else if (D == 3) hipLaunchKernelGGL((nn32seg_kernel<3, false>), dim3(rb, nseg), dim3(256), 0, s, src, Ns, tgt, Nt, keys, segLen);
+    else if (squared) hipLaunchKernelGGL((nn32seg_kernel<32, true>), dim3(rb, nseg), dim3(256), 0, s, src, Ns, tgt, Nt, keys, segLen);
+    else hipLaunchKernelGGL((nn32seg_kernel<32, false>), dim3(rb, nseg), dim3(256), 0, s, src, Ns, tgt, Nt, keys, segLen);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -340,11 +349,11 @@ int yoho_nn_search(yoho_ctx* c, const float* src, int Ns, const float* tgt, int 
     if (!c || !src || !tgt || !idx || Ns < 0 || Nt < 1) { set_error("yoho_nn_search: bad argument"); return YOHO_EINVAL; }
     if (Ns == 0) return 0;
     HIPCHK(hipSetDevice(c->device));
-    if (D == 32 && (size_t)Ns * Nt >= (1u << 20) && (dist_type == YOHO_DIST_L2 || dist_type == YOHO_DIST_SQUARE_L2)) {
+    if ((D == 32 || D == 3) && (size_t)Ns * Nt >= (1u << 20) && (dist_type == YOHO_DIST_L2 || dist_type == YOHO_DIST_SQUARE_L2)) {
         int rc;
         if ((rc = ensure_ws(c, sizeof(unsigned long long) * (size_t)Ns, (hipStream_t)stream))) return rc;
         unsigned long long* keys = (unsigned long long*)c->ws.p;
-        if ((rc = launch_nn32seg(src, Ns, tgt, Nt, dist_type == YOHO_DIST_SQUARE_L2, keys, c->nCU, (hipStream_t)stream))) return rc;
+        if ((rc = launch_nn32seg(src, Ns, tgt, Nt, dist_type == YOHO_DIST_SQUARE_L2, keys, c->nCU, (hipStream_t)stream, D))) return rc;
         return launch_nn_unpack(keys, Ns, idx, dist, (hipStream_t)stream);
     }
     return launch_nn(src, Ns, tgt, Nt, D, dist_type, idx, dist, (hipStream_t)stream);
