@@ -78,3 +78,25 @@ def test_batched_clouds_equal_separate_passes(fctx):
     # identical clouds in one batch must not see each other (cloud index is part of the voxel key)
     two = fctx.fcgf_forward_batch([clouds[0], clouds[0]])
     assert (two[0] - sep[0]).abs().max().item() < 2e-5 and torch.equal(two[0], two[1])
+
+
+def test_other_model_configs_and_tiny_clouds(hip):
+    """ResUNetBN2B channels, conv1 kernel 5, normalize_feature off; clouds of 1 and 2 voxels, negative coordinates"""
+    spec = W.fcgf_spec((None, 32, 64, 128, 256), (None, 64, 64, 64, 64), 32, 5)
+    sd = W.synth_state_dict(spec, 9)
+    c = hip.Context()
+    c.load_fcgf(sd, channels=(0, 32, 64, 128, 256), tr_channels=(0, 64, 64, 64, 64), conv1_kernel_size=5, normalize_feature=False)
+    pc = synth.surface_cloud(2500, seed=4) - 1.7                        # negative voxel indices
+    _, coords = fo.voxelize(pc, 0.025)
+    F0 = fo.resunet_forward(coords, sd, conv1_kernel_size=5, normalize_feature=False)
+    F0 = F0 / np.linalg.norm(F0, axis=1, keepdims=True)                 # fcgf_feat.py:48
+    F = c.fcgf_forward(torch.from_numpy(coords).cuda()).cpu().numpy()
+    assert rel(F, F0) < TOL
+    for cc in (np.array([[3, -4, 5]], np.int32), np.array([[0, 0, 0], [1, 0, 0]], np.int32)):
+        F0 = fo.resunet_forward(cc, sd, conv1_kernel_size=5, normalize_feature=False)
+        F0 = F0 / np.linalg.norm(F0, axis=1, keepdims=True)
+        F = c.fcgf_forward(torch.from_numpy(cc).cuda()).cpu().numpy()
+        assert rel(F, F0) < TOL
+    assert tuple(c.fcgf_forward(torch.empty((0, 3), dtype=torch.int32, device="cuda")).shape) == (0, 32)
+    with pytest.raises(RuntimeError):
+        hip.Context().fcgf_forward(torch.zeros((4, 3), dtype=torch.int32, device="cuda"))      # weights not loaded
