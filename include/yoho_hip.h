@@ -145,6 +145,14 @@ int yoho_c_ransac(yoho_ctx* ctx, const double* k0, const double* k1, int M, cons
 int yoho_group_gather(yoho_ctx* ctx, const double* keys, int K, const float* pts, const float* feat,
                       int n, int g, const double* Rg_host, float* out, int64_t* nn_idx, void* stream);
 
+/* ---- training path (reference train/trainer.py on utils/network.py *_train): one (1,13) group-conv layer on
+ * device-resident parameters, training layout.  weight (cout,cin,1,13), bias (cout) or NULL: device pointers.
+ *   transpose = 0:  y (B,cout,60) = bias + conv(x (B,cin,60))            (utils/network.py:46-52 + Conv2d(cin,cout,(1,13)))
+ *   transpose = 1:  y (B,cin,60)  = data gradient of that layer for the output gradient x (B,cout,60); bias ignored.
+ * The weight gradient is a plain contraction (dW[o,c,k] = sum_{b,g} dy[b,o,g] x[b,c,N[g,k]]) left to the caller's BLAS. */
+int yoho_gconv_layer(yoho_ctx* ctx, const float* x, int B, int cin, int cout, const float* weight, const float* bias, int transpose,
+                     float* y, void* stream);
+
 /* ---- FCGF backbone (reference fcgf_model/resunet.py ResUNet2 family, simple_yoho/fcgf_feat.py) ------------------------
  * Sparse 3-D ResUNet forward pass, fp32.  channels / tr_channels = CHANNELS / TR_CHANNELS of the model class (index 0
  * unused), e.g. ResUNetBN2C: {0,32,64,128,256} / {0,64,64,64,128}.  tensors: host pointers to the state_dict entries in

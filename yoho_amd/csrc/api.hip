@@ -237,6 +237,25 @@ int yoho_ctx_create(int device, const float* R, const uint8_t* N, const uint8_t*
         (rc = upload(n32.data(), sizeof(int) * G * NTAP, (void**)&c->dN)) || (rc = upload(p32.data(), sizeof(int) * G * G, (void**)&c->dP))) {
         delete c; return rc;
     }
+    // tap inversion table for the data gradient of the group conv (train.hip): n_k = N[e][k] with e the identity,
+    // inv[k] = k2 with n_k2 * n_k = e, i.e. N[n_k][k2] == e.  The tap set must be closed under inversion.
+    {
+        int e = -1;
+        for (int g = 0; g < G && e < 0; ++g) {
+            float d = 0.f;
+            for (int i = 0; i < 9; ++i) d += std::fabs(R[g * 9 + i] - ((i % 4 == 0) ? 1.f : 0.f));
+            if (d < 1e-4f) e = g;
+        }
+        bool ok = e >= 0;
+        for (int k = 0; k < NTAP && ok; ++k) {
+            const int nk = N[e * NTAP + k];
+            int k2 = -1;
+            for (int j = 0; j < NTAP; ++j) if (N[nk * NTAP + j] == e) k2 = j;
+            if (k2 < 0) ok = false; else c->tap_inv[k] = k2;
+        }
+        if (!ok) for (int k = 0; k < NTAP; ++k) c->tap_inv[k] = -1;          // yoho_gconv_layer(transpose) then refuses
+        if ((rc = upload(c->tap_inv, sizeof(int) * NTAP, (void**)&c->d_tap_inv))) { delete c; return rc; }
+    }
     // slot tables: which output group elements each configuration computes
     std::vector<int> slab(NCFG * NTAP * G, 0), outg(NCFG * G, -1);
     auto fill = [&](int cfg, const std::vector<int>& glist, int gpw, bool replicate) {
@@ -327,6 +346,7 @@ int yoho_ctx_destroy(yoho_ctx* c) {
     if (c->dFpad) (void)hipFree(c->dFpad);
     if (c->dF16) (void)hipFree(c->dF16);
     if (c->fcgf) fcgf_free(c->fcgf);
+    if (c->d_tap_inv) (void)hipFree(c->d_tap_inv);
     delete c->fb;
     if (c->ev_created) for (auto& e : c->ev) (void)hipEventDestroy(e);
     delete c;
@@ -719,6 +739,7 @@ int yoho_load_fcgf(yoho_ctx* c, const yoho_fcgf_config* cfg, const float* const*
     int rc = fcgf_load(&n, cfg, tensors, ntensors);
     if (rc) return rc;
     if (c->fcgf) fcgf_free(c->fcgf);
+    if (c->d_tap_inv) (void)hipFree(c->d_tap_inv);
     c->fcgf = n;
     return 0;
 }
@@ -750,6 +771,24 @@ int yoho_fcgf_forward_batch(yoho_ctx* c, const int32_t* coords, const int32_t* o
     if (!coords || !out) { set_error("yoho_fcgf_forward_batch: bad argument"); return YOHO_EINVAL; }
     HIPCHK(hipSetDevice(c->device));
     return fcgf_forward(c, c->fcgf, coords, n, offsets, nb, out, (hipStream_t)stream);
+}
+
+int yoho_gconv_layer(yoho_ctx* c, const float* x, int B, int cin, int cout, const float* weight, const float* bias, int transpose,
+                     float* y, void* stream) {
+    if (!c || B < 0 || cin < 1 || cout < 1) { set_error("yoho_gconv_layer: bad argument"); return YOHO_EINVAL; }
+    if (B == 0) return 0;
+    if (!x || !weight || !y) { set_error("yoho_gconv_layer: bad argument"); return YOHO_EINVAL; }
+    if (transpose && c->tap_inv[0] < 0) { set_error("yoho_gconv_layer: the neighbour table is not closed under inversion"); return YOHO_EINVAL; }
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    const int xc = transpose ? cout : cin, yc = transpose ? cin : cout;
+    const int MAXB = 4096;
+    for (int b0 = 0; b0 < B; b0 += MAXB) {
+        const int nb = B - b0 < MAXB ? B - b0 : MAXB;
+        int rc = gconv_layer(c, x + (size_t)b0 * xc * G, nb, cin, cout, weight, bias, transpose, y + (size_t)b0 * yc * G, s);
+        if (rc) return rc;
+    }
+    return 0;
 }
 
 }  // extern "C"

@@ -86,6 +86,8 @@ void fgemm_plane_offsets(int kppad, int cin, long long* off);
 int pack_fgemm_weights(const FourierBasis& fb, const float* W, int cin, int cout, std::vector<unsigned short>& out, float* descale);
 int launch_fgemm(const Layer& L, const char* Bplanes, int kppad, int nT32, const float* res, float* out, int flags, hipStream_t s);
 void build_gft16_frags(const FourierBasis& fb, std::vector<unsigned short>& out);
+int gconv_layer(yoho_ctx* c, const float* x, int B, int cin, int cout, const float* W, const float* bias, int transpose, float* y,
+                hipStream_t s);
 struct FcgfNet;
 int fcgf_load(FcgfNet** out, const yoho_fcgf_config* cfg, const float* const* t, int ntensors);
 void fcgf_free(FcgfNet* n);
@@ -153,6 +155,8 @@ struct yoho_ctx {
     float* dFpad = nullptr;      // F padded to 64 x 64 (device)
     void* dF16 = nullptr;        // fp16x2 MFMA fragments of F^T and F (gft16.hip)
     yoho::FcgfNet* fcgf = nullptr;   // FCGF backbone weights (sparse.hip)
+    int tap_inv[13] = {0};       // inv[k]: the tap whose group element is the inverse of tap k's (train.hip)
+    int* d_tap_inv = nullptr;
     int nCU = 256;
     // workspace (grown on demand)
     yoho::Workspace ws;

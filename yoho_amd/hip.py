@@ -18,7 +18,7 @@ _lib = None
 SYMBOLS = [
     "yoho_last_error", "yoho_version", "yoho_ctx_create", "yoho_ctx_destroy", "yoho_load_partI",
     "yoho_load_partII", "yoho_partI_forward", "yoho_group_mean_np", "yoho_nn_search", "yoho_mutual_nn",
-    "yoho_load_fcgf", "yoho_fcgf_voxelize", "yoho_fcgf_forward", "yoho_fcgf_forward_batch",
+    "yoho_gconv_layer", "yoho_load_fcgf", "yoho_fcgf_voxelize", "yoho_fcgf_forward", "yoho_fcgf_forward_batch",
     "yoho_des2r", "yoho_des2r_indexed", "yoho_partII_forward", "yoho_partII_forward_indexed", "yoho_hyp_from_quat", "yoho_o_score", "yoho_c_ransac",
     "yoho_group_gather", "yoho_set_profiling", "yoho_get_kernel_ms", "yoho_set_gconv_mode", "yoho_set_partII_mode",
 ]
@@ -84,6 +84,7 @@ def load_library():
     lib.yoho_o_score.argtypes = [vp, vp, vp, ci, vp, vp, ci, C.c_double, vp, vp, vp, vp]
     lib.yoho_c_ransac.argtypes = [vp, vp, vp, ci, vp, vp, ci, C.c_double, vp, vp, vp, vp, vp, vp]
     lib.yoho_group_gather.argtypes = [vp, vp, ci, vp, vp, ci, ci, vp, vp, vp, vp]
+    lib.yoho_gconv_layer.argtypes = [vp, vp, ci, ci, ci, vp, vp, ci, vp, vp]
     lib.yoho_load_fcgf.argtypes = [vp, C.POINTER(FcgfConfig), C.POINTER(vp), ci]
     lib.yoho_fcgf_voxelize.argtypes = [vp, vp, ci, C.c_double, vp, vp, C.POINTER(ci), vp]
     lib.yoho_fcgf_forward.argtypes = [vp, vp, ci, vp, vp]
@@ -187,6 +188,21 @@ class Context:
                           self._conv(sd, f + "0", keep), self._bn(sd, f + "1", keep),
                           self._conv(sd, f + "3", keep), self._bn(sd, f + "4", keep), self._conv(sd, f + "6", keep))
         _check(self._lib.yoho_load_partII(self._h, C.byref(w)))
+
+    # ---- training path ------------------------------------------------------------------------
+    def gconv_layer(self, x, weight, bias=None, transpose=False):
+        """One (1,13) group-conv layer on device tensors.  weight (cout,cin,1,13), bias (cout) or None.
+        transpose=False: x (B,cin,60) -> (B,cout,60); transpose=True: x = output gradient (B,cout,60) -> input gradient (B,cin,60)."""
+        cout, cin = int(weight.shape[0]), int(weight.shape[1])
+        B = x.shape[0]
+        xc, yc = (cout, cin) if transpose else (cin, cout)
+        if x.dim() != 3 or x.shape[1] != xc or x.shape[2] != 60:
+            raise ValueError(f"expected ({'B'},{xc},60), got {tuple(x.shape)}")
+        y = torch.empty((B, yc, 60), dtype=torch.float32, device=x.device)
+        _check(self._lib.yoho_gconv_layer(self._h, _dev(x, torch.float32, "x"), B, cin, cout, _dev(weight, torch.float32, "weight"),
+                                          _dev(bias, torch.float32, "bias") if (bias is not None and not transpose) else None,
+                                          1 if transpose else 0, C.c_void_p(y.data_ptr()), _stream()))
+        return y
 
     # ---- FCGF backbone ------------------------------------------------------------------------
     def load_fcgf(self, sd, channels=(0, 32, 64, 128, 256), tr_channels=(0, 64, 64, 64, 128), out_channels=32, conv1_kernel_size=7,

@@ -217,3 +217,27 @@ def surface_cloud(n, seed=0, extent=1.2):
     pc = np.concatenate(parts) + rs.randn(n, 3) * 0.002
     rs.shuffle(pc)
     return np.ascontiguousarray(pc.astype(np.float64))
+
+
+def train_batch(bn, tables_P, seed=0):
+    """One synthetic training batch in the layout of the reference's Train_val_list items (utils/dataset.py:263-270 after
+    the DataLoader's batch dimension of 1): feats0 / feats1 (1,bn,32,60), true_idx (1,bn), deltaR (1,bn,4).  feats1 is
+    feats0 with the group axis permuted by P[true_idx] plus noise, so the coarse-rotation index is learnable."""
+    rs = np.random.RandomState(seed)
+    f0 = unit_features(bn, seed=seed + 1000)
+    idx = rs.randint(0, 60, size=bn).astype(np.int64)
+    f1 = np.stack([f0[i][:, tables_P[idx[i]]] for i in range(bn)]) + 0.05 * rs.randn(bn, 32, 60).astype(np.float32)
+    f1 = (f1 / np.linalg.norm(f1, axis=1, keepdims=True)).astype(np.float32)
+    q = np.concatenate([np.ones((bn, 1)), 0.1 * rs.randn(bn, 3)], 1)
+    q = (q / np.linalg.norm(q, axis=1, keepdims=True)).astype(np.float32)
+    return {"feats0": f0[None], "feats1": f1[None], "true_idx": idx[None], "deltaR": q[None]}
+
+
+def tensor_digest(a):
+    """small fingerprint of a (large) tensor for golden files: [l2 norm, sum, dot with a fixed pattern] + first 16 values"""
+    from .weights import hash_uniform
+    a = np.asarray(a, dtype=np.float64).reshape(-1)
+    pat = hash_uniform(12345, "digest", a.size).astype(np.float64) - 0.5
+    head = np.zeros(16)
+    head[:min(16, a.size)] = a[:16]
+    return np.concatenate([[np.sqrt((a * a).sum()), a.sum(), (a * pat).sum()], head])

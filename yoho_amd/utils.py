@@ -52,3 +52,23 @@ def matrix_from_quaternion(quaternion):
 def dataset_feature_name(name):
     """'3dLomatch/..' shares the feature cache of '3dmatch/..' (tests/extractor.py:84-87, tests/matcher.py:24-27)."""
     return f"3d{name[4:]}" if name[0:4] == "3dLo" else name
+
+
+def quaternion_from_matrix(matrix):
+    """Rotation matrix (3x3 or the 3x3 block of a 4x4) -> unit quaternion (w, x, y, z) with w >= 0: the eigenvector of
+    the largest eigenvalue of the symmetric 4x4 matrix K built from the rotation (utils/r_eval.py quaternion_from_matrix,
+    isprecise=False branch, i.e. transformations.py / Bar-Itzhack)."""
+    M = np.asarray(matrix, dtype=np.float64)
+    m00, m01, m02 = M[0, 0], M[0, 1], M[0, 2]
+    m10, m11, m12 = M[1, 0], M[1, 1], M[1, 2]
+    m20, m21, m22 = M[2, 0], M[2, 1], M[2, 2]
+    K = np.array([[m00 - m11 - m22, 0.0, 0.0, 0.0],
+                  [m01 + m10, m11 - m00 - m22, 0.0, 0.0],
+                  [m02 + m20, m12 + m21, m22 - m00 - m11, 0.0],
+                  [m21 - m12, m02 - m20, m10 - m01, m00 + m11 + m22]])
+    K /= 3.0
+    w, V = np.linalg.eigh(K)
+    q = V[[3, 0, 1, 2], np.argmax(w)]
+    if q[0] < 0.0:
+        np.negative(q, q)
+    return q
