@@ -83,6 +83,11 @@ int yoho_load_partII(yoho_ctx* ctx, const yoho_partII_weights* w);
  * axis, i.e. what the matcher consumes (may be NULL).  Any B >= 1. */
 int yoho_partI_forward(yoho_ctx* ctx, const float* x, int B, float* eqv, float* inv, float* inv_np, void* stream);
 
+/* both fragments of a scene pair in one descriptor pass without concatenating them first: rows [0,B0) of the outputs
+ * belong to x0, rows [B0,B0+B1) to x1.  Default arithmetic mode only (YOHO_EINVAL otherwise), B0+B1 <= 16384. */
+int yoho_partI_forward_pair(yoho_ctx* ctx, const float* x0, int B0, const float* x1, int B1, float* eqv, float* inv, float* inv_np,
+                            void* stream);
+
 /* out (B,32) = np.mean(eqv (B,32,60), axis=-1) bit-exactly (numpy pairwise order, fp32) */
 int yoho_group_mean_np(yoho_ctx* ctx, const float* eqv, int B, float* out, void* stream);
 

@@ -100,3 +100,27 @@ def test_other_model_configs_and_tiny_clouds(hip):
     assert tuple(c.fcgf_forward(torch.empty((0, 3), dtype=torch.int32, device="cuda")).shape) == (0, 32)
     with pytest.raises(RuntimeError):
         hip.Context().fcgf_forward(torch.zeros((4, 3), dtype=torch.int32, device="cuda"))      # weights not loaded
+
+
+def test_reloading_weights_keeps_every_network_intact(hip, fsd, tables):
+    """regression: a second yoho_load_fcgf released a buffer it did not own; later loads then overwrote live weights"""
+    c = hip.Context()
+    pc = synth.surface_cloud(1500, seed=1)
+    _, coords = fo.voxelize(pc, 0.025)
+    F0 = fo.extract_features(pc, 0.025, fsd)[1]
+    cd = torch.from_numpy(coords).cuda()
+    c.load_fcgf(fsd)
+    c.load_fcgf(fsd)
+    c.load_partI(W.synth_state_dict(W.PARTI_SPEC, 7))
+    c.load_partII(W.synth_state_dict(W.PARTII_SPEC, 8))
+    assert rel(c.fcgf_forward(cd).cpu().numpy(), F0) < TOL
+    # the data-gradient path (tap inversion table) still works after the reloads
+    w = torch.randn(64, 32, 1, 13, device="cuda")
+    dy = torch.randn(3, 64, 60, device="cuda")
+    nei = torch.from_numpy(tables.N.astype(np.int64).reshape(-1)).cuda()
+    x = torch.zeros(3, 32, 60, device="cuda", requires_grad=True)
+    torch.nn.functional.conv2d(x[:, :, nei].reshape(3, 32, 60, 13), w)[:, :, :, 0].backward(dy)
+    assert rel(c.gconv_layer(dy, w, None, transpose=True).cpu().numpy(), x.grad.cpu().numpy()) < 1e-5
+    c2 = hip.Context()                                                   # a second context in the same process
+    c2.load_fcgf(fsd)
+    assert rel(c2.fcgf_forward(cd).cpu().numpy(), F0) < TOL

@@ -292,6 +292,17 @@ def test_matched_variants_equal_gathered(ctxh, tables):
     assert torch.equal(q_g, q_m)
 
 
+def test_partI_forward_pair_equals_concatenated(hip, ctxh, sd1):
+    c = hip.Context()                                       # default arithmetic mode
+    c.load_partI(sd1)
+    a, b = cu(synth.unit_features(70, seed=41)), cu(synth.unit_features(45, seed=42))
+    o1 = c.partI_forward(torch.cat([a, b]), want_inv=True, want_inv_np=True)
+    o2 = c.partI_forward_pair(a, b, want_inv=True, want_inv_np=True)
+    assert all(torch.equal(o1[k], o2[k]) for k in ("eqv", "inv", "inv_np"))
+    with pytest.raises(RuntimeError):
+        ctxh.partI_forward_pair(a, b)                       # direct-conv modes: the caller concatenates (pipeline.run_pair does)
+
+
 def test_quat2mat_bitexact(ctx, gold):
     g = gold("quat.npz")
     M = g["q"].shape[0]

@@ -505,7 +505,8 @@ static int partI_passF(yoho_ctx* c, const float* x, int B, float* eqv, float* in
 }
 
 // group-Fourier variant: all four layers as irrep GEMMs on the fp16x2 split MFMA, fp16x2 transform kernels between them
-static int partI_passG(yoho_ctx* c, const float* x, int B, float* eqv, float* inv, float* inv_np, hipStream_t s) {
+static int partI_passG(yoho_ctx* c, const float* x, int B, float* eqv, float* inv, float* inv_np, hipStream_t s, const float* x1 = nullptr,
+                       int B0 = 0) {
     const int nT = (B + TILE - 1) / TILE;
     const int kppad = (B + 255) / 256 * 256;
     const size_t nX = (size_t)nT * 4, n256 = (size_t)nT * 32, n512 = (size_t)nT * 64;
@@ -525,7 +526,7 @@ static int partI_passG(yoho_ctx* c, const float* x, int B, float* eqv, float* in
     const Layer* L = c->p1;
     for (int i = 0; i < 4; ++i) if (!L[i].wpg) { set_error("irrep-GEMM weights missing"); return YOHO_ENOWEIGHTS; }
     mark(0);
-    if ((rc = launch_head16(x, B, nT, bP32, kppad, c->dF16, s))) return rc;
+    if ((rc = launch_head16(x, B, nT, bP32, kppad, c->dF16, s, x1, B0))) return rc;
     mark(1);
     if ((rc = launch_fgemm(L[0], bP32, kppad, nT, nullptr, bH0, 0, s))) return rc;
     mark(2);
@@ -542,7 +543,7 @@ static int partI_passG(yoho_ctx* c, const float* x, int B, float* eqv, float* in
     if ((rc = launch_fgemm(L[3], bP256, kppad, nT, nullptr, bY, 0, s))) return rc;
     mark(8);
     if ((rc = launch_gft16(bY, bYs, nullptr, kppad, c->dF16, nullptr, nullptr, nT, 4, c->nCU, s, B))) return rc;
-    if ((rc = launch_finalize_partI(bYs, x, B, eqv, inv, inv_np, 2, s))) return rc;
+    if ((rc = launch_finalize_partI(bYs, x, B, eqv, inv, inv_np, 2, s, x1, B0))) return rc;
     mark(9);
     return 0;
 }
@@ -739,7 +740,6 @@ int yoho_load_fcgf(yoho_ctx* c, const yoho_fcgf_config* cfg, const float* const*
     int rc = fcgf_load(&n, cfg, tensors, ntensors);
     if (rc) return rc;
     if (c->fcgf) fcgf_free(c->fcgf);
-    if (c->d_tap_inv) (void)hipFree(c->d_tap_inv);
     c->fcgf = n;
     return 0;
 }
@@ -771,6 +771,15 @@ int yoho_fcgf_forward_batch(yoho_ctx* c, const int32_t* coords, const int32_t* o
     if (!coords || !out) { set_error("yoho_fcgf_forward_batch: bad argument"); return YOHO_EINVAL; }
     HIPCHK(hipSetDevice(c->device));
     return fcgf_forward(c, c->fcgf, coords, n, offsets, nb, out, (hipStream_t)stream);
+}
+
+int yoho_partI_forward_pair(yoho_ctx* c, const float* x0, int B0, const float* x1, int B1, float* eqv, float* inv, float* inv_np,
+                            void* stream) {
+    if (!c || !x0 || !x1 || !eqv || B0 < 1 || B1 < 1) { set_error("yoho_partI_forward_pair: bad argument"); return YOHO_EINVAL; }
+    if (!c->has_partI) { set_error("yoho_partI_forward_pair: PartI weights not loaded"); return YOHO_ENOWEIGHTS; }
+    if (c->gconv_mode != 4 || B0 + B1 > 16384) { set_error("yoho_partI_forward_pair: default arithmetic mode and at most 16384 keypoints"); return YOHO_EINVAL; }
+    HIPCHK(hipSetDevice(c->device));
+    return partI_passG(c, x0, B0 + B1, eqv, inv, inv_np, (hipStream_t)stream, x1, B0);
 }
 
 int yoho_gconv_layer(yoho_ctx* c, const float* x, int B, int cin, int cout, const float* weight, const float* bias, int transpose,

@@ -66,7 +66,8 @@ int launch_gconv(const ConvArgs& a, int gpw, int flags, hipStream_t s);
 int gconv_init();   // sets the dynamic-LDS attribute of every instantiation
 
 int launch_pack_partI(const float* x, int B, int nTiles, float* out, hipStream_t s);
-int launch_finalize_partI(const float* y, const float* x, int B, float* eqv, float* inv, float* inv_np, int layout16, hipStream_t s);
+int launch_finalize_partI(const float* y, const float* x, int B, float* eqv, float* inv, float* inv_np, int layout16, hipStream_t s,
+                          const float* x1 = nullptr, int B0 = 0);
 // group-Fourier variant (fourier.hip)
 struct FourierBasis {
     double rho[5][60][25];    // rho[r][g][a*d + b], real orthogonal irreps of dimension 1, 3, 3, 4, 5
@@ -102,7 +103,8 @@ int launch_gft16_invp(const float* in, float* res0, char* planes16, int nTiles16
 int launch_head2(const float* s0, const float* s1, const float* s2, const float* s3, const int64_t* pre_idx, const int* P, const float* bn_s,
                  const float* bn_t, int M, int nTiles, char* planes, int kppad, const void* Ffrag, hipStream_t s,
                  const int64_t* const* ridx = nullptr, int istride = 1);
-int launch_head16(const float* x, int B, int nTiles, char* planes, int kppad, const void* Ffrag, hipStream_t s);
+int launch_head16(const float* x, int B, int nTiles, char* planes, int kppad, const void* Ffrag, hipStream_t s, const float* x1 = nullptr,
+                  int B0 = 0);
 int launch_gft_planes(const float* in, char* planes, int kppad, const float* Fpad, const float* bn_s, const float* bn_t, int nTiles, int C8,
                       hipStream_t s);
 int launch_gconvf(const Layer& L, const float* X, int nTiles, const float* res, float* out, int flags, hipStream_t s);

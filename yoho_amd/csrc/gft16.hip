@@ -389,6 +389,8 @@ int launch_gft16(const float* in, float* out32, char* planes, int kppad, const v
 // ---------------------------------------------------------------------------------------------------------------
 struct Head16Args {
     const float* x;
+    const float* x1;          // rows >= B0 come from x1 (second fragment of a pair), or null
+    int B0;
     char* planes;
     const uintx4* Ffrag;
     int B, nTiles;
@@ -421,7 +423,8 @@ __global__ __launch_bounds__(256, 1) void head16_kernel(Head16Args a) {
         for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[f][rb][r] = 0.f;
-        const float* xp = a.x + ((size_t)kp * F + (8 * w + f)) * G + 8 * kg;
+        const float* xrow = (a.x1 && kp >= a.B0) ? a.x1 + (size_t)(kp - a.B0) * (F * G) : a.x + (size_t)kp * (F * G);
+        const float* xp = xrow + (size_t)(8 * w + f) * G + 8 * kg;
         floatx4 v[4][2];
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
@@ -468,9 +471,9 @@ __global__ __launch_bounds__(256, 1) void head16_kernel(Head16Args a) {
         }
 }
 
-int launch_head16(const float* x, int B, int nTiles, char* planes, int kppad, const void* Ffrag, hipStream_t s) {
+int launch_head16(const float* x, int B, int nTiles, char* planes, int kppad, const void* Ffrag, hipStream_t s, const float* x1, int B0) {
     Head16Args a;
-    a.x = x; a.planes = planes; a.Ffrag = reinterpret_cast<const uintx4*>(Ffrag); a.B = B; a.nTiles = nTiles;
+    a.x = x; a.x1 = x1; a.B0 = B0; a.planes = planes; a.Ffrag = reinterpret_cast<const uintx4*>(Ffrag); a.B = B; a.nTiles = nTiles;
     fill_qtables(kppad, 32, a.qbase, a.qstride);
     if (nTiles == 0) return 0;
     hipLaunchKernelGGL(head16_kernel, dim3(nTiles), dim3(256), 0, s, a);
@@ -523,6 +526,7 @@ __global__ __launch_bounds__(256, 1) void head2_kernel(Head2Args a) {
     if (tid < G) { qb[tid] = a.qbase[tid]; qs[tid] = a.qstride[tid]; }
     __syncthreads();
     const int tile32 = blockIdx.x;
+    const int sidx = blockIdx.y;                           // one workgroup per (match tile, source): 4x the parallelism of a tile loop
     const int m = tile32 * TILE + Lp;
     const bool ok = m < a.M;
     uintx4 A[2][4][2];
@@ -547,7 +551,7 @@ __global__ __launch_bounds__(256, 1) void head2_kernel(Head2Args a) {
     }
     const int nt = tile32 >> 3;
     const float osc = HF_ASCALE / (F_SCALE * H2_ASCALE);
-    for (int sidx = 0; sidx < 4; ++sidx) {
+    {
         const int cblk = sidx * 4 + w;                     // 8-channel block of the concatenated 128 channels
         const size_t srow = (ok && a.ridx[sidx]) ? (size_t)a.ridx[sidx][(size_t)m * a.istride] : (size_t)m;
         const float* sp = a.src[sidx] + srow * (F * G) + (size_t)(w * 8) * G;
@@ -629,7 +633,7 @@ int launch_head2(const float* s0, const float* s1, const float* s2, const float*
     a.pre_idx = pre_idx; a.P = P; a.bn_s = bn_s; a.bn_t = bn_t; a.planes = planes; a.Ffrag = reinterpret_cast<const uintx4*>(Ffrag); a.M = M;
     fill_qtables(kppad, 128, a.qbase, a.qstride);
     if (nTiles == 0) return 0;
-    hipLaunchKernelGGL(head2_kernel, dim3(nTiles), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(head2_kernel, dim3(nTiles, 4), dim3(256), 0, s, a);
     HIPCHK(hipGetLastError());
     return 0;
 }

@@ -68,14 +68,14 @@ __device__ __forceinline__ size_t iidx16(int tile, int C8, int c, int g, int kp)
 
 __global__ __launch_bounds__(64) void finalize_partI_kernel(const float* __restrict__ y, const float* __restrict__ x, int B,
                                                             float* __restrict__ eqv, float* __restrict__ inv,
-                                                            float* __restrict__ inv_np, int layout16) {
+                                                            float* __restrict__ inv_np, int layout16, const float* __restrict__ x1, int B0) {
     __shared__ float e[F * G];
     __shared__ float rn[G];
     const int b = blockIdx.x;
     const int lane = threadIdx.x;
     const int tw = layout16 == 1 ? 16 : TILE;
     const int tile = b / tw, kp = b - tile * tw;
-    const float* xb = x + (size_t)b * (F * G);
+    const float* xb = (x1 && b >= B0) ? x1 + (size_t)(b - B0) * (F * G) : x + (size_t)b * (F * G);
     for (int i = lane; i < F * G; i += 64) {
         const int c = i / G, g = i - c * G;
         // layout16: 0 = fp32 32-keypoint tile layout, 1 = 16-keypoint tile layout, 2 = plain (B,32,60)
@@ -109,8 +109,9 @@ __global__ __launch_bounds__(64) void finalize_partI_kernel(const float* __restr
     }
 }
 
-int launch_finalize_partI(const float* y, const float* x, int B, float* eqv, float* inv, float* inv_np, int layout16, hipStream_t s) {
-    hipLaunchKernelGGL(finalize_partI_kernel, dim3(B), dim3(64), 0, s, y, x, B, eqv, inv, inv_np, layout16);
+int launch_finalize_partI(const float* y, const float* x, int B, float* eqv, float* inv, float* inv_np, int layout16, hipStream_t s,
+                          const float* x1, int B0) {
+    hipLaunchKernelGGL(finalize_partI_kernel, dim3(B), dim3(64), 0, s, y, x, B, eqv, inv, inv_np, layout16, x1, B0);
     HIPCHK(hipGetLastError());
     return 0;
 }

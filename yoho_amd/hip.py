@@ -17,7 +17,7 @@ _lib = None
 
 SYMBOLS = [
     "yoho_last_error", "yoho_version", "yoho_ctx_create", "yoho_ctx_destroy", "yoho_load_partI",
-    "yoho_load_partII", "yoho_partI_forward", "yoho_group_mean_np", "yoho_nn_search", "yoho_mutual_nn",
+    "yoho_load_partII", "yoho_partI_forward", "yoho_partI_forward_pair", "yoho_group_mean_np", "yoho_nn_search", "yoho_mutual_nn",
     "yoho_gconv_layer", "yoho_load_fcgf", "yoho_fcgf_voxelize", "yoho_fcgf_forward", "yoho_fcgf_forward_batch",
     "yoho_des2r", "yoho_des2r_indexed", "yoho_partII_forward", "yoho_partII_forward_indexed", "yoho_hyp_from_quat", "yoho_o_score", "yoho_c_ransac",
     "yoho_group_gather", "yoho_set_profiling", "yoho_get_kernel_ms", "yoho_set_gconv_mode", "yoho_set_partII_mode",
@@ -73,6 +73,7 @@ def load_library():
     lib.yoho_load_partI.argtypes = [vp, C.POINTER(PartIWeights)]
     lib.yoho_load_partII.argtypes = [vp, C.POINTER(PartIIWeights)]
     lib.yoho_partI_forward.argtypes = [vp, vp, ci, vp, vp, vp, vp]
+    lib.yoho_partI_forward_pair.argtypes = [vp, vp, ci, vp, ci, vp, vp, vp, vp]
     lib.yoho_group_mean_np.argtypes = [vp, vp, ci, vp, vp]
     lib.yoho_nn_search.argtypes = [vp, vp, ci, vp, ci, ci, ci, vp, vp, vp]
     lib.yoho_mutual_nn.argtypes = [vp, vp, ci, vp, ci, vp, vp, vp]
@@ -259,6 +260,22 @@ class Context:
         _check(self._lib.yoho_partI_forward(self._h, _dev(x, torch.float32, "x"), B, C.c_void_p(eqv.data_ptr()),
                                             C.c_void_p(inv.data_ptr()) if want_inv else None,
                                             C.c_void_p(inv_np.data_ptr()) if want_inv_np else None, _stream()))
+        out = {"eqv": eqv}
+        if want_inv:
+            out["inv"] = inv
+        if want_inv_np:
+            out["inv_np"] = inv_np
+        return out
+
+    def partI_forward_pair(self, x0, x1, want_inv=True, want_inv_np=False):
+        """both fragments in one pass, no concatenation copy: outputs have B0 + B1 rows (x0's first).  Default mode only."""
+        B0, B1 = x0.shape[0], x1.shape[0]
+        eqv = torch.empty((B0 + B1, 32, 60), dtype=torch.float32, device=x0.device)
+        inv = torch.empty((B0 + B1, 32), dtype=torch.float32, device=x0.device) if want_inv else None
+        inv_np = torch.empty((B0 + B1, 32), dtype=torch.float32, device=x0.device) if want_inv_np else None
+        _check(self._lib.yoho_partI_forward_pair(self._h, _dev(x0, torch.float32, "x0"), B0, _dev(x1, torch.float32, "x1"), B1,
+                                                 C.c_void_p(eqv.data_ptr()), C.c_void_p(inv.data_ptr()) if want_inv else None,
+                                                 C.c_void_p(inv_np.data_ptr()) if want_inv_np else None, _stream()))
         out = {"eqv": eqv}
         if want_inv:
             out["inv"] = inv

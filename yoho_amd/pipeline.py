@@ -21,7 +21,10 @@ def run_pair(ctx, feat0, feat1, keys0, keys1, inlier_dist=0.09, max_iter=1000, o
         # both fragments in one descriptor batch (tests/extractor.py:51-59 batches keypoints the same way): larger
         # launches fill the chip better than two half-size passes
         n0 = feat0.shape[0]
-        o = ctx.partI_forward(torch.cat([feat0, feat1]), want_inv=False, want_inv_np=True)
+        try:
+            o = ctx.partI_forward_pair(feat0, feat1, want_inv=False, want_inv_np=True)
+        except RuntimeError:                               # non-default arithmetic mode (or > 16384 keypoints)
+            o = ctx.partI_forward(torch.cat([feat0, feat1]), want_inv=False, want_inv_np=True)
         o0 = {k: (v[:n0] if v is not None else None) for k, v in o.items()}
         o1 = {k: (v[n0:] if v is not None else None) for k, v in o.items()}
     else:
