@@ -469,6 +469,42 @@ __global__ __launch_bounds__(256) void spconv_small_kernel(SpConvArgs a) {
     a.out[(size_t)row * a.ldout + a.ocoff + co] = v;
 }
 
+// First convolution with the constant-one input feature (simple_yoho/fcgf_feat.py:41, one input channel, 32 outputs):
+//     out[n][co] = sum over the occupied voxels of the K^3 region of W[k][0][co]
+// fused with the neighbourhood lookup: a half-wave owns one output row, its 32 lanes probe the hash table for 32 kernel
+// offsets at a time (ballot), then every lane (= output channel) adds the weights of the occupied offsets in kernel-index
+// order from an LDS copy of W.  No K^3 x N kernel map is written or read.
+constexpr int C1O_MAXK = 343;
+__global__ __launch_bounds__(256) void conv1_ones_kernel(const int* __restrict__ coords, int n, const u64* __restrict__ keys, unsigned mask,
+                                                         int ksize, const float* __restrict__ W, const float* __restrict__ aff_s,
+                                                         const float* __restrict__ aff_t, float* __restrict__ out) {
+    __shared__ float Wl[C1O_MAXK * 32];
+    const int kv = ksize * ksize * ksize, hk = ksize / 2;
+    for (int i = threadIdx.x; i < kv * 32; i += 256) Wl[i] = W[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, l32 = lane & 31, hw = lane >> 5;
+    const int row = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + hw;
+    const bool valid = row < n;
+    const int4 c = valid ? reinterpret_cast<const int4*>(coords)[row] : make_int4(0, 0, 0, 0);
+    float acc = 0.f;
+    for (int k0 = 0; k0 < kv; k0 += 32) {
+        const int k = k0 + l32;
+        bool present = false;
+        if (valid && k < kv) {
+            const int ox = k % ksize - hk, oy = (k / ksize) % ksize - hk, oz = k / (ksize * ksize) - hk;
+            present = hash_find_slot(keys, mask, pack_key(c.x + ox, c.y + oy, c.z + oz, c.w)) >= 0;
+        }
+        const unsigned long long m64 = __ballot(present);
+        unsigned m = hw ? (unsigned)(m64 >> 32) : (unsigned)m64;
+        while (m) {
+            const int j = __ffs(m) - 1;
+            m &= m - 1;
+            acc += Wl[(k0 + j) * 32 + l32];
+        }
+    }
+    if (valid) out[(size_t)row * 32 + l32] = acc * (aff_s ? aff_s[l32] : 1.f) + (aff_t ? aff_t[l32] : 0.f);
+}
+
 static int launch_spconv(const SpConvArgs& a, hipStream_t s) {
     if (a.nout == 0) return 0;
     if (a.cin % 32 == 0 && a.cout % 32 == 0 && a.cout <= 256 && a.ldin % 4 == 0 && a.K <= SP_MAXK) {
@@ -749,7 +785,8 @@ int fcgf_forward(yoho_ctx* ctx, const FcgfNet* net, const int* coords0, int n0, 
                                inL.mask, ksize, ts, sign, m);
         return m;
     };
-    int* M1 = make_map(L[0], L[0], net->k1, 1, +1);
+    const bool conv1_fused = net->in_ch == 1 && C[1] == 32 && net->k1 * net->k1 * net->k1 <= C1O_MAXK;
+    int* M1 = conv1_fused ? nullptr : make_map(L[0], L[0], net->k1, 1, +1);
     int* Msame[4]; int* Mdown[3]; int* Mup[3];
     for (int l = 0; l < 4; ++l) Msame[l] = make_map(L[l], L[l], 3, L[l].ts, +1);
     for (int l = 0; l < 3; ++l) {
@@ -787,7 +824,12 @@ int fcgf_forward(yoho_ctx* ctx, const FcgfNet* net, const int* coords0, int n0, 
 
     // encoder (resunet.py:142-160).  The block outputs land in the decoder's concatenation buffers (right-hand columns).
     const int k1v = net->k1 * net->k1 * net->k1;
-    if ((rc = conv(ones, net->in_ch, net->in_ch, M1, k1v, n0, net->conv[0], C[1], x[0], C[1], 0, &net->norm[0], nullptr, nullptr, 0, 0, 0))) return rc;
+    if (conv1_fused) {
+        hipLaunchKernelGGL(conv1_ones_kernel, dim3((n0 + 7) / 8), dim3(256), 0, s, L[0].coords, n0, L[0].keys, L[0].mask, net->k1, net->conv[0].w,
+                           net->norm[0].s, net->norm[0].t, x[0]);
+        HIPCHK(hipGetLastError());
+    } else if ((rc = conv(ones, net->in_ch, net->in_ch, M1, k1v, n0, net->conv[0], C[1], x[0], C[1], 0, &net->norm[0], nullptr, nullptr, 0, 0, 0)))
+        return rc;
     if ((rc = block(0, x[0], C[1], net->bconv[0], net->bnorm[0], tmp[0], cat[0], catw[0], catoff[0]))) return rc;
     for (int l = 1; l < 4; ++l) {
         const float* in = cat[l - 1] + catoff[l - 1];
