@@ -605,7 +605,7 @@ int yoho_group_mean_np(yoho_ctx* c, const float* eqv, int B, float* out, void* s
 // PartII with the two large cone layers (128->256 @45 g, 256->512 @13 g) on the bf16x3 split MFMA; the g = 0 tail
 // (512->256 conv + the 1x1 MLP) stays on the fp32 kernels, fed through fp32 32-tile hand-over buffers.
 static bool partII_fourier_head(const yoho_ctx* c) {
-    return c->partII_mode == 2 && c->p2[0].wpg && !std::getenv("YOHO_PARTII_L0_DIRECT");
+    return c->partII_mode == 2 && c->p2[0].wpg;
 }
 
 static int partII_pass16(yoho_ctx* c, const float* s0, const float* s1, const float* s2, const float* s3, const int64_t* idx,
