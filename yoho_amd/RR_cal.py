@@ -55,183 +55,138 @@ def computeTransformationErr(trans, info):
 
 
 def read_trajectory(filename, dim=4):
-    """:68-102  -> (keys (n,3) str array, traj (n,dim,dim))"""
-    with open(filename) as f:
-        lines = f.readlines()
-    keys = lines[0::(dim + 1)]
-    final_keys = []
-    for k in keys:
-        a = k.split('\t')[0:3]
-        final_keys.append([a[0].strip(), a[1].strip(), a[2].strip()])
-    traj = []
-    for i in range(len(lines)):
-        if i % 5 != 0:
-            traj.append(lines[i].split('\t')[0:dim])
-    traj = np.asarray(traj, dtype=float).reshape(-1, dim, dim)
-    return np.asarray(final_keys), traj
+    """Redwood .log: blocks of one header line "id0 <tab> id1 <tab> n" + dim matrix rows (:68-102).
+    -> (keys (n,3) str array, traj (n,dim,dim))"""
+    with open(filename) as fh:
+        rows = fh.read().splitlines()
+    block = dim + 1
+    headers = [[tok.strip() for tok in rows[b].split('\t')[:3]] for b in range(0, len(rows), block)]
+    body = [rows[b + 1 + r].split('\t')[:dim] for b in range(0, len(rows) - dim, block) for r in range(dim)]
+    return np.asarray(headers), np.asarray(body, dtype=float).reshape(-1, dim, dim)
 
 
 def read_pre_trajectory(filename, dim=4):
-    """:104-140 (identical parsing for pre.log)"""
+    """pre.log has the same layout (:104-140)"""
     return read_trajectory(filename, dim)
 
 
 def read_trajectory_info(filename, dim=6):
-    """:142-170  -> (n_frame, cov (n,6,6))"""
-    with open(filename) as fid:
-        contents = fid.readlines()
-    n_pairs = len(contents) // 7
-    assert (len(contents) == 7 * n_pairs)
-    info_list = []
-    n_frame = 0
-    for i in range(n_pairs):
-        frame_idx0, frame_idx1, n_frame = [int(item) for item in contents[i * 7].strip().split()]
-        info_matrix = np.concatenate(
-            [np.array(item.split(), dtype=float).reshape(1, -1) for item in contents[i * 7 + 1:i * 7 + 7]], axis=0)
-        info_list.append(info_matrix)
-    cov_matrix = np.asarray(info_list, dtype=float).reshape(-1, dim, dim)
-    return n_frame, cov_matrix
+    """Redwood .info: per pair one header "i j n_frames" + a dim x dim information matrix (:142-170) -> (n_frames, (n,dim,dim))"""
+    with open(filename) as fh:
+        rows = [r for r in fh.read().splitlines()]
+    per = dim + 1
+    if len(rows) % per:
+        raise AssertionError("malformed .info file")
+    n_frames = 0
+    mats = np.empty((len(rows) // per, dim, dim))
+    for b in range(len(rows) // per):
+        n_frames = int(rows[b * per].split()[2])
+        mats[b] = [[float(v) for v in rows[b * per + 1 + r].split()] for r in range(dim)]
+    return n_frames, mats
 
 
 def extract_corresponding_trajectors(est_pairs, gt_pairs, gt_traj):
-    """:172-191 (mutates est_pairs[:,2] like the reference)"""
-    ext_traj = np.zeros((len(est_pairs), 4, 4))
-    for est_idx, pair in enumerate(est_pairs):
-        pair[2] = gt_pairs[0][2]
-        gt_idx = np.where((gt_pairs == pair).all(axis=1))[0]
-        ext_traj[est_idx, :, :] = gt_traj[gt_idx, :, :]
-    return ext_traj
+    """ground-truth pose of every estimated pair (:172-191); like the reference it overwrites the third header column of
+    est_pairs with the ground truth's fragment count before matching rows"""
+    out = np.zeros((len(est_pairs), 4, 4))
+    n_frag = gt_pairs[0][2]
+    for k, pair in enumerate(est_pairs):
+        pair[2] = n_frag
+        out[k] = gt_traj[np.where((gt_pairs == pair).all(axis=1))[0]]
+    return out
 
 
 def write_trajectory(traj, metadata, filename, dim=4):
     """:193-212"""
-    with open(filename, 'w') as f:
-        for idx in range(traj.shape[0]):
-            if metadata[idx][2]:
-                p = traj[idx, :, :].tolist()
-                f.write('\t'.join(map(str, metadata[idx])) + '\n')
-                f.write('\n'.join('\t'.join(map('{0:.12f}'.format, p[i])) for i in range(dim)))
-                f.write('\n')
+    with open(filename, 'w') as fh:
+        for meta, pose in zip(metadata, traj):
+            if not meta[2]:
+                continue
+            fh.write('\t'.join(str(m) for m in meta) + '\n')
+            fh.write('\n'.join('\t'.join('{0:.12f}'.format(v) for v in pose[r]) for r in range(dim)) + '\n')
 
 
 def evaluate_registration(num_fragment, result, result_pairs, gt_pairs, gt, gt_info, err2=0.2, nonconsecutive=True):
-    """:236-317  -> precision, recall, flags, errors"""
-    err2 = err2 ** 2
-    gt_mask = np.zeros((num_fragment, num_fragment), dtype=int)
-    flags = []
-    errors = []
-    if nonconsecutive:
-        for idx in range(gt_pairs.shape[0]):
-            i = int(gt_pairs[idx, 0]); j = int(gt_pairs[idx, 1])
-            if abs(j - i) > 1:                       # only non consecutive pairs are tested
-                gt_mask[i, j] = idx
-        n_gt = np.sum(gt_mask > 0)
-    else:
-        for idx in range(gt_pairs.shape[0]):
-            i = int(gt_pairs[idx, 0]); j = int(gt_pairs[idx, 1])
-            gt_mask[i, j] = idx
-        n_gt = np.sum(gt_mask > 0) + 1
-    good = 0
-    n_res = 0
+    """3DMatch registration benchmark for one scene (:236-317) -> precision, recall, flags, errors.
+    flags: 0 = correct, 1 = wrong, 2 = pair not evaluated.  Ground-truth pairs are addressed through their row number in
+    the .log, and - as in the reference - row 0 can therefore never be looked up (its table entry is the "empty" value 0);
+    in the consecutive protocol (WHU-TLS) the first estimate is scored against row 0 directly instead."""
+    thr = err2 ** 2
+    row_of = {}
+    for row in range(gt_pairs.shape[0]):
+        i, j = int(gt_pairs[row, 0]), int(gt_pairs[row, 1])
+        if row > 0 and (not nonconsecutive or abs(j - i) > 1):
+            row_of[(i, j)] = row
+    n_gt = len(row_of) + (0 if nonconsecutive else 1)
+    flags, errors = [], []
+    good = scored = 0
+
+    def score(est_pose, row):
+        nonlocal good, scored
+        scored += 1
+        e2 = computeTransformationErr(np.linalg.inv(gt[row]) @ est_pose, gt_info[row])
+        errors.append(np.sqrt(e2))
+        good += e2 <= thr
+        flags.append(0 if e2 <= thr else 1)
+
+    first = 0
     if not nonconsecutive:
-        start_check = 1
-        n_res += 1
-        pose = result[0, :, :]
-        p = computeTransformationErr(np.linalg.inv(gt[0, :, :]) @ pose, gt_info[0, :, :])
-        errors.append(np.sqrt(p))
-        if p <= err2:
-            good += 1
-            flags.append(0)
-        else:
-            flags.append(1)
-    else:
-        start_check = 0
-    for idx in range(start_check, result_pairs.shape[0]):
-        i = int(result_pairs[idx, 0]); j = int(result_pairs[idx, 1])
-        pose = result[idx, :, :]
-        if gt_mask[i, j] > 0:
-            n_res += 1
-            gt_idx = gt_mask[i, j]
-            p = computeTransformationErr(np.linalg.inv(gt[gt_idx, :, :]) @ pose, gt_info[gt_idx, :, :])
-            errors.append(np.sqrt(p))
-            if p <= err2:
-                good += 1
-                flags.append(0)
-            else:
-                flags.append(1)
-        else:
+        score(result[0], 0)
+        first = 1
+    for k in range(first, result_pairs.shape[0]):
+        row = row_of.get((int(result_pairs[k, 0]), int(result_pairs[k, 1])))
+        if row is None:
             flags.append(2)
-    if n_res == 0:
-        n_res += 1e6
-    precision = good * 1.0 / n_res
-    recall = good * 1.0 / n_gt
-    return precision, recall, flags, errors
+        else:
+            score(result[k], row)
+    precision = good * 1.0 / (scored if scored else 1e6)
+    return precision, good * 1.0 / n_gt, flags, errors
 
 
 def benchmark(cfg, datasets, max_iter, yoho_sign='YOHO_O'):
-    """:321-399  writes {output_cache_fn}/Testset/{wholesetname}/Eval_results/{yoho_sign}_RR/{max_iter}iters/result.txt"""
-    c_flags = {}
-    c_errors = {}
-    re_per_scene = defaultdict(list)
-    te_per_scene = defaultdict(list)
-    re_all, te_all, precision, recall = [], [], [], []
-    n_valids = []
-    nonconsecutive = True
-    wholesetname = datasets['wholesetname']
-    if wholesetname == 'WHU-TLS':
-        nonconsecutive = False
-    result_dir = f'{cfg.output_cache_fn}/Testset/{wholesetname}/Eval_results/{yoho_sign}_RR/{max_iter}iters'
-    if not os.path.exists(result_dir):
-        os.makedirs(result_dir)
-    f = open(f'{result_dir}/result.txt', 'w')
-    f.write(("Scene\t prec.\t rec.\t re\t te\t samples\t\n"))
-    for scene, dataset in datasets.items():
-        if scene == 'wholesetname':
-            continue
-        pre_dir = f'{cfg.output_cache_fn}/Testset/{dataset.name}/Match/{yoho_sign}/{max_iter}iters'
-        gt_dir_loc = str.rfind(dataset.gt_dir, '.')
-        gt_dir = dataset.gt_dir[0:gt_dir_loc]
-        gt_pairs, gt_traj = read_trajectory(f'{gt_dir}.log')
-        n_valid = 0
-        for ele in gt_pairs:
-            if nonconsecutive:
-                diff = abs(int(ele[0]) - int(ele[1]))
-                n_valid += diff > 1
-            else:
-                n_valid += 1
-        n_valids.append(n_valid)
-        n_fragments, gt_traj_cov = read_trajectory_info(f'{gt_dir}.info')
-        print(os.path.join(pre_dir, 'pre.log'))
-        est_pairs, est_traj = read_pre_trajectory(os.path.join(pre_dir, 'pre.log'))
-        temp_precision, temp_recall, c_flag, c_error = evaluate_registration(
-            n_fragments, est_traj, est_pairs, gt_pairs, gt_traj, gt_traj_cov, err2=cfg.RR_dist_threshold, nonconsecutive=nonconsecutive)
-        c_flags[dataset.name] = c_flag
-        c_errors[dataset.name] = c_error
-        ext_gt_traj = extract_corresponding_trajectors(est_pairs, gt_pairs, gt_traj)
-        ok = np.array(c_flag) == 0
-        re = rotation_error(ext_gt_traj[:, 0:3, 0:3], est_traj[:, 0:3, 0:3])[ok]
-        te = translation_error(ext_gt_traj[:, 0:3, 3:4], est_traj[:, 0:3, 3:4])[ok]
-        if re.shape[0] == 0:
-            re = np.ones([n_valid]) * 180
-        if te.shape[0] == 0:
-            te = np.ones([n_valid])
-        for d, v in ((re_per_scene, re), (te_per_scene, te)):
-            d['mean'].append(np.mean(v)); d['median'].append(np.median(v)); d['min'].append(np.min(v)); d['max'].append(np.max(v))
-        re_all.extend(re.reshape(-1).tolist())
-        te_all.extend(te.reshape(-1).tolist())
-        precision.append(temp_precision)
-        recall.append(temp_recall)
-        f.write("{}\t {:.3f}\t {:.3f}\t {:.3f}\t {:.3f}\t {:3d}\n".format(dataset.name, temp_precision, temp_recall, np.median(re), np.median(te), n_valid))
-        f.write("Mean precision: {:.3f}".format(temp_precision))
-        f.write("Registration Recall: {:.3f}\n".format(temp_recall))
-        f.write("Mean median RRE: {:.3f}: +- {:.3f}\n".format(np.mean(re), np.median(re)))
-        f.write("Mean median RTE: {:.3F}: +- {:.3f}\n".format(np.mean(te), np.median(te)))
-    weighted_precision = (np.array(n_valids) * np.array(precision)).sum() / np.sum(n_valids)
-    Registration_Recall = np.mean(np.array(recall))      # most important registration recall for eval
-    f.write("Mean precision: {:.3f}: +- {:.3f}\n".format(np.mean(precision), np.std(precision)))
-    f.write("Weighted precision: {:.3f}\n".format(weighted_precision))
-    f.write("Registration Recall: {:.3f}: +- {:.3f}\n".format(Registration_Recall, np.std(np.array(recall))))
-    f.write("Mean median RRE: {:.3f}: +- {:.3f}\n".format(np.mean(re_per_scene['median']), np.std(re_per_scene['median'])))
-    f.write("Mean median RTE: {:.3F}: +- {:.3f}\n".format(np.mean(te_per_scene['median']), np.std(te_per_scene['median'])))
-    f.close()
-    return Registration_Recall, c_flags, c_errors
+    """All scenes of a test set (:321-399): writes
+    {output_cache_fn}/Testset/{wholesetname}/Eval_results/{yoho_sign}_RR/{max_iter}iters/result.txt and returns
+    (mean registration recall over the scenes, per-scene flags, per-scene errors)."""
+    whole = datasets['wholesetname']
+    nonconsecutive = whole != 'WHU-TLS'
+    out_dir = f'{cfg.output_cache_fn}/Testset/{whole}/Eval_results/{yoho_sign}_RR/{max_iter}iters'
+    os.makedirs(out_dir, exist_ok=True)
+    c_flags, c_errors = {}, {}
+    med_re, med_te, precisions, recalls, n_valids = [], [], [], [], []
+    with open(f'{out_dir}/result.txt', 'w') as rep:
+        rep.write("Scene\t prec.\t rec.\t re\t te\t samples\t\n")
+        for scene, ds in datasets.items():
+            if scene == 'wholesetname':
+                continue
+            pre_log = os.path.join(f'{cfg.output_cache_fn}/Testset/{ds.name}/Match/{yoho_sign}/{max_iter}iters', 'pre.log')
+            gt_stem = ds.gt_dir[:ds.gt_dir.rfind('.')]
+            gt_pairs, gt_traj = read_trajectory(gt_stem + '.log')
+            n_valid = sum(1 for p in gt_pairs if (not nonconsecutive) or abs(int(p[0]) - int(p[1])) > 1)
+            n_frag, gt_cov = read_trajectory_info(gt_stem + '.info')
+            print(pre_log)
+            est_pairs, est_traj = read_pre_trajectory(pre_log)
+            prec, rec, flags, errs = evaluate_registration(n_frag, est_traj, est_pairs, gt_pairs, gt_traj, gt_cov,
+                                                           err2=cfg.RR_dist_threshold, nonconsecutive=nonconsecutive)
+            c_flags[ds.name], c_errors[ds.name] = flags, errs
+            gt_of_est = extract_corresponding_trajectors(est_pairs, gt_pairs, gt_traj)
+            ok = np.array(flags) == 0
+            re = rotation_error(gt_of_est[:, :3, :3], est_traj[:, :3, :3])[ok]
+            te = translation_error(gt_of_est[:, :3, 3:4], est_traj[:, :3, 3:4])[ok]
+            if re.shape[0] == 0:
+                re = np.full([n_valid], 180.0)
+            if te.shape[0] == 0:
+                te = np.ones([n_valid])
+            med_re.append(np.median(re)); med_te.append(np.median(te))
+            precisions.append(prec); recalls.append(rec); n_valids.append(n_valid)
+            rep.write("{}\t {:.3f}\t {:.3f}\t {:.3f}\t {:.3f}\t {:3d}\n".format(ds.name, prec, rec, np.median(re), np.median(te), n_valid))
+            rep.write("Mean precision: {:.3f}".format(prec))
+            rep.write("Registration Recall: {:.3f}\n".format(rec))
+            rep.write("Mean median RRE: {:.3f}: +- {:.3f}\n".format(np.mean(re), np.median(re)))
+            rep.write("Mean median RTE: {:.3F}: +- {:.3f}\n".format(np.mean(te), np.median(te)))
+        recall_mean = np.mean(np.array(recalls))                     # the number the papers report
+        rep.write("Mean precision: {:.3f}: +- {:.3f}\n".format(np.mean(precisions), np.std(precisions)))
+        rep.write("Weighted precision: {:.3f}\n".format((np.array(n_valids) * np.array(precisions)).sum() / np.sum(n_valids)))
+        rep.write("Registration Recall: {:.3f}: +- {:.3f}\n".format(recall_mean, np.std(np.array(recalls))))
+        rep.write("Mean median RRE: {:.3f}: +- {:.3f}\n".format(np.mean(med_re), np.std(med_re)))
+        rep.write("Mean median RTE: {:.3F}: +- {:.3f}\n".format(np.mean(med_te), np.std(med_te)))
+    return recall_mean, c_flags, c_errors
