@@ -505,6 +505,89 @@ __global__ __launch_bounds__(256) void conv1_ones_kernel(const int* __restrict__
     if (valid) out[(size_t)row * 32 + l32] = acc * (aff_s ? aff_s[l32] : 1.f) + (aff_t ? aff_t[l32] : 0.f);
 }
 
+// Dense occupancy bitmap of the level-0 voxels of every cloud of a pass (bounding box + K/2 margin, x fastest, 32 voxels per
+// word): the first convolution tests its K^3 neighbours with one cached word read each instead of a hash probe.
+struct BmDesc {
+    long long base;          // first word of this cloud's bitmap
+    int x0, y0, z0;          // voxel coordinate of bit 0 (bounding-box minimum minus the margin)
+    int wx, ny;              // words per x row, rows per z slice
+};
+
+__global__ void bbox_kernel(const int* __restrict__ coords, int n, int* __restrict__ bb) {     // bb[cloud][6] = min xyz, max xyz
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const bool valid = i < n;
+    const int4 c = valid ? reinterpret_cast<const int4*>(coords)[i] : make_int4(0, 0, 0, -1);
+    // rows of a cloud are contiguous: almost every wave sees one cloud only -> reduce in the wave, one atomic per wave
+    const int first = __builtin_amdgcn_readfirstlane(c.w);
+    if (__ballot(valid && c.w != first) == 0ull && first >= 0) {
+        int lo[3] = {valid ? c.x : 0x7FFFFFFF, valid ? c.y : 0x7FFFFFFF, valid ? c.z : 0x7FFFFFFF};
+        int hi[3] = {valid ? c.x : (int)0x80000000, valid ? c.y : (int)0x80000000, valid ? c.z : (int)0x80000000};
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+            for (int o = 32; o >= 1; o >>= 1) {
+                lo[a] = min(lo[a], __shfl_xor(lo[a], o));
+                hi[a] = max(hi[a], __shfl_xor(hi[a], o));
+            }
+        if ((threadIdx.x & 63) == 0) {
+            int* b = bb + 6 * first;
+            atomicMin(b + 0, lo[0]); atomicMin(b + 1, lo[1]); atomicMin(b + 2, lo[2]);
+            atomicMax(b + 3, hi[0]); atomicMax(b + 4, hi[1]); atomicMax(b + 5, hi[2]);
+        }
+    } else if (valid) {
+        int* b = bb + 6 * c.w;
+        atomicMin(b + 0, c.x); atomicMin(b + 1, c.y); atomicMin(b + 2, c.z);
+        atomicMax(b + 3, c.x); atomicMax(b + 4, c.y); atomicMax(b + 5, c.z);
+    }
+}
+
+__global__ void bbox_init_kernel(int* bb, int nb) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < nb * 6) bb[i] = (i % 6) < 3 ? 0x7FFFFFFF : (int)0x80000000;
+}
+
+__global__ void bitmap_fill_kernel(const int* __restrict__ coords, int n, const BmDesc* __restrict__ desc, unsigned* __restrict__ bm) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int4 c = reinterpret_cast<const int4*>(coords)[i];
+    const BmDesc d = desc[c.w];
+    const int bx = c.x - d.x0;
+    atomicOr(bm + d.base + ((long long)(c.z - d.z0) * d.ny + (c.y - d.y0)) * d.wx + (bx >> 5), 1u << (bx & 31));
+}
+
+__global__ __launch_bounds__(256) void conv1_bitmap_kernel(const int* __restrict__ coords, int n, const BmDesc* __restrict__ desc,
+                                                           const unsigned* __restrict__ bm, int ksize, const float* __restrict__ W,
+                                                           const float* __restrict__ aff_s, const float* __restrict__ aff_t,
+                                                           float* __restrict__ out) {
+    __shared__ float Wl[C1O_MAXK * 32];
+    const int kv = ksize * ksize * ksize, hk = ksize / 2;
+    for (int i = threadIdx.x; i < kv * 32; i += 256) Wl[i] = W[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, l32 = lane & 31, hw = lane >> 5;
+    const int row = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + hw;
+    const bool valid = row < n;
+    const int4 c = valid ? reinterpret_cast<const int4*>(coords)[row] : make_int4(0, 0, 0, 0);
+    const BmDesc d = desc[c.w];
+    const unsigned* bmc = bm + d.base;
+    const int bx = c.x - d.x0, by = c.y - d.y0, bz = c.z - d.z0;      // >= K/2 by construction of the margin
+    float acc = 0.f;
+    for (int k0 = 0; k0 < kv; k0 += 32) {
+        const int k = k0 + l32;
+        bool present = false;
+        if (valid && k < kv) {
+            const int x = bx + k % ksize - hk, y = by + (k / ksize) % ksize - hk, z = bz + k / (ksize * ksize) - hk;
+            present = (bmc[((long long)z * d.ny + y) * d.wx + (x >> 5)] >> (x & 31)) & 1u;
+        }
+        const unsigned long long m64 = __ballot(present);
+        unsigned m = hw ? (unsigned)(m64 >> 32) : (unsigned)m64;
+        while (m) {
+            const int j = __ffs(m) - 1;
+            m &= m - 1;
+            acc += Wl[(k0 + j) * 32 + l32];
+        }
+    }
+    if (valid) out[(size_t)row * 32 + l32] = acc * (aff_s ? aff_s[l32] : 1.f) + (aff_t ? aff_t[l32] : 0.f);
+}
+
 static int launch_spconv(const SpConvArgs& a, hipStream_t s) {
     if (a.nout == 0) return 0;
     if (a.cin % 32 == 0 && a.cout % 32 == 0 && a.cout <= 256 && a.ldin % 4 == 0 && a.K <= SP_MAXK) {
@@ -729,6 +812,7 @@ size_t fcgf_workspace_bytes(const FcgfNet* net, int n0) {
     size_t feat = 1 + 2 * C[1] + (T[2] + C[1]) + 2 * T[2] + T[1] + net->out_ch;
     feat += 2 * C[2] + (T[3] + C[2]) + 2 * T[3] + 2 * C[3] + (T[4] + C[3]) + 2 * T[4] + 3 * C[4];
     b += feat * N * 4 + 64 * 256;
+    b += (size_t)64 << 20;                                                    // occupancy bitmaps of the first convolution
     return b;
 }
 
@@ -752,6 +836,14 @@ int fcgf_forward(yoho_ctx* ctx, const FcgfNet* net, const int* coords0, int n0, 
         HIPCHK(hipMemcpyAsync(doff, hoff, sizeof(int) * (nb + 1), hipMemcpyHostToDevice, s));
         HIPCHK(hipStreamSynchronize(s));                     // hoff lives on this stack frame
         hipLaunchKernelGGL(coords4_kernel, dim3((n0 + 255) / 256), dim3(256), 0, s, coords0, n0, doff, nb, L[0].coords);
+    }
+    const bool conv1_fused = net->in_ch == 1 && C[1] == 32 && net->k1 * net->k1 * net->k1 <= C1O_MAXK;
+    int* dbb = ar.take<int>(64 * 6);
+    int hbb[64 * 6];
+    if (conv1_fused) {
+        hipLaunchKernelGGL(bbox_init_kernel, dim3(2), dim3(256), 0, s, dbb, nb);
+        hipLaunchKernelGGL(bbox_kernel, dim3((n0 + 255) / 256), dim3(256), 0, s, L[0].coords, n0, dbb);
+        HIPCHK(hipMemcpyAsync(hbb, dbb, sizeof(int) * 6 * nb, hipMemcpyDeviceToHost, s));     // completes with the level-1 sync below
     }
     for (int l = 0; l < 4; ++l) {
         L[l].ts = 1 << l;
@@ -785,8 +877,34 @@ int fcgf_forward(yoho_ctx* ctx, const FcgfNet* net, const int* coords0, int n0, 
                                inL.mask, ksize, ts, sign, m);
         return m;
     };
-    const bool conv1_fused = net->in_ch == 1 && C[1] == 32 && net->k1 * net->k1 * net->k1 <= C1O_MAXK;
     int* M1 = conv1_fused ? nullptr : make_map(L[0], L[0], net->k1, 1, +1);
+    // occupancy bitmaps for the first convolution (skipped if a cloud's bounding box is too large: hash probes then)
+    BmDesc hdesc[64];
+    BmDesc* ddesc = nullptr;
+    unsigned* dbm = nullptr;
+    if (conv1_fused) {
+        const int hk = net->k1 / 2;
+        long long words = 0;
+        bool ok = true;
+        for (int b = 0; b < nb && ok; ++b) {
+            const int* bb = hbb + 6 * b;
+            if (bb[0] > bb[3]) { hdesc[b] = BmDesc{words, 0, 0, 0, 1, 1}; continue; }       // empty cloud
+            const long long dx = (long long)bb[3] - bb[0] + 1 + 2 * hk, dy = (long long)bb[4] - bb[1] + 1 + 2 * hk,
+                            dz = (long long)bb[5] - bb[2] + 1 + 2 * hk;
+            const long long wx = (dx + 31) / 32;
+            if (wx * dy * dz > (1ll << 24)) ok = false;                                        // > 64 MiB for one cloud
+            hdesc[b] = BmDesc{words, bb[0] - hk, bb[1] - hk, bb[2] - hk, (int)wx, (int)dy};
+            words += wx * dy * dz;
+        }
+        if (ok && words > 0 && ar.off + (size_t)words * 4 + 8192 < ar.cap) {
+            dbm = ar.take<unsigned>((size_t)words);
+            ddesc = reinterpret_cast<BmDesc*>(ar.take<char>(sizeof(BmDesc) * 64));
+            HIPCHK(hipMemsetAsync(dbm, 0, (size_t)words * 4, s));
+            HIPCHK(hipMemcpyAsync(ddesc, hdesc, sizeof(BmDesc) * nb, hipMemcpyHostToDevice, s));
+            hipLaunchKernelGGL(bitmap_fill_kernel, dim3((n0 + 255) / 256), dim3(256), 0, s, L[0].coords, n0, ddesc, dbm);
+            HIPCHK(hipStreamSynchronize(s));                  // hdesc lives on this frame
+        }
+    }
     int* Msame[4]; int* Mdown[3]; int* Mup[3];
     for (int l = 0; l < 4; ++l) Msame[l] = make_map(L[l], L[l], 3, L[l].ts, +1);
     for (int l = 0; l < 3; ++l) {
@@ -825,8 +943,12 @@ int fcgf_forward(yoho_ctx* ctx, const FcgfNet* net, const int* coords0, int n0, 
     // encoder (resunet.py:142-160).  The block outputs land in the decoder's concatenation buffers (right-hand columns).
     const int k1v = net->k1 * net->k1 * net->k1;
     if (conv1_fused) {
-        hipLaunchKernelGGL(conv1_ones_kernel, dim3((n0 + 7) / 8), dim3(256), 0, s, L[0].coords, n0, L[0].keys, L[0].mask, net->k1, net->conv[0].w,
-                           net->norm[0].s, net->norm[0].t, x[0]);
+        if (dbm)
+            hipLaunchKernelGGL(conv1_bitmap_kernel, dim3((n0 + 7) / 8), dim3(256), 0, s, L[0].coords, n0, ddesc, dbm, net->k1, net->conv[0].w,
+                               net->norm[0].s, net->norm[0].t, x[0]);
+        else
+            hipLaunchKernelGGL(conv1_ones_kernel, dim3((n0 + 7) / 8), dim3(256), 0, s, L[0].coords, n0, L[0].keys, L[0].mask, net->k1,
+                               net->conv[0].w, net->norm[0].s, net->norm[0].t, x[0]);
         HIPCHK(hipGetLastError());
     } else if ((rc = conv(ones, net->in_ch, net->in_ch, M1, k1v, n0, net->conv[0], C[1], x[0], C[1], 0, &net->norm[0], nullptr, nullptr, 0, 0, 0)))
         return rc;
