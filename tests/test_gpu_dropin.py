@@ -145,7 +145,7 @@ def test_network_and_knn_mirrors(workdir, sd1, tables):
 def test_yoho_extractor_with_stub_backbone(sd1, tables):
     from yoho_amd.yoho_extract import yoho_extractor
 
-    class StubFCGF:               # stands in for the MinkowskiEngine backbone (out of scope)
+    class StubFCGF:               # any object with run(pc, voxel_size) can stand in for the backbone
         def run(self, pc, voxel_size):
             ds = pc[::3].astype(np.float32)
             rs = np.random.RandomState(len(ds))

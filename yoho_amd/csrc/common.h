@@ -105,8 +105,6 @@ int launch_head2(const float* s0, const float* s1, const float* s2, const float*
                  const int64_t* const* ridx = nullptr, int istride = 1);
 int launch_head16(const float* x, int B, int nTiles, char* planes, int kppad, const void* Ffrag, hipStream_t s, const float* x1 = nullptr,
                   int B0 = 0);
-int launch_gft_planes(const float* in, char* planes, int kppad, const float* Fpad, const float* bn_s, const float* bn_t, int nTiles, int C8,
-                      hipStream_t s);
 int launch_gconvf(const Layer& L, const float* X, int nTiles, const float* res, float* out, int flags, hipStream_t s);
 int launch_gft(int mode, const float* in, float* out, const float* Fpad, const float* bn_s, const float* bn_t, int nTiles, int C8, hipStream_t s);
 // bf16x3 variant (gconv16.hip)

@@ -431,26 +431,8 @@ int launch_gconvf(const Layer& L, const float* X, int nTiles, const float* res, 
 // Both 60x60 matmuls run on v_mfma_f32_32x32x2_f32 with the transform matrix as the A operand (held in
 // registers, padded to 64x64 with zeros) and the chunk, staged in LDS as [row 64][256 cols], as B.
 // ---------------------------------------------------------------------------------------------------
-//   GFT_ACTP: as GFT_ACT, result written as fp16x2 planes in the B-operand order of fgemm_kernel (gemmf.hip)
-enum { GFT_FWD = 0, GFT_INV = 1, GFT_ACT = 2, GFT_ACTP = 3 };
+enum { GFT_FWD = 0, GFT_INV = 1, GFT_ACT = 2 };
 
-__constant__ int c_qinfo[G * 4];              // coefficient -> (irrep slot in launch order, m, j, d)
-
-struct GftPlanes {
-    char* planes;
-    long long off[NIR_ORD];
-    int kppad;
-};
-
-typedef unsigned uintx4f __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void split2h_f(float x, unsigned& h, unsigned& l) {
-    const _Float16 hh = (_Float16)x;
-    const _Float16 ll = (_Float16)(x - (float)hh);
-    unsigned short uh, ul;
-    __builtin_memcpy(&uh, &hh, 2);
-    __builtin_memcpy(&ul, &ll, 2);
-    h = uh; l = ul;
-}
 constexpr int GFT_ROWS = 64;
 constexpr int GFT_LDS = GFT_ROWS * 256 * 4;              // 65536: the chunk is transformed in place, 2 workgroups per CU
 
@@ -475,7 +457,7 @@ __device__ __forceinline__ void gft_mm(const float (&afrag)[2][32], const float*
 
 template <int MODE>
 __global__ __launch_bounds__(256, 2) void gft_kernel(const float* __restrict__ in, float* __restrict__ out, const float* __restrict__ Fpad,
-                                                     const float* __restrict__ bn_s, const float* __restrict__ bn_t, int C8, GftPlanes pl) {
+                                                     const float* __restrict__ bn_s, const float* __restrict__ bn_t, int C8) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* ldsA = reinterpret_cast<float*>(smem);                     // [64][256] input chunk
     // A wave only ever touches its own 64 columns of the chunk (as B operand and as result), so the activated
@@ -507,7 +489,7 @@ __global__ __launch_bounds__(256, 2) void gft_kernel(const float* __restrict__ i
     const int cb0 = 2 * w;                                            // this wave's two 32-column blocks
     floatx16 acc[2][2];
     const int colj = lane & 31, half = lane >> 5;
-    if (MODE == GFT_ACT || MODE == GFT_ACTP) {
+    if (MODE == GFT_ACT) {
         gft_mm(aFt, ldsA, lane, cb0, acc);                            // group domain = F^T * coefficients
         // column -> channel: col = h*128 + kp*4 + e, channel = c8*8 + h*4 + e
 #pragma unroll
@@ -530,41 +512,6 @@ __global__ __launch_bounds__(256, 2) void gft_kernel(const float* __restrict__ i
     } else {
         gft_mm(aFt, ldsA, lane, cb0, acc);
     }
-    if (MODE == GFT_ACTP) {
-        // coefficients back into this wave's own columns of the chunk, then all threads repack (coefficient, keypoint)
-        // items: 8 channels -> 16 B of the hi plane and 16 B of the lo plane
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            const int col = (cb0 + c) * 32 + colj;
-#pragma unroll
-            for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    if (row < G) ldsB[row * 256 + col] = acc[rb][c][r];
-                }
-        }
-        __syncthreads();
-        const int tile32 = (int)(chunk / (size_t)C8), cin = C8 * 8;
-        for (int it = tid; it < G * 32; it += 256) {
-            const int q = it >> 5, kp = it & 31;
-            const float4 v0 = *reinterpret_cast<const float4*>(&ldsB[q * 256 + kp * 4]);
-            const float4 v1 = *reinterpret_cast<const float4*>(&ldsB[q * 256 + 128 + kp * 4]);
-            const int t = c_qinfo[q * 4], m = c_qinfo[q * 4 + 1], j = c_qinfo[q * 4 + 2], d = c_qinfo[q * 4 + 3];
-            const int n = j * pl.kppad + tile32 * 32 + kp, k = m * cin + 8 * c8;
-            char* dst = pl.planes + pl.off[t] + ((size_t)(n >> 8) * (d * cin / 32) + (k >> 5)) * 32768 + ((k >> 3) & 3) * 4096 + (n & 255) * 16;
-            const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-            unsigned h[8], l[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) split2h_f(x[e] * HF_ASCALE, h[e], l[e]);
-            uintx4f ph, plo;
-            ph.x = h[0] | (h[1] << 16); ph.y = h[2] | (h[3] << 16); ph.z = h[4] | (h[5] << 16); ph.w = h[6] | (h[7] << 16);
-            plo.x = l[0] | (l[1] << 16); plo.y = l[2] | (l[3] << 16); plo.z = l[4] | (l[5] << 16); plo.w = l[6] | (l[7] << 16);
-            *reinterpret_cast<uintx4f*>(dst) = ph;
-            *reinterpret_cast<uintx4f*>(dst + 16384) = plo;
-        }
-        return;
-    }
     float* dst = out + chunk * CHUNK_FLOATS;
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
@@ -584,30 +531,14 @@ int gft_init() {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gft_kernel<GFT_FWD>), hipFuncAttributeMaxDynamicSharedMemorySize, GFT_LDS));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gft_kernel<GFT_INV>), hipFuncAttributeMaxDynamicSharedMemorySize, GFT_LDS));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gft_kernel<GFT_ACT>), hipFuncAttributeMaxDynamicSharedMemorySize, GFT_LDS));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gft_kernel<GFT_ACTP>), hipFuncAttributeMaxDynamicSharedMemorySize, GFT_LDS));
-    int qi[G * 4];
-    fgemm_qinfo(qi);
-    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_qinfo), qi, sizeof(qi)));
     return 0;
 }
 
 int launch_gft(int mode, const float* in, float* out, const float* Fpad, const float* bn_s, const float* bn_t, int nTiles, int C8, hipStream_t s) {
     const dim3 grid(nTiles * C8), blk(256);
-    GftPlanes pl{};
-    if (mode == GFT_FWD) hipLaunchKernelGGL(gft_kernel<GFT_FWD>, grid, blk, GFT_LDS, s, in, out, Fpad, bn_s, bn_t, C8, pl);
-    else if (mode == GFT_INV) hipLaunchKernelGGL(gft_kernel<GFT_INV>, grid, blk, GFT_LDS, s, in, out, Fpad, bn_s, bn_t, C8, pl);
-    else hipLaunchKernelGGL(gft_kernel<GFT_ACT>, grid, blk, GFT_LDS, s, in, out, Fpad, bn_s, bn_t, C8, pl);
-    HIPCHK(hipGetLastError());
-    return 0;
-}
-
-// BN + ReLU between two convs with the result as fp16x2 B-operand planes of the irrep GEMMs (C8 * 8 channels, kppad columns per j)
-int launch_gft_planes(const float* in, char* planes, int kppad, const float* Fpad, const float* bn_s, const float* bn_t, int nTiles, int C8,
-                      hipStream_t s) {
-    GftPlanes pl;
-    pl.planes = planes; pl.kppad = kppad;
-    fgemm_plane_offsets(kppad, C8 * 8, pl.off);
-    hipLaunchKernelGGL(gft_kernel<GFT_ACTP>, dim3(nTiles * C8), dim3(256), GFT_LDS, s, in, (float*)nullptr, Fpad, bn_s, bn_t, C8, pl);
+    if (mode == GFT_FWD) hipLaunchKernelGGL(gft_kernel<GFT_FWD>, grid, blk, GFT_LDS, s, in, out, Fpad, bn_s, bn_t, C8);
+    else if (mode == GFT_INV) hipLaunchKernelGGL(gft_kernel<GFT_INV>, grid, blk, GFT_LDS, s, in, out, Fpad, bn_s, bn_t, C8);
+    else hipLaunchKernelGGL(gft_kernel<GFT_ACT>, grid, blk, GFT_LDS, s, in, out, Fpad, bn_s, bn_t, C8);
     HIPCHK(hipGetLastError());
     return 0;
 }

@@ -1,7 +1,7 @@
 """Evaluation dataset description - drop-in for the test-time half of the reference's utils/dataset.py
 (EvalDataset / ThrDMatchPartDataset :21-143, get_dataset_name :146-229, get_dataset :232-238).
 
-The training Dataset classes (:242-323) are out of scope.  open3d is not required: keypoints come from
+The training Dataset classes (:242-323) are in yoho_amd.train.trainer.  open3d is not required: keypoints come from
 `Keypoints_PC/cloud_bin_{k}Keypoints.npy` when present (what the hot path reads), otherwise from the point
 cloud (.ply parsed by a small numpy reader, or .txt) and the `Keypoints/*.txt` index files exactly as the
 reference does.

@@ -1,6 +1,6 @@
 """The 60-fold FCGF keypoint-feature gather (reference: YOHO_testset.py:153-166).
 
-For every group element g the backbone (out of scope: MinkowskiEngine FCGF)
+For every group element g the backbone (yoho_amd.fcgf_feat, or any other source of per-cloud features)
 yields the down-sampled rotated cloud ``pts_g (n_g,3) f32`` and unit-norm features ``feat_g (n_g,32)``.
 The gather rotates the keypoints by R_g in f64, finds each rotated keypoint's nearest cloud point
 (brute force, f64, sqrt(D2+1e-7) form, first minimum) and copies its feature row into

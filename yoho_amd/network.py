@@ -5,7 +5,7 @@ Same constructor (``Cls(cfg)`` reading ``cfg.SO3_related_files``), ``load_state_
 (yoho_partI_forward / yoho_partII_forward).  Differences from the reference, all supersets:
   * any batch size B >= 1 works (the reference's torch.squeeze breaks B == 1, utils/network.py:81);
   * PartII_test.forward does not permute the caller's tensors in place (utils/network.py:266-268).
-Training twins (PartI_train / PartII_train) are out of scope.
+The training twins (PartI_train / PartII_train) live in yoho_amd.train.network.
 """
 import numpy as np
 import torch
