@@ -13,6 +13,7 @@
 //                     concatenation (write at a column offset of a wider buffer) in the epilogue.
 #include <hip/hip_runtime.h>
 #include <vector>
+#include <algorithm>
 #include <cstring>
 #include <cmath>
 #include <cstdlib>
@@ -336,11 +337,27 @@ __device__ __forceinline__ void split_pair_sp(float x0, float x1, unsigned& hi, 
     __builtin_memcpy(&lo, &l, 4);
 }
 
-template <int NCB, bool SPLIT>
+// Gathered input rows are read through a raw buffer descriptor over [in, in + 2 GiB): a lane whose region cell is empty
+// uses an out-of-range offset and gets zeros without a memory access and without a branch (branches around loads make
+// the compiler drain vmcnt at every join, which serialises the load pipeline).
+constexpr unsigned SP_OOB = 0x80000000u;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t sp_rsrc(const float* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, 0x7FFFFFFF, 0x00020000);
+}
+__device__ __forceinline__ void sp_gather16(__amdgpu_buffer_rsrc_t rs, unsigned off, float (&av)[16]) {
+    // K16 step s uses channels 32 cc + 16 s + 8 h + e: two 32-byte runs of this lane's input row (off points at 32 cc + 8 h)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uintx4s v = __builtin_amdgcn_raw_buffer_load_b128(rs, off, ((q >> 1) * 16 + (q & 1) * 4) * 4, 0);
+        __builtin_memcpy(&av[4 * q], &v, 16);      // not v.x .. v.w: hipcc 7.2 then narrows the load to one dword and replicates it
+    }
+}
+
+template <int NCB, bool SPLIT, int ND>
 __global__ __launch_bounds__(256) void spconv16_kernel(SpConvArgs a) {
     __shared__ int srcl[4][SP_MAXK * 32];
     __shared__ float red[SPLIT ? 3 * NCB * 16 * 64 : 1];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int li = lane & 31, h = lane >> 5;
     const int rbase = SPLIT ? blockIdx.x * 32 : (blockIdx.x * 4 + w) * 32;
     if (!SPLIT && rbase >= a.nout) return;
@@ -361,22 +378,20 @@ __global__ __launch_bounds__(256) void spconv16_kernel(SpConvArgs a) {
     const int it0 = SPLIT ? (total * w) / 4 : 0, it1 = SPLIT ? (total * (w + 1)) / 4 : total;
     const uintx4s* Wh = reinterpret_cast<const uintx4s*>(a.Wh);
 
-    auto issue = [&](int it, float (&av)[16], uintx4s (&bv)[4 * NCB]) {
-        const int k = it / nchunk, cc = it - k * nchunk;
-        const int src = sl[k * 32 + li];
-        // K16 step s uses channels 32 cc + 16 s + 8 h + e: two 32-byte runs of this lane's input row
-        const float* ip = a.in + (size_t)(src < 0 ? 0 : src) * a.ldin + cc * 32 + h * 8;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (src >= 0) v = *reinterpret_cast<const float4*>(ip + (q >> 1) * 16 + (q & 1) * 4);
-            av[4 * q] = v.x; av[4 * q + 1] = v.y; av[4 * q + 2] = v.z; av[4 * q + 3] = v.w;
-        }
-        const uintx4s* wp = Wh + ((size_t)it * 4 * ncbt + cb0) * 64 + lane;        // [it][step][plane][cb][lane]
+    // Loads are branch-free (empty cells: out-of-range buffer offset; steps past the end re-read the last one): the
+    // compiler's vmcnt bookkeeping only keeps loads in flight across straight-line code.
+    const int nit = it1 - it0;
+    int ik = it0 / nchunk, icc = it0 - ik * nchunk, issued = 0;          // wave-uniform position of the load pointer
+    const __amdgpu_buffer_rsrc_t rs = sp_rsrc(a.in);
+    auto issue = [&](float (&av)[16], uintx4s (&bv)[4 * NCB]) {
+        const int src = sl[ik * 32 + li];
+        sp_gather16(rs, src < 0 ? SP_OOB : ((unsigned)src * (unsigned)a.ldin + icc * 32 + h * 8) * 4u, av);
+        const uintx4s* wp = Wh + ((size_t)(ik * nchunk + icc) * 4 * ncbt + cb0) * 64 + lane;    // [it][step][plane][cb][lane]
 #pragma unroll
         for (int sp = 0; sp < 4; ++sp)
 #pragma unroll
             for (int cb = 0; cb < NCB; ++cb) bv[sp * NCB + cb] = wp[((size_t)sp * ncbt + cb) * 64];
+        if (++issued < nit && ++icc == nchunk) { icc = 0; ++ik; }
     };
     auto mma = [&](const float (&av)[16], const uintx4s (&bv)[4 * NCB]) {
 #pragma unroll
@@ -396,16 +411,24 @@ __global__ __launch_bounds__(256) void spconv16_kernel(SpConvArgs a) {
             for (int cb = 0; cb < NCB; ++cb) acc[cb] = mfma_sp16(ah, bv[(2 * st + 0) * NCB + cb], acc[cb]);
         }
     };
-    float a0[16], a1[16];
-    uintx4s b0[4 * NCB], b1[4 * NCB];
-    if (it0 < it1) issue(it0, a0, b0);
-    for (int it = it0; it < it1; it += 2) {
-        if (it + 1 < it1) issue(it + 1, a1, b1);
-        mma(a0, b0);
-        if (it + 1 < it1) {
-            if (it + 2 < it1) issue(it + 2, a0, b0);
-            mma(a1, b1);
+    // register ring: the loads of step i + ND - 1 are in flight behind the MFMAs of step i (the gathers come from the
+    // MALL / a remote L2, 1-2 us away, and a coarse level has only a few waves per SIMD to hide that)
+    if (nit > 0) {
+        float av[ND][16];
+        uintx4s bv[ND][4 * NCB];
+#pragma unroll
+        for (int j = 0; j < ND - 1; ++j) issue(av[j], bv[j]);
+        const int nmain = (nit / ND) * ND;
+        for (int it = 0; it < nmain; it += ND) {
+#pragma unroll
+            for (int j = 0; j < ND; ++j) {
+                issue(av[(j + ND - 1) % ND], bv[(j + ND - 1) % ND]);
+                mma(av[j], bv[j]);
+            }
         }
+#pragma unroll
+        for (int j = 0; j < ND - 1; ++j)
+            if (nmain + j < nit) mma(av[j], bv[j]);              // already loaded by the ring
     }
     if (SPLIT) {
         if (w > 0) {
@@ -422,6 +445,124 @@ __global__ __launch_bounds__(256) void spconv16_kernel(SpConvArgs a) {
             for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[cb][r] += red[((ww * NCB + cb) * 16 + r) * 64 + lane];
+    }
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) {
+        const int co = (cb0 + cb) * 32 + li;
+        const float s = (a.aff_s ? a.aff_s[co] : 1.f) * a.descale, t = a.aff_t ? a.aff_t[co] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int orow = rbase + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (orow < a.nout) {
+                float v = acc[cb][r] * s + t;
+                if (a.res) v += a.res[(size_t)orow * a.ldres + a.rcoff + co];
+                if (a.relu) v = fmaxf(v, 0.f);
+                a.out[(size_t)orow * a.ldout + a.ocoff + co] = v;
+            }
+        }
+    }
+}
+
+// Fine levels (many rows): the four waves of a workgroup own four 32-row tiles and walk the (offset, chunk) steps in
+// lockstep, so the weight fragments of a step (4 NCB KiB) are shared: every thread fetches NCB 16-byte pieces two steps
+// ahead, they go through a double-buffered LDS stage (one barrier per step) and each wave reads its fragments from
+// there - the vector-memory pipe only carries the gathers (a quarter of the bytes of the per-wave weight loads).
+// The gathered rows run NA - 1 steps ahead in a register ring.
+template <int NCB>
+__global__ __launch_bounds__(256) void spconv16w_kernel(SpConvArgs a) {
+    __shared__ int srcl[4][SP_MAXK * 32];
+    __shared__ __attribute__((aligned(16))) uintx4s bst[2][4 * NCB * 64];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int li = lane & 31, h = lane >> 5;
+    const int rbase = (blockIdx.x * 4 + w) * 32;
+    const int cb0 = blockIdx.y * NCB;
+    const int row = rbase + li;
+    const bool valid = row < a.nout;
+    int* sl = srcl[w];
+    for (int k = h; k < a.K; k += 2) sl[k * 32 + li] = valid ? (a.map ? a.map[(size_t)k * a.nout + row] : row) : -1;
+    __builtin_amdgcn_wave_barrier();
+
+    floatx16s acc[NCB];
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[cb][r] = 0.f;
+    const int nchunk = a.cin / 32, ncbt = a.cout / 32;
+    const int total = a.K * nchunk;
+    const uintx4s* Wh = reinterpret_cast<const uintx4s*>(a.Wh);
+
+    // branch-free loads, see spconv16_kernel
+    int ak = 0, acc_ = 0, aissued = 0, bissued = 0;                       // wave-uniform load pointers
+    const __amdgpu_buffer_rsrc_t rs = sp_rsrc(a.in);
+    auto loadA = [&](float (&av)[16]) {
+        const int src = sl[ak * 32 + li];
+        sp_gather16(rs, src < 0 ? SP_OOB : ((unsigned)src * (unsigned)a.ldin + acc_ * 32 + h * 8) * 4u, av);
+        if (++aissued < total && ++acc_ == nchunk) { acc_ = 0; ++ak; }
+    };
+    // stage image = [step-plane 4][cb NCB][lane 64] fragments; piece j of this thread = image index j * 256 + tid
+    auto loadB = [&](uintx4s (&br)[NCB]) {
+        const int it = bissued < total ? bissued : total - 1;
+#pragma unroll
+        for (int j = 0; j < NCB; ++j) {
+            const int idx = j * 256 + tid, sp = idx / (NCB * 64), within = idx - sp * (NCB * 64);
+            br[j] = Wh[(((size_t)it * 4 + sp) * ncbt + cb0) * 64 + within];
+        }
+        ++bissued;
+    };
+    auto storeB = [&](int buf, const uintx4s (&br)[NCB]) {
+#pragma unroll
+        for (int j = 0; j < NCB; ++j) bst[buf][j * 256 + tid] = br[j];
+    };
+    auto mma = [&](const float (&av)[16], int buf) {
+        const uintx4s* bl = &bst[buf][lane];
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            uintx4s ah, al, bh[NCB], bw[NCB];
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) { bh[cb] = bl[((2 * st + 0) * NCB + cb) * 64]; bw[cb] = bl[((2 * st + 1) * NCB + cb) * 64]; }
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                unsigned hh, ll;
+                split_pair_sp(av[8 * st + 2 * p], av[8 * st + 2 * p + 1], hh, ll);
+                ah[p] = hh; al[p] = ll;
+            }
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) acc[cb] = mfma_sp16(al, bh[cb], acc[cb]);
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) acc[cb] = mfma_sp16(ah, bw[cb], acc[cb]);
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) acc[cb] = mfma_sp16(ah, bh[cb], acc[cb]);
+        }
+    };
+    constexpr int NA = 4;                                                 // even: the stage parity of ring slot j is j & 1
+    float av[NA][16];
+    uintx4s br[2][NCB];
+    loadB(br[0]);
+    loadB(br[1]);
+#pragma unroll
+    for (int j = 0; j < NA - 1; ++j) loadA(av[j]);
+    storeB(0, br[0]);
+    // step s: barrier (stage s & 1 complete, the other one free) -> weights of s + 1 into the free stage, fetch the
+    // weights of s + 2 and the rows of s + NA - 1, MFMAs of s
+    const int nmain = (total / NA) * NA;
+    for (int it = 0; it < nmain; it += NA) {
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            __syncthreads();
+            storeB((j + 1) & 1, br[(j + 1) & 1]);
+            loadB(br[j & 1]);
+            loadA(av[(j + NA - 1) % NA]);
+            mma(av[j], j & 1);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NA - 1; ++j) {
+        if (nmain + j < total) {                                          // uniform over the workgroup
+            __syncthreads();
+            storeB((j + 1) & 1, br[(j + 1) & 1]);
+            loadB(br[j & 1]);
+            mma(av[j], j & 1);
+        }
     }
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb) {
@@ -513,30 +654,49 @@ struct BmDesc {
     int wx, ny;              // words per x row, rows per z slice
 };
 
-__global__ void bbox_kernel(const int* __restrict__ coords, int n, int* __restrict__ bb) {     // bb[cloud][6] = min xyz, max xyz
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    const bool valid = i < n;
-    const int4 c = valid ? reinterpret_cast<const int4*>(coords)[i] : make_int4(0, 0, 0, -1);
-    // rows of a cloud are contiguous: almost every wave sees one cloud only -> reduce in the wave, one atomic per wave
-    const int first = __builtin_amdgcn_readfirstlane(c.w);
-    if (__ballot(valid && c.w != first) == 0ull && first >= 0) {
-        int lo[3] = {valid ? c.x : 0x7FFFFFFF, valid ? c.y : 0x7FFFFFFF, valid ? c.z : 0x7FFFFFFF};
-        int hi[3] = {valid ? c.x : (int)0x80000000, valid ? c.y : (int)0x80000000, valid ? c.z : (int)0x80000000};
-#pragma unroll
-        for (int a = 0; a < 3; ++a)
-            for (int o = 32; o >= 1; o >>= 1) {
-                lo[a] = min(lo[a], __shfl_xor(lo[a], o));
-                hi[a] = max(hi[a], __shfl_xor(hi[a], o));
-            }
-        if ((threadIdx.x & 63) == 0) {
-            int* b = bb + 6 * first;
-            atomicMin(b + 0, lo[0]); atomicMin(b + 1, lo[1]); atomicMin(b + 2, lo[2]);
-            atomicMax(b + 3, hi[0]); atomicMax(b + 4, hi[1]); atomicMax(b + 5, hi[2]);
+// A workgroup scans a contiguous run of rows (rows of a cloud are contiguous, so it almost always sees one cloud) and
+// issues one set of atomics per (workgroup, cloud): a few hundred atomics per pass instead of one set per wave.
+__global__ __launch_bounds__(256) void bbox_kernel(const int* __restrict__ coords, int n, int rows_per_wg, int* __restrict__ bb) {
+    __shared__ int red[4][7];
+    const int r0 = blockIdx.x * rows_per_wg, r1 = min(n, r0 + rows_per_wg);
+    auto flush = [&](int cloud, const int (&lo)[3], const int (&hi)[3]) {
+        int* b = bb + 6 * cloud;
+        atomicMin(b + 0, lo[0]); atomicMin(b + 1, lo[1]); atomicMin(b + 2, lo[2]);
+        atomicMax(b + 3, hi[0]); atomicMax(b + 4, hi[1]); atomicMax(b + 5, hi[2]);
+    };
+    int cur = -1;
+    int lo[3] = {0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF}, hi[3] = {(int)0x80000000, (int)0x80000000, (int)0x80000000};
+    for (int i = r0 + threadIdx.x; i < r1; i += 256) {
+        const int4 c = reinterpret_cast<const int4*>(coords)[i];
+        if (c.w != cur) {
+            if (cur >= 0) flush(cur, lo, hi);                       // cloud boundary inside this run (rare)
+            cur = c.w;
+            lo[0] = hi[0] = c.x; lo[1] = hi[1] = c.y; lo[2] = hi[2] = c.z;
+        } else {
+            lo[0] = min(lo[0], c.x); lo[1] = min(lo[1], c.y); lo[2] = min(lo[2], c.z);
+            hi[0] = max(hi[0], c.x); hi[1] = max(hi[1], c.y); hi[2] = max(hi[2], c.z);
         }
-    } else if (valid) {
-        int* b = bb + 6 * c.w;
-        atomicMin(b + 0, c.x); atomicMin(b + 1, c.y); atomicMin(b + 2, c.z);
-        atomicMax(b + 3, c.x); atomicMax(b + 4, c.y); atomicMax(b + 5, c.z);
+    }
+    // the cloud of the run's last row; lanes still holding another cloud (or nothing) flush on their own
+    const int last = r1 > r0 ? coords[4 * (size_t)(r1 - 1) + 3] : -1;
+    if (cur >= 0 && cur != last) flush(cur, lo, hi);
+    if (cur != last) {
+        lo[0] = lo[1] = lo[2] = 0x7FFFFFFF;
+        hi[0] = hi[1] = hi[2] = (int)0x80000000;
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+        for (int o = 32; o >= 1; o >>= 1) {
+            lo[a] = min(lo[a], __shfl_xor(lo[a], o));
+            hi[a] = max(hi[a], __shfl_xor(hi[a], o));
+        }
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[w][0] = lo[0]; red[w][1] = lo[1]; red[w][2] = lo[2]; red[w][3] = hi[0]; red[w][4] = hi[1]; red[w][5] = hi[2]; }
+    __syncthreads();
+    if (threadIdx.x == 0 && last >= 0) {
+        for (int ww = 1; ww < 4; ++ww)
+            for (int a = 0; a < 3; ++a) { lo[a] = min(lo[a], red[ww][a]); hi[a] = max(hi[a], red[ww][3 + a]); }
+        if (lo[0] <= hi[0]) flush(last, lo, hi);
     }
 }
 
@@ -554,38 +714,54 @@ __global__ void bitmap_fill_kernel(const int* __restrict__ coords, int n, const 
     atomicOr(bm + d.base + ((long long)(c.z - d.z0) * d.ny + (c.y - d.y0)) * d.wx + (bx >> 5), 1u << (bx & 31));
 }
 
+// Persistent workgroups (the 44 KiB weight table is loaded into LDS once per workgroup, not once per 8 rows); a half-wave
+// owns a row per round.  All ceil(K^3 / 32) bitmap words of a row are requested before the first one is used.
+constexpr int C1B_NIT = (C1O_MAXK + 31) / 32;
 __global__ __launch_bounds__(256) void conv1_bitmap_kernel(const int* __restrict__ coords, int n, const BmDesc* __restrict__ desc,
                                                            const unsigned* __restrict__ bm, int ksize, const float* __restrict__ W,
                                                            const float* __restrict__ aff_s, const float* __restrict__ aff_t,
                                                            float* __restrict__ out) {
     __shared__ float Wl[C1O_MAXK * 32];
+    __shared__ int koff[C1B_NIT * 32];                   // offset k -> dx | dy << 8 | dz << 16 (each 0 .. K-1), -1 past the end
     const int kv = ksize * ksize * ksize, hk = ksize / 2;
     for (int i = threadIdx.x; i < kv * 32; i += 256) Wl[i] = W[i];
+    for (int k = threadIdx.x; k < C1B_NIT * 32; k += 256)
+        koff[k] = k < kv ? (k % ksize) | (((k / ksize) % ksize) << 8) | ((k / (ksize * ksize)) << 16) : -1;
     __syncthreads();
     const int lane = threadIdx.x & 63, l32 = lane & 31, hw = lane >> 5;
-    const int row = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + hw;
-    const bool valid = row < n;
-    const int4 c = valid ? reinterpret_cast<const int4*>(coords)[row] : make_int4(0, 0, 0, 0);
-    const BmDesc d = desc[c.w];
-    const unsigned* bmc = bm + d.base;
-    const int bx = c.x - d.x0, by = c.y - d.y0, bz = c.z - d.z0;      // >= K/2 by construction of the margin
-    float acc = 0.f;
-    for (int k0 = 0; k0 < kv; k0 += 32) {
-        const int k = k0 + l32;
-        bool present = false;
-        if (valid && k < kv) {
-            const int x = bx + k % ksize - hk, y = by + (k / ksize) % ksize - hk, z = bz + k / (ksize * ksize) - hk;
-            present = (bmc[((long long)z * d.ny + y) * d.wx + (x >> 5)] >> (x & 31)) & 1u;
+    const int nit = (kv + 31) / 32;
+    const float sc = aff_s ? aff_s[l32] : 1.f, sh = aff_t ? aff_t[l32] : 0.f;
+    for (int pair = blockIdx.x * 4 + (threadIdx.x >> 6); pair * 2 < n; pair += gridDim.x * 4) {
+        const int row = pair * 2 + hw;
+        const bool valid = row < n;
+        const int4 c = valid ? reinterpret_cast<const int4*>(coords)[row] : make_int4(0, 0, 0, 0);
+        const BmDesc d = desc[c.w];
+        const unsigned* bmc = bm + d.base;
+        const int bx = c.x - d.x0 - hk, by = c.y - d.y0 - hk, bz = c.z - d.z0 - hk;      // >= 0 by construction of the margin
+        unsigned word[C1B_NIT];
+        int shift[C1B_NIT];
+#pragma unroll
+        for (int it = 0; it < C1B_NIT; ++it) {
+            const int ko = koff[it * 32 + l32];
+            const bool use = valid && ko >= 0 && it < nit;
+            const int x = bx + (ko & 255), y = by + ((ko >> 8) & 255), z = bz + (ko >> 16);
+            word[it] = bmc[use ? (z * d.ny + y) * d.wx + (x >> 5) : 0];                   // a cloud's bitmap has < 2^24 words
+            shift[it] = use ? (x & 31) : 32;
         }
-        const unsigned long long m64 = __ballot(present);
-        unsigned m = hw ? (unsigned)(m64 >> 32) : (unsigned)m64;
-        while (m) {
-            const int j = __ffs(m) - 1;
-            m &= m - 1;
-            acc += Wl[(k0 + j) * 32 + l32];
+        float acc = 0.f;
+#pragma unroll
+        for (int it = 0; it < C1B_NIT; ++it) {
+            const bool present = shift[it] < 32 && ((word[it] >> shift[it]) & 1u);
+            const unsigned long long m64 = __ballot(present);
+            unsigned m = hw ? (unsigned)(m64 >> 32) : (unsigned)m64;
+            while (m) {                                                                    // ascending offsets: fixed summation order
+                const int j = __ffs(m) - 1;
+                m &= m - 1;
+                acc += Wl[(it * 32 + j) * 32 + l32];
+            }
         }
+        if (valid) out[(size_t)row * 32 + l32] = acc * sc + sh;
     }
-    if (valid) out[(size_t)row * 32 + l32] = acc * (aff_s ? aff_s[l32] : 1.f) + (aff_t ? aff_t[l32] : 0.f);
 }
 
 static int launch_spconv(const SpConvArgs& a, hipStream_t s) {
@@ -599,14 +775,20 @@ static int launch_spconv(const SpConvArgs& a, hipStream_t s) {
         const dim3 blk(256);
         if (split) {
             const dim3 grid(rowtiles, ncbt / ncb);
-            if (a.Wh && ncb == 2) hipLaunchKernelGGL((spconv16_kernel<2, true>), grid, blk, 0, s, a);
-            else if (a.Wh) hipLaunchKernelGGL((spconv16_kernel<1, true>), grid, blk, 0, s, a);
+            static const int nd = getenv("YOHO_SPCONV_ND") ? atoi(getenv("YOHO_SPCONV_ND")) : 3;
+            if (a.Wh && ncb == 2) hipLaunchKernelGGL((spconv16_kernel<2, true, 2>), grid, blk, 0, s, a);
+            else if (a.Wh && nd == 2) hipLaunchKernelGGL((spconv16_kernel<1, true, 2>), grid, blk, 0, s, a);
+            else if (a.Wh && nd == 3) hipLaunchKernelGGL((spconv16_kernel<1, true, 3>), grid, blk, 0, s, a);
+            else if (a.Wh) hipLaunchKernelGGL((spconv16_kernel<1, true, 4>), grid, blk, 0, s, a);
             else if (ncb == 2) hipLaunchKernelGGL((spconv_kernel<2, true>), grid, blk, 0, s, a);
             else hipLaunchKernelGGL((spconv_kernel<1, true>), grid, blk, 0, s, a);
         } else {
             const dim3 grid((a.nout + 127) / 128, ncbt / ncb);
-            if (a.Wh && ncb == 2) hipLaunchKernelGGL((spconv16_kernel<2, false>), grid, blk, 0, s, a);
-            else if (a.Wh) hipLaunchKernelGGL((spconv16_kernel<1, false>), grid, blk, 0, s, a);
+            static const bool per_wave_w = getenv("YOHO_SPCONV_W") && atoi(getenv("YOHO_SPCONV_W")) == 0;
+            if (a.Wh && per_wave_w && ncb == 2) hipLaunchKernelGGL((spconv16_kernel<2, false, 2>), grid, blk, 0, s, a);
+            else if (a.Wh && per_wave_w) hipLaunchKernelGGL((spconv16_kernel<1, false, 2>), grid, blk, 0, s, a);
+            else if (a.Wh && ncb == 2) hipLaunchKernelGGL((spconv16w_kernel<2>), grid, blk, 0, s, a);
+            else if (a.Wh) hipLaunchKernelGGL((spconv16w_kernel<1>), grid, blk, 0, s, a);
             else if (ncb == 2) hipLaunchKernelGGL((spconv_kernel<2, false>), grid, blk, 0, s, a);
             else hipLaunchKernelGGL((spconv_kernel<1, false>), grid, blk, 0, s, a);
         }
@@ -821,6 +1003,11 @@ size_t fcgf_workspace_bytes(const FcgfNet* net, int n0) {
 int fcgf_forward(yoho_ctx* ctx, const FcgfNet* net, const int* coords0, int n0, const int* off_host, int nb, float* out, hipStream_t s) {
     if (nb < 1 || nb > 64) { set_error("fcgf_forward: 1..64 clouds per call"); return YOHO_EINVAL; }
     if (n0 == 0) return 0;
+    {   // the gathers address a feature matrix through a 2 GiB buffer window
+        const int* Cc = net->C; const int* Tt = net->T;
+        const int maxld = std::max(std::max(Tt[2] + Cc[1], Tt[3] + Cc[2]), std::max(Tt[4] + Cc[3], Cc[4]));
+        if ((long long)n0 * maxld * 4 >= (1ll << 31)) { set_error("fcgf_forward: %d voxels in one pass exceed the 2 GiB gather window; split the batch", n0); return YOHO_EINVAL; }
+    }
     int rc;
     if ((rc = ensure_ws(ctx, fcgf_workspace_bytes(net, n0), s))) return rc;
     Arena ar{(char*)ctx->ws.p, 0, ctx->ws.bytes};
@@ -842,7 +1029,10 @@ int fcgf_forward(yoho_ctx* ctx, const FcgfNet* net, const int* coords0, int n0, 
     int hbb[64 * 6];
     if (conv1_fused) {
         hipLaunchKernelGGL(bbox_init_kernel, dim3(2), dim3(256), 0, s, dbb, nb);
-        hipLaunchKernelGGL(bbox_kernel, dim3((n0 + 255) / 256), dim3(256), 0, s, L[0].coords, n0, dbb);
+        {
+            const int rpw = std::max(1024, (n0 + 127) / 128);              // <= 128 workgroups
+            hipLaunchKernelGGL(bbox_kernel, dim3((n0 + rpw - 1) / rpw), dim3(256), 0, s, L[0].coords, n0, rpw, dbb);
+        }
         HIPCHK(hipMemcpyAsync(hbb, dbb, sizeof(int) * 6 * nb, hipMemcpyDeviceToHost, s));     // completes with the level-1 sync below
     }
     for (int l = 0; l < 4; ++l) {
@@ -944,7 +1134,7 @@ int fcgf_forward(yoho_ctx* ctx, const FcgfNet* net, const int* coords0, int n0, 
     const int k1v = net->k1 * net->k1 * net->k1;
     if (conv1_fused) {
         if (dbm)
-            hipLaunchKernelGGL(conv1_bitmap_kernel, dim3((n0 + 7) / 8), dim3(256), 0, s, L[0].coords, n0, ddesc, dbm, net->k1, net->conv[0].w,
+            hipLaunchKernelGGL(conv1_bitmap_kernel, dim3(std::min((n0 + 7) / 8, 3 * (ctx->nCU > 0 ? ctx->nCU : 256))), dim3(256), 0, s, L[0].coords, n0, ddesc, dbm, net->k1, net->conv[0].w,
                                net->norm[0].s, net->norm[0].t, x[0]);
         else
             hipLaunchKernelGGL(conv1_ones_kernel, dim3((n0 + 7) / 8), dim3(256), 0, s, L[0].coords, n0, L[0].keys, L[0].mask, net->k1,
