@@ -353,14 +353,15 @@ __device__ __forceinline__ void sp_gather16(__amdgpu_buffer_rsrc_t rs, unsigned 
     }
 }
 
-template <int NCB, bool SPLIT, int ND>
-__global__ __launch_bounds__(256) void spconv16_kernel(SpConvArgs a) {
+// Coarse levels (few rows, many channels): the four waves share one 32-row tile and split the (offset, chunk) loop four
+// ways, each fetching its own weight fragments; the partial sums meet in LDS and are added in wave order.
+template <int NCB, int ND>
+__global__ __launch_bounds__(256) void spconv16s_kernel(SpConvArgs a) {
     __shared__ int srcl[4][SP_MAXK * 32];
-    __shared__ float red[SPLIT ? 3 * NCB * 16 * 64 : 1];
+    __shared__ float red[3 * NCB * 16 * 64];
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int li = lane & 31, h = lane >> 5;
-    const int rbase = SPLIT ? blockIdx.x * 32 : (blockIdx.x * 4 + w) * 32;
-    if (!SPLIT && rbase >= a.nout) return;
+    const int rbase = blockIdx.x * 32;
     const int cb0 = blockIdx.y * NCB;
     const int row = rbase + li;
     const bool valid = row < a.nout;
@@ -375,7 +376,7 @@ __global__ __launch_bounds__(256) void spconv16_kernel(SpConvArgs a) {
         for (int r = 0; r < 16; ++r) acc[cb][r] = 0.f;
     const int nchunk = a.cin / 32, ncbt = a.cout / 32;
     const int total = a.K * nchunk;
-    const int it0 = SPLIT ? (total * w) / 4 : 0, it1 = SPLIT ? (total * (w + 1)) / 4 : total;
+    const int it0 = (total * w) / 4, it1 = (total * (w + 1)) / 4;
     const uintx4s* Wh = reinterpret_cast<const uintx4s*>(a.Wh);
 
     // Loads are branch-free (empty cells: out-of-range buffer offset; steps past the end re-read the last one): the
@@ -430,22 +431,20 @@ __global__ __launch_bounds__(256) void spconv16_kernel(SpConvArgs a) {
         for (int j = 0; j < ND - 1; ++j)
             if (nmain + j < nit) mma(av[j], bv[j]);              // already loaded by the ring
     }
-    if (SPLIT) {
-        if (w > 0) {
+    if (w > 0) {
 #pragma unroll
-            for (int cb = 0; cb < NCB; ++cb)
+        for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) red[(((w - 1) * NCB + cb) * 16 + r) * 64 + lane] = acc[cb][r];
-        }
-        __syncthreads();
-        if (w > 0) return;
-#pragma unroll
-        for (int ww = 0; ww < 3; ++ww)
-#pragma unroll
-            for (int cb = 0; cb < NCB; ++cb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[cb][r] += red[((ww * NCB + cb) * 16 + r) * 64 + lane];
+            for (int r = 0; r < 16; ++r) red[(((w - 1) * NCB + cb) * 16 + r) * 64 + lane] = acc[cb][r];
     }
+    __syncthreads();
+    if (w > 0) return;
+#pragma unroll
+    for (int ww = 0; ww < 3; ++ww)
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[cb][r] += red[((ww * NCB + cb) * 16 + r) * 64 + lane];
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb) {
         const int co = (cb0 + cb) * 32 + li;
@@ -775,19 +774,13 @@ static int launch_spconv(const SpConvArgs& a, hipStream_t s) {
         const dim3 blk(256);
         if (split) {
             const dim3 grid(rowtiles, ncbt / ncb);
-            static const int nd = getenv("YOHO_SPCONV_ND") ? atoi(getenv("YOHO_SPCONV_ND")) : 3;
-            if (a.Wh && ncb == 2) hipLaunchKernelGGL((spconv16_kernel<2, true, 2>), grid, blk, 0, s, a);
-            else if (a.Wh && nd == 2) hipLaunchKernelGGL((spconv16_kernel<1, true, 2>), grid, blk, 0, s, a);
-            else if (a.Wh && nd == 3) hipLaunchKernelGGL((spconv16_kernel<1, true, 3>), grid, blk, 0, s, a);
-            else if (a.Wh) hipLaunchKernelGGL((spconv16_kernel<1, true, 4>), grid, blk, 0, s, a);
+            if (a.Wh && ncb == 2) hipLaunchKernelGGL((spconv16s_kernel<2, 2>), grid, blk, 0, s, a);
+            else if (a.Wh) hipLaunchKernelGGL((spconv16s_kernel<1, 3>), grid, blk, 0, s, a);
             else if (ncb == 2) hipLaunchKernelGGL((spconv_kernel<2, true>), grid, blk, 0, s, a);
             else hipLaunchKernelGGL((spconv_kernel<1, true>), grid, blk, 0, s, a);
         } else {
             const dim3 grid((a.nout + 127) / 128, ncbt / ncb);
-            static const bool per_wave_w = getenv("YOHO_SPCONV_W") && atoi(getenv("YOHO_SPCONV_W")) == 0;
-            if (a.Wh && per_wave_w && ncb == 2) hipLaunchKernelGGL((spconv16_kernel<2, false, 2>), grid, blk, 0, s, a);
-            else if (a.Wh && per_wave_w) hipLaunchKernelGGL((spconv16_kernel<1, false, 2>), grid, blk, 0, s, a);
-            else if (a.Wh && ncb == 2) hipLaunchKernelGGL((spconv16w_kernel<2>), grid, blk, 0, s, a);
+            if (a.Wh && ncb == 2) hipLaunchKernelGGL((spconv16w_kernel<2>), grid, blk, 0, s, a);
             else if (a.Wh) hipLaunchKernelGGL((spconv16w_kernel<1>), grid, blk, 0, s, a);
             else if (ncb == 2) hipLaunchKernelGGL((spconv_kernel<2, false>), grid, blk, 0, s, a);
             else hipLaunchKernelGGL((spconv_kernel<1, false>), grid, blk, 0, s, a);
