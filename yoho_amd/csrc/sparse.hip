@@ -720,10 +720,11 @@ __global__ __launch_bounds__(256) void conv1_bitmap_kernel(const int* __restrict
                                                            const unsigned* __restrict__ bm, int ksize, const float* __restrict__ W,
                                                            const float* __restrict__ aff_s, const float* __restrict__ aff_t,
                                                            float* __restrict__ out) {
-    __shared__ float Wl[C1O_MAXK * 32];
+    __shared__ float Wl[(C1O_MAXK + 1) * 32];
     __shared__ int koff[C1B_NIT * 32];                   // offset k -> dx | dy << 8 | dz << 16 (each 0 .. K-1), -1 past the end
     const int kv = ksize * ksize * ksize, hk = ksize / 2;
     for (int i = threadIdx.x; i < kv * 32; i += 256) Wl[i] = W[i];
+    if (threadIdx.x < 32) Wl[C1O_MAXK * 32 + threadIdx.x] = 0.f;
     for (int k = threadIdx.x; k < C1B_NIT * 32; k += 256)
         koff[k] = k < kv ? (k % ksize) | (((k / ksize) % ksize) << 8) | ((k / (ksize * ksize)) << 16) : -1;
     __syncthreads();
@@ -753,10 +754,15 @@ __global__ __launch_bounds__(256) void conv1_bitmap_kernel(const int* __restrict
             const bool present = shift[it] < 32 && ((word[it] >> shift[it]) & 1u);
             const unsigned long long m64 = __ballot(present);
             unsigned m = hw ? (unsigned)(m64 >> 32) : (unsigned)m64;
-            while (m) {                                                                    // ascending offsets: fixed summation order
-                const int j = __ffs(m) - 1;
-                m &= m - 1;
-                acc += Wl[(it * 32 + j) * 32 + l32];
+            while (m) {                                      // ascending offsets: fixed summation order; 4 LDS reads in flight
+                float wv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int row = m ? it * 32 + __ffs(m) - 1 : C1O_MAXK;                 // row C1O_MAXK of Wl is zero
+                    m &= m - 1;
+                    wv[u] = Wl[row * 32 + l32];
+                }
+                acc += wv[0]; acc += wv[1]; acc += wv[2]; acc += wv[3];
             }
         }
         if (valid) out[(size_t)row * 32 + l32] = acc * sc + sh;
