@@ -16,6 +16,11 @@
  *   yoho_o_score            yohoo.ransac scoring loop     tests/estimator.py:330-336, :286-290
  *   yoho_c_ransac           yohoc.ransac loop body        tests/estimator.py:119-137, :55-70
  *   yoho_group_gather       60-fold FCGF feature gather   YOHO_testset.py:153-166
+ *   yoho_partI_forward_pair      the two PartI passes of a pair  tests/extractor.py:37-62 (one pass per fragment there)
+ *   yoho_des2r_indexed           feats[match[:,0]] + Des2R       tests/extractor.py:80-103
+ *   yoho_partII_forward_indexed  batch_create + PartII_test      tests/extractor.py:125-141,178-186, utils/network.py:259-278
+ *   yoho_gconv_layer             Comb_Conv / Residual_Comb_Conv  utils/network.py:35-62 (forward) and its autograd (training)
+ *   yoho_load_fcgf / _voxelize / _forward / _forward_batch        fcgf_model/resunet.py:10-190, simple_yoho/fcgf_feat.py:33-54
  *
  * Conventions
  *   - return 0 on success, a negative YOHO_E* code on error; yoho_last_error() gives a
@@ -188,12 +193,12 @@ int yoho_fcgf_forward_batch(yoho_ctx* ctx, const int32_t* coords, const int32_t*
  * fp32-accurate 3-way bf16 split on v_mfma_f32_32x32x16_bf16 (6 products per term), 2 = group-Fourier domain conv
  * (244 instead of 780 slab products per chunk) on fp32 MFMA, 3 = direct conv with a 2-way fp16 split on
  * v_mfma_f32_32x32x16_f16 (3 products per term, error <= 3*2^-22 per product; activations must stay below 4094 in
- * magnitude, beyond that the result is inf/NaN), 4 = group-Fourier domain with the two large layers as five dense
- * irrep GEMMs on the fp16x2 split MFMA and fp16x2 transform kernels (default).  All meet the 1e-4 parity tolerance. */
+ * magnitude, beyond that the result is inf/NaN), 4 = group-Fourier domain with every layer as five dense irrep GEMMs on
+ * the fp16x2 split MFMA and fp16x2 transform kernels between them (default).  All meet the 1e-4 parity tolerance. */
 int yoho_set_gconv_mode(yoho_ctx* ctx, int mode);
 
-/* PartII cone layers (128->256 @45 group elements, 256->512 @13): 0 = fp32 MFMA, 1 = bf16x3 split MFMA (default),
- * 2 = fp16x2 split MFMA. */
+/* PartII group-conv layers: 0 = fp32 MFMA, 1 = bf16x3 split MFMA, 2 = fp16x2 split MFMA (default; first layer in the
+ * group-Fourier domain, 13-rotation cone layer direct, last layer as one dense product at the identity). */
 int yoho_set_partII_mode(yoho_ctx* ctx, int mode);
 
 /* timing hook for bench.py: average device time (ms) of the last yoho_partI_forward's dominant
