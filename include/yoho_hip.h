@@ -197,6 +197,13 @@ int yoho_fcgf_forward_batch(yoho_ctx* ctx, const int32_t* coords, const int32_t*
  * the fp16x2 split MFMA and fp16x2 transform kernels between them (default).  All meet the 1e-4 parity tolerance. */
 int yoho_set_gconv_mode(yoho_ctx* ctx, int mode);
 
+/* 3-D nearest-neighbour searches (yoho_nn_search with D = 3, yoho_group_gather) through a uniform hash grid of the given
+ * cell size instead of brute force; 0 switches back.  The answers are identical for ANY cell size (queries the grid
+ * cannot settle within 2 cells are redone by brute force), the hint only decides the speed: pass the voxel size the
+ * target cloud was down-sampled with (YOHO_testset.py:39-49 / simple_yoho/fcgf_feat.py:33-43), where every query has a
+ * target point within a voxel diagonal. */
+int yoho_set_nn_grid(yoho_ctx* ctx, double cell);
+
 /* PartII group-conv layers: 0 = fp32 MFMA, 1 = bf16x3 split MFMA, 2 = fp16x2 split MFMA (default; first layer in the
  * group-Fourier domain, 13-rotation cone layer direct, last layer as one dense product at the identity). */
 int yoho_set_partII_mode(yoho_ctx* ctx, int mode);

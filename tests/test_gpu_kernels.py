@@ -386,6 +386,47 @@ def test_group_gather(ctx, tables):
     assert np.array_equal(out.cpu().numpy(), orc.group_gather(keys, pts, feats, tables.R64))
 
 
+def test_grid_nn_equals_brute_force(hip, tables):
+    """yoho_set_nn_grid changes the search, never the answer: both fp32 distance types and the f64 group gather, for a
+    well-chosen cell, one that is far too small (most queries fall back to brute force) and a coarse one (long cell lists);
+    with far-away queries, duplicated targets (lowest index wins) and queries sitting exactly on targets."""
+    c = hip.Context()
+    rs = np.random.RandomState(3)
+    cloud = synth.surface_cloud(60000, seed=4, extent=2.0)
+    vox = np.floor(cloud / 0.025).astype(np.int64)
+    _, first = np.unique(vox, axis=0, return_index=True)
+    tgt = cloud[np.sort(first)].astype(np.float32)                       # one point per voxel, as the backbone's down-sampling leaves it
+    tgt = np.concatenate([tgt, tgt[:300]])                               # duplicates: ties on distance
+    src = np.concatenate([cloud[rs.permutation(len(cloud))[:3000]], tgt[100:400].astype(np.float64),
+                          rs.rand(200, 3) * 2 + 5.0, rs.rand(200, 3) * 2.0]).astype(np.float32)
+    s_d, t_d = cu(src), cu(tgt)
+    assert src.shape[0] * tgt.shape[0] >= 1 << 20
+    ref = {}
+    for squared in (False, True):
+        d, i = c.nn_search(s_d, t_d, squared=squared)
+        ref[squared] = (d.cpu().numpy(), i.cpu().numpy())
+    keys = np.concatenate([cloud[rs.permutation(len(cloud))[:2000]], rs.rand(100, 3) * 9.0])
+    feat = rs.randn(len(tgt), 32).astype(np.float32)
+    out0 = torch.zeros((len(keys), 32, 60), dtype=torch.float32, device="cuda")
+    gi0 = {g: c.group_gather(cu(keys), t_d, cu(feat), g, out0, want_idx=True).cpu().numpy() for g in (0, 7, 33)}
+    try:
+        for cell in (0.025, 0.004, 0.2):
+            c.set_nn_grid(cell)
+            for squared in (False, True):
+                d, i = c.nn_search(s_d, t_d, squared=squared)
+                assert np.array_equal(i.cpu().numpy(), ref[squared][1]), (cell, squared)
+                assert np.array_equal(d.cpu().numpy(), ref[squared][0]), (cell, squared)
+            out1 = torch.zeros_like(out0)
+            for g in (0, 7, 33):
+                gi = c.group_gather(cu(keys), t_d, cu(feat), g, out1, want_idx=True).cpu().numpy()
+                assert np.array_equal(gi, gi0[g]), (cell, g)
+            assert torch.equal(out1, out0)
+        with pytest.raises(hip.YohoError):
+            c.set_nn_grid(-1.0)
+    finally:
+        c.set_nn_grid(0)
+
+
 def test_error_paths(hip):
     c = hip.Context()
     x = torch.zeros((4, 32, 60), device="cuda")

@@ -43,11 +43,15 @@ class testset_create():
         k_d = torch.from_numpy(np.ascontiguousarray(np.asarray(keys, dtype=np.float64))).cuda()
         out = torch.empty((k_d.shape[0], 32, 60), dtype=torch.float32, device="cuda")
         nb = 6                                                       # rotated copies per backbone pass
-        for g0 in range(0, 60, nb):
-            xyzs = [pc_d @ torch.from_numpy(np.ascontiguousarray(self.Rgroup[g].T)).cuda() for g in range(g0, g0 + nb)]
-            for j, (sel, feat) in enumerate(self.fcgf.extract_features_dev_batch(xyzs, self.config.voxel_size)):
-                pts = xyzs[j][sel].to(torch.float32).contiguous()    # 'dspcd0' (.float(), YOHO_testset.py:92)
-                self.ctx.group_gather(k_d, pts, feat, g0 + j, out)   # keys @ R_g^T, f64 NN, feature row -> out[:, :, g]
+        self.ctx.set_nn_grid(self.config.voxel_size)                 # the targets are one point per voxel: grid search, same winners
+        try:
+            for g0 in range(0, 60, nb):
+                xyzs = [pc_d @ torch.from_numpy(np.ascontiguousarray(self.Rgroup[g].T)).cuda() for g in range(g0, g0 + nb)]
+                for j, (sel, feat) in enumerate(self.fcgf.extract_features_dev_batch(xyzs, self.config.voxel_size)):
+                    pts = xyzs[j][sel].to(torch.float32).contiguous()    # 'dspcd0' (.float(), YOHO_testset.py:92)
+                    self.ctx.group_gather(k_d, pts, feat, g0 + j, out)   # keys @ R_g^T, f64 NN, feature row -> out[:, :, g]
+        finally:
+            self.ctx.set_nn_grid(0)
         return out
 
     def Feature_extracting(self):

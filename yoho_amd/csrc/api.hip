@@ -401,6 +401,12 @@ int yoho_set_partII_mode(yoho_ctx* c, int mode) {
     return 0;
 }
 
+int yoho_set_nn_grid(yoho_ctx* c, double cell) {
+    if (!c || !(cell >= 0.0) || !std::isfinite(cell)) { set_error("yoho_set_nn_grid: cell must be a finite number >= 0 (0 = brute force)"); return YOHO_EINVAL; }
+    c->nn_cell = cell;
+    return 0;
+}
+
 int yoho_set_profiling(yoho_ctx* c, int enable) {
     if (!c) { set_error("null ctx"); return YOHO_EINVAL; }
     HIPCHK(hipSetDevice(c->device));

@@ -125,6 +125,10 @@ struct Workspace;
 struct yoho_ctx;
 namespace yoho {
 int ensure_ws(yoho_ctx* ctx, size_t bytes, hipStream_t s);
+struct GnMat3;
+size_t grid_nn_ws_bytes(int Ns, int Nt);
+int launch_grid_nn(int mode, const void* src, int Ns, const GnMat3* R, const float* tgt, int Nt, double cell, void* ws, int64_t* idx, float* dist,
+                   double* part_d, int* part_i, int nCU, hipStream_t s);
 
 struct Workspace {
     void* p = nullptr;
@@ -158,6 +162,7 @@ struct yoho_ctx {
     int tap_inv[13] = {0};       // inv[k]: the tap whose group element is the inverse of tap k's (train.hip)
     int* d_tap_inv = nullptr;
     int nCU = 256;
+    double nn_cell = 0.0;        // > 0: 3-D nearest-neighbour searches go through a hash grid of this cell size (gridnn.hip)
     // workspace (grown on demand)
     yoho::Workspace ws;
     // profiling

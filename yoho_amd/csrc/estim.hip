@@ -7,6 +7,7 @@
 //   gather_kernel   60-fold FCGF feature gather  YOHO_testset.py:153-166
 // This file is compiled with -ffp-contract=off (yoho_amd/build.py): only explicit fma() fuses.
 #include "common.h"
+#include "nnmath.h"
 
 namespace yoho {
 
@@ -276,7 +277,7 @@ __global__ void pick_T_kernel(const double* __restrict__ T_all, const int* __res
 // evaluations).  The cloud is cut into `nslice` slices across blockIdx.y; a second kernel merges the per-slice
 // winners (distance, then lower index) and copies the feature row.
 constexpr int GG_KR = 2, GG_TT = 2048;
-struct Mat3 { double m[9]; };
+typedef GnMat3 Mat3;
 
 __global__ __launch_bounds__(256) void gather_nn_kernel(const double* __restrict__ keys, int K, const float* __restrict__ pts, int n,
                                                         Mat3 Rg, int slice_len, double* __restrict__ part_d, int* __restrict__ part_i) {
@@ -289,7 +290,7 @@ __global__ __launch_bounds__(256) void gather_nn_kernel(const double* __restrict
         const int kc = k0 + q < K ? k0 + q : K - 1;
         const double* kk = keys + (size_t)kc * 3;
 #pragma unroll
-        for (int i = 0; i < 3; ++i) kr[q][i] = fma(kk[2], Rg.m[i * 3 + 2], fma(kk[1], Rg.m[i * 3 + 1], kk[0] * Rg.m[i * 3]));
+        for (int i = 0; i < 3; ++i) kr[q][i] = rotate_key_f64(kk, Rg.m + 3 * i);
         best[q] = __builtin_inf();
         besti[q] = 0;
     }
@@ -307,8 +308,7 @@ __global__ __launch_bounds__(256) void gather_nn_kernel(const double* __restrict
             const double px = tile[t * 3], py = tile[t * 3 + 1], pz = tile[t * 3 + 2];
 #pragma unroll
             for (int q = 0; q < GG_KR; ++q) {
-                const double d0 = __dsub_rn(kr[q][0], px), d1 = __dsub_rn(kr[q][1], py), d2 = __dsub_rn(kr[q][2], pz);
-                const double s = __dadd_rn(__dadd_rn(__dmul_rn(d0, d0), __dmul_rn(d1, d1)), __dmul_rn(d2, d2));
+                const double s = dist2_key_f64(kr[q], px, py, pz);
                 if (s < best[q]) {
                     if (s < best[q] * (1.0 - 1e-12) || sqrt(__dadd_rn(s, 1e-7)) < sqrt(__dadd_rn(best[q], 1e-7))) { best[q] = s; besti[q] = t0 + t; }
                 }
@@ -408,6 +408,18 @@ int yoho_group_gather(yoho_ctx* c, const double* keys, int K, const float* pts, 
     hipStream_t s = (hipStream_t)stream;
     Mat3 R;
     for (int i = 0; i < 9; ++i) R.m[i] = Rg_host[i];
+    if (c->nn_cell > 0.0 && (size_t)K * n >= (1u << 20)) {
+        // hash-grid search (gridnn.hip): same winners as the brute-force slices below
+        int rc;
+        const size_t head = ((size_t)K * (sizeof(double) + sizeof(int)) + 255) & ~(size_t)255;
+        if ((rc = ensure_ws(c, head + grid_nn_ws_bytes(K, n), s))) return rc;
+        double* pd = (double*)c->ws.p;
+        int* pi = (int*)(pd + K);
+        if ((rc = launch_grid_nn(2, keys, K, &R, pts, n, c->nn_cell, (char*)c->ws.p + head, nullptr, nullptr, pd, pi, c->nCU, s))) return rc;
+        hipLaunchKernelGGL(gather_merge_kernel, dim3((K + 15) / 16), dim3(256), 0, s, pd, pi, K, 1, feat, g, out, nn_idx);
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
     const int kblocks = (K + 256 * GG_KR - 1) / (256 * GG_KR);
     int nslice = (2048 + kblocks - 1) / kblocks;                       // aim for ~2048 workgroups
     const int max_slices = (n + 255) / 256;                             // at least 256 cloud points per slice

@@ -11,41 +11,13 @@
 // added 0..7 in sequence (pinned by tests/golden/pdist.npz).  The first minimum wins.
 // This file is compiled with -ffp-contract=off (yoho_amd/build.py).
 #include "common.h"
+#include "nnmath.h"
 
 namespace yoho {
 
 constexpr int NN_ROWS = 16;     // source rows per workgroup
 constexpr int NN_SPLIT = 16;    // target interleave per source row
 constexpr int NN_TT = 256;      // target rows per LDS tile
-
-template <int D>
-__device__ __forceinline__ float dist2_f32(const float* a, const float* b) {
-    if constexpr (D == 32) {
-        float l[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) { const float d = __fsub_rn(a[k], b[k]); l[k] = __fmul_rn(d, d); }
-#pragma unroll
-        for (int blk = 1; blk < 4; ++blk)
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const float d = __fsub_rn(a[8 * blk + k], b[8 * blk + k]);
-                l[k] = __fadd_rn(l[k], __fmul_rn(d, d));
-            }
-        float s = l[0];
-#pragma unroll
-        for (int k = 1; k < 8; ++k) s = __fadd_rn(s, l[k]);
-        return s;
-    } else {
-        float s = 0.f;
-#pragma unroll
-        for (int k = 0; k < D; ++k) {
-            const float d = __fsub_rn(a[k], b[k]);
-            const float q = __fmul_rn(d, d);
-            s = k == 0 ? q : __fadd_rn(s, q);
-        }
-        return s;
-    }
-}
 
 // src (Ns,D) f32, tgt (Nt,D) f32 -> idx (Ns) int64, dist (Ns) f32 (optional)
 template <int D, bool SQUARED>
@@ -63,7 +35,7 @@ __global__ __launch_bounds__(256) void nn_kernel(const float* __restrict__ src, 
     // best holds the squared distance.  For the 'L2' form the reference compares sqrt(D2 + 1e-7) (first minimum);
     // sqrt is monotone, so a later candidate can only win with a smaller D2, and the correctly rounded sqrt
     // (computed in f64) is evaluated only when the two D2 are close enough to round to the same distance.
-    auto dist_of = [](float d2) -> float { return (float)sqrt((double)__fadd_rn(d2, 1e-7f)); };
+    auto dist_of = [](float d2) -> float { return dist_of_f32(d2); };
     float best = __builtin_inff();
     int besti = 0;
     for (int t0 = 0; t0 < Nt; t0 += NN_TT) {
@@ -130,7 +102,7 @@ __global__ __launch_bounds__(256) void nn32seg_kernel(const float* __restrict__ 
 #pragma unroll
         for (int k = 0; k < D; ++k) { a0[k] = src[(size_t)rc0 * D + k]; a1[k] = src[(size_t)rc1 * D + k]; }
     }
-    auto dist_of = [](float d2) -> float { return (float)sqrt((double)__fadd_rn(d2, 1e-7f)); };
+    auto dist_of = [](float d2) -> float { return dist_of_f32(d2); };
     float best0 = __builtin_inff(), best1 = __builtin_inff();
     int bi0 = 0, bi1 = 0;
     const int tlo = blockIdx.y * segLen;
@@ -349,6 +321,12 @@ int yoho_nn_search(yoho_ctx* c, const float* src, int Ns, const float* tgt, int 
     if (!c || !src || !tgt || !idx || Ns < 0 || Nt < 1) { set_error("yoho_nn_search: bad argument"); return YOHO_EINVAL; }
     if (Ns == 0) return 0;
     HIPCHK(hipSetDevice(c->device));
+    if (D == 3 && c->nn_cell > 0.0 && (size_t)Ns * Nt >= (1u << 20) && (dist_type == YOHO_DIST_L2 || dist_type == YOHO_DIST_SQUARE_L2)) {
+        int rc;
+        if ((rc = ensure_ws(c, grid_nn_ws_bytes(Ns, Nt), (hipStream_t)stream))) return rc;
+        return launch_grid_nn(dist_type == YOHO_DIST_SQUARE_L2 ? 0 : 1, src, Ns, nullptr, tgt, Nt, c->nn_cell, c->ws.p, idx, dist, nullptr, nullptr,
+                              c->nCU, (hipStream_t)stream);
+    }
     if ((D == 32 || D == 3) && (size_t)Ns * Nt >= (1u << 20) && (dist_type == YOHO_DIST_L2 || dist_type == YOHO_DIST_SQUARE_L2)) {
         int rc;
         if ((rc = ensure_ws(c, sizeof(unsigned long long) * (size_t)Ns, (hipStream_t)stream))) return rc;

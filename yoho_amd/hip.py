@@ -20,7 +20,7 @@ SYMBOLS = [
     "yoho_load_partII", "yoho_partI_forward", "yoho_partI_forward_pair", "yoho_group_mean_np", "yoho_nn_search", "yoho_mutual_nn",
     "yoho_gconv_layer", "yoho_load_fcgf", "yoho_fcgf_voxelize", "yoho_fcgf_forward", "yoho_fcgf_forward_batch",
     "yoho_des2r", "yoho_des2r_indexed", "yoho_partII_forward", "yoho_partII_forward_indexed", "yoho_hyp_from_quat", "yoho_o_score", "yoho_c_ransac",
-    "yoho_group_gather", "yoho_set_profiling", "yoho_get_kernel_ms", "yoho_set_gconv_mode", "yoho_set_partII_mode",
+    "yoho_group_gather", "yoho_set_profiling", "yoho_get_kernel_ms", "yoho_set_gconv_mode", "yoho_set_partII_mode", "yoho_set_nn_grid",
 ]
 
 
@@ -93,6 +93,7 @@ def load_library():
     lib.yoho_set_profiling.argtypes = [vp, ci]
     lib.yoho_set_gconv_mode.argtypes = [vp, ci]
     lib.yoho_set_partII_mode.argtypes = [vp, ci]
+    lib.yoho_set_nn_grid.argtypes = [vp, C.c_double]
     lib.yoho_get_kernel_ms.argtypes = [vp, ci, C.POINTER(C.c_float)]
     for s in SYMBOLS[2:]:
         getattr(lib, s).restype = ci
@@ -399,6 +400,11 @@ class Context:
     def set_partII_mode(self, mode):
         """'f32', 'bf16x3' or 'fp16x2' for the two large cone layers of PartII."""
         _check(self._lib.yoho_set_partII_mode(self._h, {"f32": 0, "bf16x3": 1, "fp16x2": 2}[mode]))
+
+    def set_nn_grid(self, cell):
+        """3-D nearest-neighbour searches (nn_search with 3 columns, group_gather) through a hash grid with this cell size
+        (0 = brute force).  Same answers for any cell; pass the voxel size the target cloud was down-sampled with."""
+        _check(self._lib.yoho_set_nn_grid(self._h, float(cell)))
 
     # ---- profiling hook (bench.py) ------------------------------------------------------------
     def set_profiling(self, on=True):

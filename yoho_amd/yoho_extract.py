@@ -62,13 +62,17 @@ class yoho_extractor():
             pc_d = torch.from_numpy(np.ascontiguousarray(np.asarray(pc, dtype=np.float64))).cuda()
             kp_d = pc_d[torch.from_numpy(kpts_index).cuda()]
             G, nb = self.grs.shape[0], self.rot_batch
-            for i0 in range(0, G, nb):
-                Rts = [torch.from_numpy(np.ascontiguousarray(self.grs[i].T)).cuda() for i in range(i0, min(i0 + nb, G))]
-                pcs = [pc_d @ Rt for Rt in Rts]
-                for j, (pci, (sel, pci_f)) in enumerate(zip(pcs, self.fcgf.extract_features_dev_batch(pcs, voxel_size))):
-                    q = (kp_d @ Rts[j]).to(torch.float32).contiguous()
-                    _, idx = self.ctx.nn_search(q, pci[sel].to(torch.float32).contiguous(), want_dist=False, squared=True)
-                    kpts_f[:, :, i0 + j] = pci_f[idx]
+            self.ctx.set_nn_grid(voxel_size)       # the NN targets are one point per voxel: grid search, same winners
+            try:
+                for i0 in range(0, G, nb):
+                    Rts = [torch.from_numpy(np.ascontiguousarray(self.grs[i].T)).cuda() for i in range(i0, min(i0 + nb, G))]
+                    pcs = [pc_d @ Rt for Rt in Rts]
+                    for j, (pci, (sel, pci_f)) in enumerate(zip(pcs, self.fcgf.extract_features_dev_batch(pcs, voxel_size))):
+                        q = (kp_d @ Rts[j]).to(torch.float32).contiguous()
+                        _, idx = self.ctx.nn_search(q, pci[sel].to(torch.float32).contiguous(), want_dist=False, squared=True)
+                        kpts_f[:, :, i0 + j] = pci_f[idx]
+            finally:
+                self.ctx.set_nn_grid(0)
             self._last_group_feats = kpts_f
             out = self.ctx.partI_forward(kpts_f.contiguous(), want_inv=True)
             return kpts, out["inv"].cpu(), out["eqv"].cpu()
