@@ -16,6 +16,7 @@
  *   yoho_o_score            yohoo.ransac scoring loop     tests/estimator.py:330-336, :286-290
  *   yoho_c_ransac           yohoc.ransac loop body        tests/estimator.py:119-137, :55-70
  *   yoho_group_gather       60-fold FCGF feature gather   YOHO_testset.py:153-166
+ *   yoho_set_nn_grid             (speed hint, no counterpart)    voxel size of YOHO_testset.py:39-49 / simple_yoho/fcgf_feat.py:33-43
  *   yoho_partI_forward_pair      the two PartI passes of a pair  tests/extractor.py:37-62 (one pass per fragment there)
  *   yoho_des2r_indexed           feats[match[:,0]] + Des2R       tests/extractor.py:80-103
  *   yoho_partII_forward_indexed  batch_create + PartII_test      tests/extractor.py:125-141,178-186, utils/network.py:259-278
