@@ -17,8 +17,15 @@ against MinkowskiEngine 0.5.x, which is vendored in the reference tree as *sourc
     swapped (:756-800), i.e. out[f] += in[c] @ W[k] whenever coord(c) = coord(f) + offset(k) on the finer stride;
   * MinkowskiBatchNorm = BatchNorm1d over the feature rows (eval: running statistics, eps 1e-5); ME.cat = channel concat.
 
-PARITY UNPINNED against MinkowskiEngine itself (cannot run here, pretrained backbone checkpoint absent from the tree).
-The sparse convolution is pinned against torch.nn.functional.conv3d on densified inputs (tests/test_fcgf_oracle.py).
+Pinning (tests/test_fcgf_oracle.py): the coordinate-map and kernel-map semantics above are checked against the
+known-answer vectors of MinkowskiEngine's own tests (region order and map direction: tests/cpp/kernel_region_cpu_test.py:22-42,
+100-116; strided maps incl. negative coordinates and batches: tests/cpp/coordinate_map_cpu_test.py:95-125,
+tests/python/coordinate_manager.py:183-200; quantisation collisions: tests/python/quantization.py:104-113; not used:
+the pair count asserted in tests/python/kernel_map.py:78,109 (16), which the sources and the C++ known answers above
+contradict - the map definition yields 26 pairs on that fixture); the sparse
+convolution arithmetic is checked against torch.nn.functional.conv3d / conv_transpose3d on densified inputs.
+The END-TO-END network output remains PARITY UNPINNED against MinkowskiEngine itself (it cannot run here and the
+pretrained backbone checkpoint is absent from the tree).
 """
 import numpy as np
 
@@ -57,20 +64,31 @@ def kernel_offsets(ksize, ts):
     return out.astype(np.int32) * ts
 
 
+def kernel_map(coords_in, coords_out, ksize, ts_region, transpose=False):
+    """(K^3, Nout) input row of every (kernel index, output row), -1 where the region cell is empty
+    (src/coordinate_map_cpu.hpp:572-660 with kernel_region.hpp:196-216).  ts_region: tensor stride the kernel offsets live
+    on (input stride for a convolution, the finer = OUTPUT stride for a transposed one).
+    transpose=False: in = out + off(k); transpose=True: in + off(k) = out."""
+    index = {tuple(c): i for i, c in enumerate(np.asarray(coords_in).tolist())}
+    offs = kernel_offsets(ksize, ts_region)
+    coords_out = np.asarray(coords_out)
+    rows = np.full((len(offs), len(coords_out)), -1, dtype=np.int64)
+    for k, off in enumerate(offs):
+        src = coords_out - off if transpose else coords_out + off
+        rows[k] = np.fromiter((index.get(tuple(c), -1) for c in src.tolist()), dtype=np.int64, count=len(src))
+    return rows
+
+
 def conv(feat_in, coords_in, coords_out, W, ksize, ts_region, transpose=False):
-    """feat_in (Nin,Cin), W (K^3,Cin,Cout) or (Cin,Cout) -> (Nout,Cout) float32, accumulated in kernel-index order.
-    ts_region: tensor stride the kernel offsets live on (input stride for a convolution, the finer = OUTPUT stride for a
-    transposed one).  transpose=False: in = out + off(k); transpose=True: in + off(k) = out."""
+    """feat_in (Nin,Cin), W (K^3,Cin,Cout) or (Cin,Cout) -> (Nout,Cout) float32, accumulated in kernel-index order
+    (out[o] += in[i] @ W[k] over the pairs of kernel_map)."""
     W = np.asarray(W, dtype=np.float32)
     if W.ndim == 2:
         assert len(coords_in) == len(coords_out)
         return feat_in.astype(np.float32) @ W
-    index = {tuple(c): i for i, c in enumerate(coords_in.tolist())}
-    offs = kernel_offsets(ksize, ts_region)
+    rows_all = kernel_map(coords_in, coords_out, ksize, ts_region, transpose)
     out = np.zeros((len(coords_out), W.shape[2]), dtype=np.float32)
-    for k, off in enumerate(offs):
-        src = coords_out - off if transpose else coords_out + off
-        rows = np.fromiter((index.get(tuple(c), -1) for c in src.tolist()), dtype=np.int64, count=len(src))
+    for k, rows in enumerate(rows_all):
         m = rows >= 0
         if m.any():
             out[m] += feat_in[rows[m]].astype(np.float32) @ W[k]

@@ -86,3 +86,36 @@ def test_quantize_first_occurrence_and_unet_shapes():
     # translation by whole multiples of the coarsest stride leaves the features unchanged (all maps shift together)
     _, F2 = fo.extract_features(pc[:1200] + 8 * 0.025 * np.array([1.0, -2.0, 3.0]), 0.025, sd)
     assert F2.shape == F.shape and np.abs(F - F2).max() < 1e-5
+
+
+def test_minkowski_engine_known_answers():
+    """The coordinate-map / kernel-map semantics the oracle restates, on the known-answer vectors of MinkowskiEngine's own
+    tests (2-D cases embedded at z = 0: the 3-D kernel index of a 2-D index k with dz = 0 is k + 9)."""
+    # region order: x fastest, offsets -1..1 around (1, -1)   (tests/cpp/kernel_region_cpu_test.py:22-42)
+    offs = fo.kernel_offsets(3, 1)
+    around = (np.array([1, -1, 0]) + offs[9:18])[:, :2].tolist()
+    assert around == [[0, -2], [1, -2], [2, -2], [0, -1], [1, -1], [2, -1], [0, 0], [1, 0], [2, 0]]
+    # kernel map direction: in = out + offset   (tests/cpp/kernel_region_cpu_test.py:100-116; the third output row is
+    # another batch item there, i.e. another cloud here)
+    cin = np.array([[1, -1, 0], [2, 1, 0]], dtype=np.int32)
+    cout = np.array([[1, 0, 0], [1, 2, 0]], dtype=np.int32)
+    m = fo.kernel_map(cin, cout, 3, 1)
+    assert m.shape == (27, 2)
+    assert m[9 + 1].tolist() == [0, -1]                         # in_maps[1] = [0], out_maps[1] = [0]
+    assert m[9 + 2].tolist() == [-1, 1]                         # in_maps[2] = [1], out_maps[2] = [1]
+    assert (m[:9] < 0).all() and (m[18:] < 0).all()             # nothing off the z = 0 plane
+    # kernel size 1: identity on the shared coordinates   (:88-98)
+    assert fo.kernel_map(cin, cin, 1, 1).tolist() == [[0, 1]]
+    # strided maps   (tests/cpp/coordinate_map_cpu_test.py:95-125): two batch items = two clouds
+    b0 = np.array([[1, 1, 0], [2, 1, 0], [1, 0, 0]], dtype=np.int32)
+    b1 = np.array([[0, 3, 0], [0, 2, 0]], dtype=np.int32)
+    assert len(fo.stride_coords(b0, 4)) + len(fo.stride_coords(b1, 4)) == 2
+    assert len(fo.stride_coords(b0, 1)) + len(fo.stride_coords(b1, 1)) == 5
+    neg = np.array([[-1, 0, 0], [-2, 0, 0], [1, 0, 0], [0, 0, 0]], dtype=np.int32)
+    assert sorted(fo.stride_coords(neg, 2)[:, 0].tolist()) == [-2, 0]
+    # negative coordinates, stride 2: -3..3 -> {-4, -2, 0, 2}   (tests/python/coordinate_manager.py:183-200)
+    line = np.array([[v, 0, 0] for v in range(-3, 4)], dtype=np.int32)
+    assert sorted(fo.stride_coords(line, 2)[:, 0].tolist()) == [-4, -2, 0, 2]
+    # quantisation with collisions keeps one row per voxel   (tests/python/quantization.py:104-113)
+    q = np.array([[0, 0, 0], [0, 0, 0], [0, 0, 0], [0, 1, 0]])
+    assert q[fo.sparse_quantize(q)].tolist() == [[0, 0, 0], [0, 1, 0]]
