@@ -190,6 +190,35 @@ __global__ __launch_bounds__(256, 1) void fgemm_kernel(FGemmArgs a, int flags) {
         stage_tile(Ag + FG_STAGE, smem + 2 * FG_STAGE, w, lane);
         stage_tile(Bg + FG_STAGE, smem + 3 * FG_STAGE, w, lane);
     }
+    if ((flags & EPI_RES) && (mtile * 256 + wm * 128) < d * a.cout) {
+        // The accumulators start from the residual (scaled by 1 / descale, a power of two): its 64 loads per wave are in
+        // flight together with the first two DMA stages.  Added in the epilogue instead they are serialised behind the
+        // accumulators' registers (no room to prefetch) and cost a third of a millisecond per pass.
+        const float inv = 1.f / a.descale;
+        const int half = lane >> 5, kp32 = lane & 31, cout8 = a.cout >> 3;
+        const int col0 = ntile * 256 + wn * 128;
+        const int jidx = col0 / a.kppad, kp0 = col0 - jidx * a.kppad;
+#pragma unroll
+        for (int bi = 0; bi < 4; ++bi) {
+            const int tile32 = (kp0 >> 5) + bi;
+#pragma unroll
+            for (int ai = 0; ai < 4; ++ai) {
+                const int rowb = mtile * 256 + wm * 128 + ai * 32;
+                const int iidx = rowb / a.cout, o0 = rowb - iidx * a.cout;
+                const bool ok = tile32 < a.nT32 && iidx < d;
+                const int q = qbase + iidx * d + jidx;
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const int o = o0 + q4 * 8 + half * 4;
+                    const size_t off = (((((size_t)tile32 * cout8 + (o >> 3)) * G + q) * 2 + half) * TILE + kp32) * 4;
+                    // branch-free, so that all loads go out back to back
+                    const floatx4 v = *reinterpret_cast<const floatx4*>(a.res + (ok ? off : 0)) * (ok ? inv : 0.f);
+                    acc[ai][bi][4 * q4 + 0] = v.x; acc[ai][bi][4 * q4 + 1] = v.y;
+                    acc[ai][bi][4 * q4 + 2] = v.z; acc[ai][bi][4 * q4 + 3] = v.w;
+                }
+            }
+        }
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -251,7 +280,6 @@ __global__ __launch_bounds__(256, 1) void fgemm_kernel(FGemmArgs a, int flags) {
                 val *= a.descale;
                 if (addb) val += *reinterpret_cast<const floatx4*>(a.bias + o) * 7.745966692414834f;
                 const size_t off = (((((size_t)tile32 * cout8 + (o >> 3)) * G + q) * 2 + half) * TILE + kp32) * 4;
-                if (flags & EPI_RES) val += *reinterpret_cast<const floatx4*>(a.res + off);
                 *reinterpret_cast<floatx4*>(a.out + off) = val;
             }
         }
