@@ -42,7 +42,7 @@ class testset_create():
         pc_d = torch.from_numpy(np.ascontiguousarray(np.asarray(pc, dtype=np.float64))).cuda()
         k_d = torch.from_numpy(np.ascontiguousarray(np.asarray(keys, dtype=np.float64))).cuda()
         out = torch.empty((k_d.shape[0], 32, 60), dtype=torch.float32, device="cuda")
-        nb = 6                                                       # rotated copies per backbone pass
+        nb = 15                                                      # rotated copies per backbone pass (split further by voxel count)
         self.ctx.set_nn_grid(self.config.voxel_size)                 # the targets are one point per voxel: grid search, same winners
         try:
             for g0 in range(0, 60, nb):

@@ -58,10 +58,21 @@ class fcgf_extractor():
         sel, coords = self.ctx.fcgf_voxelize(pts, voxel_size)
         return sel, self.ctx.fcgf_forward(coords)
 
+    MAX_VOXELS_PER_PASS = 1600000
+
     def extract_features_dev_batch(self, pts_list, voxel_size):
         """several clouds (f64 cuda) in one backbone pass -> list of (sel, F)."""
         vox = [self.ctx.fcgf_voxelize(p, voxel_size) for p in pts_list]
-        feats = self.ctx.fcgf_forward_batch([c for _, c in vox])
+        # one pass addresses at most 2 GiB per feature matrix (<= 256 channels): split long lists by a voxel budget
+        feats, group, rows = [], [], 0
+        for _, c in vox:
+            if group and (rows + c.shape[0] > self.MAX_VOXELS_PER_PASS or len(group) == 64):
+                feats += self.ctx.fcgf_forward_batch(group)
+                group, rows = [], 0
+            group.append(c)
+            rows += c.shape[0]
+        if group:
+            feats += self.ctx.fcgf_forward_batch(group)
         return [(sel, f) for (sel, _), f in zip(vox, feats)]
 
     def extract_features(self, pc, voxel_size):

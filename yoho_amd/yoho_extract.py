@@ -35,7 +35,7 @@ class yoho_extractor():
         self.yoho_ckpt = yoho_ckpt
         self._load_model()
         self.bs = 500
-        self.rot_batch = 6             # rotated copies of the cloud per backbone pass (HBM-resident path)
+        self.rot_batch = 15            # rotated copies of the cloud per backbone pass (HBM-resident path; split further by voxel count)
 
     def _load_model(self):
         sd = self.yoho_ckpt if isinstance(self.yoho_ckpt, dict) else W.load_checkpoint(self.yoho_ckpt)[0]
