@@ -1,0 +1,62 @@
+"""Host-side logic that needs no GPU: batching of backbone passes, nearest-neighbour hint plumbing."""
+import types
+
+import numpy as np
+import torch
+
+from yoho_amd.fcgf_feat import fcgf_extractor
+
+
+class _FakeCtx:
+    """records what the extractor asks the library for; clouds are (n,3) int tensors, features are their row counts"""
+
+    def __init__(self, sizes):
+        self.sizes, self.batches = list(sizes), []
+        self._i = 0
+
+    def fcgf_voxelize(self, pts, voxel_size):
+        n = self.sizes[self._i]
+        self._i += 1
+        return torch.arange(n), torch.zeros((n, 3), dtype=torch.int32)
+
+    def fcgf_forward_batch(self, coords_list):
+        self.batches.append([c.shape[0] for c in coords_list])
+        return [torch.full((c.shape[0], 1), float(len(self.batches))) for c in coords_list]
+
+
+def _extractor(ctx, budget):
+    ex = object.__new__(fcgf_extractor)           # no checkpoint / library needed for the batching logic
+    ex.ctx = ctx
+    ex.MAX_VOXELS_PER_PASS = budget
+    return ex
+
+
+def test_backbone_batches_respect_voxel_budget_and_order():
+    sizes = [400, 500, 300, 900, 100, 100, 100, 1200, 50]
+    ctx = _FakeCtx(sizes)
+    out = _extractor(ctx, 1000).extract_features_dev_batch([None] * len(sizes), 0.025)
+    assert ctx.batches == [[400, 500], [300], [900, 100], [100, 100], [1200], [50]]     # a single oversize cloud still goes alone
+    assert [f.shape[0] for _, f in out] == sizes                                        # results come back in input order
+    assert [int(f[0, 0]) for _, f in out] == [1, 1, 2, 3, 3, 4, 4, 5, 6]
+
+
+def test_backbone_batches_cap_at_64_clouds():
+    ctx = _FakeCtx([10] * 150)
+    _extractor(ctx, 10 ** 9).extract_features_dev_batch([None] * 150, 0.025)
+    assert [len(b) for b in ctx.batches] == [64, 64, 22]
+
+
+def test_gather_sets_and_clears_the_grid_hint():
+    from yoho_amd import gather
+    calls = []
+    ctx = types.SimpleNamespace(set_nn_grid=lambda c: calls.append(("grid", c)),
+                                group_gather=lambda k, p, f, g, out: calls.append(("g", g)))
+    orig = torch.Tensor.to
+    try:
+        torch.Tensor.to = lambda self, *a, **k: self                      # no device here
+        out = torch.zeros((4, 32, 60))
+        gather.gather_group_features(np.zeros((4, 3)), [np.zeros((5, 3), np.float32)] * 60, [np.zeros((5, 32), np.float32)] * 60,
+                                     ctx=ctx, out=out, voxel_size=0.025)
+    finally:
+        torch.Tensor.to = orig
+    assert calls[0] == ("grid", 0.025) and calls[-1] == ("grid", 0) and [c for c in calls if c[0] == "g"] == [("g", g) for g in range(60)]
