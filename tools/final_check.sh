@@ -12,3 +12,8 @@ cd $GRAFT_REPO_ROOT
 python tools/rocpd_stats.py gpurun_out/prof_bench_h > gpurun_out/bench_h_stats.md 2>&1
 python tools/rocpd_stats.py gpurun_out/prof_fcgf_h > gpurun_out/fcgf_h_stats.md 2>&1
 tail -1 gpurun_out/bench_h.json | cut -c1-300
+cd /tmp
+rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof_extract_h -- python $GRAFT_REPO_ROOT/tools/bench_extract.py 300000 5000 > /dev/null 2>&1
+cd $GRAFT_REPO_ROOT
+python tools/rocpd_stats.py gpurun_out/prof_extract_h > gpurun_out/extract_h_stats.md 2>&1
+python tools/bench_gridnn.py | tail -2
