@@ -176,17 +176,41 @@ __global__ void hash_set_rows_kernel(const int* coords, int n, const u64* keys, 
     vals[slot] = r;
 }
 
-// map[k][n] = row of (coord(n) + sign * offset(k) * ts) in the table, -1 if absent; kernel index with x fastest
+// Dense occupancy bitmap of the level-0 voxels of every cloud of a pass (bounding box + K/2 margin, x fastest, 32 voxels per
+// word): the first convolution tests its K^3 neighbours with one cached word read each instead of a hash probe, and the
+// level-0 kernel maps use it as a presence filter in front of the hash table.
+struct BmDesc {
+    long long base;          // first word of this cloud's bitmap
+    int x0, y0, z0;          // voxel coordinate of bit 0 (bounding-box minimum minus the margin)
+    int wx, ny, nz;          // words per x row, rows per z slice, slices
+};
+
+// map[k][n] = row of (coord(n) + sign * offset(k) * ts) in the table, -1 if absent; kernel index with x fastest.
+// Two cheap rejections before the hash probe: a coordinate that is not a multiple of the table's tensor stride ts_in
+// cannot be in it (7 of 8 candidates of a transposed map, whose offsets live on the finer stride), and for a level-0
+// table the occupancy bitmap (bm != null) answers "absent" for the two thirds of a 3^3 region that are empty.
 __global__ void build_map_kernel(const int* out_coords, int nout, const u64* keys, const int* vals, unsigned mask, int ksize, int ts,
-                                 int sign, int* map) {
+                                 int sign, int ts_in, const BmDesc* __restrict__ desc, const unsigned* __restrict__ bm, int* map) {
     const int n = blockIdx.x * 256 + threadIdx.x;
     const int k = blockIdx.y;
     if (n >= nout) return;
     const int h = ksize / 2;
     const int ox = (k % ksize - h) * ts * sign, oy = ((k / ksize) % ksize - h) * ts * sign, oz = (k / (ksize * ksize) - h) * ts * sign;
     const int4 c = reinterpret_cast<const int4*>(out_coords)[n];
-    const int slot = hash_find_slot(keys, mask, pack_key(c.x + ox, c.y + oy, c.z + oz, c.w));
-    map[(size_t)k * nout + n] = slot < 0 ? -1 : vals[slot];
+    const int qx = c.x + ox, qy = c.y + oy, qz = c.z + oz;
+    int row = -1;
+    bool probe = ((qx | qy | qz) & (ts_in - 1)) == 0;                 // tensor strides are powers of two
+    if (probe && bm) {
+        const BmDesc d = desc[c.w];
+        const int bx = qx - d.x0, by = qy - d.y0, bz = qz - d.z0;
+        if (bx >= 0 && bx < d.wx * 32 && by >= 0 && by < d.ny && bz >= 0 && bz < d.nz)
+            probe = (bm[d.base + ((long long)bz * d.ny + by) * d.wx + (bx >> 5)] >> (bx & 31)) & 1u;
+    }
+    if (probe) {
+        const int slot = hash_find_slot(keys, mask, pack_key(qx, qy, qz, c.w));
+        row = slot < 0 ? -1 : vals[slot];
+    }
+    map[(size_t)k * nout + n] = row;
 }
 
 // (n,3) voxel rows of `nb` concatenated clouds (row ranges off[0..nb]) -> (n,4) rows with the cloud index
@@ -645,14 +669,6 @@ __global__ __launch_bounds__(256) void conv1_ones_kernel(const int* __restrict__
     if (valid) out[(size_t)row * 32 + l32] = acc * (aff_s ? aff_s[l32] : 1.f) + (aff_t ? aff_t[l32] : 0.f);
 }
 
-// Dense occupancy bitmap of the level-0 voxels of every cloud of a pass (bounding box + K/2 margin, x fastest, 32 voxels per
-// word): the first convolution tests its K^3 neighbours with one cached word read each instead of a hash probe.
-struct BmDesc {
-    long long base;          // first word of this cloud's bitmap
-    int x0, y0, z0;          // voxel coordinate of bit 0 (bounding-box minimum minus the margin)
-    int wx, ny;              // words per x row, rows per z slice
-};
-
 // A workgroup scans a contiguous run of rows (rows of a cloud are contiguous, so it almost always sees one cloud) and
 // issues one set of atomics per (workgroup, cloud): a few hundred atomics per pass instead of one set per wave.
 __global__ __launch_bounds__(256) void bbox_kernel(const int* __restrict__ coords, int n, int rows_per_wg, int* __restrict__ bb) {
@@ -1058,12 +1074,15 @@ int fcgf_forward(yoho_ctx* ctx, const FcgfNet* net, const int* coords0, int n0, 
         }
     }
     // ---- kernel maps
+    const BmDesc* map_desc = nullptr;          // set once the level-0 occupancy bitmaps exist
+    const unsigned* map_bm = nullptr;
     auto make_map = [&](const Level& outL, const Level& inL, int ksize, int ts, int sign) -> int* {
         const int kv = ksize * ksize * ksize;
         int* m = ar.take<int>((size_t)kv * outL.n);
+        const bool filter = map_bm && inL.ts == 1;             // the bitmap holds the level-0 voxels
         if (outL.n > 0)
             hipLaunchKernelGGL(build_map_kernel, dim3((outL.n + 255) / 256, kv), dim3(256), 0, s, outL.coords, outL.n, inL.keys, inL.vals,
-                               inL.mask, ksize, ts, sign, m);
+                               inL.mask, ksize, ts, sign, inL.ts, filter ? map_desc : nullptr, filter ? map_bm : nullptr, m);
         return m;
     };
     int* M1 = conv1_fused ? nullptr : make_map(L[0], L[0], net->k1, 1, +1);
@@ -1077,12 +1096,12 @@ int fcgf_forward(yoho_ctx* ctx, const FcgfNet* net, const int* coords0, int n0, 
         bool ok = true;
         for (int b = 0; b < nb && ok; ++b) {
             const int* bb = hbb + 6 * b;
-            if (bb[0] > bb[3]) { hdesc[b] = BmDesc{words, 0, 0, 0, 1, 1}; continue; }       // empty cloud
+            if (bb[0] > bb[3]) { hdesc[b] = BmDesc{words, 0, 0, 0, 1, 1, 1}; continue; }       // empty cloud
             const long long dx = (long long)bb[3] - bb[0] + 1 + 2 * hk, dy = (long long)bb[4] - bb[1] + 1 + 2 * hk,
                             dz = (long long)bb[5] - bb[2] + 1 + 2 * hk;
             const long long wx = (dx + 31) / 32;
             if (wx * dy * dz > (1ll << 24)) ok = false;                                        // > 64 MiB for one cloud
-            hdesc[b] = BmDesc{words, bb[0] - hk, bb[1] - hk, bb[2] - hk, (int)wx, (int)dy};
+            hdesc[b] = BmDesc{words, bb[0] - hk, bb[1] - hk, bb[2] - hk, (int)wx, (int)dy, (int)dz};
             words += wx * dy * dz;
         }
         if (ok && words > 0 && ar.off + (size_t)words * 4 + 8192 < ar.cap) {
@@ -1094,6 +1113,7 @@ int fcgf_forward(yoho_ctx* ctx, const FcgfNet* net, const int* coords0, int n0, 
             HIPCHK(hipStreamSynchronize(s));                  // hdesc lives on this frame
         }
     }
+    if (dbm) { map_desc = ddesc; map_bm = dbm; }
     int* Msame[4]; int* Mdown[3]; int* Mup[3];
     for (int l = 0; l < 4; ++l) Msame[l] = make_map(L[l], L[l], 3, L[l].ts, +1);
     for (int l = 0; l < 3; ++l) {
