@@ -821,9 +821,27 @@ __global__ void fill_ones_kernel(float* p, int n) {
     if (i < n) p[i] = 1.f;
 }
 
-// rows /= |row| (resunet.py:183-187), then once more (fcgf_feat.py:48) - one wave per row
+// rows /= |row| (resunet.py:183-187), then once more (fcgf_feat.py:48).  c <= 32: a half-wave per row (the xor tree over
+// 32 lanes gives the same sum as the 64-lane tree with zeros in the upper half), 8 rows per wave; else one wave per row.
 __global__ __launch_bounds__(256) void row_normalize_kernel(const float* in, int n, int c, float* out, int twice) {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c <= 32) {
+        const int l32 = lane & 31;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = (wave * 4 + i) * 2 + (lane >> 5);
+            const bool ok = row < n && l32 < c;
+            float v = ok ? in[(size_t)row * c + l32] : 0.f;
+            for (int pass = 0; pass < (twice ? 2 : 1); ++pass) {
+                float s = v * v;
+                for (int o = 16; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+                v = v / sqrtf(s);
+            }
+            if (ok) out[(size_t)row * c + l32] = v;
+        }
+        return;
+    }
+    const int row = wave;
     if (row >= n) return;
     float v = lane < c ? in[(size_t)row * c + lane] : 0.f;
     for (int pass = 0; pass < (twice ? 2 : 1); ++pass) {
@@ -1186,7 +1204,8 @@ int fcgf_forward(yoho_ctx* ctx, const FcgfNet* net, const int* coords0, int n0, 
     if (ar.off > ar.cap) { set_error("fcgf_forward: workspace estimate too small"); return YOHO_ENOMEM; }
     if ((rc = conv(cat[0], catw[0], catw[0], nullptr, 1, n0, net->conv1_tr, T[1], f1, T[1], 0, nullptr, nullptr, nullptr, 0, 0, 1))) return rc;
     if ((rc = conv(f1, T[1], T[1], nullptr, 1, n0, net->final_k, net->out_ch, f2, net->out_ch, 0, nullptr, net->final_b, nullptr, 0, 0, 0))) return rc;
-    hipLaunchKernelGGL(row_normalize_kernel, dim3((n0 + 3) / 4), dim3(256), 0, s, f2, n0, net->out_ch, out, net->normalize ? 1 : 0);
+    hipLaunchKernelGGL(row_normalize_kernel, dim3(net->out_ch <= 32 ? (n0 + 31) / 32 : (n0 + 3) / 4), dim3(256), 0, s, f2, n0, net->out_ch, out,
+                       net->normalize ? 1 : 0);
     HIPCHK(hipGetLastError());
     return 0;
 }
