@@ -22,6 +22,7 @@
  *   yoho_partII_forward_indexed  batch_create + PartII_test      tests/extractor.py:125-141,178-186, utils/network.py:259-278
  *   yoho_gconv_layer             Comb_Conv / Residual_Comb_Conv  utils/network.py:35-62 (forward) and its autograd (training)
  *   yoho_load_fcgf / _voxelize / _forward / _forward_batch        fcgf_model/resunet.py:10-190, simple_yoho/fcgf_feat.py:33-54
+ *   yoho_fcgf_voxelize_rotated / yoho_rotate_select               YOHO_testset.py:143-147,92, simple_yoho/yoho_extract.py:46-53
  *
  * Conventions
  *   - return 0 on success, a negative YOHO_E* code on error; yoho_last_error() gives a
@@ -183,6 +184,14 @@ int yoho_load_fcgf(yoho_ctx* ctx, const yoho_fcgf_config* cfg, const float* cons
  * *count (host) receives the number of voxels (the call synchronises the stream). */
 int yoho_fcgf_voxelize(yoho_ctx* ctx, const double* pts, int n, double voxel_size, int64_t* sel, int32_t* coords, int* count,
                        void* stream);
+/* the same on a rotated copy of the cloud, p' = R p in f64 (R: 9 doubles, row major, HOST pointer), without materialising it:
+ * one of the 60 rotated copies YOHO_testset.py:143 / simple_yoho/yoho_extract.py:47 feed to the backbone.  pts_sel (n,3) f32
+ * (may be NULL) receives the rotated selected points, i.e. pcd[sel] cast to float (YOHO_testset.py:92). */
+int yoho_fcgf_voxelize_rotated(yoho_ctx* ctx, const double* pts, int n, const double* R, double voxel_size, int64_t* sel,
+                               int32_t* coords, float* pts_sel, int* count, void* stream);
+/* out (m,3) f32 = (float)(R pts[sel[i]]) with the arithmetic of yoho_fcgf_voxelize_rotated (R may be NULL: plain gather + cast):
+ * the rotated keypoints of the feature transfer. */
+int yoho_rotate_select(yoho_ctx* ctx, const double* pts, const double* R, const int64_t* sel, int m, float* out, void* stream);
 /* resunet.py:141-190 + the final normalisation of fcgf_feat.py:48.  coords (n,3) i32 distinct voxels, out (n,out_channels). */
 int yoho_fcgf_forward(yoho_ctx* ctx, const int32_t* coords, int n, float* out, void* stream);
 /* several clouds in one pass (the 60 rotated copies of a fragment, or the reference's DataLoader batch, YOHO_testset.py:172-180):

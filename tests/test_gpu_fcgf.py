@@ -44,6 +44,24 @@ def test_voxelize_first_occurrence(fctx):
     assert sel.tolist() == [0]
 
 
+def test_voxelize_rotated_equals_voxelising_the_rotated_copy(fctx, tables):
+    """yoho_fcgf_voxelize_rotated / yoho_rotate_select: same voxels, same first points and the same down-sampled cloud as
+    rotating on the host (pc @ R^T, f64) and voxelising the copy."""
+    pc = synth.surface_cloud(30000, seed=9, extent=2.0)
+    pc_d = torch.from_numpy(pc).cuda()
+    for g in (0, 7, 41):
+        R = tables.R64[g]
+        rot = pc @ R.T
+        s0, c0 = fo.voxelize(rot, 0.025)
+        sel, coords, ps = fctx.fcgf_voxelize_rotated(pc_d, R, 0.025)
+        assert np.array_equal(sel.cpu().numpy(), s0) and np.array_equal(coords.cpu().numpy(), c0)
+        assert np.allclose(ps.cpu().numpy(), rot[s0].astype(np.float32), rtol=0, atol=5e-7)
+        kidx = torch.arange(0, 30000, 7, device="cuda")
+        q = fctx.rotate_select(pc_d, R, kidx).cpu().numpy()
+        assert np.allclose(q, rot[::7].astype(np.float32), rtol=0, atol=5e-7)
+    assert np.array_equal(fctx.rotate_select(pc_d, None, kidx).cpu().numpy(), pc[::7].astype(np.float32))
+
+
 @pytest.mark.parametrize("n,seed", [(1500, 1), (6000, 2)])
 def test_backbone_vs_oracle(fctx, fsd, n, seed):
     pc = synth.surface_cloud(n, seed=seed)

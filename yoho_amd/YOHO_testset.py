@@ -46,9 +46,10 @@ class testset_create():
         self.ctx.set_nn_grid(self.config.voxel_size)                 # the targets are one point per voxel: grid search, same winners
         try:
             for g0 in range(0, 60, nb):
-                xyzs = [pc_d @ torch.from_numpy(np.ascontiguousarray(self.Rgroup[g].T)).cuda() for g in range(g0, g0 + nb)]
-                for j, (sel, feat) in enumerate(self.fcgf.extract_features_dev_batch(xyzs, self.config.voxel_size)):
-                    pts = xyzs[j][sel].to(torch.float32).contiguous()    # 'dspcd0' (.float(), YOHO_testset.py:92)
+                # rotated copies (pc @ R_g^T, :143) are never materialised: rotation, voxelisation and 'dspcd0' (the
+                # down-sampled points, .float(), :92) come out of one pass over the cloud
+                res = self.fcgf.extract_rotated_batch(pc_d, [self.Rgroup[g] for g in range(g0, g0 + nb)], self.config.voxel_size)
+                for j, (sel, feat, pts) in enumerate(res):
                     self.ctx.group_gather(k_d, pts, feat, g0 + j, out)   # keys @ R_g^T, f64 NN, feature row -> out[:, :, g]
         finally:
             self.ctx.set_nn_grid(0)

@@ -755,7 +755,24 @@ int yoho_fcgf_voxelize(yoho_ctx* c, const double* pts, int n, double voxel_size,
     if (n == 0) { *count = 0; return 0; }
     if (!pts || !sel || !coords) { set_error("yoho_fcgf_voxelize: bad argument"); return YOHO_EINVAL; }
     HIPCHK(hipSetDevice(c->device));
-    return fcgf_voxelize(c, pts, n, voxel_size, sel, coords, count, (hipStream_t)stream);
+    return fcgf_voxelize(c, pts, n, nullptr, voxel_size, sel, coords, nullptr, count, (hipStream_t)stream);
+}
+
+int yoho_fcgf_voxelize_rotated(yoho_ctx* c, const double* pts, int n, const double* R_host, double voxel_size, int64_t* sel, int32_t* coords,
+                               float* pts_sel, int* count, void* stream) {
+    if (!c || !count || !R_host || n < 0 || !(voxel_size > 0)) { set_error("yoho_fcgf_voxelize_rotated: bad argument"); return YOHO_EINVAL; }
+    if (n == 0) { *count = 0; return 0; }
+    if (!pts || !sel || !coords) { set_error("yoho_fcgf_voxelize_rotated: bad argument"); return YOHO_EINVAL; }
+    HIPCHK(hipSetDevice(c->device));
+    return fcgf_voxelize(c, pts, n, R_host, voxel_size, sel, coords, pts_sel, count, (hipStream_t)stream);
+}
+
+int yoho_rotate_select(yoho_ctx* c, const double* pts, const double* R_host, const int64_t* sel, int m, float* out, void* stream) {
+    if (!c || m < 0) { set_error("yoho_rotate_select: bad argument"); return YOHO_EINVAL; }
+    if (m == 0) return 0;
+    if (!pts || !sel || !out) { set_error("yoho_rotate_select: bad argument"); return YOHO_EINVAL; }
+    HIPCHK(hipSetDevice(c->device));
+    return fcgf_rotate_select(pts, R_host, sel, m, out, (hipStream_t)stream);
 }
 
 int yoho_fcgf_forward(yoho_ctx* c, const int32_t* coords, int n, float* out, void* stream) {

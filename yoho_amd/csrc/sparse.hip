@@ -50,12 +50,23 @@ struct CoordSrc {
     const double* pts;       // (n,3) or null
     double voxel;
     int ts;
+    int rot;                 // pts are rotated on the fly: p' = R p  (the 60 rotated copies of a fragment, YOHO_testset.py:143)
+    double R[9];
 };
+// one coordinate of R p in f64, fixed operation order
+__device__ __forceinline__ double rot_coord(const double* R3, double p0, double p1, double p2) { return fma(p2, R3[2], fma(p1, R3[1], p0 * R3[0])); }
+__device__ __forceinline__ void point_of(const CoordSrc& s, int i, double& p0, double& p1, double& p2) {
+    const double q0 = s.pts[3 * (size_t)i], q1 = s.pts[3 * (size_t)i + 1], q2 = s.pts[3 * (size_t)i + 2];
+    if (s.rot) { p0 = rot_coord(s.R, q0, q1, q2); p1 = rot_coord(s.R + 3, q0, q1, q2); p2 = rot_coord(s.R + 6, q0, q1, q2); }
+    else { p0 = q0; p1 = q1; p2 = q2; }
+}
 __device__ __forceinline__ void voxel_of(const CoordSrc& s, int i, int& x, int& y, int& z, int& b) {
     if (s.pts) {
-        x = (int)floor(s.pts[3 * (size_t)i] / s.voxel);
-        y = (int)floor(s.pts[3 * (size_t)i + 1] / s.voxel);
-        z = (int)floor(s.pts[3 * (size_t)i + 2] / s.voxel);
+        double p0, p1, p2;
+        point_of(s, i, p0, p1, p2);
+        x = (int)floor(p0 / s.voxel);
+        y = (int)floor(p1 / s.voxel);
+        z = (int)floor(p2 / s.voxel);
         b = 0;
     } else {
         const int4 c = reinterpret_cast<const int4*>(s.coords)[i];
@@ -1075,11 +1086,11 @@ int fcgf_forward(yoho_ctx* ctx, const FcgfNet* net, const int* coords0, int n0, 
         L[l].keys = ar.take<u64>(L[l].mask + 1);
         L[l].vals = ar.take<int>(L[l].mask + 1);
         if (l == 0) {
-            CoordSrc src{L[0].coords, nullptr, 1.0, 1};
+            CoordSrc src{L[0].coords, nullptr, 1.0, 1, 0, {0}};
             if ((rc = build_table(src, n0, L[0], s))) return rc;
             // distinct input voxels: value = row (atomicMin of the single source row)
         } else {
-            CoordSrc src{L[l - 1].coords, nullptr, 1.0, L[l].ts};
+            CoordSrc src{L[l - 1].coords, nullptr, 1.0, L[l].ts, 0, {0}};
             if ((rc = build_table(src, nprev, L[l], s))) return rc;
             L[l].coords = ar.take<int>((size_t)nprev * 4);
             int* bsum = ar.take<int>((size_t)(nprev + 1023) / 1024 + 1);
@@ -1211,7 +1222,29 @@ int fcgf_forward(yoho_ctx* ctx, const FcgfNet* net, const int* coords0, int n0, 
 }
 
 // voxelisation (fcgf_feat.py:33-43): first point of every voxel in input order -> sel (ascending), integer coordinates
-int fcgf_voxelize(yoho_ctx* ctx, const double* pts, int n, double voxel, int64_t* sel, int* coords, int* count_host, hipStream_t s) {
+// the selected points, rotated like the voxelisation saw them, as fp32 (the reference's pcd[sel].float())
+__global__ void rotate_sel_kernel(CoordSrc src, const int64_t* __restrict__ sel, int m, float* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= m) return;
+    double p0, p1, p2;
+    point_of(src, (int)sel[i], p0, p1, p2);
+    out[3 * (size_t)i] = (float)p0; out[3 * (size_t)i + 1] = (float)p1; out[3 * (size_t)i + 2] = (float)p2;
+}
+
+int fcgf_rotate_select(const double* pts, const double* R_host, const int64_t* sel, int m, float* out, hipStream_t s) {
+    if (m == 0) return 0;
+    CoordSrc src{nullptr, pts, 1.0, 1, R_host ? 1 : 0, {0}};
+    if (R_host) for (int i = 0; i < 9; ++i) src.R[i] = R_host[i];
+    hipLaunchKernelGGL(rotate_sel_kernel, dim3((m + 255) / 256), dim3(256), 0, s, src, sel, m, out);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// voxelisation (fcgf_feat.py:33-43): first point of every voxel in input order -> sel (ascending), integer coordinates.
+// R_host (9 doubles, row major) or null: the points are rotated (p' = R p, f64) on the fly; pts_sel (n,3) f32 or null
+// receives the rotated selected points.
+int fcgf_voxelize(yoho_ctx* ctx, const double* pts, int n, const double* R_host, double voxel, int64_t* sel, int* coords, float* pts_sel,
+                  int* count_host, hipStream_t s) {
     if (n == 0) { *count_host = 0; return 0; }
     int rc;
     const unsigned cap = table_cap(n);
@@ -1220,12 +1253,14 @@ int fcgf_voxelize(yoho_ctx* ctx, const double* pts, int n, double voxel, int64_t
     Level L;
     L.mask = cap - 1; L.keys = ar.take<u64>(cap); L.vals = ar.take<int>(cap);
     int* dcount = ar.take<int>(1);
-    CoordSrc src{nullptr, pts, voxel, 1};
+    CoordSrc src{nullptr, pts, voxel, 1, R_host ? 1 : 0, {0}};
+    if (R_host) for (int i = 0; i < 9; ++i) src.R[i] = R_host[i];
     if ((rc = build_table(src, n, L, s))) return rc;
     int* bsum = ar.take<int>((size_t)(n + 1023) / 1024 + 1);
     if ((rc = launch_first_compact(src, n, L.keys, L.vals, L.mask, bsum, coords, 3, sel, dcount, s))) return rc;
     HIPCHK(hipMemcpyAsync(count_host, dcount, sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
+    if (pts_sel) return fcgf_rotate_select(pts, R_host, sel, *count_host, pts_sel, s);
     return 0;
 }
 

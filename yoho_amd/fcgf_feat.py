@@ -75,6 +75,22 @@ class fcgf_extractor():
             feats += self.ctx.fcgf_forward_batch(group)
         return [(sel, f) for (sel, _), f in zip(vox, feats)]
 
+    def extract_rotated_batch(self, pts, rotations, voxel_size):
+        """the backbone on rotated copies of one cloud: pts (n,3) f64 cuda, rotations = list of (3,3) R (p' = R p) ->
+        list of (sel, F, rotated selected points (m,3) f32).  The copies are never materialised: rotation, voxelisation and
+        the down-sampled points come from one pass over pts (yoho_fcgf_voxelize_rotated)."""
+        vox = [self.ctx.fcgf_voxelize_rotated(pts, R, voxel_size) for R in rotations]
+        feats, group, rows = [], [], 0
+        for _, c, _ in vox:
+            if group and (rows + c.shape[0] > self.MAX_VOXELS_PER_PASS or len(group) == 64):
+                feats += self.ctx.fcgf_forward_batch(group)
+                group, rows = [], 0
+            group.append(c)
+            rows += c.shape[0]
+        if group:
+            feats += self.ctx.fcgf_forward_batch(group)
+        return [(sel, f, ps) for (sel, _, ps), f in zip(vox, feats)]
+
     def extract_features(self, pc, voxel_size):
         pts = torch.from_numpy(np.ascontiguousarray(np.asarray(pc, dtype=np.float64))).cuda()
         sel, F = self.extract_features_dev(pts, voxel_size)

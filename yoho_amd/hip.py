@@ -18,7 +18,7 @@ _lib = None
 SYMBOLS = [
     "yoho_last_error", "yoho_version", "yoho_ctx_create", "yoho_ctx_destroy", "yoho_load_partI",
     "yoho_load_partII", "yoho_partI_forward", "yoho_partI_forward_pair", "yoho_group_mean_np", "yoho_nn_search", "yoho_mutual_nn",
-    "yoho_gconv_layer", "yoho_load_fcgf", "yoho_fcgf_voxelize", "yoho_fcgf_forward", "yoho_fcgf_forward_batch",
+    "yoho_gconv_layer", "yoho_load_fcgf", "yoho_fcgf_voxelize", "yoho_fcgf_forward", "yoho_fcgf_forward_batch", "yoho_fcgf_voxelize_rotated", "yoho_rotate_select",
     "yoho_des2r", "yoho_des2r_indexed", "yoho_partII_forward", "yoho_partII_forward_indexed", "yoho_hyp_from_quat", "yoho_o_score", "yoho_c_ransac",
     "yoho_group_gather", "yoho_set_profiling", "yoho_get_kernel_ms", "yoho_set_gconv_mode", "yoho_set_partII_mode", "yoho_set_nn_grid",
 ]
@@ -94,6 +94,8 @@ def load_library():
     lib.yoho_set_gconv_mode.argtypes = [vp, ci]
     lib.yoho_set_partII_mode.argtypes = [vp, ci]
     lib.yoho_set_nn_grid.argtypes = [vp, C.c_double]
+    lib.yoho_fcgf_voxelize_rotated.argtypes = [vp, vp, ci, vp, C.c_double, vp, vp, vp, vp, vp]
+    lib.yoho_rotate_select.argtypes = [vp, vp, vp, vp, ci, vp, vp]
     lib.yoho_get_kernel_ms.argtypes = [vp, ci, C.POINTER(C.c_float)]
     for s in SYMBOLS[2:]:
         getattr(lib, s).restype = ci
@@ -230,6 +232,30 @@ class Context:
         _check(self._lib.yoho_fcgf_voxelize(self._h, _dev(pts, torch.float64, "pts"), n, float(voxel_size), C.c_void_p(sel.data_ptr()),
                                             C.c_void_p(coords.data_ptr()), C.byref(cnt), _stream()))
         return sel[:cnt.value], coords[:cnt.value]
+
+    def fcgf_voxelize_rotated(self, pts, R, voxel_size, want_points=True):
+        """voxelise the copy of pts (n,3) f64 cuda rotated by R (3,3) (p' = R p) without materialising it ->
+        (sel, coords[, rotated selected points (m,3) f32])."""
+        n = pts.shape[0]
+        Rh = np.ascontiguousarray(np.asarray(R, dtype=np.float64).reshape(3, 3))
+        sel = torch.empty((n,), dtype=torch.int64, device=pts.device)
+        coords = torch.empty((n, 3), dtype=torch.int32, device=pts.device)
+        ps = torch.empty((n, 3), dtype=torch.float32, device=pts.device) if want_points else None
+        cnt = C.c_int(0)
+        _check(self._lib.yoho_fcgf_voxelize_rotated(self._h, _dev(pts, torch.float64, "pts"), n, _np_ptr(Rh), float(voxel_size),
+                                                    C.c_void_p(sel.data_ptr()), C.c_void_p(coords.data_ptr()),
+                                                    C.c_void_p(ps.data_ptr()) if want_points else None, C.byref(cnt), _stream()))
+        m = cnt.value
+        return (sel[:m], coords[:m], ps[:m]) if want_points else (sel[:m], coords[:m])
+
+    def rotate_select(self, pts, R, sel):
+        """(float32)(R pts[sel]) for pts (n,3) f64 cuda, sel (m,) int64 cuda; R (3,3) or None."""
+        m = sel.shape[0]
+        out = torch.empty((m, 3), dtype=torch.float32, device=pts.device)
+        Rh = None if R is None else np.ascontiguousarray(np.asarray(R, dtype=np.float64).reshape(3, 3))
+        _check(self._lib.yoho_rotate_select(self._h, _dev(pts, torch.float64, "pts"), _np_ptr(Rh) if Rh is not None else None,
+                                            _dev(sel, torch.int64, "sel"), m, C.c_void_p(out.data_ptr()), _stream()))
+        return out
 
     def fcgf_forward(self, coords):
         """coords (n,3) int32 cuda, distinct voxels -> (n, out_channels) f32 unit rows."""

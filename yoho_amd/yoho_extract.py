@@ -60,13 +60,23 @@ class yoho_extractor():
             # HBM-resident path: the cloud is uploaded once; rotation (f64), voxelisation, backbone and the NN feature
             # transfer of all 60 group elements run on the device (same operations as the loop below)
             pc_d = torch.from_numpy(np.ascontiguousarray(np.asarray(pc, dtype=np.float64))).cuda()
-            kp_d = pc_d[torch.from_numpy(kpts_index).cuda()]
+            kidx_d = torch.from_numpy(kpts_index.astype(np.int64)).cuda()
             G, nb = self.grs.shape[0], self.rot_batch
             self.ctx.set_nn_grid(voxel_size)       # the NN targets are one point per voxel: grid search, same winners
             try:
                 for i0 in range(0, G, nb):
-                    Rts = [torch.from_numpy(np.ascontiguousarray(self.grs[i].T)).cuda() for i in range(i0, min(i0 + nb, G))]
+                    Rs = [self.grs[i] for i in range(i0, min(i0 + nb, G))]
+                    if hasattr(self.fcgf, "extract_rotated_batch"):
+                        # rotated copies never materialised: rotation + voxelisation + down-sampled points in one pass
+                        res = self.fcgf.extract_rotated_batch(pc_d, Rs, voxel_size)
+                        for j, (sel, pci_f, ds) in enumerate(res):
+                            q = self.ctx.rotate_select(pc_d, Rs[j], kidx_d)
+                            _, idx = self.ctx.nn_search(q, ds, want_dist=False, squared=True)
+                            kpts_f[:, :, i0 + j] = pci_f[idx]
+                        continue
+                    Rts = [torch.from_numpy(np.ascontiguousarray(R.T)).cuda() for R in Rs]
                     pcs = [pc_d @ Rt for Rt in Rts]
+                    kp_d = pc_d[kidx_d]
                     for j, (pci, (sel, pci_f)) in enumerate(zip(pcs, self.fcgf.extract_features_dev_batch(pcs, voxel_size))):
                         q = (kp_d @ Rts[j]).to(torch.float32).contiguous()
                         _, idx = self.ctx.nn_search(q, pci[sel].to(torch.float32).contiguous(), want_dist=False, squared=True)
