@@ -48,7 +48,7 @@ struct FGemmArgs {
     const char* A;        // weight planes, all irreps
     const char* B;        // activation planes, all irreps
     const float* bias;
-    const float* res;     // fp32 coefficient slabs [tile32][cout8][60][h][kp32][4] or null
+    const float* res;     // fp32 coefficient slabs [tile32][60 q][cout8][h][kp32][4] or null (q-major: a workgroup owns one q)
     float* out;           // same layout
     long long a_off[NIR_ORD], b_off[NIR_ORD];
     int NT[NIR_ORD], MT[NIR_ORD], rot[NIR_ORD];
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(256, 1) void fgemm_kernel(FGemmArgs a, int flags) {
 #pragma unroll
                 for (int q4 = 0; q4 < 4; ++q4) {
                     const int o = o0 + q4 * 8 + half * 4;
-                    const size_t off = (((((size_t)tile32 * cout8 + (o >> 3)) * G + q) * 2 + half) * TILE + kp32) * 4;
+                    const size_t off = (((((size_t)tile32 * G + q) * cout8 + (o >> 3)) * 2 + half) * TILE + kp32) * 4;
                     // branch-free, so that all loads go out back to back
                     const floatx4 v = *reinterpret_cast<const floatx4*>(a.res + (ok ? off : 0)) * (ok ? inv : 0.f);
                     acc[ai][bi][4 * q4 + 0] = v.x; acc[ai][bi][4 * q4 + 1] = v.y;
@@ -279,7 +279,7 @@ __global__ __launch_bounds__(256, 1) void fgemm_kernel(FGemmArgs a, int flags) {
                 val.z = acc[ai][bi][4 * q4 + 2]; val.w = acc[ai][bi][4 * q4 + 3];
                 val *= a.descale;
                 if (addb) val += *reinterpret_cast<const floatx4*>(a.bias + o) * 7.745966692414834f;
-                const size_t off = (((((size_t)tile32 * cout8 + (o >> 3)) * G + q) * 2 + half) * TILE + kp32) * 4;
+                const size_t off = (((((size_t)tile32 * G + q) * cout8 + (o >> 3)) * 2 + half) * TILE + kp32) * 4;
                 *reinterpret_cast<floatx4*>(a.out + off) = val;
             }
         }

@@ -10,6 +10,7 @@
 // Output: fp16x2 operand planes of the irrep GEMMs (gemmf.hip), gathered to 16-byte units through LDS, or the fp32
 // coefficient chunk again (input of the fp32 Fourier kernel).
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <type_traits>
 #include <vector>
 #include <cmath>
@@ -63,9 +64,13 @@ __device__ __forceinline__ void split_pair(float x0, float x1, unsigned& hi, uns
     __builtin_memcpy(&lo, &l, 4);
 }
 
-__device__ __forceinline__ void stage_chunk(const float* src, char* dst, int w, int lane) {
-    const char* s = reinterpret_cast<const char*>(src);
-    for (int p = w; p < G; p += 4) __builtin_amdgcn_global_load_lds((gptr_t)(s + p * 1024 + lane * 16), (lptr_t)(dst + p * 1024), 16, 0, 0);
+// the 60 coefficient rows (1 KiB each) of chunk (tile32, c8) of an irrep-GEMM output, stored [tile32][q][C8][1 KiB] (the GEMM
+// workgroup that owns one coefficient q of 32 channel groups then writes 32 KiB contiguously; the rows read here are C8 KiB apart)
+__device__ __forceinline__ void stage_chunk(const float* in, int chunk, int C8, char* dst, int w, int lane) {
+    const int c8 = chunk % C8, tile32 = chunk / C8;
+    const char* s = reinterpret_cast<const char*>(in) + ((size_t)tile32 * G * C8 + c8) * 1024;
+    const size_t rs = (size_t)C8 * 1024;
+    for (int p = w; p < G; p += 4) __builtin_amdgcn_global_load_lds((gptr_t)(s + p * rs + lane * 16), (lptr_t)(dst + p * 1024), 16, 0, 0);
 }
 
 enum { G16_ACT32 = 0, G16_ACTP = 1, G16_INV = 2, G16_INVP = 3 };
@@ -99,13 +104,13 @@ __global__ __launch_bounds__(256, 1) void gft16_kernel(Gft16Args a) {
             }
 
     int chunk = blockIdx.x;
-    if (chunk < a.nChunks) stage_chunk(a.in + (size_t)chunk * CHUNK_FLOATS, smem, w, lane);
+    if (chunk < a.nChunks) stage_chunk(a.in, chunk, a.C8, smem, w, lane);
     for (int it = 0; chunk < a.nChunks; chunk += gridDim.x, ++it) {
         char* cur = smem + (it & 1) * GB;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         const int next = chunk + gridDim.x;
-        if (next < a.nChunks) stage_chunk(a.in + (size_t)next * CHUNK_FLOATS, smem + ((it + 1) & 1) * GB, w, lane);
+        if (next < a.nChunks) stage_chunk(a.in, next, a.C8, smem + ((it + 1) & 1) * GB, w, lane);
         const int c8 = chunk % a.C8, tile32 = chunk / a.C8;
 
         // ---- product 1: group domain = F^T * coefficients (this wave's 64 columns: lane -> columns 64w + 2Lp + {0,1})
