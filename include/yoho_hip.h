@@ -15,6 +15,8 @@
  *   yoho_hyp_from_quat      quat -> [R|t] loops           tests/extractor.py:187-199, utils/r_eval.py:94-110
  *   yoho_o_score            yohoo.ransac scoring loop     tests/estimator.py:330-336, :286-290
  *   yoho_c_ransac           yohoc.ransac loop body        tests/estimator.py:119-137, :55-70
+ *   yoho_c_ransac_device    yohoc.ransac incl. sampling   tests/estimator.py:34-51,:119-137 (device RNG)
+ *   yoho_range_status       (fp16 range guard, no counterpart: the reference computes in fp32)
  *   yoho_group_gather       60-fold FCGF feature gather   YOHO_testset.py:153-166
  *   yoho_set_nn_grid             (speed hint, no counterpart)    voxel size of YOHO_testset.py:39-49 / simple_yoho/fcgf_feat.py:33-43
  *   yoho_partI_forward_pair      the two PartI passes of a pair  tests/extractor.py:37-62 (one pass per fragment there)
@@ -50,6 +52,7 @@ extern "C" {
 #define YOHO_EHIP         -2   /* HIP runtime error (message has the hipError string) */
 #define YOHO_ENOWEIGHTS   -3   /* forward called before yoho_load_* */
 #define YOHO_ENOMEM       -4
+#define YOHO_ERANGE       -5   /* a value left the fp16 range of the fp16x2 arithmetic (yoho_range_status) */
 
 typedef struct yoho_ctx yoho_ctx;
 
@@ -151,6 +154,21 @@ int yoho_c_ransac(yoho_ctx* ctx, const double* k0, const double* k1, int M, cons
                   const uint8_t* reflect, int I, double d, double* best_T, int* best_iter,
                   int* best_count, double* T_out, int32_t* counts, void* stream);
 
+/* YOHO-C with no host work (throughput mode of yohoc.ransac, tests/estimator.py:28-141): the histogram of dr_index over
+ * the M matches, the weights n (n - .01)(n - .02) (:34-51), the two draws of every iteration (:119-128) from a
+ * counter-based Philox4x32-10 stream keyed by `seed`, the 3-point Kabsch (proper rotation) and the inlier vote run on the
+ * device; exactly max_iter iterations are scored.  keys0 / keys1 (.,3) f64 are addressed through the row indices
+ * i0[m * istride] / i1[m * istride] (e.g. the two columns of a (M,2) match list, istride 2), or directly when i0 / i1 are
+ * NULL.  best_T (3,4) f64, best_iter = 1-based index of the first best iteration (0: no inlier anywhere, best_T = eye;
+ * 50001: fewer than two matches share a coarse rotation, the reference's 'no estimate' code), best_count = its inliers.
+ * triples_out (max_iter,3) int64 receives the sampled matches, or NULL.  Deviation from the reference, stated: numpy's
+ * MT19937 stream cannot be continued on the device, so for a given seed the triples are those of
+ * oracle/yoho_oracle.py:yohoc_device_triples, not np.random's, and reflections (LAPACK's arbitrary det = -1 answers, see
+ * yoho_c_ransac) are never scored.  The host-RNG parity mode is yoho_c_ransac. */
+int yoho_c_ransac_device(yoho_ctx* ctx, const double* keys0, const int64_t* i0, const double* keys1, const int64_t* i1,
+                         int istride, const int64_t* dr_index, int M, int max_iter, uint64_t seed, double d,
+                         double* best_T, int* best_iter, int* best_count, int64_t* triples_out, void* stream);
+
 /* one group element of the 60-fold gather: rotate keys (K,3) f64 by Rg (3x3 f64, host ptr),
  * 1-NN among pts (n,3) f32 in f64, copy feat (n,32) rows into out[:, :, g] of (K,32,60);
  * nn_idx (K) int64 may be NULL. */
@@ -220,6 +238,16 @@ int yoho_set_partII_mode(yoho_ctx* ctx, int mode);
 
 /* timing hook for bench.py: average device time (ms) of the last yoho_partI_forward's dominant
  * group-conv launches, measured with hipEvents on the call's own stream.  <0 if unavailable. */
+/* fp16 range guard.  The default arithmetic (PartI mode 4, PartII mode 2; also PartI mode 3) keeps activations and
+ * Fourier coefficients as fixed power-of-two multiples in fp16 planes (|activation| < 4094, |coefficient| < 16376).
+ * Every kernel that writes such planes raises a device-side flag when a value falls outside; nothing else in the
+ * forward calls changes (they stay asynchronous, and their outputs are then not to be trusted).
+ * yoho_range_status waits for `stream`, reports and clears the flags (out pointers may be NULL) and returns
+ * YOHO_ERANGE if either was set, 0 otherwise; the caller then repeats the pass after yoho_set_gconv_mode(ctx, 1) /
+ * yoho_set_partII_mode(ctx, 1) (bf16x3 planes carry the fp32 exponent range) - yoho_amd/hip.py does exactly that.
+ * The reference computes in fp32 throughout (utils/network.py:12-105, 259-278), so it has no counterpart. */
+int yoho_range_status(yoho_ctx* ctx, int* partI_overflow, int* partII_overflow, void* stream);
+
 int yoho_set_profiling(yoho_ctx* ctx, int enable);
 int yoho_get_kernel_ms(yoho_ctx* ctx, int which, float* ms);
 

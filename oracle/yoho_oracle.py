@@ -366,6 +366,53 @@ def yohoc_draw_triples(dr_idx, max_iter, rng):
     return np.array(tri, dtype=np.int64).reshape(-1, 3)
 
 
+def philox4x32_10(counter, key):
+    """Philox4x32-10 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3", SC'11): counter = 4 and key = 2 words
+    of 32 bits, plain Python integers.  The generator of the build's device-side YOHO-C sampling (csrc/estim.hip)."""
+    c0, c1, c2, c3 = (int(v) & 0xFFFFFFFF for v in counter)
+    k0, k1 = (int(v) & 0xFFFFFFFF for v in key)
+    for _ in range(10):
+        p0, p1 = 0xD2511F53 * c0, 0xCD9E8D57 * c2
+        c0, c1, c2, c3 = ((p1 >> 32) ^ c1 ^ k0) & 0xFFFFFFFF, p1 & 0xFFFFFFFF, ((p0 >> 32) ^ c3 ^ k1) & 0xFFFFFFFF, p0 & 0xFFFFFFFF
+        k0, k1 = (k0 + 0x9E3779B9) & 0xFFFFFFFF, (k1 + 0xBB67AE85) & 0xFFFFFFFF
+    return c0, c1, c2, c3
+
+
+def yohoc_device_triples(dr_idx, max_iter, seed):
+    """The sampling half of yohoc.ransac (tests/estimator.py:34-51,119-128) as yoho_c_ransac_device draws it: same
+    statistic (buckets in ascending match order, weights n(n-.01)(n-.02) for buckets of >= 2 matches), same kind of draw
+    (a cdf search for the coarse index, then three members of its bucket with replacement), but from a counter-based
+    Philox stream keyed by `seed` instead of numpy's global MT19937 stream:
+        iteration it: (w0, w1, .., ..) = philox((it,0,0,0), seed) -> u = ((w0 << 21) | (w1 >> 11)) / 2^53,
+                      bucket = first b with cumsum(p)[b] > u * sum(p)   (p unnormalised, summed b = 0..59 in f64);
+                      (v0, v1, v2, ..) = philox((it,1,0,0), seed) -> member j = bucket[(v_j * len(bucket)) >> 32].
+    Returns the (max_iter,3) int64 triples, or None when no bucket has two matches (reference: recalltime 50001)."""
+    dr = np.clip(np.asarray(dr_idx, dtype=np.int64), 0, G - 1)
+    buckets = [np.nonzero(dr == b)[0] for b in range(G)]
+    run, cdf = 0.0, []
+    for b in range(G):
+        p = 0.0
+        if len(buckets[b]) >= 2:
+            num = float(len(buckets[b])) / 100.0
+            p = (num * (num - 0.01)) * (num - 0.02)
+        run = run + p
+        cdf.append(run)
+    if run < 1e-4:
+        return None
+    key = (seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+    tri = np.zeros((max_iter, 3), dtype=np.int64)
+    for it in range(max_iter):
+        w = philox4x32_10((it, 0, 0, 0), key)
+        v = philox4x32_10((it, 1, 0, 0), key)
+        u = float((w[0] << 21) | (w[1] >> 11)) * 2.0 ** -53
+        thr = u * cdf[-1]
+        b = next((j for j in range(G) if cdf[j] > thr), G - 1)
+        n = len(buckets[b])
+        for p_ in range(3):
+            tri[it, p_] = buckets[b][(v[p_] * n) >> 32]
+    return tri
+
+
 # ----------------------------------------------------------------------------------------
 # a2: 60-fold FCGF feature gather
 # ----------------------------------------------------------------------------------------

@@ -1,0 +1,200 @@
+"""Parity of the path that ships, at the size it is benchmarked at (-m gpu).
+
+bench.py times pipeline.run_pair on 2 x 5000 keypoints in the DEFAULT arithmetic (PartI: irrep GEMMs on the
+fp16x2 split MFMA, 'fgemm'; PartII: Fourier first layer + cone kernels, 'fp16x2'), which produces ~3200 mutual
+matches.  This file checks exactly that configuration stage by stage against the oracle (each stage's oracle
+is fed the GPU outputs of the stage before it, so every comparison isolates one kernel chain), the behaviour
+for inputs far from unit scale, and the fp16 range guard (BN gamma blown up 100x -> flag -> bf16x3 repeat).
+"""
+import os
+import sys
+import warnings
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+import yoho_oracle as orc  # noqa: E402
+from yoho_amd import synth, weights as W, pipeline  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4          # relative fp32 tolerance from BASELINE.json north_star
+
+
+def rel(a, b):
+    return float(np.max(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64))) / max(np.max(np.abs(b)), 1e-30))
+
+
+def cu(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.fixture(scope="module")
+def dctx(hip, sd1, sd2):
+    """context in the default arithmetic modes (what bench.py runs)"""
+    c = hip.Context()
+    c.load_partI(sd1)
+    c.load_partII(sd2)
+    assert c.gconv_mode == "fgemm" and c.partII_mode == "fp16x2"
+    return c
+
+
+def test_run_pair_full_size_default_modes_vs_oracle(dctx, sd1, sd2, tables):
+    KP = 5000
+    pr = synth.make_pair(KP, seed=10)                       # bench.py's rank-0 pair
+    f0, f1, k0, k1 = cu(pr["feat0"]), cu(pr["feat1"]), cu(pr["keys0"]), cu(pr["keys1"])
+    res = pipeline.run_pair(dctx, f0, f1, k0, k1, inlier_dist=0.09, max_iter=1000, order_rng=np.random.RandomState(1234))
+    assert res.range_repeats == 0
+    e0, e1 = res.eqv[0]["eqv"].cpu().numpy(), res.eqv[1]["eqv"].cpu().numpy()
+    # -- PartI (a5): rows are independent, so a random sample of 256 of the 10000 rows pins the pass
+    rs = np.random.RandomState(0)
+    for feat, e in ((pr["feat0"], e0), (pr["feat1"], e1)):
+        rows = np.sort(rs.permutation(KP)[:128])
+        eo, _ = orc.partI_forward(feat[rows], sd1, tables.N)
+        r = rel(e[rows], eo)
+        print("PartI fgemm at 10000 kp, 128 sampled rows: rel err vs oracle %.3g" % r)
+        assert r < TOL
+    # -- invariant pooling + matcher (a7): bit-exact numpy-order mean, bit-exact match list
+    i0, i1 = res.eqv[0]["inv_np"].cpu().numpy(), res.eqv[1]["inv_np"].cpu().numpy()
+    assert np.array_equal(i0, np.mean(e0, axis=-1)) and np.array_equal(i1, np.mean(e1, axis=-1))
+    match = res.match.cpu().numpy()
+    assert np.array_equal(match, orc.mutual_match(i0, i1))
+    M = match.shape[0]
+    assert 2500 < M < 4000, M
+    m0, m1 = match[:, 0], match[:, 1]
+    # -- Des2R (a8) in full; the reference's einsum order is BLAS-defined, so near-ties (top-2 gap < 1e-4) may differ
+    cor = orc.des2r_cor(e1[m1], e0[m0], tables.P)
+    dr_o = np.argmax(cor, axis=1)
+    dr = res.dr_index.cpu().numpy()
+    top2 = np.sort(cor, axis=1)[:, -2:]
+    gap = top2[:, 1] - top2[:, 0]
+    differ = dr != dr_o
+    print("Des2R at M=%d: %d near-ties (gap < 1e-4), %d index disagreements (all of them near-ties: %s)"
+          % (M, int((gap < 1e-4).sum()), int(differ.sum()), bool((gap[differ] < 1e-4).all())))
+    assert (gap[differ] < 1e-4).all()
+    assert differ.sum() <= 2
+    # -- PartII (a9) for every match, default arithmetic
+    qo = np.concatenate([orc.partII_forward(pr["feat1"][m1[s:s + 400]], pr["feat0"][m0[s:s + 400]], e1[m1[s:s + 400]], e0[m0[s:s + 400]],
+                                            dr[s:s + 400], sd2, tables.N, tables.P) for s in range(0, M, 400)])
+    q = res.quat.cpu().numpy()
+    r = rel(q, qo)
+    print("PartII (Fourier first layer + cone kernels) at M=%d: rel err vs oracle %.3g" % (M, r))
+    assert r < TOL
+    # -- hypotheses (a10) and the YOHO-O vote (a11)
+    k0m, k1m = pr["keys0"][m0], pr["keys1"][m1]
+    T = res.trans_pre.cpu().numpy()
+    assert rel(T, orc.hyp_from_quat(qo, dr, k0m, k1m, tables.R32)) < TOL
+    bid, cnt, Tb = orc.yohoo_select(k0m, k1m, T, res.order, 0.09, 1000)
+    assert (res.best_h, res.best_count) == (bid, cnt)
+    assert np.array_equal(res.trans, Tb)
+    # the planted transform is recovered
+    R_err = np.degrees(np.arccos(np.clip((np.trace(pr["gt"][:, :3].T @ res.trans[:, :3]) - 1) / 2, -1, 1)))
+    print("YOHO-O: hypothesis %d, %d inliers of %d, rotation error %.2f deg" % (bid, cnt, M, R_err))
+    assert R_err < 5.0
+
+
+@pytest.mark.parametrize("scale", [1e-3, 30.0, 300.0])
+def test_default_modes_off_nominal_input_scales(dctx, sd1, sd2, tables, scale):
+    """inputs far from unit norm through the DEFAULT modes (fgemm / PartII fp16x2): tiny values exercise the low planes
+    near the bottom of the fp16 exponent range, large ones the top (the range guard may repeat the pass in bf16x3;
+    either way the result must match the oracle)"""
+    x = synth.unit_features(70, seed=77) * np.float32(scale)
+    with warnings.catch_warnings(record=True) as wrn:
+        warnings.simplefilter("always")
+        before = dctx.range_fallbacks
+        o = dctx.partI_forward(cu(x), want_inv=True)
+        e, i = orc.partI_forward(x, sd1, tables.N)
+        r = rel(o["eqv"].cpu().numpy(), e)
+        print("fgemm, input scale %g: rel err %.3g, %d bf16x3 repeats" % (scale, r, dctx.range_fallbacks - before))
+        assert r < TOL and rel(o["inv"].cpu().numpy(), i) < TOL
+        M = 40
+        rs = np.random.RandomState(5)
+        a, b, c_, d = (synth.unit_features(M, seed=sdd) * np.float32(scale) for sdd in (1, 2, 3, 4))
+        dr = rs.randint(0, 60, size=M).astype(np.int64)
+        before = dctx.range_fallbacks
+        q = dctx.partII_forward(cu(a), cu(b), cu(c_), cu(d), cu(dr)).cpu().numpy()
+        qo = orc.partII_forward(a, b, c_, d, dr, sd2, tables.N, tables.P)
+        print("PartII default, input scale %g: rel err %.3g, %d bf16x3 repeats" % (scale, rel(q, qo), dctx.range_fallbacks - before))
+        assert np.isfinite(q).all() and rel(q, qo) < TOL
+    assert all(issubclass(w.category, RuntimeWarning) for w in wrn)
+
+
+def _blow_up(sd, key, factor):
+    sd = {k: v.copy() for k, v in sd.items()}
+    sd[key] = (sd[key] * np.float32(factor)).astype(np.float32)
+    return sd
+
+
+def test_fp16_range_guard_partI(hip, sd1, tables):
+    """BN gamma of the 512-channel layer blown up 100x on top of large inputs: activations leave the fp16 planes'
+    range.  The kernels must raise the flag (yoho_range_status -> YOHO_ERANGE) and the wrapper must deliver the
+    bf16x3 result, equal to the oracle's; unguarded fp16 output is wrong (that is what the guard is for)."""
+    sdx = _blow_up(sd1, "PartI_net.SO3_Conv_layers.0.comb_layer_out.0.weight", 100.0)
+    c = hip.Context()
+    c.load_partI(sdx)
+    x = synth.unit_features(50, seed=9) * np.float32(100.0)     # activations ~1e4 after the blown-up BN: beyond 65504 / 16
+    xd = cu(x)
+    eo, io = orc.partI_forward(x, sdx, tables.N)
+    # raw library behaviour: flag raised, status call reports and clears it
+    raw = c.partI_forward(xd, want_inv=True, check_range=False)
+    st = c.range_status()
+    assert st == (True, False), st
+    assert c.range_status() == (False, False)               # cleared
+    rc = c._lib.yoho_range_status(c._h, None, None, None)
+    assert rc == 0
+    raw_err = rel(np.nan_to_num(raw["eqv"].cpu().numpy(), nan=1e9, posinf=1e9, neginf=-1e9), eo)
+    # guarded call: repeated in bf16x3
+    with pytest.warns(RuntimeWarning, match="fp16 range"):
+        out = c.partI_forward(xd, want_inv=True)
+    assert c.range_fallbacks == 1 and c.gconv_mode == "fgemm"      # mode restored
+    r = rel(out["eqv"].cpu().numpy(), eo)
+    print("range guard: unguarded fp16x2 rel err %.3g -> guarded (bf16x3 repeat) %.3g" % (raw_err, r))
+    assert r < TOL and rel(out["inv"].cpu().numpy(), io) < TOL
+    assert raw_err > TOL
+    # nominal inputs with the same context afterwards: no flag, no repeat
+    x1 = synth.unit_features(33, seed=10) * np.float32(1e-2)
+    o1 = c.partI_forward(cu(x1))
+    assert c.range_fallbacks == 1
+    assert rel(o1["eqv"].cpu().numpy(), orc.partI_forward(x1, sdx, tables.N)[0]) < TOL
+    # the C ABI reports YOHO_ERANGE (-5) with a message when polled after an overflowing pass
+    c.partI_forward(xd, check_range=False)
+    rc = c._lib.yoho_range_status(c._h, None, None, None)
+    assert rc == -5 and b"fp16 range" in c._lib.yoho_last_error()
+
+
+def test_fp16_range_guard_partII_and_pipeline(hip, sd1, sd2, tables):
+    """the same for PartII (BN after the first layer blown up) through pipeline.run_pair: the pair is repeated with
+    PartII in bf16x3 and ends with the oracle's quaternions"""
+    sdx = _blow_up(sd2, "PartII_SO3_Conv_layers.0.comb_layer_in.0.weight", 20000.0)
+    c = hip.Context()
+    c.load_partI(sd1)
+    c.load_partII(sdx)
+    pr = synth.make_pair(300, seed=6)
+    with pytest.warns(RuntimeWarning, match="fp16 range"):
+        res = pipeline.run_pair(c, cu(pr["feat0"]), cu(pr["feat1"]), cu(pr["keys0"]), cu(pr["keys1"]), order_rng=np.random.RandomState(0))
+    assert res.range_repeats == 1 and c.partII_mode == "fp16x2"
+    m = res.match.cpu().numpy()
+    e0, e1 = res.eqv[0]["eqv"].cpu().numpy(), res.eqv[1]["eqv"].cpu().numpy()
+    dr = res.dr_index.cpu().numpy()
+    qo = orc.partII_forward(pr["feat1"][m[:, 1]], pr["feat0"][m[:, 0]], e1[m[:, 1]], e0[m[:, 0]], dr, sdx, tables.N, tables.P)
+    r = rel(res.quat.cpu().numpy(), qo)
+    print("PartII range guard through run_pair: rel err %.3g (M=%d)" % (r, len(m)))
+    assert r < TOL
+
+
+def test_network_objects_keep_their_own_weights(hip, sd1, tables):
+    """two PartI_test objects with different checkpoints share the device context but answer with their own weights
+    (the reference's nn.Modules are independent, utils/network.py:140-147)"""
+    from yoho_amd import network
+
+    class Cfg:
+        SO3_related_files = None
+    sdb = W.synth_state_dict(W.PARTI_SPEC, 99)
+    na, nb = network.PartI_test(Cfg()), network.PartI_test(Cfg())
+    na.load_state_dict(sd1)
+    nb.load_state_dict(sdb)                                  # now resident: b's weights
+    x = synth.unit_features(20, seed=1)
+    ea = na(cu(x))["eqv"].cpu().numpy()                      # must re-upload a's
+    eb = nb(cu(x))["eqv"].cpu().numpy()
+    assert rel(ea, orc.partI_forward(x, sd1, tables.N)[0]) < TOL
+    assert rel(eb, orc.partI_forward(x, sdb, tables.N)[0]) < TOL

@@ -13,6 +13,12 @@ class _FakeCtx:
     def __init__(self, sizes):
         self.sizes, self.batches = list(sizes), []
         self._i = 0
+        self.fcgf_owner = None
+        self.loads = 0
+
+    def load_fcgf(self, owner=None, **kw):
+        self.fcgf_owner = owner
+        self.loads += 1
 
     def fcgf_voxelize(self, pts, voxel_size):
         n = self.sizes[self._i]
@@ -28,6 +34,7 @@ def _extractor(ctx, budget):
     ex = object.__new__(fcgf_extractor)           # no checkpoint / library needed for the batching logic
     ex.ctx = ctx
     ex.MAX_VOXELS_PER_PASS = budget
+    ex._load_args = {}
     return ex
 
 

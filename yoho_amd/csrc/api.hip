@@ -326,6 +326,8 @@ int yoho_ctx_create(int device, const float* R, const uint8_t* N, const uint8_t*
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->nCU = prop.multiProcessorCount;
     }
+    HIPCHK(hipMalloc((void**)&c->d_rflag, 4 * sizeof(int)));
+    HIPCHK(hipMemset(c->d_rflag, 0, 4 * sizeof(int)));
     *out = c;
     return 0;
 }
@@ -347,6 +349,7 @@ int yoho_ctx_destroy(yoho_ctx* c) {
     if (c->dF16) (void)hipFree(c->dF16);
     if (c->fcgf) fcgf_free(c->fcgf);
     if (c->d_tap_inv) (void)hipFree(c->d_tap_inv);
+    if (c->d_rflag) (void)hipFree(c->d_rflag);
     delete c->fb;
     if (c->ev_created) for (auto& e : c->ev) (void)hipEventDestroy(e);
     delete c;
@@ -407,6 +410,24 @@ int yoho_set_nn_grid(yoho_ctx* c, double cell) {
     return 0;
 }
 
+int yoho_range_status(yoho_ctx* c, int* partI_overflow, int* partII_overflow, void* stream) {
+    if (!c) { set_error("yoho_range_status: null ctx"); return YOHO_EINVAL; }
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    int h[2] = {0, 0};
+    HIPCHK(hipMemcpyAsync(h, c->d_rflag, sizeof(h), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (h[0] || h[1]) HIPCHK(hipMemsetAsync(c->d_rflag, 0, sizeof(h), s));
+    if (partI_overflow) *partI_overflow = h[0];
+    if (partII_overflow) *partII_overflow = h[1];
+    if (h[0] || h[1]) {
+        set_error("fp16 range exceeded in the fp16x2 arithmetic of %s%s%s since the last check: repeat the pass in mode 1 (bf16x3) or 0 (f32)",
+                  h[0] ? "PartI" : "", (h[0] && h[1]) ? " and " : "", h[1] ? "PartII" : "");
+        return YOHO_ERANGE;
+    }
+    return 0;
+}
+
 int yoho_set_profiling(yoho_ctx* c, int enable) {
     if (!c) { set_error("null ctx"); return YOHO_EINVAL; }
     HIPCHK(hipSetDevice(c->device));
@@ -455,15 +476,16 @@ static int partI_pass16(yoho_ctx* c, const float* x, int B, float* eqv, float* i
     const bool prof = c->profiling && c->ev_created;
     auto mark = [&](int i) { if (prof) (void)hipEventRecord(c->ev[i], s); };
     mark(0);
-    if ((rc = launch_pack16_partI(x, B, nT, bX, s, npl))) return rc;
+    int* rf = c->d_rflag;
+    if ((rc = launch_pack16_partI(x, B, nT, bX, s, npl, rf))) return rc;
     mark(1);
-    if ((rc = launch_gconv16(c->p1[0], bX, nT, nullptr, bH0, bA, EPI_RAW | EPI_ACT, s, 0, nullptr, nullptr, npl))) return rc;
+    if ((rc = launch_gconv16(c->p1[0], bX, nT, nullptr, bH0, bA, EPI_RAW | EPI_ACT, s, 0, nullptr, nullptr, npl, rf))) return rc;
     mark(2); mark(3);
-    if ((rc = launch_gconv16(c->p1[1], bA, nT, nullptr, nullptr, bA1, EPI_ACT, s, 0, nullptr, nullptr, npl))) return rc;
+    if ((rc = launch_gconv16(c->p1[1], bA, nT, nullptr, nullptr, bA1, EPI_ACT, s, 0, nullptr, nullptr, npl, rf))) return rc;
     mark(4); mark(5);
-    if ((rc = launch_gconv16(c->p1[2], bA1, nT, bH0, nullptr, bA, EPI_RES | EPI_ACT, s, 0, nullptr, nullptr, npl))) return rc;
+    if ((rc = launch_gconv16(c->p1[2], bA1, nT, bH0, nullptr, bA, EPI_RES | EPI_ACT, s, 0, nullptr, nullptr, npl, rf))) return rc;
     mark(6); mark(7);
-    if ((rc = launch_gconv16(c->p1[3], bA, nT, nullptr, bY, nullptr, EPI_RAW, s, 0, nullptr, nullptr, npl))) return rc;
+    if ((rc = launch_gconv16(c->p1[3], bA, nT, nullptr, bY, nullptr, EPI_RAW, s, 0, nullptr, nullptr, npl, rf))) return rc;
     mark(8);
     if ((rc = launch_finalize_partI(bY, x, B, eqv, inv, inv_np, 1, s))) return rc;
     mark(9);
@@ -532,23 +554,24 @@ static int partI_passG(yoho_ctx* c, const float* x, int B, float* eqv, float* in
     const Layer* L = c->p1;
     for (int i = 0; i < 4; ++i) if (!L[i].wpg) { set_error("irrep-GEMM weights missing"); return YOHO_ENOWEIGHTS; }
     mark(0);
-    if ((rc = launch_head16(x, B, nT, bP32, kppad, c->dF16, s, x1, B0))) return rc;
+    int* rf = c->d_rflag;
+    if ((rc = launch_head16(x, B, nT, bP32, kppad, c->dF16, s, x1, B0, rf))) return rc;
     mark(1);
     if ((rc = launch_fgemm(L[0], bP32, kppad, nT, nullptr, bH0, 0, s))) return rc;
     mark(2);
-    if ((rc = launch_gft16(bH0, nullptr, bP256, kppad, c->dF16, L[0].bn_s, L[0].bn_t, nT, 32, c->nCU, s))) return rc;
+    if ((rc = launch_gft16(bH0, nullptr, bP256, kppad, c->dF16, L[0].bn_s, L[0].bn_t, nT, 32, c->nCU, s, 0, rf))) return rc;
     mark(3);
     if ((rc = launch_fgemm(L[1], bP256, kppad, nT, nullptr, bM, 0, s))) return rc;
     mark(4);
-    if ((rc = launch_gft16(bM, nullptr, bP512, kppad, c->dF16, L[1].bn_s, L[1].bn_t, nT, 64, c->nCU, s))) return rc;
+    if ((rc = launch_gft16(bM, nullptr, bP512, kppad, c->dF16, L[1].bn_s, L[1].bn_t, nT, 64, c->nCU, s, 0, rf))) return rc;
     mark(5);
     if ((rc = launch_fgemm(L[2], bP512, kppad, nT, bH0, bA, EPI_RES, s))) return rc;
     mark(6);
-    if ((rc = launch_gft16(bA, nullptr, bP256, kppad, c->dF16, L[2].bn_s, L[2].bn_t, nT, 32, c->nCU, s))) return rc;
+    if ((rc = launch_gft16(bA, nullptr, bP256, kppad, c->dF16, L[2].bn_s, L[2].bn_t, nT, 32, c->nCU, s, 0, rf))) return rc;
     mark(7);
     if ((rc = launch_fgemm(L[3], bP256, kppad, nT, nullptr, bY, 0, s))) return rc;
     mark(8);
-    if ((rc = launch_gft16(bY, bYs, nullptr, kppad, c->dF16, nullptr, nullptr, nT, 4, c->nCU, s, B))) return rc;
+    if ((rc = launch_gft16(bY, bYs, nullptr, kppad, c->dF16, nullptr, nullptr, nT, 4, c->nCU, s, B, rf))) return rc;
     if ((rc = launch_finalize_partI(bYs, x, B, eqv, inv, inv_np, 2, s, x1, B0))) return rc;
     mark(9);
     return 0;
@@ -622,6 +645,7 @@ static int partII_pass16(yoho_ctx* c, const float* s0, const float* s1, const fl
     const size_t szX = (size_t)nT16 * 16 * ch16, szA0 = (size_t)nT16 * 32 * ch16;
     const size_t szA1p = npl == 2 ? (size_t)nT16 * 64 * ch16 : 0;      // fp16x2: 13-cone activation planes for cone1_kernel
     int rc;
+    int* rf = c->d_rflag + 1;                           // PartII's range word
     if ((rc = ensure_ws(c, szX + szA0 + szA1p + (n256 + n512 + n256 + n512 + n128 + n32) * ch, s))) return rc;
     char* bX = (char*)c->ws.p;                          // 128 ch planes
     char* bA0 = bX + szX;                               // 256 ch planes (45 slabs valid)
@@ -644,17 +668,17 @@ static int partII_pass16(yoho_ctx* c, const float* s0, const float* s1, const fl
         bF = bA1 + n512 * CHUNK_FLOATS; bF0 = bF + n256 * CHUNK_FLOATS; bF1 = bF0 + n512 * CHUNK_FLOATS; bQ = bF1 + n128 * CHUNK_FLOATS;
         char* bP = (char*)(bQ + n32 * CHUNK_FLOATS);
         float* bC = (float*)(bP + szP);                 // raw Fourier coefficients of the first layer
-        if ((rc = launch_head2(s0, s1, s2, s3, idx, c->dP, c->p2_init_bn_s, c->p2_init_bn_t, M, nT, bP, kppad, c->dF16, s, ridx, istride))) return rc;
+        if ((rc = launch_head2(s0, s1, s2, s3, idx, c->dP, c->p2_init_bn_s, c->p2_init_bn_t, M, nT, bP, kppad, c->dF16, s, ridx, istride, rf))) return rc;
         if ((rc = launch_fgemm(c->p2[0], bP, kppad, nT, nullptr, bC, 0, s))) return rc;
-        if ((rc = launch_gft16_invp(bC, bH0, bA0, nT16, c->dF16, c->p2[0].bn_s, c->p2[0].bn_t, nT, 32, c->nCU, s))) return rc;
+        if ((rc = launch_gft16_invp(bC, bH0, bA0, nT16, c->dF16, c->p2[0].bn_s, c->p2[0].bn_t, nT, 32, c->nCU, s, rf))) return rc;
     } else {
-        if ((rc = launch_pack16_partII(s0, s1, s2, s3, idx, c->dP, c->p2_init_bn_s, c->p2_init_bn_t, M, nT16, bX, s, npl))) return rc;
-        if ((rc = launch_gconv16(c->p2[0], bX, nT16, nullptr, nullptr, bA0, EPI_RAW32 | EPI_ACT, s, 1, bH0, nullptr, npl))) return rc;
+        if ((rc = launch_pack16_partII(s0, s1, s2, s3, idx, c->dP, c->p2_init_bn_s, c->p2_init_bn_t, M, nT16, bX, s, npl, rf))) return rc;
+        if ((rc = launch_gconv16(c->p2[0], bX, nT16, nullptr, nullptr, bA0, EPI_RAW32 | EPI_ACT, s, 1, bH0, nullptr, npl, rf))) return rc;
     }
     if (npl == 2) {
         int n0[NTAP];
         for (int k = 0; k < NTAP; ++k) n0[k] = c->hN[k];
-        if ((rc = launch_gconv16(c->p2[1], bA0, nT16, nullptr, nullptr, bA1p, EPI_ACT, s, 2, nullptr, nullptr, npl))) return rc;
+        if ((rc = launch_gconv16(c->p2[1], bA0, nT16, nullptr, nullptr, bA1p, EPI_ACT, s, 2, nullptr, nullptr, npl, rf))) return rc;
         if ((rc = launch_cone1(c->p2[2], bA1p, nT, nT16, bH0, bF, n0, s))) return rc;
     } else {
         if ((rc = launch_gconv16(c->p2[1], bA0, nT16, nullptr, nullptr, nullptr, EPI_ACT32, s, 2, nullptr, bA1, npl))) return rc;

@@ -30,6 +30,16 @@ constexpr float HF_ASCALE = 4.f;      // Fourier-coefficient planes of the irrep
 constexpr int NIR_ORD = 5;            // irreps of the icosahedral group
 constexpr float H2_ASCALE = 16.f;     // fp16x2 activations are stored as 16 * x (|x| < 4094)
 
+// fp16 range guard.  The fp16x2 paths store activations / Fourier coefficients as fixed power-of-two multiples in fp16
+// planes; a value beyond the fp16 range would become +-inf there and (through relu(NaN) = 0) could vanish silently.
+// Every kernel that converts to fp16 tracks the largest magnitude it converted and raises the word `flag` points to
+// (device memory owned by the context: one word per network) when it exceeds the largest finite fp16 number; the host
+// reads it with yoho_range_status and repeats the pass in the bf16x3 format (fp32 exponent range).
+constexpr float FP16_MAX = 65504.f;
+__device__ __forceinline__ void note_range(int* flag, float amax) {
+    if (flag && !(amax <= FP16_MAX)) atomicOr(flag, 1);
+}
+
 struct Layer {
     int cin = 0, cout = 0, cout_pad = 0, ntaps = 0;
     float* wp = nullptr;      // packed MFMA A-fragments [ob][c8][tap][lane64][4]
@@ -99,24 +109,24 @@ int fcgf_rotate_select(const double* pts, const double* R_host, const int64_t* s
 int launch_cone1(const Layer& L, const char* X, int nTiles32, int nTiles16, const float* res, float* out, const int* n0, hipStream_t s);
 int gft16_init();
 int launch_gft16(const float* in, float* out32, char* planes, int kppad, const void* Ffrag, const float* bn_s, const float* bn_t, int nTiles,
-                 int C8, int nCU, hipStream_t s, int B = 0);
+                 int C8, int nCU, hipStream_t s, int B = 0, int* rflag = nullptr);
 int launch_gft16_invp(const float* in, float* res0, char* planes16, int nTiles16, const void* Ffrag, const float* bn_s, const float* bn_t,
-                      int nTiles, int C8, int nCU, hipStream_t s);
+                      int nTiles, int C8, int nCU, hipStream_t s, int* rflag = nullptr);
 int launch_head2(const float* s0, const float* s1, const float* s2, const float* s3, const int64_t* pre_idx, const int* P, const float* bn_s,
                  const float* bn_t, int M, int nTiles, char* planes, int kppad, const void* Ffrag, hipStream_t s,
-                 const int64_t* const* ridx = nullptr, int istride = 1);
+                 const int64_t* const* ridx = nullptr, int istride = 1, int* rflag = nullptr);
 int launch_head16(const float* x, int B, int nTiles, char* planes, int kppad, const void* Ffrag, hipStream_t s, const float* x1 = nullptr,
-                  int B0 = 0);
+                  int B0 = 0, int* rflag = nullptr);
 int launch_gconvf(const Layer& L, const float* X, int nTiles, const float* res, float* out, int flags, hipStream_t s);
 int launch_gft(int mode, const float* in, float* out, const float* Fpad, const float* bn_s, const float* bn_t, int nTiles, int C8, hipStream_t s);
 // bf16x3 variant (gconv16.hip)
 int upload_slot_tables16(const int* slab4_h, const int* unitg_h);
 int gconv16_init();
 int launch_gconv16(const Layer& L, const char* X, int nTiles, const float* res, float* out_raw, char* out_act, int flags, hipStream_t s,
-                   int cfg = 0, float* out_raw32 = nullptr, float* out_act32 = nullptr, int npl = 3);
+                   int cfg = 0, float* out_raw32 = nullptr, float* out_act32 = nullptr, int npl = 3, int* rflag = nullptr);
 int launch_pack16_partII(const float* s0, const float* s1, const float* s2, const float* s3, const int64_t* pre_idx, const int* P,
-                         const float* bn_s, const float* bn_t, int M, int nTiles16, char* out, hipStream_t s, int npl = 3);
-int launch_pack16_partI(const float* x, int B, int nTiles, char* out, hipStream_t s, int npl = 3);
+                         const float* bn_s, const float* bn_t, int M, int nTiles16, char* out, hipStream_t s, int npl = 3, int* rflag = nullptr);
+int launch_pack16_partI(const float* x, int B, int nTiles, char* out, hipStream_t s, int npl = 3, int* rflag = nullptr);
 int launch_group_mean_np(const float* eqv, int B, float* out, hipStream_t s);
 int launch_pack_partII(const float* s0, const float* s1, const float* s2, const float* s3, const int64_t* pre_idx,
                        const int* P, const float* bn_s, const float* bn_t, int M, int nTiles, float* out, hipStream_t s);
@@ -164,6 +174,7 @@ struct yoho_ctx {
     int tap_inv[13] = {0};       // inv[k]: the tap whose group element is the inverse of tap k's (train.hip)
     int* d_tap_inv = nullptr;
     int nCU = 256;
+    int* d_rflag = nullptr;      // fp16 range words (note_range): [0] PartI, [1] PartII; read and cleared by yoho_range_status
     double nn_cell = 0.0;        // > 0: 3-D nearest-neighbour searches go through a hash grid of this cell size (gridnn.hip)
     // workspace (grown on demand)
     yoho::Workspace ws;

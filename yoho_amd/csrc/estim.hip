@@ -270,6 +270,136 @@ __global__ void pick_T_kernel(const double* __restrict__ T_all, const int* __res
     if (i == 0) *best_iter = any ? *best_h + 1 : 0;
 }
 
+// ---- YOHO-C with the sampling on the device (yoho_c_ransac_device) -----------------------------
+// tests/estimator.py:34-51 (DR_statictic) + :119-128 (the two np.random.choice draws of an iteration) without the host:
+//   1. cstat_kernel (one workgroup): histogram of the coarse-rotation index over the matches, the bucket lists in
+//      ascending match order (R_index_pre_statistic), the weights p_b = n (n - 0.01)(n - 0.02), n = count / 100 for
+//      count >= 2 (else 0) as a running sum (cdf, f64, summed b = 0..59), and the matched keypoints gathered once.
+//      sum p < 1e-4 -> no estimate (the reference saves eye(4) with recalltime 50001, :103-107).
+//   2. kabsch_sample_kernel (one workgroup per iteration it): counter-based Philox4x32-10 keyed by the caller's seed,
+//      counter = it -> four 32-bit words: (w0, w1) -> u in [0,1) with 53 bits -> bucket b = first with cdf[b] > u * total
+//      (np.random.choice(range(60), p) is a cdf search as well), w1', w2', w3' of a second block -> three members of the
+//      bucket, with replacement (np.random.choice(bucket, 3)).  Every bucket with p > 0 has >= 2 members, so each draw
+//      is an accepted iteration (:123-125 never skips).  Then Kabsch + vote as kabsch_score_kernel.
+// The random stream is Philox, not numpy's MT19937: for a given seed the sampled triples are those of
+// oracle/yoho_oracle.py:yohoc_device_triples (bit-exact, tested), not those of np.random.seed(seed).
+struct CStat {
+    int count[G];
+    int start[G];
+    double cdf[G];
+    int valid;
+    int pad;
+};
+
+__global__ __launch_bounds__(64) void cstat_kernel(const int64_t* __restrict__ dr, int M, const double* __restrict__ keys0,
+                                                   const double* __restrict__ keys1, const int64_t* __restrict__ i0,
+                                                   const int64_t* __restrict__ i1, int istride, CStat* __restrict__ st,
+                                                   int* __restrict__ members, double* __restrict__ k0m, double* __restrict__ k1m) {
+    __shared__ int cnt[G];
+    __shared__ int start[G];
+    const int b = threadIdx.x;
+    int c = 0;
+    if (b < G) {
+        for (int m = 0; m < M; ++m) {
+            long long v = dr[m];
+            v = v < 0 ? 0 : (v > G - 1 ? G - 1 : v);
+            c += ((int)v == b) ? 1 : 0;
+        }
+        cnt[b] = c;
+    }
+    __syncthreads();
+    if (b == 0) {
+        int acc = 0;
+        double run = 0.0;
+        for (int j = 0; j < G; ++j) {
+            start[j] = acc;
+            acc += cnt[j];
+            double p = 0.0;
+            if (cnt[j] >= 2) {
+                const double num = (double)cnt[j] / 100.0;
+                p = __dmul_rn(__dmul_rn(num, __dsub_rn(num, 0.01)), __dsub_rn(num, 0.02));
+            }
+            run = __dadd_rn(run, p);
+            st->cdf[j] = run;
+            st->count[j] = cnt[j];
+            st->start[j] = start[j];
+        }
+        st->valid = run < 1e-4 ? 0 : 1;
+    }
+    __syncthreads();
+    if (b < G) {
+        int pos = start[b];
+        for (int m = 0; m < M; ++m) {
+            long long v = dr[m];
+            v = v < 0 ? 0 : (v > G - 1 ? G - 1 : v);
+            if ((int)v == b) members[pos++] = m;
+        }
+    }
+    for (int i = threadIdx.x; i < M * 3; i += 64) {
+        const int m = i / 3, j = i - m * 3;
+        const size_t r0 = i0 ? (size_t)i0[(size_t)m * istride] : (size_t)m;
+        const size_t r1 = i1 ? (size_t)i1[(size_t)m * istride] : (size_t)m;
+        k0m[i] = keys0[r0 * 3 + j];
+        k1m[i] = keys1[r1 * 3 + j];
+    }
+}
+
+__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1, unsigned* out) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+        const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__global__ __launch_bounds__(256) void kabsch_sample_kernel(const double* __restrict__ k0, const double* __restrict__ k1, int M,
+                                                            const CStat* __restrict__ st, const int* __restrict__ members,
+                                                            unsigned seed_lo, unsigned seed_hi, double d2thr, double* __restrict__ T_out,
+                                                            int32_t* __restrict__ counts, int64_t* __restrict__ triples_out) {
+    __shared__ double Ts[12];
+    __shared__ int red[4];
+    const int it = blockIdx.x;
+    if (!st->valid) {                                       // no bucket with two matches: nothing to sample
+        if (threadIdx.x == 0) counts[it] = 0;
+        return;
+    }
+    if (threadIdx.x == 0) {
+        unsigned w[4], v[4];
+        philox4x32_10((unsigned)it, 0u, 0u, 0u, seed_lo, seed_hi, w);
+        philox4x32_10((unsigned)it, 1u, 0u, 0u, seed_lo, seed_hi, v);
+        const double u = (double)(((unsigned long long)w[0] << 21) | (w[1] >> 11)) * 0x1p-53;
+        const double thr = __dmul_rn(u, st->cdf[G - 1]);
+        int b = G - 1;
+        for (int j = G - 1; j >= 0; --j) if (st->cdf[j] > thr) b = j;          // first bucket whose running sum exceeds thr
+        const int n = st->count[b], s0 = st->start[b];
+        double a0[9], a1[9];
+        for (int p = 0; p < 3; ++p) {
+            const int mi = members[s0 + (int)(((unsigned long long)v[p] * (unsigned)n) >> 32)];
+            if (triples_out) triples_out[(size_t)it * 3 + p] = mi;
+            for (int j = 0; j < 3; ++j) { a0[p * 3 + j] = k0[(size_t)mi * 3 + j]; a1[p * 3 + j] = k1[(size_t)mi * 3 + j]; }
+        }
+        double T[12];
+        kabsch3(a0, a1, false, T);
+        for (int i = 0; i < 12; ++i) { Ts[i] = T[i]; T_out[(size_t)it * 12 + i] = T[i]; }
+    }
+    __syncthreads();
+    int local = 0;
+    for (int m = threadIdx.x; m < M; m += 256) local += inlier(Ts, k0 + (size_t)m * 3, k1 + (size_t)m * 3, d2thr) ? 1 : 0;
+    const int tot = block_count(false, local, red);
+    if (threadIdx.x == 0) counts[it] = tot;
+}
+
+__global__ void pick_T_dev_kernel(const double* __restrict__ T_all, const int* __restrict__ best_h, const int* __restrict__ best_count,
+                                  const CStat* __restrict__ st, double* __restrict__ best_T, int* __restrict__ best_iter) {
+    const int i = threadIdx.x;
+    const bool any = st->valid && *best_count > 0;
+    if (i < 12) best_T[i] = any ? T_all[(size_t)(*best_h) * 12 + i] : ((i % 5 == 0) ? 1.0 : 0.0);   // eye(4)[:3]
+    if (i == 0) *best_iter = !st->valid ? 50001 : (any ? *best_h + 1 : 0);                               // tests/estimator.py:107
+}
+
 // ---- group-feature gather (one group element) ------------------------------------------------
 // kr = keys @ Rg^T (f64); NN among pts (f32, widened) with sqrt(D2 + 1e-7) in f64; copy feature row.
 // N-body style: a thread owns GG_KR rotated keys in registers and walks a slice of the cloud that the workgroup
@@ -395,6 +525,41 @@ int yoho_c_ransac(yoho_ctx* c, const double* k0, const double* k1, int M, const 
     hipLaunchKernelGGL(argbest_kernel, dim3(1), dim3(256), 0, s, cnt, I, bh, best_count);
     HIPCHK(hipGetLastError());
     hipLaunchKernelGGL(pick_T_kernel, dim3(1), dim3(64), 0, s, Tall, bh, best_count, best_T, best_iter);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int yoho_c_ransac_device(yoho_ctx* c, const double* keys0, const int64_t* i0, const double* keys1, const int64_t* i1, int istride,
+                         const int64_t* dr_index, int M, int max_iter, uint64_t seed, double d, double* best_T, int* best_iter,
+                         int* best_count, int64_t* triples_out, void* stream) {
+    if (!c || !keys0 || !keys1 || !dr_index || !best_T || !best_iter || !best_count || M < 1 || max_iter < 1 || istride < 1) {
+        set_error("yoho_c_ransac_device: bad argument"); return YOHO_EINVAL;
+    }
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    int rc;
+    const size_t I = (size_t)max_iter;
+    // workspace: T (I,12) f64 | matched keys 2 x (M,3) f64 | CStat | counts (I) i32 | members (M) i32 | best_h
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off = (off + bytes + 255) & ~(size_t)255; return o; };
+    const size_t oT = take(sizeof(double) * 12 * I), oK0 = take(sizeof(double) * 3 * (size_t)M), oK1 = take(sizeof(double) * 3 * (size_t)M);
+    const size_t oS = take(sizeof(CStat)), oC = take(sizeof(int32_t) * I), oM = take(sizeof(int) * (size_t)M), oB = take(16);
+    if ((rc = ensure_ws(c, off, s))) return rc;
+    char* w = (char*)c->ws.p;
+    double* Tall = (double*)(w + oT);
+    double *k0m = (double*)(w + oK0), *k1m = (double*)(w + oK1);
+    CStat* st = (CStat*)(w + oS);
+    int32_t* cnt = (int32_t*)(w + oC);
+    int* members = (int*)(w + oM);
+    int* bh = (int*)(w + oB);
+    hipLaunchKernelGGL(cstat_kernel, dim3(1), dim3(64), 0, s, dr_index, M, keys0, keys1, i0, i1, istride, st, members, k0m, k1m);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(kabsch_sample_kernel, dim3(max_iter), dim3(256), 0, s, k0m, k1m, M, st, members, (unsigned)(seed & 0xFFFFFFFFu),
+                       (unsigned)(seed >> 32), d * d, Tall, cnt, triples_out);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(argbest_kernel, dim3(1), dim3(256), 0, s, cnt, max_iter, bh, best_count);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(pick_T_dev_kernel, dim3(1), dim3(64), 0, s, Tall, bh, best_count, st, best_T, best_iter);
     HIPCHK(hipGetLastError());
     return 0;
 }

@@ -104,10 +104,15 @@ __device__ __forceinline__ void split2h(float x, unsigned& h, unsigned& l) {
     l = half_bits(r);
 }
 // planes of one fp32 value, plane order = LDS plane order (0 = hi)
+// amax: largest fp16-bound magnitude converted (fp16 range guard, common.h; bf16 planes have the fp32 exponent range)
 template <int NPL>
-__device__ __forceinline__ void split_planes(float x, unsigned (&p)[3]) {
+__device__ __forceinline__ void split_planes(float x, unsigned (&p)[3], float& amax) {
     if constexpr (NPL == 3) split3(x, p[0], p[1], p[2]);
-    else { split2h(x * H2_ASCALE, p[0], p[1]); p[2] = 0; }       // exact power-of-two scaling keeps the lo plane out of the fp16 subnormals
+    else {
+        const float xs = x * H2_ASCALE;                          // exact power-of-two scaling keeps the lo plane out of the fp16 subnormals
+        amax = fmaxf(amax, fabsf(xs));
+        split2h(xs, p[0], p[1]); p[2] = 0;
+    }
 }
 // D += A(plane pa) * B(plane pb) on the MFMA of the plane type
 template <int NPL>
@@ -159,6 +164,7 @@ struct Conv16Args {
     float* out_act32;      // same layout, relu(v*s + t) (EPI_ACT32)
     int nTiles, cin8, cout8, nOBgrid, cfg;
     float descale;         // fp16x2: 1 / (weight scale * H2_ASCALE), a power of two; bf16x3: unused
+    int* rflag;            // fp16 range flag (note_range)
 };
 
 template <int UPW, int NOB, int NPL>
@@ -281,6 +287,7 @@ __global__ __launch_bounds__(256, 1) void gconv16_kernel(Conv16Args a, int flags
     // ---- epilogue.  D[i = o][j = col]: lane (col = lane&31, half = lane>>5), reg r -> o = (r&3) + 8*(r>>2) + 4*half
     const int kp = lane & 15, half = lane >> 5, gsel = (lane >> 4) & 1;
     const int* ug = &c_unitg[cfg][ubase * 2];
+    float amax = 0.f;
 #pragma unroll
     for (int j = 0; j < UPW; ++j) {
         const int g = gsel ? ug[2 * j + 1] : ug[2 * j];
@@ -311,10 +318,10 @@ __global__ __launch_bounds__(256, 1) void gconv16_kernel(Conv16Args a, int flags
                 }
                 if (!(flags & EPI_ACT)) continue;
                 unsigned p0[3], p1[3], p2[3], p3[3];
-                split_planes<NPL>(fmaxf(y.x, 0.f), p0);
-                split_planes<NPL>(fmaxf(y.y, 0.f), p1);
-                split_planes<NPL>(fmaxf(y.z, 0.f), p2);
-                split_planes<NPL>(fmaxf(y.w, 0.f), p3);
+                split_planes<NPL>(fmaxf(y.x, 0.f), p0, amax);
+                split_planes<NPL>(fmaxf(y.y, 0.f), p1, amax);
+                split_planes<NPL>(fmaxf(y.z, 0.f), p2, amax);
+                split_planes<NPL>(fmaxf(y.w, 0.f), p3, amax);
                 // plane layout: [tile][c8][plane][g][kp][8 ch], 16-bit elements
                 char* base = a.out_act + ((size_t)tile * a.cout8 + ob * 4 + q) * CHB + (size_t)g * SLAB16_BYTES + kp * 16 + half * 8;
 #pragma unroll
@@ -326,6 +333,7 @@ __global__ __launch_bounds__(256, 1) void gconv16_kernel(Conv16Args a, int flags
             }
         }
     }
+    if constexpr (NPL == 2) note_range(a.rflag, amax);
 }
 
 template <int UPW, int NOB, int NPL>
@@ -370,8 +378,9 @@ static int launch16_cfg(Conv16Args& a, const Layer& L, int cfg, int flags, hipSt
 // layer launch.  npl = 3: bf16x3 planes (L.wp16), npl = 2: fp16x2 planes (L.wph).  cfg 0 (all 60 outputs): cout_pad
 // multiple of 64 -> NOB = 2, else the single-block variant; cfg 1 (45 outputs, 23 units): <12,2>; cfg 2 (13 outputs): <7,4>.
 int launch_gconv16(const Layer& L, const char* X, int nTiles, const float* res, float* out_raw, char* out_act, int flags, hipStream_t s,
-                   int cfg, float* out_raw32, float* out_act32, int npl) {
+                   int cfg, float* out_raw32, float* out_act32, int npl, int* rflag) {
     Conv16Args a;
+    a.rflag = rflag;
     a.X = X; a.Wp = reinterpret_cast<const char*>(npl == 2 ? L.wph : L.wp16); a.bias = L.bias; a.bn_s = L.bn_s; a.bn_t = L.bn_t;
     a.res = res; a.out_raw = out_raw; a.out_act = out_act; a.out_raw32 = out_raw32; a.out_act32 = out_act32;
     a.nTiles = nTiles; a.cin8 = L.cin / 8; a.cout8 = L.cout_pad / 8; a.cfg = cfg; a.nOBgrid = 1;
@@ -384,10 +393,11 @@ int launch_gconv16(const Layer& L, const char* X, int nTiles, const float* res, 
 // ---------------------------------------------------------------------------------------------
 // x (B,32,60) f32 -> planes [tile][c8 = 4][3][60][16][8] bf16.  One workgroup per (tile, c8).
 template <int NPL>
-__global__ __launch_bounds__(256) void pack16_partI_kernel(const float* __restrict__ x, int B, char* __restrict__ out) {
+__global__ __launch_bounds__(256) void pack16_partI_kernel(const float* __restrict__ x, int B, char* __restrict__ out, int* rflag) {
     constexpr int CHB = chunk16_bytes(NPL);
     __shared__ __attribute__((aligned(16))) unsigned short lds[CHB / 2];
     const int tile = blockIdx.x >> 2, c8 = blockIdx.x & 3;
+    float amax = 0.f;
     for (int i = threadIdx.x; i < T16 * 8 * G; i += 256) {
         const int kp = i / (8 * G);
         const int r = i - kp * (8 * G);
@@ -395,7 +405,7 @@ __global__ __launch_bounds__(256) void pack16_partI_kernel(const float* __restri
         const int bb = tile * T16 + kp;
         const float v = bb < B ? x[(size_t)bb * (F * G) + (c8 * 8 + cl) * G + g] : 0.f;
         unsigned pp[3];
-        split_planes<NPL>(v, pp);
+        split_planes<NPL>(v, pp, amax);
         const int o = (g * T16 + kp) * 8 + cl;
 #pragma unroll
         for (int pl = 0; pl < NPL; ++pl) lds[pl * (PLANE16_BYTES / 2) + o] = (unsigned short)pp[pl];
@@ -404,11 +414,12 @@ __global__ __launch_bounds__(256) void pack16_partI_kernel(const float* __restri
     uintx4* o = reinterpret_cast<uintx4*>(out + ((size_t)tile * 4 + c8) * CHB);
     const uintx4* l = reinterpret_cast<const uintx4*>(lds);
     for (int i = threadIdx.x; i < CHB / 16; i += 256) o[i] = l[i];
+    if constexpr (NPL == 2) note_range(rflag, amax);
 }
 
-int launch_pack16_partI(const float* x, int B, int nTiles, char* out, hipStream_t s, int npl) {
-    if (npl == 2) hipLaunchKernelGGL(pack16_partI_kernel<2>, dim3(nTiles * 4), dim3(256), 0, s, x, B, out);
-    else hipLaunchKernelGGL(pack16_partI_kernel<3>, dim3(nTiles * 4), dim3(256), 0, s, x, B, out);
+int launch_pack16_partI(const float* x, int B, int nTiles, char* out, hipStream_t s, int npl, int* rflag) {
+    if (npl == 2) hipLaunchKernelGGL(pack16_partI_kernel<2>, dim3(nTiles * 4), dim3(256), 0, s, x, B, out, rflag);
+    else hipLaunchKernelGGL(pack16_partI_kernel<3>, dim3(nTiles * 4), dim3(256), 0, s, x, B, out, rflag);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -421,10 +432,11 @@ __global__ __launch_bounds__(256) void pack16_partII_kernel(const float* __restr
                                                             const float* __restrict__ s2, const float* __restrict__ s3,
                                                             const int64_t* __restrict__ pre_idx, const int* __restrict__ P,
                                                             const float* __restrict__ bn_s, const float* __restrict__ bn_t,
-                                                            int M, char* __restrict__ out) {
+                                                            int M, char* __restrict__ out, int* rflag) {
     constexpr int CHB = chunk16_bytes(NPL);
     __shared__ __attribute__((aligned(16))) unsigned short lds[CHB / 2];
     const int tile = blockIdx.x >> 4, c8 = blockIdx.x & 15;
+    float amax = 0.f;
     const int src = c8 >> 2;
     const float* sp = src == 0 ? s0 : (src == 1 ? s1 : (src == 2 ? s2 : s3));
     const bool permute = (src == 0) || (src == 2);
@@ -447,7 +459,7 @@ __global__ __launch_bounds__(256) void pack16_partII_kernel(const float* __restr
             v = fmaxf(v * bn_s[cc] + bn_t[cc], 0.f);
         }
         unsigned pp[3];
-        split_planes<NPL>(v, pp);
+        split_planes<NPL>(v, pp, amax);
         const int o = (g * T16 + kp) * 8 + cl;
 #pragma unroll
         for (int pl = 0; pl < NPL; ++pl) lds[pl * (PLANE16_BYTES / 2) + o] = (unsigned short)pp[pl];
@@ -456,12 +468,13 @@ __global__ __launch_bounds__(256) void pack16_partII_kernel(const float* __restr
     uintx4* o = reinterpret_cast<uintx4*>(out + ((size_t)tile * 16 + c8) * CHB);
     const uintx4* l = reinterpret_cast<const uintx4*>(lds);
     for (int i = threadIdx.x; i < CHB / 16; i += 256) o[i] = l[i];
+    if constexpr (NPL == 2) note_range(rflag, amax);
 }
 
 int launch_pack16_partII(const float* s0, const float* s1, const float* s2, const float* s3, const int64_t* pre_idx, const int* P,
-                         const float* bn_s, const float* bn_t, int M, int nTiles16, char* out, hipStream_t s, int npl) {
-    if (npl == 2) hipLaunchKernelGGL(pack16_partII_kernel<2>, dim3(nTiles16 * 16), dim3(256), 0, s, s0, s1, s2, s3, pre_idx, P, bn_s, bn_t, M, out);
-    else hipLaunchKernelGGL(pack16_partII_kernel<3>, dim3(nTiles16 * 16), dim3(256), 0, s, s0, s1, s2, s3, pre_idx, P, bn_s, bn_t, M, out);
+                         const float* bn_s, const float* bn_t, int M, int nTiles16, char* out, hipStream_t s, int npl, int* rflag) {
+    if (npl == 2) hipLaunchKernelGGL(pack16_partII_kernel<2>, dim3(nTiles16 * 16), dim3(256), 0, s, s0, s1, s2, s3, pre_idx, P, bn_s, bn_t, M, out, rflag);
+    else hipLaunchKernelGGL(pack16_partII_kernel<3>, dim3(nTiles16 * 16), dim3(256), 0, s, s0, s1, s2, s3, pre_idx, P, bn_s, bn_t, M, out, rflag);
     HIPCHK(hipGetLastError());
     return 0;
 }

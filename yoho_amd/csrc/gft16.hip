@@ -45,6 +45,7 @@ struct Gft16Args {
     int nTiles16;             // G16_INVP: activated values as direct-conv planes [tile16][C8][plane][60][16][8] into `planes`
     long long qbase[G];       // byte offset of coefficient q inside the operand planes (irrep pack + j and m terms)
     int qstride[G];           // bytes per 256-column tile of q's irrep (= K stages * 32 KiB)
+    int* rflag;               // fp16 range flag of the context (note_range)
 };
 
 __device__ __forceinline__ floatx16 mfma_hh(uintx4 a, uintx4 b, floatx16 c) {
@@ -54,7 +55,10 @@ __device__ __forceinline__ floatx16 mfma_hh(uintx4 a, uintx4 b, floatx16 c) {
 }
 
 // (x0, x1) -> packed fp16 hi pair and lo pair (round to nearest even)
-__device__ __forceinline__ void split_pair(float x0, float x1, unsigned& hi, unsigned& lo) {
+// amax collects the largest magnitude converted: above the fp16 range the hi plane is +-inf, which the kernel reports
+// through the context's range flag (common.h: note_range) so that the host can repeat the pass in a wider format
+__device__ __forceinline__ void split_pair(float x0, float x1, unsigned& hi, unsigned& lo, float& amax) {
+    amax = fmaxf(fmaxf(amax, fabsf(x0)), fabsf(x1));
     floatx2 x;
     x.x = x0; x.y = x1;
     const halfx2 h = __builtin_convertvector(x, halfx2);
@@ -103,6 +107,7 @@ __global__ __launch_bounds__(256, 1) void gft16_kernel(Gft16Args a) {
                 A2[rb][kb][pl] = a.Ffrag[(((1 * 2 + rb) * 4 + kb) * 2 + pl) * 64 + lane];
             }
 
+    float amax = 0.f;
     int chunk = blockIdx.x;
     if (chunk < a.nChunks) stage_chunk(a.in, chunk, a.C8, smem, w, lane);
     for (int it = 0; chunk < a.nChunks; chunk += gridDim.x, ++it) {
@@ -131,8 +136,8 @@ __global__ __launch_bounds__(256, 1) void gft16_kernel(Gft16Args a) {
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
                 unsigned h0, l0, h1, l1;
-                split_pair(v[2 * p].x, v[2 * p + 1].x, h0, l0);
-                split_pair(v[2 * p].y, v[2 * p + 1].y, h1, l1);
+                split_pair(v[2 * p].x, v[2 * p + 1].x, h0, l0, amax);
+                split_pair(v[2 * p].y, v[2 * p + 1].y, h1, l1, amax);
                 bh[0][p] = h0; bl[0][p] = l0; bh[1][p] = h1; bl[1][p] = l1;
             }
 #pragma unroll
@@ -193,7 +198,7 @@ __global__ __launch_bounds__(256, 1) void gft16_kernel(Gft16Args a) {
                 for (int r = 0; r < 16; ++r) {
                     const int g = 32 * rb + (r & 3) + 8 * (r >> 2) + 4 * kg;
                     unsigned hi, lo;
-                    split_pair(fmaxf(acc[rb][0][r] * s0 + t0, 0.f), fmaxf(acc[rb][1][r] * s1 + t1, 0.f), hi, lo);
+                    split_pair(fmaxf(acc[rb][0][r] * s0 + t0, 0.f), fmaxf(acc[rb][1][r] * s1 + t1, 0.f), hi, lo, amax);
                     if (g < G) {
                         *reinterpret_cast<unsigned*>(st + g * 512) = hi;
                         *reinterpret_cast<unsigned*>(st + 30720 + g * 512) = lo;
@@ -239,8 +244,8 @@ __global__ __launch_bounds__(256, 1) void gft16_kernel(Gft16Args a) {
                 const float y00 = fmaxf(acc[kb >> 1][0][r] * s0 + t0, 0.f), y01 = fmaxf(acc[kb >> 1][0][r + 1] * s0 + t0, 0.f);
                 const float y10 = fmaxf(acc[kb >> 1][1][r] * s1 + t1, 0.f), y11 = fmaxf(acc[kb >> 1][1][r + 1] * s1 + t1, 0.f);
                 unsigned h0, l0, h1, l1;
-                split_pair(y00, y01, h0, l0);
-                split_pair(y10, y11, h1, l1);
+                split_pair(y00, y01, h0, l0, amax);
+                split_pair(y10, y11, h1, l1, amax);
                 bh[0][p] = h0; bl[0][p] = l0; bh[1][p] = h1; bl[1][p] = l1;
             }
 #pragma unroll
@@ -270,7 +275,7 @@ __global__ __launch_bounds__(256, 1) void gft16_kernel(Gft16Args a) {
                 for (int r = 0; r < 16; ++r) {
                     const int q = 32 * rb + (r & 3) + 8 * (r >> 2) + 4 * kg;
                     unsigned hi, lo;
-                    split_pair(acc2[rb][0][r] * osc, acc2[rb][1][r] * osc, hi, lo);
+                    split_pair(acc2[rb][0][r] * osc, acc2[rb][1][r] * osc, hi, lo, amax);
                     if (q < G) {
                         *reinterpret_cast<unsigned*>(st + q * 512) = hi;
                         *reinterpret_cast<unsigned*>(st + 30720 + q * 512) = lo;
@@ -303,6 +308,7 @@ __global__ __launch_bounds__(256, 1) void gft16_kernel(Gft16Args a) {
                 }
         }
     }
+    note_range(a.rflag, amax);
 }
 
 static inline unsigned short hbits(float x) {
@@ -367,9 +373,9 @@ static void fill_qtables(int kppad, int cin, long long* qbase, int* qstride) {
 // else bn_s != null: BN + ReLU, fp32 chunks to out32 (may alias in);
 // else: inverse transform only, out32 = group-domain values (B,32,60) (C8 must be 4)
 int launch_gft16(const float* in, float* out32, char* planes, int kppad, const void* Ffrag, const float* bn_s, const float* bn_t, int nTiles,
-                 int C8, int nCU, hipStream_t s, int B) {
+                 int C8, int nCU, hipStream_t s, int B, int* rflag) {
     Gft16Args a;
-    a.B = B; a.res0 = nullptr; a.nTiles16 = 0;
+    a.B = B; a.res0 = nullptr; a.nTiles16 = 0; a.rflag = rflag;
     a.in = in; a.out32 = out32; a.planes = planes; a.Ffrag = reinterpret_cast<const uintx4*>(Ffrag); a.bn_s = bn_s; a.bn_t = bn_t;
     a.nChunks = nTiles * C8; a.C8 = C8;
     if (planes) {
@@ -401,6 +407,7 @@ struct Head16Args {
     int B, nTiles;
     long long qbase[G];
     int qstride[G];
+    int* rflag;
 };
 
 __global__ __launch_bounds__(256, 1) void head16_kernel(Head16Args a) {
@@ -413,6 +420,7 @@ __global__ __launch_bounds__(256, 1) void head16_kernel(Head16Args a) {
     __syncthreads();
     const int tile32 = blockIdx.x;
     const int kp = tile32 * TILE + Lp;
+    float amax = 0.f;
     uintx4 A[2][4][2];
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb)
@@ -441,10 +449,10 @@ __global__ __launch_bounds__(256, 1) void head16_kernel(Head16Args a) {
         for (int kb = 0; kb < 4; ++kb) {
             uintx4 bh, bl;
             unsigned h, l;
-            split_pair(v[kb][0].x * H2_ASCALE, v[kb][0].y * H2_ASCALE, h, l); bh.x = h; bl.x = l;
-            split_pair(v[kb][0].z * H2_ASCALE, v[kb][0].w * H2_ASCALE, h, l); bh.y = h; bl.y = l;
-            split_pair(v[kb][1].x * H2_ASCALE, v[kb][1].y * H2_ASCALE, h, l); bh.z = h; bl.z = l;
-            split_pair(v[kb][1].z * H2_ASCALE, v[kb][1].w * H2_ASCALE, h, l); bh.w = h; bl.w = l;
+            split_pair(v[kb][0].x * H2_ASCALE, v[kb][0].y * H2_ASCALE, h, l, amax); bh.x = h; bl.x = l;
+            split_pair(v[kb][0].z * H2_ASCALE, v[kb][0].w * H2_ASCALE, h, l, amax); bh.y = h; bl.y = l;
+            split_pair(v[kb][1].x * H2_ASCALE, v[kb][1].y * H2_ASCALE, h, l, amax); bh.z = h; bl.z = l;
+            split_pair(v[kb][1].z * H2_ASCALE, v[kb][1].w * H2_ASCALE, h, l, amax); bh.w = h; bl.w = l;
 #pragma unroll
             for (int rb = 0; rb < 2; ++rb) acc[f][rb] = mfma_hh(A[rb][kb][1], bh, acc[f][rb]);
 #pragma unroll
@@ -464,20 +472,23 @@ __global__ __launch_bounds__(256, 1) void head16_kernel(Head16Args a) {
             const int q = 32 * rb + (r & 3) + 8 * (r >> 2) + 4 * kg;
             uintx4 ph, pl;
             unsigned h, l;
-            split_pair(acc[0][rb][r] * osc, acc[1][rb][r] * osc, h, l); ph.x = h; pl.x = l;
-            split_pair(acc[2][rb][r] * osc, acc[3][rb][r] * osc, h, l); ph.y = h; pl.y = l;
-            split_pair(acc[4][rb][r] * osc, acc[5][rb][r] * osc, h, l); ph.z = h; pl.z = l;
-            split_pair(acc[6][rb][r] * osc, acc[7][rb][r] * osc, h, l); ph.w = h; pl.w = l;
+            split_pair(acc[0][rb][r] * osc, acc[1][rb][r] * osc, h, l, amax); ph.x = h; pl.x = l;
+            split_pair(acc[2][rb][r] * osc, acc[3][rb][r] * osc, h, l, amax); ph.y = h; pl.y = l;
+            split_pair(acc[4][rb][r] * osc, acc[5][rb][r] * osc, h, l, amax); ph.z = h; pl.z = l;
+            split_pair(acc[6][rb][r] * osc, acc[7][rb][r] * osc, h, l, amax); ph.w = h; pl.w = l;
             if (q < G) {
                 char* d = dst0 + qb[q] + (long long)nt * qs[q];
                 *reinterpret_cast<uintx4*>(d) = ph;
                 *reinterpret_cast<uintx4*>(d + 16384) = pl;
             }
         }
+    note_range(a.rflag, amax);
 }
 
-int launch_head16(const float* x, int B, int nTiles, char* planes, int kppad, const void* Ffrag, hipStream_t s, const float* x1, int B0) {
+int launch_head16(const float* x, int B, int nTiles, char* planes, int kppad, const void* Ffrag, hipStream_t s, const float* x1, int B0,
+                  int* rflag) {
     Head16Args a;
+    a.rflag = rflag;
     a.x = x; a.x1 = x1; a.B0 = B0; a.planes = planes; a.Ffrag = reinterpret_cast<const uintx4*>(Ffrag); a.B = B; a.nTiles = nTiles;
     fill_qtables(kppad, 32, a.qbase, a.qstride);
     if (nTiles == 0) return 0;
@@ -489,8 +500,9 @@ int launch_head16(const float* x, int B, int nTiles, char* planes, int kppad, co
 // PartII: fp32 coefficients (C8 * 8 channels) -> inverse transform; raw values at group element 0 -> res0 (fp32 tile layout),
 // relu(bn) of all 60 group elements -> fp16x2 planes of the direct cone kernels
 int launch_gft16_invp(const float* in, float* res0, char* planes16, int nTiles16, const void* Ffrag, const float* bn_s, const float* bn_t,
-                      int nTiles, int C8, int nCU, hipStream_t s) {
+                      int nTiles, int C8, int nCU, hipStream_t s, int* rflag) {
     Gft16Args a;
+    a.rflag = rflag;
     a.in = in; a.out32 = nullptr; a.planes = planes16; a.Ffrag = reinterpret_cast<const uintx4*>(Ffrag); a.bn_s = bn_s; a.bn_t = bn_t;
     a.nChunks = nTiles * C8; a.C8 = C8; a.B = 0; a.res0 = res0; a.nTiles16 = nTiles16;
     for (int q = 0; q < G; ++q) { a.qbase[q] = 0; a.qstride[q] = 0; }
@@ -520,6 +532,7 @@ struct Head2Args {
     int M;
     long long qbase[G];
     int qstride[G];
+    int* rflag;
 };
 
 __global__ __launch_bounds__(256, 1) void head2_kernel(Head2Args a) {
@@ -534,6 +547,7 @@ __global__ __launch_bounds__(256, 1) void head2_kernel(Head2Args a) {
     const int sidx = blockIdx.y;                           // one workgroup per (match tile, source): 4x the parallelism of a tile loop
     const int m = tile32 * TILE + Lp;
     const bool ok = m < a.M;
+    float amax = 0.f;
     uintx4 A[2][4][2];
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb)
@@ -595,7 +609,7 @@ __global__ __launch_bounds__(256, 1) void head2_kernel(Head2Args a) {
                     const float y0 = v0 ? fmaxf(v[kb][2 * p] * bs + bt, 0.f) : 0.f;
                     const float y1 = v1 ? fmaxf(v[kb][2 * p + 1] * bs + bt, 0.f) : 0.f;
                     unsigned h, l;
-                    split_pair(y0, y1, h, l);
+                    split_pair(y0, y1, h, l, amax);
                     bh[p] = h; bl[p] = l;
                 }
 #pragma unroll
@@ -615,10 +629,10 @@ __global__ __launch_bounds__(256, 1) void head2_kernel(Head2Args a) {
                 const int q = 32 * rb + (r & 3) + 8 * (r >> 2) + 4 * kg;
                 uintx4 ph, pl;
                 unsigned h, l;
-                split_pair(acc[0][rb][r] * osc, acc[1][rb][r] * osc, h, l); ph.x = h; pl.x = l;
-                split_pair(acc[2][rb][r] * osc, acc[3][rb][r] * osc, h, l); ph.y = h; pl.y = l;
-                split_pair(acc[4][rb][r] * osc, acc[5][rb][r] * osc, h, l); ph.z = h; pl.z = l;
-                split_pair(acc[6][rb][r] * osc, acc[7][rb][r] * osc, h, l); ph.w = h; pl.w = l;
+                split_pair(acc[0][rb][r] * osc, acc[1][rb][r] * osc, h, l, amax); ph.x = h; pl.x = l;
+                split_pair(acc[2][rb][r] * osc, acc[3][rb][r] * osc, h, l, amax); ph.y = h; pl.y = l;
+                split_pair(acc[4][rb][r] * osc, acc[5][rb][r] * osc, h, l, amax); ph.z = h; pl.z = l;
+                split_pair(acc[6][rb][r] * osc, acc[7][rb][r] * osc, h, l, amax); ph.w = h; pl.w = l;
                 if (q < G) {
                     char* d = dst0 + qb[q] + (long long)nt * qs[q];
                     *reinterpret_cast<uintx4*>(d) = ph;
@@ -626,12 +640,14 @@ __global__ __launch_bounds__(256, 1) void head2_kernel(Head2Args a) {
                 }
             }
     }
+    note_range(a.rflag, amax);
 }
 
 int launch_head2(const float* s0, const float* s1, const float* s2, const float* s3, const int64_t* pre_idx, const int* P, const float* bn_s,
                  const float* bn_t, int M, int nTiles, char* planes, int kppad, const void* Ffrag, hipStream_t s, const int64_t* const* ridx,
-                 int istride) {
+                 int istride, int* rflag) {
     Head2Args a;
+    a.rflag = rflag;
     a.src[0] = s0; a.src[1] = s1; a.src[2] = s2; a.src[3] = s3;
     for (int i = 0; i < 4; ++i) a.ridx[i] = ridx ? ridx[i] : nullptr;
     a.istride = istride;

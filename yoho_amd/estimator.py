@@ -1,17 +1,23 @@
 """Drop-in for tests/estimator.py: YOHO-C (3-match Kabsch RANSAC) and YOHO-O (one-shot hypothesis
 vote) on the HIP library, same class / method names, .npz outputs and pre.log.
 
-Randomness: the reference draws from the global ``np.random`` stream (tests/estimator.py:122,126,
-322).  These classes draw from the same stream, in the same order, on the host (a permutation /
-<= 1000 index triples per pair) and hand the indices to the GPU, so that with the same seed the
-same hypotheses are scored.
+Two sampling modes for YOHO-C:
 
-YOHO-C reflections: the reference's Kabsch has no determinant fix (tests/estimator.py:59-60) and a
-3-point covariance has rank <= 2, so LAPACK decides the sign of the null direction - about half of the
-reference's hypotheses are reflections.  With ``cfg.yohoc_lapack_parity`` (default True) the sign
-is taken from a batched ``np.linalg.svd`` on the host (a few ms per pair) and passed to the kernel
-as a mask, reproducing the reference's result; set it False to get proper rotations for every
-sample (a strictly stronger estimator, no host SVD).
+* parity (default).  The reference draws from the global ``np.random`` stream (tests/estimator.py:122,126).
+  The same draws are made on the host, in the same order (<= 1000 index triples per pair), and handed to
+  the GPU (``yoho_c_ransac``), so that with the same seed the same hypotheses are scored.  The reference's
+  Kabsch has no determinant fix (:59-60) and a 3-point covariance has rank <= 2, so LAPACK decides the sign
+  of the null direction - about half of the reference's hypotheses are reflections.  With
+  ``cfg.yohoc_lapack_parity`` (default True) that sign comes from one batched ``np.linalg.svd`` on the host
+  and is passed as a mask.  It cannot come from the device: the sign is that of a singular value which is
+  zero up to rounding, i.e. it is decided by the last bits of one particular LAPACK build's
+  bidiagonalisation (reflector count) and QR sweep - reproducing it needs that library, not its algorithm.
+* throughput (``cfg.yohoc_device_sampling = True``).  Nothing but one 64-bit seed (drawn from
+  ``np.random``) crosses to the device: statistic, sampling, Kabsch and vote run there
+  (``yoho_c_ransac_device``; Philox stream, proper rotations only).  Same estimator, a different random
+  sequence - what the multi-GPU driver and ``bench.py``'s YOHO-C leg use.
+
+YOHO-O shuffles the hypothesis order on the host (one permutation per pair, :321-323) and scores on the GPU.
 """
 import numpy as np
 import torch
@@ -19,43 +25,56 @@ import torch
 from . import hip
 from .utils import transform_points, make_non_exists_dir, dataset_feature_name
 
+G = 60
+NO_ESTIMATE = 50001            # recalltime the reference stores when no rotation bucket has two matches (:107)
+
+
+def format_log_entry(id0, id1, n_fragments, trans):
+    """one Redwood-trajectory record of pre.log (tests/estimator.py:18-23): header, the 3 rows of trans, '0 0 0 1'"""
+    rows = "".join("\t".join(f"{v}" for v in trans[r][:4]) + "\n" for r in range(3))
+    return f"{int(id0)}\t{int(id1)}\t{int(n_fragments)}\n{rows}{0.0}\t{0.0}\t{0.0}\t{1.0}\n"
+
+
+def write_pre_log(path, n_fragments, entries):
+    """entries: iterable of (id0, id1, trans) in the order they are to appear"""
+    with open(path, "w") as f:
+        f.write("".join(format_log_entry(a, b, n_fragments, T) for a, b, T in entries))
+
 
 def R_pre_log(dataset, save_dir):
-    """tests/estimator.py:12-24 (Redwood-format trajectory)."""
-    writer = open(f'{save_dir}/pre.log', 'w')
-    pair_num = int(len(dataset.pc_ids))
-    for pair in dataset.pair_ids:
-        pc0, pc1 = pair
-        ransac_result = np.load(f'{save_dir}/{pc0}-{pc1}.npz', allow_pickle=True)
-        transform_pr = ransac_result['trans']
-        writer.write(f'{int(pc0)}\t{int(pc1)}\t{pair_num}\n')
-        writer.write(f'{transform_pr[0][0]}\t{transform_pr[0][1]}\t{transform_pr[0][2]}\t{transform_pr[0][3]}\n')
-        writer.write(f'{transform_pr[1][0]}\t{transform_pr[1][1]}\t{transform_pr[1][2]}\t{transform_pr[1][3]}\n')
-        writer.write(f'{transform_pr[2][0]}\t{transform_pr[2][1]}\t{transform_pr[2][2]}\t{transform_pr[2][3]}\n')
-        writer.write(f'{0.0}\t{0.0}\t{0.0}\t{1.0}\n')
-    writer.close()
+    """tests/estimator.py:12-24: collect the per-pair .npz results of save_dir into save_dir/pre.log, dataset.pair_ids order"""
+    n = len(dataset.pc_ids)
+    write_pre_log(f"{save_dir}/pre.log", n,
+                  ((a, b, np.load(f"{save_dir}/{a}-{b}.npz", allow_pickle=True)["trans"]) for a, b in dataset.pair_ids))
 
 
 def _cu(a, dtype):
     return torch.from_numpy(np.ascontiguousarray(a, dtype=dtype)).cuda()
 
 
-def _compute_R_diff(R_gt, R):
-    """utils/r_eval.py:112-119 via the trace (same angle as the quaternion formula)."""
+def rotation_angle_deg(R_gt, R):
+    """angle of R_gt^T R in degrees (utils/r_eval.py:112-119 computes the same angle from quaternions)"""
     c = (np.trace(R_gt.T @ R) - 1.0) / 2.0
     return np.rad2deg(np.abs(np.arccos(np.clip(c, -1.0, 1.0))))
 
 
+def draw_seed():
+    """a 63-bit seed for the device sampler, taken from the global np.random stream (so np.random.seed governs it)"""
+    return int(np.random.randint(0, 2 ** 63 - 1, dtype=np.int64))
+
+
 class _Base:
+    inliner_dist = None
+
     def overlap_cal(self, key_m0, key_m1, T):
-        key_m1 = transform_points(key_m1, T)
-        diff = np.sum(np.square(key_m0 - key_m1), axis=-1)
-        return np.mean(diff < self.inliner_dist * self.inliner_dist)
+        """inlier ratio of the matches under T (tests/estimator.py:66-70 / :286-290)"""
+        residual = key_m0 - transform_points(key_m1, T)
+        return np.mean(np.sum(residual * residual, axis=-1) < self.inliner_dist * self.inliner_dist)
 
     def transdiff(self, gt, pre):
-        Rdiff = _compute_R_diff(gt[0:3:, 0:3], pre[0:3:, 0:3])
-        tdiff = np.sqrt(np.sum(np.square(gt[0:3, 3] - pre[0:3, 3])))
-        return Rdiff, tdiff
+        """(rotation error in degrees, translation error) between two [R|t] (tests/estimator.py:72-75)"""
+        shift = gt[:3, 3] - pre[:3, 3]
+        return rotation_angle_deg(gt[:3, :3], pre[:3, :3]), np.sqrt(np.sum(shift * shift))
 
 
 class yohoc(_Base):
@@ -63,25 +82,22 @@ class yohoc(_Base):
         self.cfg = cfg
         self.inliner_dist = cfg.ransac_c_inlinerdist
         self.lapack_parity = bool(getattr(cfg, "yohoc_lapack_parity", True))
+        self.device_sampling = bool(getattr(cfg, "yohoc_device_sampling", False))
         self.ctx = hip.get_context(so3_dir=getattr(cfg, "SO3_related_files", None))
 
     def DR_statictic(self, DR_indexs):
-        """tests/estimator.py:34-51"""
-        R_index_pre_statistic = {i: [] for i in range(60)}
-        for t in range(DR_indexs.shape[0]):
-            R_index_pre_statistic[int(DR_indexs[t])].append(t)
-        R_index_pre_probability = []
-        for i in range(60):
-            if len(R_index_pre_statistic[i]) < 2:
-                R_index_pre_probability.append(0)
-            else:
-                num = float(len(R_index_pre_statistic[i])) / 100.0
-                R_index_pre_probability.append(num * (num - 0.01) * (num - 0.02))
-        R_index_pre_probability = np.array(R_index_pre_probability)
-        if np.sum(R_index_pre_probability) < 1e-4:
+        """tests/estimator.py:34-51: matches bucketed by coarse rotation (ascending match index) and the sampling
+        weight of every bucket, n (n - 0.01)(n - 0.02) with n = size / 100 for buckets of at least two matches."""
+        idx = np.asarray(DR_indexs).astype(np.int64).reshape(-1)
+        size = np.bincount(idx, minlength=G)[:G]
+        by_rot = np.split(np.argsort(idx, kind="stable"), np.cumsum(size)[:-1])
+        buckets = {i: by_rot[i].tolist() for i in range(G)}
+        n = size / 100.0
+        weight = np.where(size >= 2, n * (n - 0.01) * (n - 0.02), 0.0)
+        total = np.sum(weight)
+        if total < 1e-4:
             return None, None
-        R_index_pre_probability = R_index_pre_probability / np.sum(R_index_pre_probability)
-        return R_index_pre_statistic, R_index_pre_probability
+        return buckets, weight / total
 
     def Threepps2Tran(self, kps0_init, kps1_init):
         """tests/estimator.py:55-63 for one triple, computed by the Kabsch kernel (proper rotation
@@ -95,53 +111,63 @@ class yohoc(_Base):
 
     @staticmethod
     def _reflect_mask(k0s, k1s):
-        """det sign LAPACK gives the reference's R = Vt.T @ U.T for every triple ((I,3,3) inputs)."""
-        c0 = np.mean(k0s, 1, keepdims=True)
-        c1 = np.mean(k1s, 1, keepdims=True)
-        m = np.stack([(k1s[i] - c1[i]).T @ (k0s[i] - c0[i]) for i in range(k0s.shape[0])])
-        U, S, VT = np.linalg.svd(m)
-        det = np.linalg.det(np.transpose(VT, (0, 2, 1)) @ np.transpose(U, (0, 2, 1)))
-        return (det < 0).astype(np.uint8)
+        """1 where LAPACK's SVD makes the reference's R = Vt.T @ U.T a reflection, for (I,3,3) sampled triples.
+        The sign hangs on the rounding of the covariance, so each 3x3 is formed by the very expression the reference
+        evaluates (tests/estimator.py:56-58: centre with np.mean, then a 3x3 matmul); only the SVDs are batched."""
+        cov = np.empty((k0s.shape[0], 3, 3))
+        for i in range(k0s.shape[0]):
+            cov[i] = (k1s[i] - np.mean(k1s[i], 0, keepdims=True)).T @ (k0s[i] - np.mean(k0s[i], 0, keepdims=True))
+        U, _, VT = np.linalg.svd(cov)
+        return (np.linalg.det(U) * np.linalg.det(VT) < 0).astype(np.uint8)
 
-    def _draw(self, R_index_pre_statistic, R_index_pre_probability, max_iter):
-        """the sampling half of tests/estimator.py:119-128 (consumes np.random exactly like the loop)."""
-        triples, iter_ransac, exec_time, max_time = [], 0, 0, 50000
-        while iter_ransac < max_iter:
-            if exec_time > max_time:
-                break
-            exec_time += 1
-            R_index = np.random.choice(range(60), p=R_index_pre_probability)
-            if len(R_index_pre_statistic[R_index]) < 2:
-                continue
-            iter_ransac += 1
-            triples.append(np.random.choice(np.array(R_index_pre_statistic[R_index]), 3))   # guarantee the same index
+    def _draw(self, buckets, prob, max_iter):
+        """the sampling half of tests/estimator.py:119-128: consumes np.random exactly as the reference's loop does
+        (one weighted draw of a rotation, then three matches of its bucket with replacement, per accepted iteration)"""
+        triples, draws = [], 0
+        while len(triples) < max_iter and draws <= 50000:
+            draws += 1
+            rot = np.random.choice(range(G), p=prob)
+            if len(buckets[rot]) >= 2:
+                triples.append(np.random.choice(np.array(buckets[rot]), 3))
         return np.array(triples, dtype=np.int64).reshape(-1, 3)
 
     def _ransac_pair(self, dataset, max_iter, pair, Save_dir, match_dir, Index_dir, Keys_dir):
         id0, id1 = pair
-        Keys0 = np.load(f'{Keys_dir}/cloud_bin_{id0}Keypoints.npy')
-        Keys1 = np.load(f'{Keys_dir}/cloud_bin_{id1}Keypoints.npy')
+        keys0 = np.load(f'{Keys_dir}/cloud_bin_{id0}Keypoints.npy')
+        keys1 = np.load(f'{Keys_dir}/cloud_bin_{id1}Keypoints.npy')
         pps = np.load(f'{match_dir}/{id0}-{id1}.npy')
-        Keys_m0 = Keys0[pps[:, 0]]
-        Keys_m1 = Keys1[pps[:, 1]]
-        Index = np.load(f'{Index_dir}/{id0}-{id1}.npy')
-        R_index_pre_statistic, R_index_pre_probability = self.DR_statictic(Index)
-        if R_index_pre_probability is None:
-            np.savez(f'{Save_dir}/{id0}-{id1}.npz', trans=np.eye(4), center=0, axis=0, recalltime=50001)
-            return
-        triples = self._draw(R_index_pre_statistic, R_index_pre_probability, max_iter)
-        best_trans_ransac, recall_time = np.eye(4), 0
-        best_3p_in_0, best_3p_in_1 = np.ones([3, 3]), np.ones([3, 3])
-        if triples.shape[0] > 0:
-            refl = _cu(self._reflect_mask(Keys_m0[triples], Keys_m1[triples]), np.uint8) if self.lapack_parity else None
-            best_T, res, _, _ = self.ctx.c_ransac(_cu(Keys_m0, np.float64), _cu(Keys_m1, np.float64), _cu(triples, np.int64),
-                                                  refl, self.inliner_dist)
-            it, cnt = (int(v) for v in res.cpu().numpy())
-            if cnt > 0:
-                best_trans_ransac, recall_time = best_T.cpu().numpy(), it
-                best_3p_in_0, best_3p_in_1 = Keys_m0[triples[it - 1]], Keys_m1[triples[it - 1]]
-        np.savez(f'{Save_dir}/{id0}-{id1}.npz', trans=best_trans_ransac,
-                 center=np.concatenate([best_3p_in_0, best_3p_in_1], axis=0), recalltime=recall_time)
+        dr = np.load(f'{Index_dir}/{id0}-{id1}.npy')
+        out = f'{Save_dir}/{id0}-{id1}.npz'
+        trans, recall, tri = np.eye(4), 0, None
+        if self.device_sampling:
+            if len(pps):
+                T, res, tris = self.ctx.c_ransac_device(_cu(keys0, np.float64), _cu(keys1, np.float64), _cu(dr, np.int64), max_iter,
+                                                        draw_seed(), self.inliner_dist, match=_cu(pps, np.int64), want_triples=True)
+                recall, cnt = (int(v) for v in res.cpu().numpy())
+                if recall == NO_ESTIMATE:
+                    np.savez(out, trans=np.eye(4), center=0, axis=0, recalltime=NO_ESTIMATE)
+                    return
+                if cnt > 0:
+                    trans, tri = T.cpu().numpy(), tris[recall - 1].cpu().numpy()
+            else:
+                np.savez(out, trans=np.eye(4), center=0, axis=0, recalltime=NO_ESTIMATE)
+                return
+            km0, km1 = keys0[pps[:, 0]], keys1[pps[:, 1]]
+        else:
+            km0, km1 = keys0[pps[:, 0]], keys1[pps[:, 1]]
+            buckets, prob = self.DR_statictic(dr)
+            if prob is None:
+                np.savez(out, trans=np.eye(4), center=0, axis=0, recalltime=NO_ESTIMATE)
+                return
+            triples = self._draw(buckets, prob, max_iter)
+            if triples.shape[0] > 0:
+                refl = _cu(self._reflect_mask(km0[triples], km1[triples]), np.uint8) if self.lapack_parity else None
+                T, res, _, _ = self.ctx.c_ransac(_cu(km0, np.float64), _cu(km1, np.float64), _cu(triples, np.int64), refl, self.inliner_dist)
+                it, cnt = (int(v) for v in res.cpu().numpy())
+                if cnt > 0:
+                    trans, recall, tri = T.cpu().numpy(), it, triples[it - 1]
+        center = np.concatenate([km0[tri], km1[tri]], axis=0) if tri is not None else np.ones([6, 3])
+        np.savez(out, trans=trans, center=center, recalltime=recall)
 
     def _dirs(self, dataset, max_iter):
         match_dir = f'{self.cfg.output_cache_fn}/Testset/{dataset.name}/Match'
@@ -195,25 +221,22 @@ class yohoo(_Base):
         Save_dir = f'{match_dir}/YOHO_O/{max_iter}iters'
         make_non_exists_dir(Save_dir)
         print(f'Ransac with YOHO-O on {dataset.name}:')
-        for pair in dataset.pair_ids:
-            id0, id1 = pair
-            Keys0 = dataset.get_kps(id0)
-            Keys1 = dataset.get_kps(id1)
+        for id0, id1 in dataset.pair_ids:
             pps = np.load(f'{match_dir}/{id0}-{id1}.npy')
-            Keys_m0 = Keys0[pps[:, 0]]
-            Keys_m1 = Keys1[pps[:, 1]]
-            Trans = np.load(f'{Trans_dir}/{id0}-{id1}.npy')
-            index = np.arange(Trans.shape[0])
-            np.random.shuffle(index)
-            H = min(max_iter, Trans.shape[0])      # Trans[index[0:max_iter]] (tests/estimator.py:323)
-            recall_time, best_trans_ransac = 0, np.eye(4)
+            km0 = dataset.get_kps(id0)[pps[:, 0]]
+            km1 = dataset.get_kps(id1)[pps[:, 1]]
+            hyps = np.load(f'{Trans_dir}/{id0}-{id1}.npy')
+            order = np.arange(hyps.shape[0])
+            np.random.shuffle(order)                       # tests/estimator.py:321-323: Trans[index[0:max_iter]]
+            H = min(max_iter, hyps.shape[0])
+            trans, recall = np.eye(4), 0
             if H > 0:
-                res, _ = self.ctx.o_score(_cu(Keys_m0, np.float64), _cu(Keys_m1, np.float64), _cu(Trans, np.float64),
-                                          _cu(index, np.int64), H, self.inliner_dist)
+                res, _ = self.ctx.o_score(_cu(km0, np.float64), _cu(km1, np.float64), _cu(hyps, np.float64), _cu(order, np.int64), H,
+                                          self.inliner_dist)
                 bh, cnt = (int(v) for v in res.cpu().numpy())
                 if cnt > 0:
-                    recall_time, best_trans_ransac = bh, Trans[index[bh]]
-            np.savez(f'{Save_dir}/{id0}-{id1}.npz', trans=best_trans_ransac, recalltime=recall_time)
+                    trans, recall = hyps[order[bh]], bh
+            np.savez(f'{Save_dir}/{id0}-{id1}.npz', trans=trans, recalltime=recall)
         R_pre_log(dataset, Save_dir)
 
 

@@ -48,13 +48,21 @@ class fcgf_extractor():
         ch, tr = MODEL_CHANNELS[name]
         if name == "ResUNet2":
             raise ValueError("ResUNet2 has no normalisation layers (NORM_TYPE None); use a BN variant")
-        self.ctx.load_fcgf(checkpoint['state_dict'], channels=ch, tr_channels=tr,
-                           out_channels=int(_cfg_get(config, 'model_n_out', 32)),
-                           conv1_kernel_size=int(_cfg_get(config, 'conv1_kernel_size', 7)), in_channels=1,
-                           normalize_feature=bool(_cfg_get(config, 'normalize_feature', True)))
+        # simple_yoho/fcgf_feat.py:48-49 normalises the rows once more whatever config.normalize_feature says, so the
+        # features this class returns are always unit rows
+        self._load_args = dict(sd=checkpoint['state_dict'], channels=ch, tr_channels=tr,
+                               out_channels=int(_cfg_get(config, 'model_n_out', 32)),
+                               conv1_kernel_size=int(_cfg_get(config, 'conv1_kernel_size', 7)), in_channels=1,
+                               normalize_feature=True)
+        self.ctx.load_fcgf(owner=self, **self._load_args)
+
+    def _resident(self):
+        if self.ctx.fcgf_owner is not self:           # another backbone object loaded its weights into the shared context
+            self.ctx.load_fcgf(owner=self, **self._load_args)
 
     def extract_features_dev(self, pts, voxel_size):
         """HBM-resident variant: pts (n,3) f64 cuda -> (sel int64 cuda, F (m,32) f32 cuda); no host copies."""
+        self._resident()
         sel, coords = self.ctx.fcgf_voxelize(pts, voxel_size)
         return sel, self.ctx.fcgf_forward(coords)
 
@@ -62,6 +70,7 @@ class fcgf_extractor():
 
     def extract_features_dev_batch(self, pts_list, voxel_size):
         """several clouds (f64 cuda) in one backbone pass -> list of (sel, F)."""
+        self._resident()
         vox = [self.ctx.fcgf_voxelize(p, voxel_size) for p in pts_list]
         # one pass addresses at most 2 GiB per feature matrix (<= 256 channels): split long lists by a voxel budget
         feats, group, rows = [], [], 0
@@ -79,6 +88,7 @@ class fcgf_extractor():
         """the backbone on rotated copies of one cloud: pts (n,3) f64 cuda, rotations = list of (3,3) R (p' = R p) ->
         list of (sel, F, rotated selected points (m,3) f32).  The copies are never materialised: rotation, voxelisation and
         the down-sampled points come from one pass over pts (yoho_fcgf_voxelize_rotated)."""
+        self._resident()
         vox = [self.ctx.fcgf_voxelize_rotated(pts, R, voxel_size) for R in rotations]
         feats, group, rows = [], [], 0
         for _, c, _ in vox:

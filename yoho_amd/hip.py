@@ -6,6 +6,7 @@ library cannot be loaded, importing a GPU op raises.
 """
 import ctypes as C
 import os
+import warnings
 import numpy as np
 import torch  # must be imported before the library so that both share one HIP runtime (libamdhip64.so.7)
 
@@ -21,6 +22,7 @@ SYMBOLS = [
     "yoho_gconv_layer", "yoho_load_fcgf", "yoho_fcgf_voxelize", "yoho_fcgf_forward", "yoho_fcgf_forward_batch", "yoho_fcgf_voxelize_rotated", "yoho_rotate_select",
     "yoho_des2r", "yoho_des2r_indexed", "yoho_partII_forward", "yoho_partII_forward_indexed", "yoho_hyp_from_quat", "yoho_o_score", "yoho_c_ransac",
     "yoho_group_gather", "yoho_set_profiling", "yoho_get_kernel_ms", "yoho_set_gconv_mode", "yoho_set_partII_mode", "yoho_set_nn_grid",
+    "yoho_range_status", "yoho_c_ransac_device",
 ]
 
 
@@ -97,6 +99,8 @@ def load_library():
     lib.yoho_fcgf_voxelize_rotated.argtypes = [vp, vp, ci, vp, C.c_double, vp, vp, vp, vp, vp]
     lib.yoho_rotate_select.argtypes = [vp, vp, vp, vp, ci, vp, vp]
     lib.yoho_get_kernel_ms.argtypes = [vp, ci, C.POINTER(C.c_float)]
+    lib.yoho_range_status.argtypes = [vp, C.POINTER(ci), C.POINTER(ci), vp]
+    lib.yoho_c_ransac_device.argtypes = [vp, vp, vp, vp, vp, ci, vp, ci, ci, C.c_uint64, C.c_double, vp, vp, vp, vp, vp]
     for s in SYMBOLS[2:]:
         getattr(lib, s).restype = ci
     _lib = lib
@@ -104,12 +108,20 @@ def load_library():
 
 
 class YohoError(RuntimeError):
-    pass
+    def __init__(self, msg, code=0):
+        super().__init__(msg)
+        self.code = code
+
+
+GCONV_MODES = {"f32": 0, "bf16x3": 1, "fourier": 2, "fp16x2": 3, "fgemm": 4}
+PARTII_MODES = {"f32": 0, "bf16x3": 1, "fp16x2": 2}
+FP16_GCONV_MODES = ("fp16x2", "fgemm")      # arithmetic with fp16 planes: guarded by the range flag (yoho_range_status)
+MAX_PAIR_KEYPOINTS = 16384                  # yoho_partI_forward_pair takes both fragments in one pass up to this many rows
 
 
 def _check(rc):
     if rc != 0:
-        raise YohoError(f"libyoho_hip error {rc}: {_lib.yoho_last_error().decode()}")
+        raise YohoError(f"libyoho_hip error {rc}: {_lib.yoho_last_error().decode()}", rc)
 
 
 def _np_ptr(a):
@@ -144,6 +156,14 @@ class Context:
         _check(lib.yoho_ctx_create(self.device, _np_ptr(R), _np_ptr(self.tables.N_u8), _np_ptr(self.tables.P_u8), C.byref(h)))
         self._h = h
         self._lib = lib
+        # arithmetic modes are tracked here as well (the library reads the same variables at yoho_ctx_create)
+        gm, pm = os.environ.get("YOHO_GCONV", "fgemm"), os.environ.get("YOHO_PARTII", "fp16x2")
+        self.gconv_mode = gm if gm in GCONV_MODES else "fourier"
+        self.partII_mode = pm if pm in PARTII_MODES else "bf16x3"
+        self.set_gconv_mode(self.gconv_mode)
+        self.set_partII_mode(self.partII_mode)
+        self.range_fallbacks = 0            # passes repeated in bf16x3 because a value left the fp16 range
+        self.partI_owner = self.partII_owner = self.fcgf_owner = None      # whose weights are resident (network objects)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -151,10 +171,8 @@ class Context:
             self._h = None
 
     def __del__(self):
-        try:
+        if getattr(self, "_h", None) and getattr(self, "_lib", None) is not None:
             self.close()
-        except Exception:
-            pass
 
     # ---- weights ---------------------------------------------------------------------------
     @staticmethod
@@ -170,7 +188,10 @@ class Context:
         keep += arrs
         return BnW(*[a.ctypes.data for a in arrs])
 
-    def load_partI(self, sd):
+    def load_partI(self, sd, owner=None):
+        """owner: the network object these weights belong to; objects sharing the context compare ``ctx.partI_owner``
+        with themselves before a forward pass and upload again when another checkpoint has been loaded since."""
+        self.partI_owner = owner
         sd = _weights.to_numpy_state_dict(sd)
         _weights.check_state_dict(sd, _weights.PARTI_SPEC, strict=False)
         keep = []
@@ -181,7 +202,8 @@ class Context:
                          self._bn(sd, p + "Conv_out.comb_layer.0", keep), self._conv(sd, p + "Conv_out.comb_layer.2", keep))
         _check(self._lib.yoho_load_partI(self._h, C.byref(w)))
 
-    def load_partII(self, sd):
+    def load_partII(self, sd, owner=None):
+        self.partII_owner = owner
         sd = _weights.to_numpy_state_dict(sd)
         _weights.check_state_dict(sd, _weights.PARTII_SPEC, strict=False)
         keep = []
@@ -210,8 +232,9 @@ class Context:
 
     # ---- FCGF backbone ------------------------------------------------------------------------
     def load_fcgf(self, sd, channels=(0, 32, 64, 128, 256), tr_channels=(0, 64, 64, 64, 128), out_channels=32, conv1_kernel_size=7,
-                  in_channels=1, normalize_feature=True):
+                  in_channels=1, normalize_feature=True, owner=None):
         """sd: FCGF backbone state_dict (torch tensors or ndarrays); architecture parameters as in fcgf_model/resunet.py."""
+        self.fcgf_owner = owner
         sd = _weights.to_numpy_state_dict(sd)
         spec = _weights.fcgf_spec(tuple(channels), tuple(tr_channels), out_channels, conv1_kernel_size, in_channels)
         _weights.check_state_dict(sd, spec, strict=False)
@@ -276,8 +299,45 @@ class Context:
         return [out[int(off[b]):int(off[b + 1])] for b in range(nb)]
 
     # ---- descriptor path -------------------------------------------------------------------
-    def partI_forward(self, x, want_inv=True, want_inv_np=False):
-        """x (B,32,60) f32 cuda -> dict(eqv, inv[, inv_np])."""
+    # ---- fp16 range guard -------------------------------------------------------------------
+    def range_status(self):
+        """(partI_overflow, partII_overflow) since the last call: waits for the current stream, reads and clears the
+        device flags the fp16x2 kernels raise when a value does not fit an fp16 plane (include/yoho_hip.h)."""
+        a, b = C.c_int(0), C.c_int(0)
+        rc = self._lib.yoho_range_status(self._h, C.byref(a), C.byref(b), _stream())
+        if rc not in (0, -5):                      # YOHO_ERANGE is the report itself
+            _check(rc)
+        return bool(a.value), bool(b.value)
+
+    def _repeat_wider(self, which, fn):
+        """repeat fn() with `which` ('gconv' / 'partII') switched to the bf16x3 planes (fp32 exponent range)"""
+        self.range_fallbacks += 1
+        warnings.warn(f"yoho_amd: a value left the fp16 range of the {which} fp16x2 arithmetic; pass repeated in bf16x3", RuntimeWarning)
+        attr, setter = ("gconv_mode", self.set_gconv_mode) if which == "gconv" else ("partII_mode", self.set_partII_mode)
+        old = getattr(self, attr)
+        setter("bf16x3")
+        try:
+            return fn()
+        finally:
+            setter(old)
+
+    def supports_pair(self, n_rows):
+        """yoho_partI_forward_pair (no concatenation copy) exists for the default arithmetic mode and one pass"""
+        return self.gconv_mode == "fgemm" and n_rows <= MAX_PAIR_KEYPOINTS
+
+    def supports_matched(self):
+        """row-indexed PartII (yoho_partII_forward_indexed) exists for the default PartII mode"""
+        return self.partII_mode == "fp16x2"
+
+    def partI_forward(self, x, want_inv=True, want_inv_np=False, check_range=True):
+        """x (B,32,60) f32 cuda -> dict(eqv, inv[, inv_np]).  check_range: in the fp16x2 modes verify the range flag
+        (one stream synchronisation) and repeat the pass in bf16x3 if it is raised; callers that pass False poll
+        range_status() themselves (pipeline.run_pair does, at its first host read-back)."""
+        if check_range and self.gconv_mode in FP16_GCONV_MODES:
+            out = self.partI_forward(x, want_inv, want_inv_np, check_range=False)
+            if self.range_status()[0]:
+                out = self._repeat_wider("gconv", lambda: self.partI_forward(x, want_inv, want_inv_np, check_range=False))
+            return out
         B = x.shape[0]
         if x.dim() != 3 or x.shape[1] != 32 or x.shape[2] != 60:
             raise ValueError(f"group feature must be (B,32,60), got {tuple(x.shape)}")
@@ -294,8 +354,15 @@ class Context:
             out["inv_np"] = inv_np
         return out
 
-    def partI_forward_pair(self, x0, x1, want_inv=True, want_inv_np=False):
-        """both fragments in one pass, no concatenation copy: outputs have B0 + B1 rows (x0's first).  Default mode only."""
+    def partI_forward_pair(self, x0, x1, want_inv=True, want_inv_np=False, check_range=True):
+        """both fragments in one pass, no concatenation copy: outputs have B0 + B1 rows (x0's first).  Default mode only
+        (supports_pair)."""
+        if check_range:
+            out = self.partI_forward_pair(x0, x1, want_inv, want_inv_np, check_range=False)
+            if self.range_status()[0]:
+                xc = torch.cat([x0, x1])
+                out = self._repeat_wider("gconv", lambda: self.partI_forward(xc, want_inv, want_inv_np, check_range=False))
+            return out
         B0, B1 = x0.shape[0], x1.shape[0]
         eqv = torch.empty((B0 + B1, 32, 60), dtype=torch.float32, device=x0.device)
         inv = torch.empty((B0 + B1, 32), dtype=torch.float32, device=x0.device) if want_inv else None
@@ -353,9 +420,15 @@ class Context:
                                             _dev(e2, torch.float32, "e2"), mp, 2, M, C.c_void_p(idx.data_ptr()), None, _stream()))
         return idx
 
-    def partII_forward_matched(self, feat0, feat1, eqv0, eqv1, match, pre_idx):
+    def partII_forward_matched(self, feat0, feat1, eqv0, eqv1, match, pre_idx, check_range=True):
         """partII_forward(feat1[m1], feat0[m0], eqv1[m1], eqv0[m0], pre_idx) with m0, m1 = match[:,0], match[:,1], rows read
-        in place.  Default PartII arithmetic mode only (raises RuntimeError otherwise)."""
+        in place.  Default PartII arithmetic mode only (supports_matched)."""
+        if check_range:
+            q = self.partII_forward_matched(feat0, feat1, eqv0, eqv1, match, pre_idx, check_range=False)
+            if self.range_status()[1]:
+                m0, m1 = match[:, 0], match[:, 1]
+                q = self._repeat_wider("partII", lambda: self.partII_forward(feat1[m1], feat0[m0], eqv1[m1], eqv0[m0], pre_idx, check_range=False))
+            return q
         M = match.shape[0]
         quat = torch.empty((M, 4), dtype=torch.float32, device=feat0.device)
         m0p, m1p = C.c_void_p(_dev(match, torch.int64, "match").value), C.c_void_p(match.data_ptr() + 8)
@@ -365,7 +438,13 @@ class Context:
             _dev(pre_idx, torch.int64, "pre_idx"), M, C.c_void_p(quat.data_ptr()), _stream()))
         return quat
 
-    def partII_forward(self, before_eqv0, before_eqv1, after_eqv0, after_eqv1, pre_idx):
+    def partII_forward(self, before_eqv0, before_eqv1, after_eqv0, after_eqv1, pre_idx, check_range=True):
+        if check_range and self.partII_mode == "fp16x2":
+            args = (before_eqv0, before_eqv1, after_eqv0, after_eqv1, pre_idx)
+            q = self.partII_forward(*args, check_range=False)
+            if self.range_status()[1]:
+                q = self._repeat_wider("partII", lambda: self.partII_forward(*args, check_range=False))
+            return q
         M = before_eqv0.shape[0]
         quat = torch.empty((M, 4), dtype=torch.float32, device=before_eqv0.device)
         _check(self._lib.yoho_partII_forward(
@@ -408,6 +487,24 @@ class Context:
                                        C.c_void_p(counts.data_ptr()) if want_all else None, _stream()))
         return best_T, res, T_all, counts
 
+    def c_ransac_device(self, keys0, keys1, dr_index, max_iter, seed, d, match=None, want_triples=False):
+        """YOHO-C with the sampling on the device (yoho_c_ransac_device): keys0 / keys1 (.,3) f64 cuda, addressed through
+        the columns of match (M,2) int64 if given (else row m = match m), dr_index (M,) int64.
+        Returns (best_T (3,4) f64, res int32[2] = (best_iter, best_count), triples (max_iter,3) int64 or None): device tensors."""
+        M = dr_index.shape[0]
+        best_T = torch.empty((3, 4), dtype=torch.float64, device=keys0.device)
+        res = torch.zeros((2,), dtype=torch.int32, device=keys0.device)
+        tri = torch.empty((max_iter, 3), dtype=torch.int64, device=keys0.device) if want_triples else None
+        if match is not None:
+            i0, i1, istride = C.c_void_p(_dev(match, torch.int64, "match").value), C.c_void_p(match.data_ptr() + 8), 2
+        else:
+            i0, i1, istride = None, None, 1
+        _check(self._lib.yoho_c_ransac_device(self._h, _dev(keys0, torch.float64, "keys0"), i0, _dev(keys1, torch.float64, "keys1"), i1,
+                                              istride, _dev(dr_index, torch.int64, "dr_index"), M, int(max_iter), int(seed) & (2 ** 64 - 1),
+                                              float(d), C.c_void_p(best_T.data_ptr()), C.c_void_p(res.data_ptr()),
+                                              C.c_void_p(res.data_ptr() + 4), C.c_void_p(tri.data_ptr()) if want_triples else None, _stream()))
+        return best_T, res, tri
+
     def group_gather(self, keys, pts, feat, g, out, want_idx=False):
         K, n = keys.shape[0], pts.shape[0]
         Rg = np.ascontiguousarray(self.tables.R64[g], dtype=np.float64)
@@ -421,11 +518,13 @@ class Context:
     def set_gconv_mode(self, mode):
         """'f32' (direct conv, fp32 MFMA), 'bf16x3' (direct conv, fp32-accurate 3-way bf16 split MFMA),
         'fourier' (group-Fourier domain conv, fp32 MFMA) or 'fp16x2' (direct conv, 2-way fp16 split MFMA) for PartI."""
-        _check(self._lib.yoho_set_gconv_mode(self._h, {"f32": 0, "bf16x3": 1, "fourier": 2, "fp16x2": 3, "fgemm": 4}[mode]))
+        _check(self._lib.yoho_set_gconv_mode(self._h, GCONV_MODES[mode]))
+        self.gconv_mode = mode
 
     def set_partII_mode(self, mode):
         """'f32', 'bf16x3' or 'fp16x2' for the two large cone layers of PartII."""
-        _check(self._lib.yoho_set_partII_mode(self._h, {"f32": 0, "bf16x3": 1, "fp16x2": 2}[mode]))
+        _check(self._lib.yoho_set_partII_mode(self._h, PARTII_MODES[mode]))
+        self.partII_mode = mode
 
     def set_nn_grid(self, cell):
         """3-D nearest-neighbour searches (nn_search with 3 columns, group_gather) through a hash grid with this cell size

@@ -39,8 +39,14 @@ class yoho_extractor():
 
     def _load_model(self):
         sd = self.yoho_ckpt if isinstance(self.yoho_ckpt, dict) else W.load_checkpoint(self.yoho_ckpt)[0]
-        W.check_state_dict(W.to_numpy_state_dict(sd), W.PARTI_SPEC, strict=False)
-        self.ctx.load_partI(sd)
+        self._sd = W.to_numpy_state_dict(sd)
+        W.check_state_dict(self._sd, W.PARTI_SPEC, strict=False)
+        self.ctx.load_partI(self._sd, owner=self)
+
+    def _partI(self, kpts_f):
+        if self.ctx.partI_owner is not self:          # another network object loaded its checkpoint into the shared context
+            self.ctx.load_partI(self._sd, owner=self)
+        return self.ctx.partI_forward(kpts_f.contiguous(), want_inv=True)
 
     def _feature_transfer_xyz(self, query, source, source_f):
         """NN in xyz (fp32, 'SquareL2') and feature row transfer (simple_yoho/yoho_extract.py:33-39)."""
@@ -84,7 +90,7 @@ class yoho_extractor():
             finally:
                 self.ctx.set_nn_grid(0)
             self._last_group_feats = kpts_f
-            out = self.ctx.partI_forward(kpts_f.contiguous(), want_inv=True)
+            out = self._partI(kpts_f)
             return kpts, out["inv"].cpu(), out["eqv"].cpu()
         for i in range(self.grs.shape[0]):
             kptsi = transform_points(kpts.copy(), self.grs[i])
@@ -92,7 +98,7 @@ class yoho_extractor():
             pci_ds, pci_f = self.fcgf.run(pci, voxel_size)
             kpts_f[:, :, i] = self._feature_transfer_xyz(kptsi, pci_ds, pci_f)
         self._last_group_feats = kpts_f                     # (n,32,60) group features, kept for inspection
-        out = self.ctx.partI_forward(kpts_f.contiguous(), want_inv=True)
+        out = self._partI(kpts_f)
         # output: n*32; n*32*60 (cpu tensors, as the reference)
         return kpts, out["inv"].cpu(), out["eqv"].cpu()
 
