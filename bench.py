@@ -6,12 +6,16 @@ in HBM:  PartI descriptor on both fragments (2 x 5000 keypoints x 60 rotations x
 -> numpy-order invariant pooling -> mutual NN -> coarse rotation index -> PartII -> per-match
 hypotheses -> YOHO-O vote (<=1000 hypotheses).  Whole-job keypoints/s = 10000 * pairs / time.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--scaling weak|strong]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
-N > 1: one process per GPU; every rank runs its own pairs (weak scaling, no data-path collective);
-the checkpoint is broadcast once from rank 0 over RCCL.  Prints ONE JSON line on rank 0.
+N > 1: one process per GPU; the checkpoint is broadcast once from rank 0 over RCCL, no data-path collective.
+  --scaling weak (default): every rank runs its own pair per step (per-GPU work fixed);
+  --scaling strong: a step is one sweep over a FIXED list of 64 pairs (8 synthetic scenes x 8 pairs) dealt to the ranks by
+    yoho_amd.run_dataset.plan_shards (the dataset driver's plan); value = 64 * 10000 * steps / time.
+Besides the headline (descriptor + YOHO-O) the line carries "yohoc": the same step with the YOHO-C estimator (config 5:
+descriptor + 1000 RANSAC iterations sampled on the device, no PartII).  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -48,15 +52,32 @@ def fgemm_issued_flops(nkp):
     return tot
 
 
+def fgemm_issued_flops_per_layer(nkp):
+    kppad = (nkp + 255) // 256 * 256
+    return [sum(2 * 3 * ((d * cout + 255) // 256 * 256) * (d * kppad) * (d * cin) for d in (1, 3, 3, 4, 5))
+            for cin, cout in ((32, 256), (256, 512), (512, 256), (256, 32))]
+
+
+PMC_FILES = ("r02_pmc_traffic.json", "r01_pmc_traffic.json")     # newest first
+
+
 def pmc_traffic(mode):
-    """HBM bytes per group-conv launch (average over the 4 launches of a PartI pass at 5000 keypoints), measured
-    offline with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes and corrected as MI355X_MICROARCH.md
-    prescribes (FETCH_SIZE x2 on gfx950); see profiles/r01_pmc_traffic.md.  None if the file is absent."""
-    try:
-        d = json.load(open(os.path.join(REPO, "profiles", "r01_pmc_traffic.json")))
-        return round(d["partI_pass_gconv_bytes"][mode] / d["partI_pass_gconv_bytes"]["launches_per_pass"])
-    except Exception:
-        return None
+    """(HBM bytes per group-conv launch, provenance).  Average over the 4 launches of a PartI pass, measured with
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (tools/pmc_traffic.py over tools/pmc_partI.py) and corrected
+    as MI355X_MICROARCH.md prescribes (FETCH_SIZE x2 on gfx950).  Counters cannot be read from inside a timed run, so the
+    figure comes from the newest profiles/*_pmc_traffic.json, whose commit and pass totals are reported beside it."""
+    for fn in PMC_FILES:
+        path = os.path.join(REPO, "profiles", fn)
+        if not os.path.exists(path):
+            continue
+        d = json.load(open(path))
+        per = d.get("partI_pass_gconv_bytes", {})
+        if mode not in per:
+            continue
+        src = {"file": "profiles/" + fn, "commit": d.get("commit"), "pass_gconv_bytes": round(per[mode]),
+               "pass_total_bytes": d.get("partI_pass_total_bytes", {}).get(mode)}
+        return round(per[mode] / per.get("launches_per_pass", 4)), src
+    return None, None
 
 
 def cpu_baseline(K=600):
@@ -76,17 +97,27 @@ def cpu_baseline(K=600):
     e1 = np.concatenate([orc.partI_forward_torch(pr["feat1"][s:s + 900], sd1, tb.N)[0] for s in range(0, K, 900)])
     t_desc = time.time() - t0
     m = orc.mutual_match(orc.group_mean_np(e0), orc.group_mean_np(e1))
-    dr = orc.des2r(e1[m[:, 1]], e0[m[:, 0]], tb.P)
-    q = orc.partII_forward(pr["feat1"][m[:, 1]], pr["feat0"][m[:, 0]], e1[m[:, 1]], e0[m[:, 0]], dr, sd2, tb.N, tb.P)
+    dr = orc.des2r_torch(e1[m[:, 1]], e0[m[:, 0]], tb.P)
+    q = np.concatenate([orc.partII_forward_torch(pr["feat1"][m[s:s + 1000, 1]], pr["feat0"][m[s:s + 1000, 0]], e1[m[s:s + 1000, 1]],
+                                                 e0[m[s:s + 1000, 0]], dr[s:s + 1000], sd2, tb.N, tb.P) for s in range(0, len(m), 1000)])
     k0, k1 = pr["keys0"][m[:, 0]], pr["keys1"][m[:, 1]]
     T = orc.hyp_from_quat(q, dr, k0, k1, tb.R32)
     order = np.arange(len(m))
     np.random.RandomState(0).shuffle(order)
     orc.yohoo_select(k0, k1, T, order, 0.09, 1000)
     dt = time.time() - t0
-    return {"value": round(2 * K / dt, 2), "unit": "keypoints/s", "cores": os.cpu_count(), "kind": "port",
-            "sample": f"one synthetic pair, {K} keypoints/fragment ({len(m)} matches): PartI (torch-CPU conv2d, bs=900) "
-                      f"{t_desc:.1f}s of {dt:.1f}s total, then matcher + Des2R + PartII + YOHO-O in numpy"}
+    out = {"value": round(2 * K / dt, 2), "unit": "keypoints/s", "cores": os.cpu_count(), "kind": "port",
+           "sample": f"one synthetic pair, {K} keypoints/fragment ({len(m)} matches): PartI (torch-CPU conv2d, bs=900) "
+                     f"{t_desc:.1f}s of {dt:.1f}s total, then matcher (numpy) + Des2R + PartII (torch-CPU ops of the reference, bs=1000) "
+                     f"+ YOHO-O (numpy)"}
+    chk = os.path.join(REPO, "profiles", "r02_reference_vs_port.json")
+    if os.path.exists(chk):
+        # the port against the real reference in the build container, same inputs (tools/time_reference_vs_port.py)
+        c = json.load(open(chk))
+        out["reference_timing_check"] = {k: c[k] for k in ("keypoints_per_fragment", "cores", "reference_total_s", "port_total_s",
+                                                            "port_over_reference_time", "outputs")}
+        out["reference_timing_check"]["source"] = "profiles/r02_reference_vs_port.json (tools/time_reference_vs_port.py, build container)"
+    return out
 
 
 def main():
@@ -95,6 +126,8 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--no-yohoc", action="store_true", help="skip the YOHO-C leg")
     ap.add_argument("--gconv", choices=["f32", "bf16x3", "fourier", "fp16x2", "fgemm"], default=os.environ.get("YOHO_GCONV", "fgemm"),
                     help="PartI group conv: group-Fourier domain (fp32 MFMA), direct fp32 MFMA, direct 3-way bf16 split MFMA, "
                          "or direct 2-way fp16 split MFMA")
@@ -118,26 +151,66 @@ def main():
     ctx.set_gconv_mode(args.gconv)
     ctx.set_partII_mode(args.partII)
 
-    # every rank owns a different synthetic pair (weak scaling: per-GPU work is fixed)
-    pr = synth.make_pair(KP, seed=10 + rank)
     cu = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
-    f0, f1, k0, k1 = cu(pr["feat0"]), cu(pr["feat1"]), cu(pr["keys0"]), cu(pr["keys1"])
     rng = np.random.RandomState(1234 + rank)
+    if args.scaling == "weak":
+        # every rank owns a different synthetic pair (weak scaling: per-GPU work is fixed)
+        pr = synth.make_pair(KP, seed=10 + rank)
+        mine = [(cu(pr["feat0"]), cu(pr["feat1"]), cu(pr["keys0"]), cu(pr["keys1"]))]
+        pairs_per_step = world
+    else:
+        # a fixed list of 64 pairs = 8 scenes x 8 pairs, dealt to the ranks by the dataset driver's plan (scenes whole, a
+        # scene larger than a rank's share cut round-robin).  8 distinct synthetic pairs, each listed 8 times.
+        from yoho_amd.run_dataset import plan_shards
+        plan = plan_shards({f"scene{i}": 8 for i in range(8)}, world)[rank]
+        distinct = {}
+        mine = []
+        for scene, positions in plan:
+            for p in positions:
+                sid = (int(scene[5:]) * 8 + p) % 8
+                if sid not in distinct:
+                    q = synth.make_pair(KP, seed=10 + sid)
+                    distinct[sid] = (cu(q["feat0"]), cu(q["feat1"]), cu(q["keys0"]), cu(q["keys1"]))
+                mine.append(distinct[sid])
+        pairs_per_step = 64
+    f0, f1, k0, k1 = mine[0]
 
-    def step():
-        return pipeline.run_pair(ctx, f0, f1, k0, k1, inlier_dist=0.09, max_iter=1000, order_rng=rng)
+    def step(estimator="yohoo", seed=0):
+        r = None
+        for (a0, a1, b0, b1) in mine:
+            r = pipeline.run_pair(ctx, a0, a1, b0, b1, inlier_dist=0.09 if estimator == "yohoo" else 0.07, max_iter=1000, order_rng=rng,
+                                  estimator=estimator, seed=seed)
+        return r
 
-    for _ in range(args.warmup):
-        res = step()
-    ydist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res = step()
-    torch.cuda.synchronize()
-    ydist.barrier()
-    dt = time.perf_counter() - t0
-    dt = ydist.max_over_ranks(dt)
+    def timed(fn, steps, warmup):
+        for _ in range(warmup):
+            r = fn()
+        ydist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            r = fn()
+        torch.cuda.synchronize()
+        ydist.barrier()
+        return ydist.max_over_ranks(time.perf_counter() - t0), r
+
+    dt, res = timed(step, args.steps, args.warmup)
+    yohoc = None
+    if not args.no_yohoc:
+        seeds = iter(range(1, 10 ** 9))
+        dtc, resc = timed(lambda: step("yohoc", next(seeds)), args.steps, min(args.warmup, 2))
+        # host time per pair of the estimator call alone (launches only: nothing is read back inside the call)
+        m_, dr_ = res.match, res.dr_index
+        torch.cuda.synchronize()
+        th = time.perf_counter()
+        for i in range(20):
+            ctx.c_ransac_device(k0, k1, dr_, 1000, 100 + i, 0.07, match=m_)
+        host_ms = (time.perf_counter() - th) / 20 * 1e3
+        torch.cuda.synchronize()
+        yohoc = {"metric": "keypoints/sec (5000 kp x60 rot desc + YOHO-C, 1000 iterations sampled on the device)",
+                 "value": round(pairs_per_step * 2 * KP * args.steps / dtc, 1), "ms_per_step": round(dtc / args.steps * 1e3, 3),
+                 "iterations": 1000, "estimator_host_ms_per_pair": round(host_ms, 4),
+                 "winner_inliers": int(resc.best_count), "matches": int(resc.match.shape[0])}
 
     # per-kernel timing of the dominant kernel (group conv), HIP events on the launch stream; same batch as the
     # timed step (both fragments in one pass)
@@ -146,24 +219,56 @@ def main():
     ctx.set_profiling(True)
     conv_ms = []
     for _ in range(3):
-        ctx.partI_forward(fboth, want_inv=False, want_inv_np=True)
+        ctx.partI_forward(fboth, want_inv=False, want_inv_np=True, check_range=False)
         torch.cuda.synchronize()
-        conv_ms.append([ctx.kernel_ms(i) for i in range(7)])
+        conv_ms.append([ctx.kernel_ms(i) for i in range(12)])
     ctx.set_profiling(False)
     conv_ms = np.array(conv_ms).mean(0)
     gconv_total_ms = float(conv_ms[:4].sum())
     achieved = FLOP_PER_KP * nkp / (gconv_total_ms * 1e-3) / 1e12      # algorithmic (direct 13-tap) FLOP/s
+    conv_total_ms = float(conv_ms[:4].sum() + conv_ms[4] + conv_ms[5] + conv_ms[6])    # GEMMs + head + tail + transforms
+
+    # the HBM-bound kernels of a step, each against its ALGORITHMIC bytes (what the kernel must read and write once)
+    def ev_ms(fn, n=5):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n
+    o0, o1 = res.eqv
+    M = int(res.match.shape[0])
+    nn_ms = ev_ms(lambda: ctx.mutual_nn(o0["inv_np"], o1["inv_np"]))
+    des_ms = ev_ms(lambda: ctx.des2r_matched(o1["eqv"], o0["eqv"], res.match))
+    coef = lambda ch: 60 * ch * 4 * nkp                  # bytes of one fp32 coefficient (or fp16x2 plane) tensor with ch channels
+    hbm = {}
+
+    def add(name, ms, nbytes, note):
+        hbm[name] = {"ms": round(float(ms), 4), "bytes": int(nbytes), "TBps": round(nbytes / (ms * 1e-3) / 1e12, 3) if ms > 0 else None,
+                     "frac_of_8TBps": round(nbytes / (ms * 1e-3) / 8e12, 4) if ms > 0 else None, "what": note}
+    if args.gconv == "fgemm":
+        add("head16_kernel", conv_ms[4], 2 * coef(32), "x (B,32,60) f32 in, cin=32 operand planes out")
+        for i, ch in ((7, 256), (8, 512), (9, 256)):
+            add(f"gft16_kernel<ACTP> {ch}ch", conv_ms[i], 2 * coef(ch), "fp32 coefficients in, BN+ReLU in the group domain, fp16x2 operand planes out")
+        add("gft16_kernel<INV>", conv_ms[10], 2 * coef(32), "fp32 coefficients in, group-domain fp32 out")
+        add("finalize_partI_kernel", conv_ms[11], 3 * coef(32) + 128 * nkp, "y + x in, eqv + inv_np out")
+    add("nn32seg + mutual_compact (both directions)", nn_ms, 4 * KP * 128 + 16 * M,
+        "vector-fp32-bound, not HBM-bound: 2 x 5000 x 5000 x 32 x 3 flop = %.1f TFLOP/s of the 157.3 fp32 peak" % (2 * KP * KP * 32 * 3 / (nn_ms * 1e-3) / 1e12))
+    add("des2r_kernel", des_ms, M * (2 * 7680 + 8), "two (32,60) descriptors per match in, index out")
 
     if rank == 0:
         M = int(res.match.shape[0])
         if args.gconv == "f32":
             roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK, "unit": "TFLOP/s",
-                    "frac": round(achieved / FP32_MFMA_PEAK, 4), "traffic": pmc_traffic("f32"),
+                    "frac": round(achieved / FP32_MFMA_PEAK, 4), "traffic": pmc_traffic("f32")[0],
                     "kernel": "gconv_kernel<15,false> (4 launches = 4 PartI layers, 2.1725 algorithmic TFLOP per 5000 kp)"}
             dtype = "f32"
         elif args.gconv == "bf16x3":
             roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": BF16_MFMA_PEAK, "unit": "TFLOP/s",
-                    "frac": round(achieved / BF16_MFMA_PEAK, 4), "traffic": pmc_traffic("bf16x3"),
+                    "frac": round(achieved / BF16_MFMA_PEAK, 4), "traffic": pmc_traffic("bf16x3")[0],
                     "kernel": "gconv16_kernel<15,2> + <8,1> (4 launches = 4 PartI layers, 2.1725 algorithmic TFLOP per 5000 kp)",
                     "executed_tflops": round(achieved * BF16X3_EXEC_PER_ALG, 1),
                     "executed_frac": round(achieved * BF16X3_EXEC_PER_ALG / BF16_MFMA_PEAK, 4),
@@ -172,7 +277,7 @@ def main():
             dtype = "bf16x3 split (fp32-accurate, fp32 accumulate)"
         elif args.gconv == "fp16x2":
             roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": BF16_MFMA_PEAK, "unit": "TFLOP/s",
-                    "frac": round(achieved / BF16_MFMA_PEAK, 4), "traffic": pmc_traffic("fp16x2"),
+                    "frac": round(achieved / BF16_MFMA_PEAK, 4), "traffic": pmc_traffic("fp16x2")[0],
                     "kernel": "gconv16_kernel<15,2,2> + <8,1,2> (4 launches = 4 PartI layers, 2.1725 algorithmic TFLOP per 5000 kp)",
                     "executed_tflops": round(achieved * BF16X3_EXEC_PER_ALG / 2, 1),
                     "executed_frac": round(achieved * BF16X3_EXEC_PER_ALG / 2 / BF16_MFMA_PEAK, 4),
@@ -182,9 +287,13 @@ def main():
         elif args.gconv == "fgemm":
             issued = fgemm_issued_flops(nkp) / (gconv_total_ms * 1e-3) / 1e12
             roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP16_MFMA_PEAK, "unit": "TFLOP/s",
-                    "frac": round(achieved / FP16_MFMA_PEAK, 4), "traffic": pmc_traffic("fgemm"),
+                    "frac": round(achieved / FP16_MFMA_PEAK, 4), "traffic": pmc_traffic("fgemm")[0], "traffic_source": pmc_traffic("fgemm")[1],
                     "kernel": "fgemm_kernel (4 launches = 4 PartI layers over both fragments, 4.345 algorithmic TFLOP per 10000 kp)",
                     "executed_tflops": round(issued, 1), "executed_frac": round(issued / FP16_MFMA_PEAK, 4),
+                    "executed_frac_per_launch": [round(f / (ms * 1e-3) / 1e12 / FP16_MFMA_PEAK, 4)
+                                                 for f, ms in zip(fgemm_issued_flops_per_layer(nkp), conv_ms[:4])],
+                    "conv_total_frac": round(FLOP_PER_KP * nkp / (conv_total_ms * 1e-3) / 1e12 / FP16_MFMA_PEAK, 4),
+                    "conv_total_ms": round(conv_total_ms, 3),
                     "note": "achieved = algorithmic FLOP/s of the reference's direct 13-tap formulation (SURVEY 8d) over the 4 "
                             "fgemm launches. The kernel evaluates the same convolution on group-Fourier coefficients as five dense "
                             "irrep GEMMs (244/780 of the multiply-adds) with every product as 3 fp16 MFMA products (fp16x2 split, "
@@ -195,7 +304,7 @@ def main():
         else:
             ex = achieved * FOURIER_EXEC_PER_ALG
             roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK, "unit": "TFLOP/s",
-                    "frac": round(achieved / FP32_MFMA_PEAK, 4), "traffic": pmc_traffic("fourier"),
+                    "frac": round(achieved / FP32_MFMA_PEAK, 4), "traffic": pmc_traffic("fourier")[0],
                     "kernel": "gconvf_kernel (4 launches = 4 PartI layers, 2.1725 algorithmic TFLOP per 5000 kp)",
                     "executed_tflops": round(ex, 2), "executed_frac": round(ex / FP32_MFMA_PEAK, 4),
                     "note": "achieved = algorithmic FLOP/s of the reference's direct 13-tap formulation (SURVEY 8d) over the 4 "
@@ -206,21 +315,26 @@ def main():
             dtype = "f32"
         out = {
             "metric": "keypoints/sec (5000 kp x60 rot desc+YOHO-O)",
-            "value": round(world * 2 * KP * args.steps / dt, 1),
+            "value": round(pairs_per_step * 2 * KP * args.steps / dt, 1),
             "unit": "keypoints/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": dtype, "data": "synthetic",
             "config": {"workload": "one synthetic scene pair per step per GPU: 2 fragments x 5000 keypoints x 60 rotations x 32-D "
                                    "-> PartI group conv + invariant pooling -> mutual NN -> Des2R -> PartII -> YOHO-O (<=1000 hypotheses); "
                                    "random-init weights (seeded), inputs resident in HBM",
                        "keypoints_per_fragment": KP, "partI_batch": nkp, "matches": M, "hypotheses": min(1000, M), "gconv": args.gconv, "partII": args.partII,
-                       "parallelism": f"pairs sharded over {world} GPU(s), no data-path collective"},
+                       "pairs_per_step": pairs_per_step,
+                       "parallelism": (f"one pair per GPU per step, {world} GPU(s), no data-path collective" if args.scaling == "weak" else
+                                       f"64 pairs (8 scenes x 8) per step dealt to {world} rank(s) by run_dataset.plan_shards, no data-path collective")},
             "roofline": roof,
             "roofline_extra": {"launch_ms": [round(float(v), 3) for v in conv_ms[:4]], "head_ms": round(float(conv_ms[4]), 3),
-                               "tail_ms": round(float(conv_ms[5]), 3), "transform_ms": round(float(conv_ms[6]), 3)},
+                               "tail_ms": round(float(conv_ms[5]), 3), "transform_ms": round(float(conv_ms[6]), 3), "hbm": hbm,
+                               "range_repeats": int(ctx.range_fallbacks)},
         }
+        if yohoc is not None:
+            out["yohoc"] = yohoc
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

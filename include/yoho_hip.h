@@ -236,8 +236,9 @@ int yoho_set_nn_grid(yoho_ctx* ctx, double cell);
  * group-Fourier domain, 13-rotation cone layer direct, last layer as one dense product at the identity). */
 int yoho_set_partII_mode(yoho_ctx* ctx, int mode);
 
-/* timing hook for bench.py: average device time (ms) of the last yoho_partI_forward's dominant
- * group-conv launches, measured with hipEvents on the call's own stream.  <0 if unavailable. */
+/* timing hook for bench.py: device time (ms) of the stages of the last yoho_partI_forward pass, measured with hipEvents
+ * on the call's own stream.  which 0..3: the four group-conv launches; 4: head; 5: tail (inverse transform + finalize);
+ * 6: the three inter-layer transform launches together, 7 / 8 / 9 each of them; 10: inverse transform; 11: finalize. */
 /* fp16 range guard.  The default arithmetic (PartI mode 4, PartII mode 2; also PartI mode 3) keeps activations and
  * Fourier coefficients as fixed power-of-two multiples in fp16 planes (|activation| < 4094, |coefficient| < 16376).
  * Every kernel that writes such planes raises a device-side flag when a value falls outside; nothing else in the

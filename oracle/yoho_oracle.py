@@ -237,6 +237,55 @@ def partII_forward(bf0, bf1, af0, af1, pre_idx, sd, N, P):
     return (q / np.sqrt(np.sum(q * q, axis=1))[:, None]).astype(np.float32)    # :277 (no clamp)
 
 
+def des2r_torch(d1, d2, P):
+    """Batch_Des2R_torch on torch's CPU kernels, the op sequence of tests/extractor.py:74-78 (index gather, einsum,
+    argmax): the timed CPU baseline of this stage (the numpy einsum of des2r_cor is several times slower)."""
+    import torch
+    with torch.no_grad():
+        a, b = torch.from_numpy(np.ascontiguousarray(d1, dtype=np.float32)), torch.from_numpy(np.ascontiguousarray(d2, dtype=np.float32))
+        B, Fd, _ = a.shape
+        idx = torch.from_numpy(np.ascontiguousarray(P.reshape(-1), dtype=np.int64))
+        cor = torch.einsum('bfag,bfg->ba', a[:, :, idx].reshape([B, Fd, G, G]), b)
+        return torch.argmax(cor, dim=1).numpy().astype(np.int64)
+
+
+def partII_forward_torch(bf0, bf1, af0, af1, pre_idx, sd, N, P):
+    """PartII_test.forward on torch's CPU kernels, the reference's op sequence (utils/network.py:259-278 with :243-256 and
+    :12-65): per-match permutation, cat, [index-gather -> batch_norm -> relu -> conv2d (1,13)] x 3 with the residual, then the
+    1x1 conv / BN / ReLU head on all 60 group elements, [:, :, 0, 0], normalise.  Timed CPU baseline of the stage."""
+    import torch
+    import torch.nn.functional as Fn
+    t = lambda k: torch.from_numpy(sd[k])
+    Nf = torch.from_numpy(np.ascontiguousarray(N.reshape(-1), dtype=np.int64))
+    Pt = torch.from_numpy(np.ascontiguousarray(P, dtype=np.int64))
+
+    def gather(v):
+        return v[:, :, Nf].reshape(v.shape[0], v.shape[1], G, NTAP)
+
+    def bn(v, pre):
+        return Fn.batch_norm(v, t(pre + ".running_mean"), t(pre + ".running_var"), t(pre + ".weight"), t(pre + ".bias"), False, 0.1, 1e-5)
+
+    def comb(v, pre):                                   # Comb_Conv: BN -> ReLU -> Conv2d on the gathered tensor
+        return Fn.conv2d(Fn.relu(bn(gather(v), pre + ".0")), t(pre + ".2.weight"), t(pre + ".2.bias"))[:, :, :, 0]
+    with torch.no_grad():
+        b0, b1, a0, a1 = (torch.from_numpy(np.array(x, dtype=np.float32)) for x in (bf0, bf1, af0, af1))
+        idx = torch.from_numpy(np.ascontiguousarray(pre_idx, dtype=np.int64))
+        for i in range(b0.shape[0]):                    # :266-268 (on copies: the callers' arrays stay untouched)
+            b0[i] = b0[i, :, Pt[idx[i]]]
+            a0[i] = a0[i, :, Pt[idx[i]]]
+        x = torch.cat([b0, b1, a0, a1], dim=1)
+        h = comb(x, "Conv_init.comb_layer")
+        r = "PartII_SO3_Conv_layers.0"
+        h = comb(comb(h, r + ".comb_layer_in"), r + ".comb_layer_out") + h
+        v = h.unsqueeze(-1)
+        f = "PartII_To_R_FC."
+        v = Fn.relu(bn(Fn.conv2d(v, t(f + "0.weight"), t(f + "0.bias")), f + "1"))
+        v = Fn.relu(bn(Fn.conv2d(v, t(f + "3.weight"), t(f + "3.bias")), f + "4"))
+        q = Fn.conv2d(v, t(f + "6.weight"), t(f + "6.bias"))[:, :, 0, 0]
+        q = q / torch.norm(q, dim=1)[:, None]
+    return q.numpy()
+
+
 def batch_create(feats0_fcgf, feats1_fcgf, feats0_yoho, feats1_yoho, index_pre):
     """extractor_PartII.batch_create (tests/extractor.py:125-138): note the 0<->1 exchange."""
     return dict(before_eqv0=feats1_fcgf, before_eqv1=feats0_fcgf,

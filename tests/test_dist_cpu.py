@@ -59,3 +59,106 @@ def test_single_process_noops():
     assert ydist.broadcast_state_dict(sd, W.PARTII_SPEC) is sd
     assert ydist.shard(list(range(5)), 0, 1) == list(range(5))
     assert ydist.max_over_ranks(3.5) == 3.5 and ydist.gather_results([1]) == [[1]]
+
+
+# ---- dataset-level driver (yoho_amd/run_dataset.py): plan, ordering, completeness ------------------------------------
+class _FakeScene:
+    def __init__(self, name, nfrag, npairs, seed):
+        rs = np.random.RandomState(seed)
+        self.name = name
+        self.pc_ids = [str(i) for i in range(nfrag)]
+        allp = [(str(a), str(b)) for a in range(nfrag) for b in range(a + 1, nfrag)]
+        self.pair_ids = [allp[i] for i in sorted(rs.permutation(len(allp))[:npairs])]
+
+
+def _fake_datasets():
+    # sizes shaped like 3DMatch (utils/dataset.py:163-167): one scene much larger than the per-rank share
+    ds = {"wholesetname": "fake"}
+    for i, (nf, npair) in enumerate([(12, 40), (6, 9), (5, 7), (7, 11), (4, 3)]):
+        ds[f"scene{i}"] = _FakeScene(f"fake/scene{i}", nf, npair, i)
+    return ds
+
+
+def _fake_pair_fn(calls):
+    from yoho_amd import run_dataset as rd
+
+    def fn(dataset, pair):
+        calls.append((dataset.name, pair))
+        seed = rd.pair_seed(5, dataset.name, *pair)
+        rs = np.random.RandomState(seed & 0xFFFFFFFF)
+        T = np.concatenate([np.eye(3), rs.rand(3, 1)], 1)
+        return {"trans": T, "recalltime": int(seed % 1000), "rank": int(os.environ.get("RANK", "0"))}
+    return fn
+
+
+def test_plan_shards_properties():
+    from yoho_amd import run_dataset as rd
+    sizes = {"kitchen": 506, "home1": 156, "home2": 208, "hotel1": 226, "hotel2": 104, "hotel3": 54, "study": 292, "lab": 77}
+    for world in (1, 2, 3, 8, 16):
+        plan = rd.plan_shards(sizes, world)
+        assert len(plan) == world
+        seen = sorted((s, p) for part in plan for s, pos in part for p in pos)
+        assert seen == sorted((s, p) for s, n in sizes.items() for p in range(n))          # each pair exactly once
+        loads = [sum(len(pos) for _, pos in part) for part in plan]
+        share = -(-sum(sizes.values()) // world)
+        assert max(loads) <= 2 * share
+        if world == 8:
+            # scenes first: only scenes above the per-rank share are cut, and their pairs go round-robin
+            cut = {s for s in sizes if sum(1 for part in plan for t, _ in part if t == s) > 1}
+            assert cut == {s for s, n in sizes.items() if n > share}
+            pos = [pos for part in plan for s, pos in part if s == "kitchen"]
+            assert all(p == list(range(p[0], 506, len(pos))) for p in pos)
+    assert rd.plan_shards(sizes, 8) == rd.plan_shards(dict(reversed(list(sizes.items()))), 8)       # independent of dict order
+
+
+def _driver_worker(rank, world, port, q, tmp):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from yoho_amd import dist as ydist, run_dataset as rd
+    ydist.init_from_env("gloo")
+    ds = _fake_datasets()
+    calls, setups = [], []
+    res = rd.run_sharded(ds, _fake_pair_fn(calls), rank=rank, world=world, scene_fn=lambda d, pairs: setups.append((d.name, len(pairs))))
+    if rank == 0:
+        class Cfg:
+            output_cache_fn = tmp
+        for key, d in rd.scene_items(ds):
+            rd.write_scene_results(Cfg, d, res[key], "YOHO_O", 1000)
+    ydist.barrier()
+    q.put((rank, calls, setups, {k: [(r["recalltime"], r["rank"]) for r in v] for k, v in res.items()}))
+    torch.distributed.destroy_process_group()
+
+
+def test_sharded_driver_world2_matches_world1(tmp_path):
+    from yoho_amd import run_dataset as rd
+    from yoho_amd.estimator import format_log_entry
+    ds = _fake_datasets()
+    calls1 = []
+    ref = rd.run_sharded(ds, _fake_pair_fn(calls1), rank=0, world=1)
+    assert [c for c in calls1] == [(d.name, tuple(p)) for _, d in sorted(rd.scene_items(ds), key=lambda kd: -len(kd[1].pair_ids))
+                                   for p in d.pair_ids]
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_driver_worker, args=(r, world, port, q, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = sorted(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    # completeness: every pair ran on exactly one rank; both ranks hold the full, identically ordered result
+    ran = sorted(c for _, calls, _, _ in out for c in calls)
+    assert ran == sorted((d.name, tuple(p)) for _, d in rd.scene_items(ds) for p in d.pair_ids)
+    assert out[0][3] == out[1][3]
+    for key, d in rd.scene_items(ds):
+        assert [t for t, _ in out[0][3][key]] == [r["recalltime"] for r in ref[key]]      # same numbers as the 1-rank run
+    # the big scene was cut over both ranks, the small ones were not; descriptors are set up once per (rank, scene part)
+    ranks_of = {key: {rk for _, rk in out[0][3][key]} for key in out[0][3]}
+    assert ranks_of["scene0"] == {0, 1} and all(len(v) == 1 for k, v in ranks_of.items() if k != "scene0")
+    assert sorted(s for _, _, setups, _ in out for s, _ in setups).count("fake/scene0") == 2
+    # rank 0 wrote pre.log in dataset.pair_ids order with the gathered transforms
+    for key, d in rd.scene_items(ds):
+        text = open(f"{tmp_path}/Testset/{d.name}/Match/YOHO_O/1000iters/pre.log").read()
+        assert text == "".join(format_log_entry(a, b, len(d.pc_ids), r["trans"]) for (a, b), r in zip(d.pair_ids, ref[key]))
+        z = np.load(f"{tmp_path}/Testset/{d.name}/Match/YOHO_O/1000iters/{d.pair_ids[-1][0]}-{d.pair_ids[-1][1]}.npz")
+        assert np.array_equal(z["trans"], ref[key][-1]["trans"]) and int(z["recalltime"]) == ref[key][-1]["recalltime"]

@@ -142,3 +142,23 @@ def test_reloading_weights_keeps_every_network_intact(hip, fsd, tables):
     c2 = hip.Context()                                                   # a second context in the same process
     c2.load_fcgf(fsd)
     assert rel(c2.fcgf_forward(cd).cpu().numpy(), F0) < TOL
+
+
+def test_voxel_indices_outside_the_key_range_are_refused(hip, fsd):
+    """the packed 64-bit voxel keys hold 19 bits per axis: far-away or non-finite points must be an error, never an
+    aliased (silently wrong) coordinate map"""
+    c = hip.Context()
+    c.load_fcgf(fsd)
+    pc = synth.surface_cloud(800, seed=2)
+    for bad in (1e9, -7000.0, np.nan, np.inf):
+        p = pc.copy()
+        p[17, 1] = bad                                       # -7000 m / 0.025 = -280000 < -2^18
+        with pytest.raises(hip.YohoError, match="voxel index"):
+            c.fcgf_voxelize(torch.from_numpy(p).cuda(), 0.025)
+    sel, coords = c.fcgf_voxelize(torch.from_numpy(pc).cuda(), 0.025)      # the context still works afterwards
+    assert sel.shape[0] > 0
+    far = coords.clone()
+    far[5, 0] = 300000
+    with pytest.raises(hip.YohoError, match="voxel index"):
+        c.fcgf_forward(far)
+    assert c.fcgf_forward(coords).shape[0] == coords.shape[0]

@@ -157,3 +157,26 @@ def test_group_gather_small(tables):
     kr = keys @ tables.R64[g].T
     j = np.argmin(((kr[:, None] - pts[g][None].astype(np.float64)) ** 2).sum(-1), 1)
     assert np.array_equal(out[:, :, g], feats[g][j])
+
+
+def test_philox_known_answers_and_device_sampler_statistic():
+    """Philox4x32-10 against the Random123 known-answer vectors; the oracle's restatement of the device-side YOHO-C
+    sampler draws from the same statistic as the reference's DR_statictic (tests/estimator.py:34-51)"""
+    assert orc.philox4x32_10((0, 0, 0, 0), (0, 0)) == (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)
+    assert orc.philox4x32_10((0xffffffff,) * 4, (0xffffffff,) * 2) == (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)
+    assert orc.philox4x32_10((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0)) == \
+        (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1)
+    rs = np.random.RandomState(0)
+    dr = rs.randint(0, 60, 400)
+    dr[:150] = 17
+    dr[150:210] = 42
+    tri = orc.yohoc_device_triples(dr, 4000, seed=2024)
+    assert tri.shape == (4000, 3) and tri.dtype == np.int64
+    buckets, prob = orc.dr_statistic(dr)
+    rot = dr[tri[:, 0]]
+    assert (dr[tri[:, 1]] == rot).all() and (dr[tri[:, 2]] == rot).all()        # the three matches share a coarse rotation
+    freq = np.bincount(rot, minlength=60) / 4000.0
+    assert np.abs(freq - prob).max() < 0.03                                      # drawn with the reference's weights
+    assert (prob[np.bincount(dr, minlength=60) < 2] == 0).all() and (freq[prob == 0] == 0).all()
+    assert orc.yohoc_device_triples(np.arange(60), 10, 1) is None                # no bucket with two matches
+    assert np.array_equal(tri, orc.yohoc_device_triples(dr, 4000, seed=2024)) and not np.array_equal(tri, orc.yohoc_device_triples(dr, 4000, seed=2025))

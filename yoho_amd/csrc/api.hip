@@ -442,13 +442,18 @@ int yoho_set_profiling(yoho_ctx* c, int enable) {
 
 // which: 0..3 = PartI group-conv launches (conv_in, res_in, res_out, conv_out) of the last profiled
 // yoho_partI_forward pass; 4 = head (pack [+ forward transform]), 5 = tail ([inverse transform +] finalize),
-// 6 = the inter-layer transform kernels (group-Fourier mode).  Synchronises on the recorded events.
+// 6 = the inter-layer transform kernels together (group-Fourier modes), 7 / 8 / 9 = each of them, 10 = the inverse
+// transform of the tail, 11 = finalize alone.  Synchronises on the recorded events.
 int yoho_get_kernel_ms(yoho_ctx* c, int which, float* ms) {
-    if (!c || !ms || which < 0 || which > 6) { set_error("yoho_get_kernel_ms: bad argument"); return YOHO_EINVAL; }
+    if (!c || !ms || which < 0 || which > 11) { set_error("yoho_get_kernel_ms: bad argument"); return YOHO_EINVAL; }
     if (!c->ev_created) { set_error("profiling was not enabled"); return YOHO_EINVAL; }
-    // event order: e0 head e1 conv0 e2 xf e3 conv1 e4 xf e5 conv2 e6 xf e7 conv3 e8 tail e9
+    // event order: e0 head e1 conv0 e2 xf e3 conv1 e4 xf e5 conv2 e6 xf e7 conv3 e8 inverse transform e10 finalize e9
     static const int first[6] = {1, 3, 5, 7, 0, 8};
     HIPCHK(hipEventSynchronize(c->ev[9]));
+    if (which >= 7 && which <= 9) { HIPCHK(hipEventElapsedTime(ms, c->ev[2 * (which - 6)], c->ev[2 * (which - 6) + 1])); return 0; }
+    if (which == 10) { HIPCHK(hipEventElapsedTime(ms, c->ev[8], c->ev[10])); return 0; }
+    if (which == 11) { HIPCHK(hipEventElapsedTime(ms, c->ev[10], c->ev[9])); return 0; }
+    if (which == 5) { HIPCHK(hipEventElapsedTime(ms, c->ev[8], c->ev[9])); return 0; }
     if (which == 6) {            // the three inter-layer transform kernels (group-Fourier mode; ~0 otherwise)
         float t = 0.f, d = 0.f;
         for (int i = 2; i <= 6; i += 2) { HIPCHK(hipEventElapsedTime(&d, c->ev[i], c->ev[i + 1])); t += d; }
@@ -486,7 +491,7 @@ static int partI_pass16(yoho_ctx* c, const float* x, int B, float* eqv, float* i
     if ((rc = launch_gconv16(c->p1[2], bA1, nT, bH0, nullptr, bA, EPI_RES | EPI_ACT, s, 0, nullptr, nullptr, npl, rf))) return rc;
     mark(6); mark(7);
     if ((rc = launch_gconv16(c->p1[3], bA, nT, nullptr, bY, nullptr, EPI_RAW, s, 0, nullptr, nullptr, npl, rf))) return rc;
-    mark(8);
+    mark(8); mark(10);
     if ((rc = launch_finalize_partI(bY, x, B, eqv, inv, inv_np, 1, s))) return rc;
     mark(9);
     return 0;
@@ -527,6 +532,7 @@ static int partI_passF(yoho_ctx* c, const float* x, int B, float* eqv, float* in
     if ((rc = launch_gconvf(L[3], bA, nT, nullptr, bY, 0, s))) return rc;
     mark(8);
     if ((rc = launch_gft(1, bY, bYs, c->dFpad, nullptr, nullptr, nT, 4, s))) return rc;
+    mark(10);
     if ((rc = launch_finalize_partI(bYs, x, B, eqv, inv, inv_np, 0, s))) return rc;
     mark(9);
     return 0;
@@ -572,6 +578,7 @@ static int partI_passG(yoho_ctx* c, const float* x, int B, float* eqv, float* in
     if ((rc = launch_fgemm(L[3], bP256, kppad, nT, nullptr, bY, 0, s))) return rc;
     mark(8);
     if ((rc = launch_gft16(bY, bYs, nullptr, kppad, c->dF16, nullptr, nullptr, nT, 4, c->nCU, s, B, rf))) return rc;
+    mark(10);
     if ((rc = launch_finalize_partI(bYs, x, B, eqv, inv, inv_np, 2, s, x1, B0))) return rc;
     mark(9);
     return 0;
@@ -603,7 +610,7 @@ static int partI_pass(yoho_ctx* c, const float* x, int B, float* eqv, float* inv
     if ((rc = launch_gconv(conv_args(c->p1[2], bA1, nT, bH0, nullptr, bA, false), 15, EPI_RES | EPI_ACT, s))) return rc;
     mark(6); mark(7);
     if ((rc = launch_gconv(conv_args(c->p1[3], bA, nT, nullptr, bY, nullptr, false), 15, EPI_RAW, s))) return rc;
-    mark(8);
+    mark(8); mark(10);
     if ((rc = launch_finalize_partI(bY, x, B, eqv, inv, inv_np, 0, s))) return rc;
     mark(9);
     return 0;

@@ -52,7 +52,14 @@ struct CoordSrc {
     int ts;
     int rot;                 // pts are rotated on the fly: p' = R p  (the 60 rotated copies of a fragment, YOHO_testset.py:143)
     double R[9];
+    int* oor;                // optional device flag: raised when a point's voxel index does not fit the 19-bit key fields
 };
+constexpr int VOX_LIM = (1 << 18) - 16;      // |voxel index| bound of pack_key, minus the reach of the coarsest kernel offsets
+// floor(p / voxel) as an int with defined behaviour for huge or non-finite values (they land outside VOX_LIM)
+__device__ __forceinline__ int voxel_index(double p, double voxel) {
+    const double q = floor(p / voxel);
+    return (q >= -1073741824.0 && q <= 1073741824.0) ? (int)q : 1073741824;
+}
 // one coordinate of R p in f64, fixed operation order
 __device__ __forceinline__ double rot_coord(const double* R3, double p0, double p1, double p2) { return fma(p2, R3[2], fma(p1, R3[1], p0 * R3[0])); }
 __device__ __forceinline__ void point_of(const CoordSrc& s, int i, double& p0, double& p1, double& p2) {
@@ -64,10 +71,11 @@ __device__ __forceinline__ void voxel_of(const CoordSrc& s, int i, int& x, int& 
     if (s.pts) {
         double p0, p1, p2;
         point_of(s, i, p0, p1, p2);
-        x = (int)floor(p0 / s.voxel);
-        y = (int)floor(p1 / s.voxel);
-        z = (int)floor(p2 / s.voxel);
+        x = voxel_index(p0, s.voxel);
+        y = voxel_index(p1, s.voxel);
+        z = voxel_index(p2, s.voxel);
         b = 0;
+        if (s.oor && (x < -VOX_LIM || x > VOX_LIM || y < -VOX_LIM || y > VOX_LIM || z < -VOX_LIM || z > VOX_LIM)) atomicOr(s.oor, 1);
     } else {
         const int4 c = reinterpret_cast<const int4*>(s.coords)[i];
         x = floor_to(c.x, s.ts); y = floor_to(c.y, s.ts); z = floor_to(c.z, s.ts); b = c.w;
@@ -1071,7 +1079,7 @@ int fcgf_forward(yoho_ctx* ctx, const FcgfNet* net, const int* coords0, int n0, 
     const bool conv1_fused = net->in_ch == 1 && C[1] == 32 && net->k1 * net->k1 * net->k1 <= C1O_MAXK;
     int* dbb = ar.take<int>(64 * 6);
     int hbb[64 * 6];
-    if (conv1_fused) {
+    {   // per-cloud bounding boxes of the voxel indices: range check of the 19-bit key fields, and the first convolution's bitmaps
         hipLaunchKernelGGL(bbox_init_kernel, dim3(2), dim3(256), 0, s, dbb, nb);
         {
             const int rpw = std::max(1024, (n0 + 127) / 128);              // <= 128 workgroups
@@ -1101,6 +1109,19 @@ int fcgf_forward(yoho_ctx* ctx, const FcgfNet* net, const int* coords0, int n0, 
                                L[l].mask);
             HIPCHK(hipGetLastError());
         }
+    }
+    // the packed 64-bit voxel keys hold 19 bits per axis: indices outside +-(2^18 - 16) (16 = reach of the coarsest kernel
+    // offsets) would alias other voxels and give wrong kernel maps without any error - refuse them here
+    for (int b = 0; b < nb; ++b) {
+        const int* bb = hbb + 6 * b;
+        if (bb[0] > bb[3]) continue;                        // empty cloud
+        const int lim = VOX_LIM;
+        for (int a = 0; a < 3; ++a)
+            if (bb[a] < -lim || bb[3 + a] > lim) {
+                set_error("FCGF backbone: voxel index %d of cloud %d is outside +-%d (cloud extent / voxel size too large, or a non-finite point)",
+                          bb[a] < -lim ? bb[a] : bb[3 + a], b, lim);
+                return YOHO_EINVAL;
+            }
     }
     // ---- kernel maps
     const BmDesc* map_desc = nullptr;          // set once the level-0 occupancy bitmaps exist
@@ -1252,14 +1273,22 @@ int fcgf_voxelize(yoho_ctx* ctx, const double* pts, int n, const double* R_host,
     Arena ar{(char*)ctx->ws.p, 0, ctx->ws.bytes};
     Level L;
     L.mask = cap - 1; L.keys = ar.take<u64>(cap); L.vals = ar.take<int>(cap);
-    int* dcount = ar.take<int>(1);
-    CoordSrc src{nullptr, pts, voxel, 1, R_host ? 1 : 0, {0}};
+    int* dcount = ar.take<int>(2);                       // [0] number of voxels, [1] out-of-range flag
+    HIPCHK(hipMemsetAsync(dcount, 0, 2 * sizeof(int), s));
+    CoordSrc src{nullptr, pts, voxel, 1, R_host ? 1 : 0, {0}, dcount + 1};
     if (R_host) for (int i = 0; i < 9; ++i) src.R[i] = R_host[i];
     if ((rc = build_table(src, n, L, s))) return rc;
     int* bsum = ar.take<int>((size_t)(n + 1023) / 1024 + 1);
     if ((rc = launch_first_compact(src, n, L.keys, L.vals, L.mask, bsum, coords, 3, sel, dcount, s))) return rc;
-    HIPCHK(hipMemcpyAsync(count_host, dcount, sizeof(int), hipMemcpyDeviceToHost, s));
+    int hc[2] = {0, 0};
+    HIPCHK(hipMemcpyAsync(hc, dcount, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
+    *count_host = hc[0];
+    if (hc[1]) {
+        *count_host = 0;
+        set_error("voxelisation: a point's voxel index is outside +-%d (cloud extent / voxel size too large, or a non-finite point)", VOX_LIM);
+        return YOHO_EINVAL;
+    }
     if (pts_sel) return fcgf_rotate_select(pts, R_host, sel, *count_host, pts_sel, s);
     return 0;
 }

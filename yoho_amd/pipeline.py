@@ -29,12 +29,15 @@ def describe_pair(ctx, feat0, feat1, check_range=True):
     return {k: v[:n0] for k, v in o.items()}, {k: v[n0:] for k, v in o.items()}
 
 
-def run_pair(ctx, feat0, feat1, keys0, keys1, inlier_dist=0.09, max_iter=1000, order_rng=None, eqv=None):
+def run_pair(ctx, feat0, feat1, keys0, keys1, inlier_dist=0.09, max_iter=1000, order_rng=None, eqv=None, estimator="yohoo", seed=0):
     """feat0/feat1 (K,32,60) f32 cuda (FCGF group features), keys0/keys1 (K,3) f64 cuda.
-    Returns PairResult with device tensors (trans is a (3,4) f64 host array, eye(4) rows if no
-    hypothesis has an inlier, as tests/estimator.py:327-336)."""
+    estimator 'yohoo' (tests/evaluator.py:112-117: PartII + one-shot vote over <= max_iter per-match hypotheses, order
+    shuffled by order_rng) or 'yohoc' (tests/evaluator.py:41-47: max_iter Kabsch RANSAC iterations sampled on the device
+    from the Philox stream `seed`; no PartII).  Returns PairResult with device tensors (trans is a (3,4) f64 host array,
+    eye(4) rows if no hypothesis has an inlier, as tests/estimator.py:327-336; best_h is the reference's recalltime)."""
     r = PairResult()
     r.range_repeats = 0
+    r.quat = r.trans_pre = r.order = None
     if eqv is None:
         o0, o1 = describe_pair(ctx, feat0, feat1, check_range=False)
     else:
@@ -56,6 +59,15 @@ def run_pair(ctx, feat0, feat1, keys0, keys1, inlier_dist=0.09, max_iter=1000, o
     m0, m1 = match[:, 0], match[:, 1]
     # tests/extractor.py:97-99: Batch_Des2R_torch(feats1, feats0); rows addressed in place through the match list
     r.dr_index = ctx.des2r_matched(o1["eqv"], o0["eqv"], match)
+    if estimator == "yohoc":
+        # tests/estimator.py:28-141 with statistic, sampling, Kabsch and vote on the device; one read-back
+        T, res, _ = ctx.c_ransac_device(keys0, keys1, r.dr_index, max_iter, seed, inlier_dist, match=match)
+        host = torch.cat([T.reshape(-1), res.to(torch.float64)]).cpu().numpy()
+        r.best_h, r.best_count = int(host[12]), int(host[13])
+        r.trans = host[:12].reshape(3, 4) if r.best_count > 0 else np.eye(4)
+        return r
+    if estimator != "yohoo":
+        raise ValueError(f"estimator must be 'yohoo' or 'yohoc', got {estimator!r}")
     k0m, k1m = keys0[m0].contiguous(), keys1[m1].contiguous()
     order = np.arange(M)
     (order_rng if order_rng is not None else np.random).shuffle(order)      # tests/estimator.py:321-323

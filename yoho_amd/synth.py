@@ -118,13 +118,15 @@ def estimator_case(M=1500, H=1000, seed=0, inlier_frac=0.3, tables=None):
     return dict(k0=k0, k1=k1, T=T, dr=gidx, gi=gi, gt=np.concatenate([R, t[:, None]], 1), inl=inl)
 
 
-def make_scene(nfrag=4, K=64, seed=0, tables=None, noise=0.02, outlier_frac=0.3, key_noise=0.01):
+def make_scene(nfrag=4, K=64, seed=0, tables=None, noise=0.02, outlier_frac=0.3, key_noise=0.01, res_deg=None):
     """A synthetic multi-fragment scene for the evaluator / Registration-Recall rows.
 
     Every fragment f is a copy of one base fragment moved by its own rigid motion T_f = [Rres_f R_{g_f} | t_f] with
     the group axis of its features permuted by P[g_f] (+ noise, outliers, row shuffle).  Returns
     dict(feats [nfrag](K,32,60) f32, keys [nfrag](K,3) f64, poses [nfrag](3,4), pairs [(i,j) i<j],
          gt {(i,j): (4,4) with keys_i = R keys_j + t}).
+    res_deg: optional list of the residual rotation angle (degrees) of every fragment instead of a hashed angle below
+    15 degrees; pairs of fragments with small residuals are then recoverable from the coarse group rotation alone.
     """
     tb = tables or default_tables()
     base_f = unit_features(K, seed, "scene_base")
@@ -135,7 +137,7 @@ def make_scene(nfrag=4, K=64, seed=0, tables=None, noise=0.02, outlier_frac=0.3,
         gi = int(u[0] * G) % G
         ax = u[1:4] - 0.5
         ax = ax / np.sqrt((ax[0] * ax[0] + ax[1] * ax[1]) + ax[2] * ax[2])
-        half = 0.5 * np.deg2rad(15.0) * u[4]
+        half = 0.5 * np.deg2rad(15.0) * u[4] if res_deg is None else 0.5 * np.deg2rad(float(res_deg[f]))
         s = half - half ** 3 / 6.0
         c = np.sqrt(1.0 - s * s)
         Rres = quat_to_mat64(np.array([c, ax[0] * s, ax[1] * s, ax[2] * s]))

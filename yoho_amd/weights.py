@@ -126,6 +126,18 @@ def synth_state_dict(spec, seed=0):
     return sd
 
 
+def identity_head(sd2, gain=0.02):
+    """A PartII state dict whose quaternion head answers close to the identity rotation: the last 1x1 layer
+    (PartII_To_R_FC.6) scaled by `gain`, its bias set to (1, 0, 0, 0).  With random-init weights the head's output is
+    an arbitrary rotation, so no YOHO-O hypothesis can ever be right; with this head a hypothesis is R_residual ~ I
+    times the coarse group rotation, i.e. right exactly for the pairs whose planted residual rotation is small -
+    which is what lets a synthetic scene have a Registration Recall strictly between 0 and 1 (tests/golden/scene6.npz)."""
+    sd = {k: np.array(v, copy=True) for k, v in sd2.items()}
+    sd["PartII_To_R_FC.6.weight"] = (sd["PartII_To_R_FC.6.weight"] * np.float32(gain)).astype(np.float32)
+    sd["PartII_To_R_FC.6.bias"] = np.array([1.0, 0.0, 0.0, 0.0], dtype=np.float32)
+    return sd
+
+
 def to_numpy_state_dict(sd):
     """Accept a torch state_dict or a dict of ndarrays; return contiguous ndarrays."""
     out = {}
