@@ -87,10 +87,19 @@ def test_run_pair_full_size_default_modes_vs_oracle(dctx, sd1, sd2, tables):
     bid, cnt, Tb = orc.yohoo_select(k0m, k1m, T, res.order, 0.09, 1000)
     assert (res.best_h, res.best_count) == (bid, cnt)
     assert np.array_equal(res.trans, Tb)
-    # the planted transform is recovered
-    R_err = np.degrees(np.arccos(np.clip((np.trace(pr["gt"][:, :3].T @ res.trans[:, :3]) - 1) / 2, -1, 1)))
-    print("YOHO-O: hypothesis %d, %d inliers of %d, rotation error %.2f deg" % (bid, cnt, M, R_err))
-    assert R_err < 5.0
+    print("YOHO-O: hypothesis %d, %d inliers of %d" % (bid, cnt, M))
+    # -- YOHO-C (a12) on the same matches with the sampling on the device: the oracle's restatement of the sampler gives the same
+    #    1000 triples, its loop the same winner; and the planted transform is recovered (the random-init PartII head cannot do
+    #    that for YOHO-O: its quaternions are arbitrary rotations)
+    rc = pipeline.run_pair(dctx, f0, f1, k0, k1, inlier_dist=0.07, max_iter=1000, estimator="yohoc", seed=4242, eqv=res.eqv)
+    assert np.array_equal(rc.match.cpu().numpy(), match)
+    tri = orc.yohoc_device_triples(dr, 1000, 4242)
+    it, cntc, Tc, _ = orc.yohoc_select(k0m, k1m, tri, 0.07, proper=True)
+    assert (rc.best_h, rc.best_count) == (it, cntc) and np.allclose(rc.trans, Tc, rtol=0, atol=1e-9)
+    R_err = np.degrees(np.arccos(np.clip((np.trace(pr["gt"][:, :3].T @ rc.trans[:, :3]) - 1) / 2, -1, 1)))
+    t_err = np.linalg.norm(pr["gt"][:, 3] - rc.trans[:, 3])
+    print("YOHO-C (device sampling): iteration %d, %d inliers of %d, rotation error %.3f deg, translation error %.4f" % (it, cntc, M, R_err, t_err))
+    assert R_err < 1.0 and t_err < 0.05
 
 
 @pytest.mark.parametrize("scale", [1e-3, 30.0, 300.0])

@@ -563,19 +563,19 @@ static int partI_passG(yoho_ctx* c, const float* x, int B, float* eqv, float* in
     int* rf = c->d_rflag;
     if ((rc = launch_head16(x, B, nT, bP32, kppad, c->dF16, s, x1, B0, rf))) return rc;
     mark(1);
-    if ((rc = launch_fgemm(L[0], bP32, kppad, nT, nullptr, bH0, 0, s))) return rc;
+    if ((rc = launch_fgemm(L[0], bP32, kppad, nT, nullptr, bH0, 0, s, rf))) return rc;
     mark(2);
     if ((rc = launch_gft16(bH0, nullptr, bP256, kppad, c->dF16, L[0].bn_s, L[0].bn_t, nT, 32, c->nCU, s, 0, rf))) return rc;
     mark(3);
-    if ((rc = launch_fgemm(L[1], bP256, kppad, nT, nullptr, bM, 0, s))) return rc;
+    if ((rc = launch_fgemm(L[1], bP256, kppad, nT, nullptr, bM, 0, s, rf))) return rc;
     mark(4);
     if ((rc = launch_gft16(bM, nullptr, bP512, kppad, c->dF16, L[1].bn_s, L[1].bn_t, nT, 64, c->nCU, s, 0, rf))) return rc;
     mark(5);
-    if ((rc = launch_fgemm(L[2], bP512, kppad, nT, bH0, bA, EPI_RES, s))) return rc;
+    if ((rc = launch_fgemm(L[2], bP512, kppad, nT, bH0, bA, EPI_RES, s, rf))) return rc;
     mark(6);
     if ((rc = launch_gft16(bA, nullptr, bP256, kppad, c->dF16, L[2].bn_s, L[2].bn_t, nT, 32, c->nCU, s, 0, rf))) return rc;
     mark(7);
-    if ((rc = launch_fgemm(L[3], bP256, kppad, nT, nullptr, bY, 0, s))) return rc;
+    if ((rc = launch_fgemm(L[3], bP256, kppad, nT, nullptr, bY, 0, s, rf))) return rc;
     mark(8);
     if ((rc = launch_gft16(bY, bYs, nullptr, kppad, c->dF16, nullptr, nullptr, nT, 4, c->nCU, s, B, rf))) return rc;
     mark(10);
@@ -676,7 +676,7 @@ static int partII_pass16(yoho_ctx* c, const float* s0, const float* s1, const fl
         char* bP = (char*)(bQ + n32 * CHUNK_FLOATS);
         float* bC = (float*)(bP + szP);                 // raw Fourier coefficients of the first layer
         if ((rc = launch_head2(s0, s1, s2, s3, idx, c->dP, c->p2_init_bn_s, c->p2_init_bn_t, M, nT, bP, kppad, c->dF16, s, ridx, istride, rf))) return rc;
-        if ((rc = launch_fgemm(c->p2[0], bP, kppad, nT, nullptr, bC, 0, s))) return rc;
+        if ((rc = launch_fgemm(c->p2[0], bP, kppad, nT, nullptr, bC, 0, s, rf))) return rc;
         if ((rc = launch_gft16_invp(bC, bH0, bA0, nT16, c->dF16, c->p2[0].bn_s, c->p2[0].bn_t, nT, 32, c->nCU, s, rf))) return rc;
     } else {
         if ((rc = launch_pack16_partII(s0, s1, s2, s3, idx, c->dP, c->p2_init_bn_s, c->p2_init_bn_t, M, nT16, bX, s, npl, rf))) return rc;

@@ -39,6 +39,10 @@ constexpr float FP16_MAX = 65504.f;
 __device__ __forceinline__ void note_range(int* flag, float amax) {
     if (flag && !(amax <= FP16_MAX)) atomicOr(flag, 1);
 }
+// the same for a running maximum kept as the bit pattern of |x| (unsigned order: finite < inf < NaN)
+__device__ __forceinline__ void note_range_bits(int* flag, unsigned top, float limit = FP16_MAX) {
+    if (flag && top > __float_as_uint(limit)) atomicOr(flag, 1);
+}
 
 struct Layer {
     int cin = 0, cout = 0, cout_pad = 0, ntaps = 0;
@@ -95,7 +99,8 @@ size_t fgemm_planes_bytes(int kppad, int cin);
 void fgemm_qinfo(int* qi);
 void fgemm_plane_offsets(int kppad, int cin, long long* off);
 int pack_fgemm_weights(const FourierBasis& fb, const float* W, int cin, int cout, std::vector<unsigned short>& out, float* descale);
-int launch_fgemm(const Layer& L, const char* Bplanes, int kppad, int nT32, const float* res, float* out, int flags, hipStream_t s);
+int launch_fgemm(const Layer& L, const char* Bplanes, int kppad, int nT32, const float* res, float* out, int flags, hipStream_t s,
+                 int* rflag = nullptr);
 void build_gft16_frags(const FourierBasis& fb, std::vector<unsigned short>& out);
 int gconv_layer(yoho_ctx* c, const float* x, int B, int cin, int cout, const float* W, const float* bias, int transpose, float* y,
                 hipStream_t s);

@@ -291,28 +291,31 @@ struct CStat {
     int pad;
 };
 
-__global__ __launch_bounds__(64) void cstat_kernel(const int64_t* __restrict__ dr, int M, const double* __restrict__ keys0,
-                                                   const double* __restrict__ keys1, const int64_t* __restrict__ i0,
-                                                   const int64_t* __restrict__ i1, int istride, CStat* __restrict__ st,
-                                                   int* __restrict__ members, double* __restrict__ k0m, double* __restrict__ k1m) {
+constexpr int CS_CHUNK = 8192;      // matches staged in LDS per round of the bucket placement
+
+__global__ __launch_bounds__(256) void cstat_kernel(const int64_t* __restrict__ dr, int M, const double* __restrict__ keys0,
+                                                    const double* __restrict__ keys1, const int64_t* __restrict__ i0,
+                                                    const int64_t* __restrict__ i1, int istride, CStat* __restrict__ st,
+                                                    int* __restrict__ members, double* __restrict__ k0m, double* __restrict__ k1m) {
     __shared__ int cnt[G];
-    __shared__ int start[G];
-    const int b = threadIdx.x;
-    int c = 0;
-    if (b < G) {
-        for (int m = 0; m < M; ++m) {
-            long long v = dr[m];
-            v = v < 0 ? 0 : (v > G - 1 ? G - 1 : v);
-            c += ((int)v == b) ? 1 : 0;
-        }
-        cnt[b] = c;
-    }
+    __shared__ int pos[G];
+    __shared__ unsigned drs[CS_CHUNK / 4];        // coarse rotation of 4 matches per word
+    const int tid = threadIdx.x;
+    auto rot_of = [&](int m) -> int {
+        long long v = dr[m];
+        return (int)(v < 0 ? 0 : (v > G - 1 ? G - 1 : v));
+    };
+    if (tid < G) cnt[tid] = 0;
     __syncthreads();
-    if (b == 0) {
+    for (int m = tid; m < M; m += 256) atomicAdd(&cnt[rot_of(m)], 1);
+    __syncthreads();
+    if (tid == 0) {
         int acc = 0;
         double run = 0.0;
         for (int j = 0; j < G; ++j) {
-            start[j] = acc;
+            pos[j] = acc;
+            st->start[j] = acc;
+            st->count[j] = cnt[j];
             acc += cnt[j];
             double p = 0.0;
             if (cnt[j] >= 2) {
@@ -321,21 +324,31 @@ __global__ __launch_bounds__(64) void cstat_kernel(const int64_t* __restrict__ d
             }
             run = __dadd_rn(run, p);
             st->cdf[j] = run;
-            st->count[j] = cnt[j];
-            st->start[j] = start[j];
         }
         st->valid = run < 1e-4 ? 0 : 1;
     }
-    __syncthreads();
-    if (b < G) {
-        int pos = start[b];
-        for (int m = 0; m < M; ++m) {
-            long long v = dr[m];
-            v = v < 0 ? 0 : (v > G - 1 ? G - 1 : v);
-            if ((int)v == b) members[pos++] = m;
+    // bucket lists in ascending match order: thread b walks the staged chunk and appends its own matches
+    for (int base = 0; base < M; base += CS_CHUNK) {
+        const int n = M - base < CS_CHUNK ? M - base : CS_CHUNK;
+        __syncthreads();
+        for (int w4 = tid; w4 * 4 < n; w4 += 256) {
+            unsigned pk = 0;
+            for (int e = 0; e < 4; ++e) pk |= (unsigned)(w4 * 4 + e < n ? rot_of(base + w4 * 4 + e) : 255) << (8 * e);
+            drs[w4] = pk;
+        }
+        __syncthreads();
+        if (tid < G) {
+            int p = pos[tid];
+            for (int w4 = 0; w4 * 4 < n; ++w4) {
+                const unsigned pk = drs[w4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (((pk >> (8 * e)) & 255u) == (unsigned)tid) members[p++] = base + w4 * 4 + e;
+            }
+            pos[tid] = p;
         }
     }
-    for (int i = threadIdx.x; i < M * 3; i += 64) {
+    for (int i = tid; i < M * 3; i += 256) {
         const int m = i / 3, j = i - m * 3;
         const size_t r0 = i0 ? (size_t)i0[(size_t)m * istride] : (size_t)m;
         const size_t r1 = i1 ? (size_t)i1[(size_t)m * istride] : (size_t)m;
@@ -552,7 +565,7 @@ int yoho_c_ransac_device(yoho_ctx* c, const double* keys0, const int64_t* i0, co
     int32_t* cnt = (int32_t*)(w + oC);
     int* members = (int*)(w + oM);
     int* bh = (int*)(w + oB);
-    hipLaunchKernelGGL(cstat_kernel, dim3(1), dim3(64), 0, s, dr_index, M, keys0, keys1, i0, i1, istride, st, members, k0m, k1m);
+    hipLaunchKernelGGL(cstat_kernel, dim3(1), dim3(256), 0, s, dr_index, M, keys0, keys1, i0, i1, istride, st, members, k0m, k1m);
     HIPCHK(hipGetLastError());
     hipLaunchKernelGGL(kabsch_sample_kernel, dim3(max_iter), dim3(256), 0, s, k0m, k1m, M, st, members, (unsigned)(seed & 0xFFFFFFFFu),
                        (unsigned)(seed >> 32), d * d, Tall, cnt, triples_out);

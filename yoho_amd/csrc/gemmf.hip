@@ -54,6 +54,7 @@ struct FGemmArgs {
     int NT[NIR_ORD], MT[NIR_ORD], rot[NIR_ORD];
     int cin, cout, kppad, nT32;
     float descale;
+    int* rflag;           // fp16 range flag: raised when an output coefficient will not fit the consumer's fp16 planes (x HF_ASCALE)
 };
 
 template <int I, int N, typename Fn>
@@ -260,6 +261,7 @@ __global__ __launch_bounds__(256, 1) void fgemm_kernel(FGemmArgs a, int flags) {
     const int col0 = ntile * 256 + wn * 128;
     const int jidx = col0 / a.kppad, kp0 = col0 - jidx * a.kppad;
     const bool addb = (d == 1);                              // trivial irrep: coefficient 0 carries sqrt(60) * bias
+    unsigned top = 0u;                                       // largest |coefficient| written (bit pattern; inf / NaN order above)
 #pragma unroll
     for (int bi = 0; bi < 4; ++bi) {
         const int tile32 = (kp0 >> 5) + bi;
@@ -281,9 +283,13 @@ __global__ __launch_bounds__(256, 1) void fgemm_kernel(FGemmArgs a, int flags) {
                 if (addb) val += *reinterpret_cast<const floatx4*>(a.bias + o) * 7.745966692414834f;
                 const size_t off = (((((size_t)tile32 * G + q) * cout8 + (o >> 3)) * 2 + half) * TILE + kp32) * 4;
                 *reinterpret_cast<floatx4*>(a.out + off) = val;
+                top = max(max(top, __float_as_uint(val.x) & 0x7FFFFFFFu), __float_as_uint(val.y) & 0x7FFFFFFFu);
+                top = max(max(top, __float_as_uint(val.z) & 0x7FFFFFFFu), __float_as_uint(val.w) & 0x7FFFFFFFu);
             }
         }
     }
+    // the transform kernel that reads these coefficients multiplies them by HF_ASCALE and converts to fp16
+    note_range_bits(a.rflag, top, FP16_MAX / HF_ASCALE);
 }
 
 int fgemm_init() {
@@ -378,8 +384,9 @@ int pack_fgemm_weights(const FourierBasis& fb, const float* W, int cin, int cout
     return 0;
 }
 
-int launch_fgemm(const Layer& L, const char* Bplanes, int kppad, int nT32, const float* res, float* out, int flags, hipStream_t s) {
+int launch_fgemm(const Layer& L, const char* Bplanes, int kppad, int nT32, const float* res, float* out, int flags, hipStream_t s, int* rflag) {
     FGemmArgs a;
+    a.rflag = rflag;
     a.A = reinterpret_cast<const char*>(L.wpg); a.B = Bplanes; a.bias = L.bias; a.res = res; a.out = out;
     a.cin = L.cin; a.cout = L.cout; a.kppad = kppad; a.nT32 = nT32; a.descale = L.wpg_descale;
     static const int ROT[NIR_ORD] = {0, 0, 4, 4, 2};

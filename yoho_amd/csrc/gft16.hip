@@ -55,10 +55,13 @@ __device__ __forceinline__ floatx16 mfma_hh(uintx4 a, uintx4 b, floatx16 c) {
 }
 
 // (x0, x1) -> packed fp16 hi pair and lo pair (round to nearest even)
-// amax collects the largest magnitude converted: above the fp16 range the hi plane is +-inf, which the kernel reports
-// through the context's range flag (common.h: note_range) so that the host can repeat the pass in a wider format
-__device__ __forceinline__ void split_pair(float x0, float x1, unsigned& hi, unsigned& lo, float& amax) {
-    amax = fmaxf(fmaxf(amax, fabsf(x0)), fabsf(x1));
+// `top` collects the largest magnitude a kernel WRITES as fp16 planes (bit pattern of |x|, compared as an unsigned integer: inf and
+// NaN then order above every finite value, so a non-finite result is caught as well).  Above the fp16 range the hi plane would be
+// +-inf; the kernel reports it through the context's range flag (common.h: note_range_bits) and the host repeats the pass in a
+// wider format.  Conversions of a kernel's INPUTS (B operands built in registers) are not tracked: nothing between them and the
+// kernel's outputs can swallow an inf (no ReLU on that path), so an overflow there surfaces as inf / NaN in the tracked outputs -
+// and tracking inside the MFMA loops costs 40-70 registers (spills in head16 / head2).
+__device__ __forceinline__ void split_pair(float x0, float x1, unsigned& hi, unsigned& lo) {
     floatx2 x;
     x.x = x0; x.y = x1;
     const halfx2 h = __builtin_convertvector(x, halfx2);
@@ -66,6 +69,10 @@ __device__ __forceinline__ void split_pair(float x0, float x1, unsigned& hi, uns
     const halfx2 l = __builtin_convertvector(r, halfx2);
     __builtin_memcpy(&hi, &h, 4);
     __builtin_memcpy(&lo, &l, 4);
+}
+__device__ __forceinline__ void split_pair(float x0, float x1, unsigned& hi, unsigned& lo, unsigned& top) {
+    top = max(max(top, __float_as_uint(x0) & 0x7FFFFFFFu), __float_as_uint(x1) & 0x7FFFFFFFu);
+    split_pair(x0, x1, hi, lo);
 }
 
 // the 60 coefficient rows (1 KiB each) of chunk (tile32, c8) of an irrep-GEMM output, stored [tile32][q][C8][1 KiB] (the GEMM
@@ -107,7 +114,7 @@ __global__ __launch_bounds__(256, 1) void gft16_kernel(Gft16Args a) {
                 A2[rb][kb][pl] = a.Ffrag[(((1 * 2 + rb) * 4 + kb) * 2 + pl) * 64 + lane];
             }
 
-    float amax = 0.f;
+    unsigned top = 0u;
     int chunk = blockIdx.x;
     if (chunk < a.nChunks) stage_chunk(a.in, chunk, a.C8, smem, w, lane);
     for (int it = 0; chunk < a.nChunks; chunk += gridDim.x, ++it) {
@@ -136,8 +143,8 @@ __global__ __launch_bounds__(256, 1) void gft16_kernel(Gft16Args a) {
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
                 unsigned h0, l0, h1, l1;
-                split_pair(v[2 * p].x, v[2 * p + 1].x, h0, l0, amax);
-                split_pair(v[2 * p].y, v[2 * p + 1].y, h1, l1, amax);
+                split_pair(v[2 * p].x, v[2 * p + 1].x, h0, l0);
+                split_pair(v[2 * p].y, v[2 * p + 1].y, h1, l1);
                 bh[0][p] = h0; bl[0][p] = l0; bh[1][p] = h1; bl[1][p] = l1;
             }
 #pragma unroll
@@ -198,7 +205,7 @@ __global__ __launch_bounds__(256, 1) void gft16_kernel(Gft16Args a) {
                 for (int r = 0; r < 16; ++r) {
                     const int g = 32 * rb + (r & 3) + 8 * (r >> 2) + 4 * kg;
                     unsigned hi, lo;
-                    split_pair(fmaxf(acc[rb][0][r] * s0 + t0, 0.f), fmaxf(acc[rb][1][r] * s1 + t1, 0.f), hi, lo, amax);
+                    split_pair(fmaxf(acc[rb][0][r] * s0 + t0, 0.f), fmaxf(acc[rb][1][r] * s1 + t1, 0.f), hi, lo, top);
                     if (g < G) {
                         *reinterpret_cast<unsigned*>(st + g * 512) = hi;
                         *reinterpret_cast<unsigned*>(st + 30720 + g * 512) = lo;
@@ -244,8 +251,8 @@ __global__ __launch_bounds__(256, 1) void gft16_kernel(Gft16Args a) {
                 const float y00 = fmaxf(acc[kb >> 1][0][r] * s0 + t0, 0.f), y01 = fmaxf(acc[kb >> 1][0][r + 1] * s0 + t0, 0.f);
                 const float y10 = fmaxf(acc[kb >> 1][1][r] * s1 + t1, 0.f), y11 = fmaxf(acc[kb >> 1][1][r + 1] * s1 + t1, 0.f);
                 unsigned h0, l0, h1, l1;
-                split_pair(y00, y01, h0, l0, amax);
-                split_pair(y10, y11, h1, l1, amax);
+                split_pair(y00, y01, h0, l0);
+                split_pair(y10, y11, h1, l1);
                 bh[0][p] = h0; bl[0][p] = l0; bh[1][p] = h1; bl[1][p] = l1;
             }
 #pragma unroll
@@ -275,7 +282,7 @@ __global__ __launch_bounds__(256, 1) void gft16_kernel(Gft16Args a) {
                 for (int r = 0; r < 16; ++r) {
                     const int q = 32 * rb + (r & 3) + 8 * (r >> 2) + 4 * kg;
                     unsigned hi, lo;
-                    split_pair(acc2[rb][0][r] * osc, acc2[rb][1][r] * osc, hi, lo, amax);
+                    split_pair(acc2[rb][0][r] * osc, acc2[rb][1][r] * osc, hi, lo, top);
                     if (q < G) {
                         *reinterpret_cast<unsigned*>(st + q * 512) = hi;
                         *reinterpret_cast<unsigned*>(st + 30720 + q * 512) = lo;
@@ -308,7 +315,7 @@ __global__ __launch_bounds__(256, 1) void gft16_kernel(Gft16Args a) {
                 }
         }
     }
-    note_range(a.rflag, amax);
+    note_range_bits(a.rflag, top);
 }
 
 static inline unsigned short hbits(float x) {
@@ -420,7 +427,7 @@ __global__ __launch_bounds__(256, 1) void head16_kernel(Head16Args a) {
     __syncthreads();
     const int tile32 = blockIdx.x;
     const int kp = tile32 * TILE + Lp;
-    float amax = 0.f;
+    unsigned top = 0u;
     uintx4 A[2][4][2];
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb)
@@ -449,10 +456,10 @@ __global__ __launch_bounds__(256, 1) void head16_kernel(Head16Args a) {
         for (int kb = 0; kb < 4; ++kb) {
             uintx4 bh, bl;
             unsigned h, l;
-            split_pair(v[kb][0].x * H2_ASCALE, v[kb][0].y * H2_ASCALE, h, l, amax); bh.x = h; bl.x = l;
-            split_pair(v[kb][0].z * H2_ASCALE, v[kb][0].w * H2_ASCALE, h, l, amax); bh.y = h; bl.y = l;
-            split_pair(v[kb][1].x * H2_ASCALE, v[kb][1].y * H2_ASCALE, h, l, amax); bh.z = h; bl.z = l;
-            split_pair(v[kb][1].z * H2_ASCALE, v[kb][1].w * H2_ASCALE, h, l, amax); bh.w = h; bl.w = l;
+            split_pair(v[kb][0].x * H2_ASCALE, v[kb][0].y * H2_ASCALE, h, l); bh.x = h; bl.x = l;
+            split_pair(v[kb][0].z * H2_ASCALE, v[kb][0].w * H2_ASCALE, h, l); bh.y = h; bl.y = l;
+            split_pair(v[kb][1].x * H2_ASCALE, v[kb][1].y * H2_ASCALE, h, l); bh.z = h; bl.z = l;
+            split_pair(v[kb][1].z * H2_ASCALE, v[kb][1].w * H2_ASCALE, h, l); bh.w = h; bl.w = l;
 #pragma unroll
             for (int rb = 0; rb < 2; ++rb) acc[f][rb] = mfma_hh(A[rb][kb][1], bh, acc[f][rb]);
 #pragma unroll
@@ -472,17 +479,17 @@ __global__ __launch_bounds__(256, 1) void head16_kernel(Head16Args a) {
             const int q = 32 * rb + (r & 3) + 8 * (r >> 2) + 4 * kg;
             uintx4 ph, pl;
             unsigned h, l;
-            split_pair(acc[0][rb][r] * osc, acc[1][rb][r] * osc, h, l, amax); ph.x = h; pl.x = l;
-            split_pair(acc[2][rb][r] * osc, acc[3][rb][r] * osc, h, l, amax); ph.y = h; pl.y = l;
-            split_pair(acc[4][rb][r] * osc, acc[5][rb][r] * osc, h, l, amax); ph.z = h; pl.z = l;
-            split_pair(acc[6][rb][r] * osc, acc[7][rb][r] * osc, h, l, amax); ph.w = h; pl.w = l;
+            split_pair(acc[0][rb][r] * osc, acc[1][rb][r] * osc, h, l, top); ph.x = h; pl.x = l;
+            split_pair(acc[2][rb][r] * osc, acc[3][rb][r] * osc, h, l, top); ph.y = h; pl.y = l;
+            split_pair(acc[4][rb][r] * osc, acc[5][rb][r] * osc, h, l, top); ph.z = h; pl.z = l;
+            split_pair(acc[6][rb][r] * osc, acc[7][rb][r] * osc, h, l, top); ph.w = h; pl.w = l;
             if (q < G) {
                 char* d = dst0 + qb[q] + (long long)nt * qs[q];
                 *reinterpret_cast<uintx4*>(d) = ph;
                 *reinterpret_cast<uintx4*>(d + 16384) = pl;
             }
         }
-    note_range(a.rflag, amax);
+    note_range_bits(a.rflag, top);
 }
 
 int launch_head16(const float* x, int B, int nTiles, char* planes, int kppad, const void* Ffrag, hipStream_t s, const float* x1, int B0,
@@ -547,7 +554,7 @@ __global__ __launch_bounds__(256, 1) void head2_kernel(Head2Args a) {
     const int sidx = blockIdx.y;                           // one workgroup per (match tile, source): 4x the parallelism of a tile loop
     const int m = tile32 * TILE + Lp;
     const bool ok = m < a.M;
-    float amax = 0.f;
+    unsigned top = 0u;
     uintx4 A[2][4][2];
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb)
@@ -609,7 +616,7 @@ __global__ __launch_bounds__(256, 1) void head2_kernel(Head2Args a) {
                     const float y0 = v0 ? fmaxf(v[kb][2 * p] * bs + bt, 0.f) : 0.f;
                     const float y1 = v1 ? fmaxf(v[kb][2 * p + 1] * bs + bt, 0.f) : 0.f;
                     unsigned h, l;
-                    split_pair(y0, y1, h, l, amax);
+                    split_pair(y0, y1, h, l);
                     bh[p] = h; bl[p] = l;
                 }
 #pragma unroll
@@ -629,10 +636,10 @@ __global__ __launch_bounds__(256, 1) void head2_kernel(Head2Args a) {
                 const int q = 32 * rb + (r & 3) + 8 * (r >> 2) + 4 * kg;
                 uintx4 ph, pl;
                 unsigned h, l;
-                split_pair(acc[0][rb][r] * osc, acc[1][rb][r] * osc, h, l, amax); ph.x = h; pl.x = l;
-                split_pair(acc[2][rb][r] * osc, acc[3][rb][r] * osc, h, l, amax); ph.y = h; pl.y = l;
-                split_pair(acc[4][rb][r] * osc, acc[5][rb][r] * osc, h, l, amax); ph.z = h; pl.z = l;
-                split_pair(acc[6][rb][r] * osc, acc[7][rb][r] * osc, h, l, amax); ph.w = h; pl.w = l;
+                split_pair(acc[0][rb][r] * osc, acc[1][rb][r] * osc, h, l, top); ph.x = h; pl.x = l;
+                split_pair(acc[2][rb][r] * osc, acc[3][rb][r] * osc, h, l, top); ph.y = h; pl.y = l;
+                split_pair(acc[4][rb][r] * osc, acc[5][rb][r] * osc, h, l, top); ph.z = h; pl.z = l;
+                split_pair(acc[6][rb][r] * osc, acc[7][rb][r] * osc, h, l, top); ph.w = h; pl.w = l;
                 if (q < G) {
                     char* d = dst0 + qb[q] + (long long)nt * qs[q];
                     *reinterpret_cast<uintx4*>(d) = ph;
@@ -640,7 +647,7 @@ __global__ __launch_bounds__(256, 1) void head2_kernel(Head2Args a) {
                 }
             }
     }
-    note_range(a.rflag, amax);
+    note_range_bits(a.rflag, top);
 }
 
 int launch_head2(const float* s0, const float* s1, const float* s2, const float* s3, const int64_t* pre_idx, const int* P, const float* bn_s,
