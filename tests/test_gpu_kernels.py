@@ -128,7 +128,7 @@ def test_partI_split_golden_and_vs_f32(ctx, ctx_of, mode, dmax, gold, sd1, table
     assert (ei - e16[:, :, P[17]]).abs().max().item() < 2e-5
 
 
-@pytest.mark.parametrize("fmode", ["fourier", "fgemm"])
+@pytest.mark.parametrize("fmode", ["fourier", "fgemm", "fgemm256"])
 def test_partI_group_fourier_mode(hip, ctx, gold, sd1, tables, fmode):
     """modes 'fourier' / 'fgemm': the conv runs on group-Fourier coefficients (244 instead of 780 slab products),
     on fp32 MFMA, or with the two large layers as irrep GEMMs on the fp16x2 split MFMA"""
@@ -149,6 +149,23 @@ def test_partI_group_fourier_mode(hip, ctx, gold, sd1, tables, fmode):
     d = (ctx.partI_forward(x)["eqv"] - c.partI_forward(x)["eqv"]).abs().max().item()
     print("%s vs direct f32 MFMA at 5000 kp: max abs diff %.3g" % (fmode, d))
     assert d < 1e-5
+
+
+def test_fgemm_tile_variants_are_bit_identical(hip, sd1):
+    """the two GEMM blockings of the default mode (256 x 128 tiles, two workgroups per CU | 256 x 256, one) issue the same
+    products in the same order per accumulator: identical bits, at ragged and full sizes and for a pair pass"""
+    c2, c1 = hip.Context(), hip.Context()
+    for c, m in ((c2, "fgemm"), (c1, "fgemm256")):
+        c.load_partI(sd1)
+        c.set_gconv_mode(m)
+    for B in (1, 33, 257, 1000, 5000):
+        x = cu(synth.unit_features(B, seed=700 + B))
+        o2, o1 = c2.partI_forward(x, want_inv=True, want_inv_np=True), c1.partI_forward(x, want_inv=True, want_inv_np=True)
+        assert all(torch.equal(o2[k], o1[k]) for k in ("eqv", "inv", "inv_np")), B
+    a, b = cu(synth.unit_features(5000, seed=41)), cu(synth.unit_features(4999, seed=42))
+    p2, p1 = c2.partI_forward_pair(a, b, want_inv=False, want_inv_np=True), c1.partI_forward_pair(a, b, want_inv=False, want_inv_np=True)
+    assert torch.equal(p2["eqv"], p1["eqv"]) and torch.equal(p2["inv_np"], p1["inv_np"])
+    assert torch.isfinite(p2["eqv"]).all()
 
 
 def test_group_mean_np_bitexact(ctx):

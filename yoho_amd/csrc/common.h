@@ -100,7 +100,7 @@ void fgemm_qinfo(int* qi);
 void fgemm_plane_offsets(int kppad, int cin, long long* off);
 int pack_fgemm_weights(const FourierBasis& fb, const float* W, int cin, int cout, std::vector<unsigned short>& out, float* descale);
 int launch_fgemm(const Layer& L, const char* Bplanes, int kppad, int nT32, const float* res, float* out, int flags, hipStream_t s,
-                 int* rflag = nullptr);
+                 int* rflag = nullptr, int variant = 2);
 void build_gft16_frags(const FourierBasis& fb, std::vector<unsigned short>& out);
 int gconv_layer(yoho_ctx* c, const float* x, int B, int cin, int cout, const float* W, const float* bias, int transpose, float* y,
                 hipStream_t s);

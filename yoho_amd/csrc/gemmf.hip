@@ -23,53 +23,9 @@
 #include <cstdlib>
 
 #include "common.h"
+#include "gemmf.h"
 
 namespace yoho {
-
-typedef float floatx16 __attribute__((ext_vector_type(16)));
-typedef float floatx4 __attribute__((ext_vector_type(4)));
-typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
-typedef _Float16 halfx8 __attribute__((ext_vector_type(8)));
-typedef const __attribute__((address_space(1))) void* gptr_t;
-typedef __attribute__((address_space(3))) void* lptr_t;
-
-constexpr int FG_STAGE = 32768;               // bytes of one operand tile per K32 stage
-constexpr int FG_LDS = 4 * FG_STAGE;          // 2 buffers x (A + B)
-
-// irreps in launch order (heaviest first)
-__constant__ int c_fg_d[NIR_ORD];             // dimension of the t-th irrep in launch order
-__constant__ int c_fg_base[NIR_ORD];          // first coefficient index
-static const int FG_ORD_D[NIR_ORD] = {5, 4, 3, 3, 1};
-static const int FG_ORD_R[NIR_ORD] = {4, 3, 1, 2, 0};
-static const int FG_IR_BASE[5] = {0, 1, 10, 19, 35};
-static const int FG_IR_D[5] = {1, 3, 3, 4, 5};
-
-struct FGemmArgs {
-    const char* A;        // weight planes, all irreps
-    const char* B;        // activation planes, all irreps
-    const float* bias;
-    const float* res;     // fp32 coefficient slabs [tile32][60 q][cout8][h][kp32][4] or null (q-major: a workgroup owns one q)
-    float* out;           // same layout
-    long long a_off[NIR_ORD], b_off[NIR_ORD];
-    int NT[NIR_ORD], MT[NIR_ORD], rot[NIR_ORD];
-    int cin, cout, kppad, nT32;
-    float descale;
-    int* rflag;           // fp16 range flag: raised when an output coefficient will not fit the consumer's fp16 planes (x HF_ASCALE)
-};
-
-template <int I, int N, typename Fn>
-__device__ __forceinline__ void sfor(Fn&& f) {
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        sfor<I + 1, N>(f);
-    }
-}
-
-__device__ __forceinline__ floatx16 mfma_h(uintx4 a, uintx4 b, floatx16 c) {
-    union { uintx4 u; halfx8 h; } ca, cb;
-    ca.u = a; cb.u = b;
-    return __builtin_amdgcn_mfma_f32_32x32x16_f16(ca.h, cb.h, c, 0, 0, 0);
-}
 
 struct Frags {
     uintx4 ah[4], al[4], bh[4], bl[4];
@@ -100,12 +56,6 @@ __device__ __forceinline__ void stage_unit(const char* srcA, const char* srcB, c
     const char* src = (U < 8 ? srcA : srcB) + blk * 1024;
     char* d = dst + (U < 8 ? 0 : FG_STAGE) + blk * 1024;
     __builtin_amdgcn_global_load_lds((gptr_t)(src + lane16), (lptr_t)d, 16, 0, 0);
-}
-
-__device__ __forceinline__ const char* uniform_ptr(const char* p) {
-    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-    return reinterpret_cast<const char*>(((unsigned long long)hi << 32) | lo);
 }
 
 __device__ __forceinline__ void stage_tile(const char* src, char* dst, int w, int lane) {
@@ -164,7 +114,7 @@ __global__ __launch_bounds__(256, 1) void fgemm_kernel(FGemmArgs a, int flags) {
         }
     }
     if (t < 0) return;
-    const int d = c_fg_d[t], qbase = c_fg_base[t];
+    const int d = a.dim[t], qbase = a.qbase[t];
     const int MT = a.MT[t], KS = d * a.cin / 32;
     const int cg = local / MT, mtile = local - cg * MT;
     const int ntile = r + 8 * cg;
@@ -294,11 +244,7 @@ __global__ __launch_bounds__(256, 1) void fgemm_kernel(FGemmArgs a, int flags) {
 
 int fgemm_init() {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&fgemm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, FG_LDS));
-    int dd[NIR_ORD], bb[NIR_ORD];
-    for (int t = 0; t < NIR_ORD; ++t) { dd[t] = FG_ORD_D[t]; bb[t] = FG_IR_BASE[FG_ORD_R[t]]; }
-    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_fg_d), dd, sizeof(dd)));
-    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_fg_base), bb, sizeof(bb)));
-    return 0;
+    return fgemm2_init();
 }
 
 // byte offset of the t-th (launch order) irrep inside an operand pack with `rows` rows/cols per irrep-dimension unit
@@ -384,8 +330,7 @@ int pack_fgemm_weights(const FourierBasis& fb, const float* W, int cin, int cout
     return 0;
 }
 
-int launch_fgemm(const Layer& L, const char* Bplanes, int kppad, int nT32, const float* res, float* out, int flags, hipStream_t s, int* rflag) {
-    FGemmArgs a;
+void fgemm_fill_args(FGemmArgs& a, const Layer& L, const char* Bplanes, int kppad, int nT32, const float* res, float* out, int* rflag) {
     a.rflag = rflag;
     a.A = reinterpret_cast<const char*>(L.wpg); a.B = Bplanes; a.bias = L.bias; a.res = res; a.out = out;
     a.cin = L.cin; a.cout = L.cout; a.kppad = kppad; a.nT32 = nT32; a.descale = L.wpg_descale;
@@ -396,7 +341,17 @@ int launch_fgemm(const Layer& L, const char* Bplanes, int kppad, int nT32, const
         a.MT[t] = (FG_ORD_D[t] * L.cout + 255) / 256;
         a.NT[t] = FG_ORD_D[t] * kppad / 256;
         a.rot[t] = ROT[t];
+        a.dim[t] = FG_ORD_D[t];
+        a.qbase[t] = FG_IR_BASE[FG_ORD_R[t]];
     }
+}
+
+// variant 2 (default): 256 x 128 tiles, two workgroups per CU (gemmf2.hip); variant 1: 256 x 256 tiles, one workgroup per CU
+int launch_fgemm(const Layer& L, const char* Bplanes, int kppad, int nT32, const float* res, float* out, int flags, hipStream_t s, int* rflag,
+                 int variant) {
+    FGemmArgs a;
+    fgemm_fill_args(a, L, Bplanes, kppad, nT32, res, out, rflag);
+    if (variant != 1) return launch_fgemm2(a, flags, s);
     int tot = 0;
     for (int x = 0; x < 8; ++x) {
         int n = 0;

@@ -1,0 +1,268 @@
+// Irrep GEMMs of the group-Fourier conv (see gemmf.hip for the algebra and the operand packs), second blocking:
+// 256 x 128 output tile per workgroup, TWO workgroups per CU.
+//
+// Why.  With one 256 x 256 workgroup per CU (gemmf.hip) nothing overlaps a workgroup's epilogue: its four waves hold 256
+// accumulator registers each, write 256 KiB of fp32 coefficients and only then can the CU start the next tile - a quarter
+// of the kernel's time is spent draining stores with the matrix pipes idle.  Here a wave owns 128 x 64 outputs (128
+// accumulator registers, at most 256 registers in all), a workgroup needs 72 KiB of LDS, and two workgroups share a CU:
+// while one of them runs its prologue (first DMA stages, residual loads) or its epilogue (stores), the other one's K loop
+// has the matrix pipes to itself.
+//
+// K loop.  Steps of K = 16 (one MFMA sub-step): a step is 16 KiB of the A tile (256 rows x 16 k x {hi, lo}) + 8 KiB of
+// one 128-column half of the B tile, copied by LDS DMA straight from the packs into a ring of three 24 KiB buffers
+// (the packs are unchanged: a half column tile is four 2 KiB runs of the 256-column pack).  In iteration s a wave issues
+// its 24 MFMAs on the fragments of step s (registers), reads the 12 fragments of step s+1 from the ring and issues its
+// six 1 KiB pieces of the DMA of step s+3; at the end `s_waitcnt vmcnt(6)` (the six pieces just issued stay in flight) and
+// one barrier make step s+2 readable: the DMA runs two steps ahead of its consumers.
+#include <hip/hip_runtime.h>
+#include "common.h"
+#include "gemmf.h"
+
+namespace yoho {
+
+constexpr int F2_BUF = 24576;                 // one ring buffer: A 16 KiB [plane 2][k-group 2][row 256][16 B] | B 8 KiB [plane 2][k-group 2][col 128][16 B]
+constexpr int F2_LDS = 3 * F2_BUF;
+
+struct Frags2 {
+    uintx4 ah[4], al[4], bh[2], bl[2];
+};
+
+// fragment read R (0..11) of a step, in the order of use: A lo x4, B hi x2 (products lo.hi), A hi x4, B lo x2
+template <int R>
+__device__ __forceinline__ void read_frag2(const char* pa, const char* pb, Frags2& f) {
+    if constexpr (R < 4) f.al[R] = *reinterpret_cast<const uintx4*>(pa + 8192 + R * 512);
+    else if constexpr (R < 6) f.bh[R - 4] = *reinterpret_cast<const uintx4*>(pb + (R - 4) * 512);
+    else if constexpr (R < 10) f.ah[R - 6] = *reinterpret_cast<const uintx4*>(pa + (R - 6) * 512);
+    else f.bl[R - 10] = *reinterpret_cast<const uintx4*>(pb + 4096 + (R - 10) * 512);
+}
+
+// piece U (0..5) of this wave's share of the DMA of one K16 step: 1 KiB each.  srcA / srcB point at the step inside the packs
+// (stage * 32 KiB + sub-step * 8 KiB, wave uniform), la / lb are the per-lane byte offsets inside the A and B parts.
+template <int U>
+__device__ __forceinline__ void dma_piece(const char* srcA, const char* srcB, char* buf, int la, int lb, int w, int wkg, int wcb) {
+    if constexpr (U < 4) {
+        constexpr int plane = U >> 1, kg = U & 1;                       // A: piece (plane, kg, 64-row block w)
+        __builtin_amdgcn_global_load_lds((gptr_t)(srcA + plane * 16384 + kg * 4096 + la), (lptr_t)(buf + plane * 8192 + kg * 4096 + w * 1024), 16, 0, 0);
+    } else {
+        constexpr int plane = U - 4;                                    // B: piece (plane, kg = w >> 1, 64-column block w & 1)
+        __builtin_amdgcn_global_load_lds((gptr_t)(srcB + plane * 16384 + lb), (lptr_t)(buf + 16384 + plane * 4096 + wkg * 2048 + wcb * 1024), 16, 0, 0);
+    }
+}
+
+__device__ __forceinline__ void dma_step(const char* srcA, const char* srcB, char* buf, int la, int lb, int w, int wkg, int wcb) {
+    sfor<0, 6>([&](auto uc) { dma_piece<decltype(uc)::value>(srcA, srcB, buf, la, lb, w, wkg, wcb); });
+}
+
+// One K16 step: 24 MFMAs on `f` (every accumulator gets lo.hi, hi.lo, hi.hi, 8 MFMAs apart); behind them, one per MFMA, the
+// 12 fragment reads of the next step and (DMA) the six DMA pieces of the step three ahead.
+template <bool DMA>
+__device__ __forceinline__ void step2(const Frags2& f, floatx16 (&acc)[4][2], const char* ra, const char* rb, Frags2& nf,
+                                      const char* srcA, const char* srcB, char* dmabuf, int la, int lb, int w, int wkg, int wcb) {
+    sfor<0, 8>([&](auto gc) {
+        constexpr int g = decltype(gc)::value;
+        acc[g >> 1][g & 1] = mfma_h(f.al[g >> 1], f.bh[g & 1], acc[g >> 1][g & 1]);
+        read_frag2<g>(ra, rb, nf);
+        __builtin_amdgcn_sched_barrier(0);
+    });
+    sfor<0, 8>([&](auto gc) {
+        constexpr int g = decltype(gc)::value;
+        acc[g >> 1][g & 1] = mfma_h(f.ah[g >> 1], f.bl[g & 1], acc[g >> 1][g & 1]);
+        if constexpr (g < 4) read_frag2<8 + g>(ra, rb, nf);
+        else if constexpr (DMA && g >= 4 && g < 8) dma_piece<g - 4>(srcA, srcB, dmabuf, la, lb, w, wkg, wcb);
+        __builtin_amdgcn_sched_barrier(0);
+    });
+    sfor<0, 8>([&](auto gc) {
+        constexpr int g = decltype(gc)::value;
+        acc[g >> 1][g & 1] = mfma_h(f.ah[g >> 1], f.bh[g & 1], acc[g >> 1][g & 1]);
+        if constexpr (DMA && g < 2) dma_piece<4 + g>(srcA, srcB, dmabuf, la, lb, w, wkg, wcb);
+        __builtin_amdgcn_sched_barrier(0);
+    });
+}
+
+// byte offset of K16 step ks inside a tile's pack: stage (ks >> 1) * 32 KiB + sub-step (ks & 1) * 8 KiB
+__device__ __forceinline__ size_t step_off(int ks) { return (size_t)(ks >> 1) * FG_STAGE + (size_t)(ks & 1) * 8192; }
+
+__global__ __launch_bounds__(256, 2) void fgemm2_kernel(FGemmArgs a, int flags) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // Work map (as gemmf.hip, with two workgroups - the two 128-column halves - per (column tile, row tile), consecutive on
+    // one XCD: they stream the same A stages at the same time, so one of the two reads hits that XCD's L2).
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    int t = -1, local = 0, r = 0;
+    {
+        int start = 0;
+#pragma unroll
+        for (int u = 0; u < NIR_ORD; ++u) {
+            const int ru = (xcd + a.rot[u]) & 7;
+            const int cnt = a.NT[u] > ru ? ((a.NT[u] - 1 - ru) / 8 + 1) * a.MT[u] * 2 : 0;
+            if (t < 0 && slot < start + cnt) { t = u; local = slot - start; r = ru; }
+            start += cnt;
+        }
+    }
+    if (t < 0) return;
+    const int d = a.dim[t], qbase = a.qbase[t];
+    const int MT = a.MT[t], KS = d * a.cin / 32, KT = 2 * KS;
+    const int nh = local & 1, pair = local >> 1;
+    const int cg = pair / MT, mtile = pair - cg * MT;
+    const int ntile = r + 8 * cg;
+    const char* Ag = a.A + a.a_off[t] + (size_t)mtile * KS * FG_STAGE;
+    const char* Bg = a.B + a.b_off[t] + (size_t)ntile * KS * FG_STAGE + nh * 2048;
+    const int wm = w >> 1, wn = w & 1;
+    const int wkg = w >> 1, wcb = w & 1;                                 // this wave's B piece: k-group, 64-column block
+    const int la = w * 1024 + lane * 16;                                 // DMA source offsets inside a step
+    const int lb = wkg * 4096 + wcb * 1024 + lane * 16;
+
+    floatx16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int lane_a = (lane >> 5) * 4096 + (wm * 128 + (lane & 31)) * 16;
+    const int lane_b = 16384 + (lane >> 5) * 2048 + (wn * 64 + (lane & 31)) * 16;
+
+    // prologue: steps 0, 1, 2 into the three buffers
+    dma_step(Ag, Bg, smem, la, lb, w, wkg, wcb);
+    dma_step(Ag + step_off(1), Bg + step_off(1), smem + F2_BUF, la, lb, w, wkg, wcb);
+    if (KT > 2) dma_step(Ag + step_off(2), Bg + step_off(2), smem + 2 * F2_BUF, la, lb, w, wkg, wcb);
+    const bool rows_live = (mtile * 256 + wm * 128) < d * a.cout;       // else: all 128 rows of this wave are padding (cout = 32)
+    const int colbase = ntile * 256 + nh * 128 + wn * 64;
+    const int jidx = colbase / a.kppad, kp0 = colbase - jidx * a.kppad;
+    if ((flags & EPI_RES) && rows_live) {
+        // the accumulators start from the residual (x 1 / descale, a power of two): its loads fly with the first DMA stages
+        const float inv = 1.f / a.descale;
+        const int half = lane >> 5, kp32 = lane & 31, cout8 = a.cout >> 3;
+#pragma unroll
+        for (int bi = 0; bi < 2; ++bi) {
+            const int tile32 = (kp0 >> 5) + bi;
+#pragma unroll
+            for (int ai = 0; ai < 4; ++ai) {
+                const int rowb = mtile * 256 + wm * 128 + ai * 32;
+                const int iidx = rowb / a.cout, o0 = rowb - iidx * a.cout;
+                const bool ok = tile32 < a.nT32 && iidx < d;
+                const int q = qbase + iidx * d + jidx;
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const int o = o0 + q4 * 8 + half * 4;
+                    const size_t off = (((((size_t)tile32 * G + q) * cout8 + (o >> 3)) * 2 + half) * TILE + kp32) * 4;
+                    const floatx4 v = *reinterpret_cast<const floatx4*>(a.res + (ok ? off : 0)) * (ok ? inv : 0.f);     // branch-free
+                    acc[ai][bi][4 * q4 + 0] = v.x; acc[ai][bi][4 * q4 + 1] = v.y;
+                    acc[ai][bi][4 * q4 + 2] = v.z; acc[ai][bi][4 * q4 + 3] = v.w;
+                }
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    if (!rows_live) {
+        // keep this wave's share of the DMA and the barriers going (the live waves meet at one barrier per step but the last)
+        for (int s = 0; s + 1 < KT; ++s) {
+            if (s + 3 < KT) dma_step(Ag + step_off(s + 3), Bg + step_off(s + 3), smem + (s % 3) * F2_BUF, la, lb, w, wkg, wcb);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        return;
+    }
+
+    Frags2 P, Q;
+    sfor<0, 12>([&](auto rc) { read_frag2<decltype(rc)::value>(smem + lane_a, smem + lane_b, P); });
+    // ring offsets: step s lives in buffer s % 3
+    int cur = 0, nxt = F2_BUF;                   // buffer of step s (already in registers: the target of the DMA of step s+3), of step s+1
+    int s = 0;
+    auto advance = [&]() { cur = nxt; nxt = nxt == 2 * F2_BUF ? 0 : nxt + F2_BUF; ++s; };
+    // main loop: both steps of a pair still have a DMA to issue (s + 4 < KT)
+    for (; s + 4 < KT;) {
+        step2<true>(P, acc, smem + nxt + lane_a, smem + nxt + lane_b, Q, uniform_ptr(Ag + step_off(s + 3)), uniform_ptr(Bg + step_off(s + 3)),
+                    smem + cur, la, lb, w, wkg, wcb);
+        asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        advance();
+        step2<true>(Q, acc, smem + nxt + lane_a, smem + nxt + lane_b, P, uniform_ptr(Ag + step_off(s + 3)), uniform_ptr(Bg + step_off(s + 3)),
+                    smem + cur, la, lb, w, wkg, wcb);
+        asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        advance();
+    }
+    // tail: the last four steps (two if KT == 2); only the first of them still has a DMA (step KT - 1) to issue
+    if (KT >= 4) {
+        step2<true>(P, acc, smem + nxt + lane_a, smem + nxt + lane_b, Q, uniform_ptr(Ag + step_off(s + 3)), uniform_ptr(Bg + step_off(s + 3)),
+                    smem + cur, la, lb, w, wkg, wcb);
+        asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        advance();
+        step2<false>(Q, acc, smem + nxt + lane_a, smem + nxt + lane_b, P, nullptr, nullptr, nullptr, la, lb, w, wkg, wcb);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        advance();
+    }
+    step2<false>(P, acc, smem + nxt + lane_a, smem + nxt + lane_b, Q, nullptr, nullptr, nullptr, la, lb, w, wkg, wcb);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    advance();
+    // last step: its "next" fragments are read from a buffer that holds valid (unused) data
+    step2<false>(Q, acc, smem + cur + lane_a, smem + cur + lane_b, P, nullptr, nullptr, nullptr, la, lb, w, wkg, wcb);
+
+    // ---- epilogue: D[row][col]: lane (col = lane & 31, half = lane >> 5), reg e -> row = (e & 3) + 8 * (e >> 2) + 4 * half
+    const int half = lane >> 5, kp32 = lane & 31;
+    const int cout8 = a.cout >> 3;
+    const bool addb = (d == 1);                              // trivial irrep: coefficient 0 carries sqrt(60) * bias
+    unsigned top = 0u;                                       // largest |coefficient| written (bit pattern; inf / NaN order above)
+#pragma unroll
+    for (int bi = 0; bi < 2; ++bi) {
+        const int tile32 = (kp0 >> 5) + bi;
+        if (tile32 >= a.nT32) continue;
+#pragma unroll
+        for (int ai = 0; ai < 4; ++ai) {
+            const int rowb = mtile * 256 + wm * 128 + ai * 32;     // the 32 rows of an MFMA tile share i (cout is a multiple of 32)
+            const int iidx = rowb / a.cout, o0 = rowb - iidx * a.cout;
+            if (iidx >= d) continue;
+            const int q = qbase + iidx * d + jidx;
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const int o = o0 + q4 * 8 + half * 4;
+                floatx4 val;
+                val.x = acc[ai][bi][4 * q4 + 0]; val.y = acc[ai][bi][4 * q4 + 1];
+                val.z = acc[ai][bi][4 * q4 + 2]; val.w = acc[ai][bi][4 * q4 + 3];
+                val *= a.descale;
+                if (addb) val += *reinterpret_cast<const floatx4*>(a.bias + o) * 7.745966692414834f;
+                const size_t off = (((((size_t)tile32 * G + q) * cout8 + (o >> 3)) * 2 + half) * TILE + kp32) * 4;
+                *reinterpret_cast<floatx4*>(a.out + off) = val;
+                top = max(max(top, __float_as_uint(val.x) & 0x7FFFFFFFu), __float_as_uint(val.y) & 0x7FFFFFFFu);
+                top = max(max(top, __float_as_uint(val.z) & 0x7FFFFFFFu), __float_as_uint(val.w) & 0x7FFFFFFFu);
+            }
+        }
+    }
+    note_range_bits(a.rflag, top, FP16_MAX / HF_ASCALE);     // the consumer multiplies by HF_ASCALE and converts to fp16
+}
+
+int fgemm2_init() {
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&fgemm2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, F2_LDS));
+    return 0;
+}
+
+int launch_fgemm2(const FGemmArgs& a, int flags, hipStream_t s) {
+    int tot = 0;
+    for (int x = 0; x < 8; ++x) {
+        int n = 0;
+        for (int t = 0; t < NIR_ORD; ++t) {
+            const int r = (x + a.rot[t]) & 7;
+            if (a.NT[t] > r) n += ((a.NT[t] - 1 - r) / 8 + 1) * a.MT[t] * 2;
+        }
+        tot = n > tot ? n : tot;
+    }
+    tot *= 8;
+    hipLaunchKernelGGL(fgemm2_kernel, dim3(tot), dim3(256), F2_LDS, s, a, flags);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+}  // namespace yoho
