@@ -15,6 +15,8 @@
 // six 1 KiB pieces of the DMA of step s+3; at the end `s_waitcnt vmcnt(6)` (the six pieces just issued stay in flight) and
 // one barrier make step s+2 readable: the DMA runs two steps ahead of its consumers.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
+#include <cstring>
 #include "common.h"
 #include "gemmf.h"
 
@@ -79,6 +81,39 @@ __device__ __forceinline__ void step2(const Frags2& f, floatx16 (&acc)[4][2], co
     });
 }
 
+// Work map.  Workgroup b runs on XCD b & 7; a column tile (irrep t, ntile) and all its row tiles stay on one XCD (the B panel is
+// read from HBM once and served from that XCD's L2), column tiles of an irrep are dealt round-robin over the XCDs (gemmf.hip).
+// The two workgroups of a CU must NOT run in lockstep - if both reach their epilogue together nothing is gained over one large
+// tile - so the slots of an XCD alternate between the d = 5 irrep (long K loops: 40000 of an XCD's 78000 steps for 256 -> 512)
+// and the other four (shorter K loops, in launch order): co-resident workgroups then have different lengths and drift apart
+// after the first round.  Returns false for a slot beyond the XCD's work.
+enum { F2_NOSTORE = 0x100, F2_CONTIG = 0x200 };      // debug flags (YOHO_FGEMM_DEBUG): timing without the stores | irreps not interleaved
+__host__ __device__ inline bool fg2_map(const FGemmArgs& a, int xcd, int slot, bool contiguous, int& t, int& local, int& r) {
+    int cnt[NIR_ORD], ru[NIR_ORD];
+    for (int u = 0; u < NIR_ORD; ++u) {
+        ru[u] = (xcd + a.rot[u]) & 7;
+        cnt[u] = a.NT[u] > ru[u] ? ((a.NT[u] - 1 - ru[u]) / 8 + 1) * a.MT[u] * 2 : 0;
+    }
+    const int L = cnt[0], S = cnt[1] + cnt[2] + cnt[3] + cnt[4];
+    int list, idx;                                   // list 0: the first irrep, list 1: the others, idx: position in that list
+    if (contiguous) { list = slot < L ? 0 : 1; idx = slot < L ? slot : slot - L; }
+    else {
+        const int P = L < S ? L : S;
+        if (slot < 2 * P) { list = slot & 1; idx = slot >> 1; }
+        else { list = L > S ? 0 : 1; idx = P + (slot - 2 * P); }
+    }
+    if (list == 0) {
+        if (idx >= L) return false;
+        t = 0; local = idx; r = ru[0];
+        return true;
+    }
+    for (int u = 1; u < NIR_ORD; ++u) {
+        if (idx < cnt[u]) { t = u; local = idx; r = ru[u]; return true; }
+        idx -= cnt[u];
+    }
+    return false;
+}
+
 // byte offset of K16 step ks inside a tile's pack: stage (ks >> 1) * 32 KiB + sub-step (ks & 1) * 8 KiB
 __device__ __forceinline__ size_t step_off(int ks) { return (size_t)(ks >> 1) * FG_STAGE + (size_t)(ks & 1) * 8192; }
 
@@ -86,21 +121,10 @@ __global__ __launch_bounds__(256, 2) void fgemm2_kernel(FGemmArgs a, int flags) 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // Work map (as gemmf.hip, with two workgroups - the two 128-column halves - per (column tile, row tile), consecutive on
-    // one XCD: they stream the same A stages at the same time, so one of the two reads hits that XCD's L2).
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    int t = -1, local = 0, r = 0;
-    {
-        int start = 0;
-#pragma unroll
-        for (int u = 0; u < NIR_ORD; ++u) {
-            const int ru = (xcd + a.rot[u]) & 7;
-            const int cnt = a.NT[u] > ru ? ((a.NT[u] - 1 - ru) / 8 + 1) * a.MT[u] * 2 : 0;
-            if (t < 0 && slot < start + cnt) { t = u; local = slot - start; r = ru; }
-            start += cnt;
-        }
-    }
-    if (t < 0) return;
+    // two workgroups - the two 128-column halves - per (column tile, row tile), neighbours in their irrep's list: they stream the
+    // same A stages at about the same time, so one of the two reads hits the XCD's L2
+    int t = 0, local = 0, r = 0;
+    if (!fg2_map(a, blockIdx.x & 7, blockIdx.x >> 3, (flags & F2_CONTIG) != 0, t, local, r)) return;
     const int d = a.dim[t], qbase = a.qbase[t];
     const int MT = a.MT[t], KS = d * a.cin / 32, KT = 2 * KS;
     const int nh = local & 1, pair = local >> 1;
@@ -235,7 +259,7 @@ __global__ __launch_bounds__(256, 2) void fgemm2_kernel(FGemmArgs a, int flags) 
                 val *= a.descale;
                 if (addb) val += *reinterpret_cast<const floatx4*>(a.bias + o) * 7.745966692414834f;
                 const size_t off = (((((size_t)tile32 * G + q) * cout8 + (o >> 3)) * 2 + half) * TILE + kp32) * 4;
-                *reinterpret_cast<floatx4*>(a.out + off) = val;
+                if (!(flags & F2_NOSTORE)) *reinterpret_cast<floatx4*>(a.out + off) = val;
                 top = max(max(top, __float_as_uint(val.x) & 0x7FFFFFFFu), __float_as_uint(val.y) & 0x7FFFFFFFu);
                 top = max(max(top, __float_as_uint(val.z) & 0x7FFFFFFFu), __float_as_uint(val.w) & 0x7FFFFFFFu);
             }
@@ -250,6 +274,10 @@ int fgemm2_init() {
 }
 
 int launch_fgemm2(const FGemmArgs& a, int flags, hipStream_t s) {
+    if (const char* dbg = std::getenv("YOHO_FGEMM_DEBUG")) {          // kernel-timing experiments only (results are not valid with nostore)
+        if (std::strstr(dbg, "nostore")) flags |= F2_NOSTORE;
+        if (std::strstr(dbg, "contig")) flags |= F2_CONTIG;
+    }
     int tot = 0;
     for (int x = 0; x < 8; ++x) {
         int n = 0;
