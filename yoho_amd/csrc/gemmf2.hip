@@ -87,7 +87,7 @@ __device__ __forceinline__ void step2(const Frags2& f, floatx16 (&acc)[4][2], co
 // tile - so the slots of an XCD alternate between the d = 5 irrep (long K loops: 40000 of an XCD's 78000 steps for 256 -> 512)
 // and the other four (shorter K loops, in launch order): co-resident workgroups then have different lengths and drift apart
 // after the first round.  Returns false for a slot beyond the XCD's work.
-enum { F2_NOSTORE = 0x100, F2_CONTIG = 0x200 };      // debug flags (YOHO_FGEMM_DEBUG): timing without the stores | irreps not interleaved
+enum { F2_NOSTORE = 0x100, F2_MIX = 0x200, F2_ST_SC1 = 0x400, F2_ST_NT = 0x800, F2_SPARSE4 = 0x1000, F2_SPARSE16 = 0x2000 };   // YOHO_FGEMM_DEBUG experiments, see launch_fgemm2
 __host__ __device__ inline bool fg2_map(const FGemmArgs& a, int xcd, int slot, bool contiguous, int& t, int& local, int& r) {
     int cnt[NIR_ORD], ru[NIR_ORD];
     for (int u = 0; u < NIR_ORD; ++u) {
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256, 2) void fgemm2_kernel(FGemmArgs a, int flags) 
     // two workgroups - the two 128-column halves - per (column tile, row tile), neighbours in their irrep's list: they stream the
     // same A stages at about the same time, so one of the two reads hits the XCD's L2
     int t = 0, local = 0, r = 0;
-    if (!fg2_map(a, blockIdx.x & 7, blockIdx.x >> 3, (flags & F2_CONTIG) != 0, t, local, r)) return;
+    if (!fg2_map(a, blockIdx.x & 7, blockIdx.x >> 3, (flags & F2_MIX) == 0, t, local, r)) return;
     const int d = a.dim[t], qbase = a.qbase[t];
     const int MT = a.MT[t], KS = d * a.cin / 32, KT = 2 * KS;
     const int nh = local & 1, pair = local >> 1;
@@ -239,7 +239,10 @@ __global__ __launch_bounds__(256, 2) void fgemm2_kernel(FGemmArgs a, int flags) 
     const int half = lane >> 5, kp32 = lane & 31;
     const int cout8 = a.cout >> 3;
     const bool addb = (d == 1);                              // trivial irrep: coefficient 0 carries sqrt(60) * bias
+    if ((flags & F2_SPARSE4) && (blockIdx.x >> 3) % 4 != 0) flags |= F2_NOSTORE;          // experiment: only every 4th / 16th workgroup stores
+    if ((flags & F2_SPARSE16) && (blockIdx.x >> 3) % 16 != 0) flags |= F2_NOSTORE;
     unsigned top = 0u;                                       // largest |coefficient| written (bit pattern; inf / NaN order above)
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, 0x7FFFFFFF, 0x00020000);
 #pragma unroll
     for (int bi = 0; bi < 2; ++bi) {
         const int tile32 = (kp0 >> 5) + bi;
@@ -259,7 +262,9 @@ __global__ __launch_bounds__(256, 2) void fgemm2_kernel(FGemmArgs a, int flags) 
                 val *= a.descale;
                 if (addb) val += *reinterpret_cast<const floatx4*>(a.bias + o) * 7.745966692414834f;
                 const size_t off = (((((size_t)tile32 * G + q) * cout8 + (o >> 3)) * 2 + half) * TILE + kp32) * 4;
-                if (!(flags & F2_NOSTORE)) *reinterpret_cast<floatx4*>(a.out + off) = val;
+                if (flags & F2_ST_SC1) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uintx4, val), orsrc, (int)(off * 4), 0, 16);
+                else if (flags & F2_ST_NT) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uintx4, val), orsrc, (int)(off * 4), 0, 2);
+                else if (!(flags & F2_NOSTORE)) *reinterpret_cast<floatx4*>(a.out + off) = val;
                 top = max(max(top, __float_as_uint(val.x) & 0x7FFFFFFFu), __float_as_uint(val.y) & 0x7FFFFFFFu);
                 top = max(max(top, __float_as_uint(val.z) & 0x7FFFFFFFu), __float_as_uint(val.w) & 0x7FFFFFFFu);
             }
@@ -275,8 +280,12 @@ int fgemm2_init() {
 
 int launch_fgemm2(const FGemmArgs& a, int flags, hipStream_t s) {
     if (const char* dbg = std::getenv("YOHO_FGEMM_DEBUG")) {          // kernel-timing experiments only (results are not valid with nostore)
-        if (std::strstr(dbg, "nostore")) flags |= F2_NOSTORE;
-        if (std::strstr(dbg, "contig")) flags |= F2_CONTIG;
+        if (std::strstr(dbg, "nostore")) flags |= F2_NOSTORE;       // no coefficient stores at all (K loops alone)
+        if (std::strstr(dbg, "mix")) flags |= F2_MIX;               // slots alternate between the d = 5 irrep and the others
+        if (std::strstr(dbg, "sc1")) flags |= F2_ST_SC1;            // write-through stores that do not stay in the L2
+        if (std::strstr(dbg, "nt")) flags |= F2_ST_NT;              // non-temporal stores
+        if (std::strstr(dbg, "sparse4")) flags |= F2_SPARSE4;
+        if (std::strstr(dbg, "sparse16")) flags |= F2_SPARSE16;
     }
     int tot = 0;
     for (int x = 0; x < 8; ++x) {
