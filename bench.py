@@ -128,6 +128,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--no-yohoc", action="store_true", help="skip the YOHO-C leg")
+    ap.add_argument("--in-flight", type=int, choices=[1, 2], default=2,
+                    help="pairs in flight: 2 (default) queues the descriptor pass of the next pair on a second HIP stream before waiting for "
+                         "the current pair's read-backs (pipeline.PairStreamer); 1 runs the pairs strictly one after the other")
     ap.add_argument("--gconv", choices=["f32", "bf16x3", "fourier", "fp16x2", "fgemm", "fgemm256"], default=os.environ.get("YOHO_GCONV", "fgemm"),
                     help="PartI group conv: group-Fourier domain (fp32 MFMA), direct fp32 MFMA, direct 3-way bf16 split MFMA, "
                          "or direct 2-way fp16 split MFMA")
@@ -175,30 +178,37 @@ def main():
         pairs_per_step = 64
     f0, f1, k0, k1 = mine[0]
 
-    def step(estimator="yohoo", seed=0):
+    streamer = None
+    if args.in_flight == 2:
+        streamer = pipeline.PairStreamer(lambda: hip.Context(dev), sd1, sd2)
+        streamer.set_modes(args.gconv, args.partII)
+
+    def run_steps(n, estimator="yohoo", seed0=0):
+        """n steps = n sweeps over this rank's pair list, all inside one call so that consecutive steps can overlap"""
+        todo = [p for _ in range(n) for p in mine]
+        dist = 0.09 if estimator == "yohoo" else 0.07
+        if streamer is not None:
+            return streamer.run(todo, inlier_dist=dist, max_iter=1000, order_rng=rng, estimator=estimator,
+                                seeds=[seed0 + i for i in range(len(todo))])[-1]
         r = None
-        for (a0, a1, b0, b1) in mine:
-            r = pipeline.run_pair(ctx, a0, a1, b0, b1, inlier_dist=0.09 if estimator == "yohoo" else 0.07, max_iter=1000, order_rng=rng,
-                                  estimator=estimator, seed=seed)
+        for i, (a0, a1, b0, b1) in enumerate(todo):
+            r = pipeline.run_pair(ctx, a0, a1, b0, b1, inlier_dist=dist, max_iter=1000, order_rng=rng, estimator=estimator, seed=seed0 + i)
         return r
 
-    def timed(fn, steps, warmup):
-        for _ in range(warmup):
-            r = fn()
+    def timed(estimator, steps, warmup):
+        r = run_steps(warmup, estimator, 1)
         ydist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(steps):
-            r = fn()
+        r = run_steps(steps, estimator, 1000)
         torch.cuda.synchronize()
         ydist.barrier()
         return ydist.max_over_ranks(time.perf_counter() - t0), r
 
-    dt, res = timed(step, args.steps, args.warmup)
+    dt, res = timed("yohoo", args.steps, max(args.warmup, 1))
     yohoc = None
     if not args.no_yohoc:
-        seeds = iter(range(1, 10 ** 9))
-        dtc, resc = timed(lambda: step("yohoc", next(seeds)), args.steps, min(args.warmup, 2))
+        dtc, resc = timed("yohoc", args.steps, max(min(args.warmup, 2), 1))
         # host time per pair of the estimator call alone (launches only: nothing is read back inside the call)
         m_, dr_ = res.match, res.dr_index
         torch.cuda.synchronize()
@@ -326,13 +336,13 @@ def main():
                                    "-> PartI group conv + invariant pooling -> mutual NN -> Des2R -> PartII -> YOHO-O (<=1000 hypotheses); "
                                    "random-init weights (seeded), inputs resident in HBM",
                        "keypoints_per_fragment": KP, "partI_batch": nkp, "matches": M, "hypotheses": min(1000, M), "gconv": args.gconv, "partII": args.partII,
-                       "pairs_per_step": pairs_per_step,
+                       "pairs_per_step": pairs_per_step, "pairs_in_flight": args.in_flight,
                        "parallelism": (f"one pair per GPU per step, {world} GPU(s), no data-path collective" if args.scaling == "weak" else
                                        f"64 pairs (8 scenes x 8) per step dealt to {world} rank(s) by run_dataset.plan_shards, no data-path collective")},
             "roofline": roof,
             "roofline_extra": {"launch_ms": [round(float(v), 3) for v in conv_ms[:4]], "head_ms": round(float(conv_ms[4]), 3),
                                "tail_ms": round(float(conv_ms[5]), 3), "transform_ms": round(float(conv_ms[6]), 3), "hbm": hbm,
-                               "range_repeats": int(ctx.range_fallbacks)},
+                               "range_repeats": int(ctx.range_fallbacks + (sum(c.range_fallbacks for c in streamer.desc + [streamer.est]) if streamer else 0))},
         }
         if yohoc is not None:
             out["yohoc"] = yohoc

@@ -207,3 +207,23 @@ def test_network_objects_keep_their_own_weights(hip, sd1, tables):
     eb = nb(cu(x))["eqv"].cpu().numpy()
     assert rel(ea, orc.partI_forward(x, sd1, tables.N)[0]) < TOL
     assert rel(eb, orc.partI_forward(x, sdb, tables.N)[0]) < TOL
+
+
+def test_pair_streamer_equals_sequential_run_pair(hip, dctx, sd1, sd2):
+    """two pairs in flight on two streams (pipeline.PairStreamer, what bench.py times) give, pair by pair, the bits of the
+    sequential pipeline.run_pair - for YOHO-O and for YOHO-C"""
+    prs = [synth.make_pair(k, seed=40 + i) for i, k in enumerate((700, 333, 1200, 64, 700))]
+    pairs = [(cu(p["feat0"]), cu(p["feat1"]), cu(p["keys0"]), cu(p["keys1"])) for p in prs]
+    st = pipeline.PairStreamer(lambda: hip.Context(), sd1, sd2)
+    for est, dist in (("yohoo", 0.09), ("yohoc", 0.07)):
+        seeds = [11 * (i + 1) for i in range(len(pairs))]
+        got = st.run(pairs, inlier_dist=dist, max_iter=300, order_rng=np.random.RandomState(5), estimator=est, seeds=seeds)
+        rng = np.random.RandomState(5)
+        for i, (p, g) in enumerate(zip(pairs, got)):
+            ref = pipeline.run_pair(dctx, *p, inlier_dist=dist, max_iter=300, order_rng=rng, estimator=est, seed=seeds[i])
+            assert torch.equal(g.match, ref.match) and torch.equal(g.dr_index, ref.dr_index), (est, i)
+            assert (g.best_h, g.best_count) == (ref.best_h, ref.best_count) and np.array_equal(g.trans, ref.trans), (est, i)
+            if est == "yohoo":
+                assert torch.equal(g.quat, ref.quat) and torch.equal(g.trans_pre, ref.trans_pre)
+            assert g.range_repeats == 0
+    assert st.run([]) == []

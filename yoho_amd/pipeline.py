@@ -92,3 +92,75 @@ def run_pair(ctx, feat0, feat1, keys0, keys1, inlier_dist=0.09, max_iter=1000, o
     r.best_h, r.best_count = bh, bc
     r.trans = r.trans_pre[int(order[bh])].cpu().numpy() if bc > 0 else np.eye(4)
     return r
+
+
+class PairStreamer:
+    """Throughput mode for many pairs: two pairs in flight on two HIP streams.
+
+    The descriptor pass of a pair keeps the matrix pipes busy for ~5 ms and ends in a host read-back (the match count);
+    the rest of the pair (matcher, coarse rotation, PartII / Kabsch, vote: ~1.4 ms) is a chain of short kernels with two
+    more read-backs.  Run back to back, the chip idles through every read-back and the short kernels never fill it.  Here
+    the descriptor pass of pair i+1 is queued on stream A BEFORE the host starts waiting on pair i's read-backs on stream
+    B, so both streams always have work: per pair the time of the descriptor pass remains, the rest hides behind it.
+
+    Three library contexts (a context owns one workspace and one pair of range flags, and is single-stream by contract,
+    include/yoho_hip.h): two descriptor contexts used alternately - the flags of pair i are read while pair i+1 runs in the
+    other one - and one for the estimator side.  Results are those of run_pair, pair by pair (tests/test_gpu_fullsize.py).
+    """
+
+    def __init__(self, make_context, sd_partI, sd_partII=None):
+        """make_context() -> a fresh hip.Context on the current device; the state dicts are loaded into the three contexts"""
+        self.desc = [make_context(), make_context()]
+        for c in self.desc:
+            c.load_partI(sd_partI)
+        self.est = make_context()
+        if sd_partII is not None:
+            self.est.load_partII(sd_partII)
+        self.sa, self.sb = torch.cuda.Stream(), torch.cuda.Stream()
+
+    def set_modes(self, gconv=None, partII=None):
+        for c in self.desc:
+            if gconv:
+                c.set_gconv_mode(gconv)
+        if partII:
+            self.est.set_partII_mode(partII)
+
+    def _describe(self, i, pair):
+        f0, f1 = pair[0], pair[1]
+        with torch.cuda.stream(self.sa):
+            o0, o1 = describe_pair(self.desc[i & 1], f0, f1, check_range=False)
+            ev = torch.cuda.Event()
+            ev.record(self.sa)
+        for o in (o0, o1):
+            for t in o.values():
+                t.record_stream(self.sb)
+        return o0, o1, ev
+
+    def run(self, pairs, inlier_dist=0.09, max_iter=1000, order_rng=None, estimator="yohoo", seeds=None):
+        """pairs: sequence of (feat0, feat1, keys0, keys1) device tensors.  Returns the list of PairResult."""
+        pairs = list(pairs)
+        out = []
+        if not pairs:
+            return out
+        cur = torch.cuda.current_stream()
+        self.sa.wait_stream(cur)
+        self.sb.wait_stream(cur)
+        nxt = self._describe(0, pairs[0])
+        for i, pair in enumerate(pairs):
+            o0, o1, ev = nxt
+            if i + 1 < len(pairs):
+                nxt = self._describe(i + 1, pairs[i + 1])           # queued before this pair's read-backs block the host
+            with torch.cuda.stream(self.sb):
+                self.sb.wait_event(ev)
+                r = run_pair(self.est, pair[0], pair[1], pair[2], pair[3], inlier_dist=inlier_dist, max_iter=max_iter, order_rng=order_rng,
+                             eqv=(o0, o1), estimator=estimator, seed=(seeds[i] if seeds is not None else 0))
+                d = self.desc[i & 1]
+                if d.range_status()[0]:                    # the descriptor pass left the fp16 range: descriptors again in bf16x3, then the rest
+                    o0, o1 = d._repeat_wider("gconv", lambda: describe_pair(d, pair[0], pair[1], check_range=False))
+                    r = run_pair(self.est, pair[0], pair[1], pair[2], pair[3], inlier_dist=inlier_dist, max_iter=max_iter, order_rng=order_rng,
+                                 eqv=(o0, o1), estimator=estimator, seed=(seeds[i] if seeds is not None else 0))
+                    r.range_repeats += 1
+            out.append(r)
+        cur.wait_stream(self.sa)
+        cur.wait_stream(self.sb)
+        return out
