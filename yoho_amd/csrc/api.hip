@@ -566,15 +566,15 @@ static int partI_passG(yoho_ctx* c, const float* x, int B, float* eqv, float* in
     mark(1);
     if ((rc = launch_fgemm(L[0], bP32, kppad, nT, nullptr, bH0, 0, s, rf, gv))) return rc;
     mark(2);
-    if ((rc = launch_gft16(bH0, nullptr, bP256, kppad, c->dF16, L[0].bn_s, L[0].bn_t, nT, 32, c->nCU, s, 0, rf))) return rc;
+    if ((rc = launch_gft16(bH0, nullptr, bP256, kppad, c->dF16, L[0].bn_s, L[0].bn_t, nT, 32, c->nCU, s, 0, rf, gv))) return rc;
     mark(3);
     if ((rc = launch_fgemm(L[1], bP256, kppad, nT, nullptr, bM, 0, s, rf, gv))) return rc;
     mark(4);
-    if ((rc = launch_gft16(bM, nullptr, bP512, kppad, c->dF16, L[1].bn_s, L[1].bn_t, nT, 64, c->nCU, s, 0, rf))) return rc;
+    if ((rc = launch_gft16(bM, nullptr, bP512, kppad, c->dF16, L[1].bn_s, L[1].bn_t, nT, 64, c->nCU, s, 0, rf, gv))) return rc;
     mark(5);
     if ((rc = launch_fgemm(L[2], bP512, kppad, nT, bH0, bA, EPI_RES, s, rf, gv))) return rc;
     mark(6);
-    if ((rc = launch_gft16(bA, nullptr, bP256, kppad, c->dF16, L[2].bn_s, L[2].bn_t, nT, 32, c->nCU, s, 0, rf))) return rc;
+    if ((rc = launch_gft16(bA, nullptr, bP256, kppad, c->dF16, L[2].bn_s, L[2].bn_t, nT, 32, c->nCU, s, 0, rf, gv))) return rc;
     mark(7);
     if ((rc = launch_fgemm(L[3], bP256, kppad, nT, nullptr, bY, 0, s, rf, gv))) return rc;
     mark(8);

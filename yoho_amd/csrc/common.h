@@ -114,7 +114,7 @@ int fcgf_rotate_select(const double* pts, const double* R_host, const int64_t* s
 int launch_cone1(const Layer& L, const char* X, int nTiles32, int nTiles16, const float* res, float* out, const int* n0, hipStream_t s);
 int gft16_init();
 int launch_gft16(const float* in, float* out32, char* planes, int kppad, const void* Ffrag, const float* bn_s, const float* bn_t, int nTiles,
-                 int C8, int nCU, hipStream_t s, int B = 0, int* rflag = nullptr);
+                 int C8, int nCU, hipStream_t s, int B = 0, int* rflag = nullptr, int variant = 2);
 int launch_gft16_invp(const float* in, float* res0, char* planes16, int nTiles16, const void* Ffrag, const float* bn_s, const float* bn_t,
                       int nTiles, int C8, int nCU, hipStream_t s, int* rflag = nullptr);
 int launch_head2(const float* s0, const float* s1, const float* s2, const float* s3, const int64_t* pre_idx, const int* P, const float* bn_s,

@@ -318,6 +318,152 @@ __global__ __launch_bounds__(256, 1) void gft16_kernel(Gft16Args a) {
     note_range_bits(a.rflag, top);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// gft16x_kernel: the BN + ReLU transform between two irrep GEMMs (gft16_kernel<G16_ACTP>) with TWO waves per SIMD.
+// gft16_kernel runs one wave per SIMD (388 registers: both transform matrices as A fragments + 2 x 64 accumulators), and a wave
+// is in order: while it converts, stages or stores, its matrix pipe idles - the kernel's time follows the shader clock, not the
+// HBM rate.  Here the 256 columns of a chunk are split over eight waves (32 columns each: half the accumulators, <= 256
+// registers), so every SIMD has a second wave to fill those phases.  Same products in the same order per column: bit-identical
+// planes.  Wave w8: columns 32 w8 + n (n = lane & 31), i.e. col = h*128 + kp*4 + e with h = w8 >> 2, kp = 8 (w8 & 3) + (n >> 2),
+// e = n & 3.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned half_of(float x) {
+    const _Float16 h = (_Float16)x;
+    unsigned short u;
+    __builtin_memcpy(&u, &h, 2);
+    return u;
+}
+
+__global__ __launch_bounds__(512, 2) void gft16x_kernel(Gft16Args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 31, kg = lane >> 5;
+
+    for (int i = tid; i < 2 * 256; i += 512) {               // zero rows 60..63 of both buffers (never overwritten)
+        const int bsel = i >> 8, j = i & 255;
+        reinterpret_cast<uintx4*>(smem + bsel * GB + G * 1024)[j] = uintx4{0u, 0u, 0u, 0u};
+    }
+    long long* qb = reinterpret_cast<long long*>(smem + 2 * GB);
+    int* qs = reinterpret_cast<int*>(smem + 2 * GB + 512);
+    if (tid < G) { qb[tid] = a.qbase[tid]; qs[tid] = a.qstride[tid]; }
+
+    uintx4 A1[2][4][2], A2[2][4][2];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+                A1[rb][kb][pl] = a.Ffrag[(((0 * 2 + rb) * 4 + kb) * 2 + pl) * 64 + lane];
+                A2[rb][kb][pl] = a.Ffrag[(((1 * 2 + rb) * 4 + kb) * 2 + pl) * 64 + lane];
+            }
+    auto stage = [&](int chunk, char* dst) {
+        const int c8 = chunk % a.C8, tile32 = chunk / a.C8;
+        const char* src = reinterpret_cast<const char*>(a.in) + ((size_t)tile32 * G * a.C8 + c8) * 1024;
+        const size_t rs = (size_t)a.C8 * 1024;
+        for (int p = w8; p < G; p += 8) __builtin_amdgcn_global_load_lds((gptr_t)(src + p * rs + lane * 16), (lptr_t)(dst + p * 1024), 16, 0, 0);
+    };
+    const int hsel = w8 >> 2, kp = 8 * (w8 & 3) + (n >> 2), e = n & 3;
+    unsigned top = 0u;
+    int chunk = blockIdx.x;
+    if (chunk < a.nChunks) stage(chunk, smem);
+    for (int it = 0; chunk < a.nChunks; chunk += gridDim.x, ++it) {
+        char* cur = smem + (it & 1) * GB;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const int next = chunk + gridDim.x;
+        if (next < a.nChunks) stage(next, smem + ((it + 1) & 1) * GB);
+        const int c8 = chunk % a.C8, tile32 = chunk / a.C8;
+
+        // ---- product 1: group domain = F^T * coefficients, this lane's column
+        floatx16 acc[2];
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[rb][r] = 0.f;
+        const char* colp = cur + (32 * w8 + n) * 4 + kg * 8 * 1024;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            float v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const float*>(colp + (kb * 16 + i) * 1024) * HF_ASCALE;
+            uintx4 bh, bl;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                unsigned h, l;
+                split_pair(v[2 * p], v[2 * p + 1], h, l);
+                bh[p] = h; bl[p] = l;
+            }
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) acc[rb] = mfma_hh(A1[rb][kb][1], bh, acc[rb]);
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) acc[rb] = mfma_hh(A1[rb][kb][0], bl, acc[rb]);
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) acc[rb] = mfma_hh(A1[rb][kb][0], bh, acc[rb]);
+        }
+        // ---- BN + ReLU in registers, product 2: coefficients = F * activated (K order of A2 = accumulator register order)
+        const int ch = c8 * 8 + hsel * 4 + e;
+        const float dscale1 = 1.f / (F_SCALE * HF_ASCALE);
+        const float sc = a.bn_s[ch] * dscale1 * H2_ASCALE, sh = a.bn_t[ch] * H2_ASCALE;
+        floatx16 acc2[2];
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc2[rb][r] = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            uintx4 bh, bl;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int r = 8 * (kb & 1) + 2 * p;
+                unsigned h, l;
+                split_pair(fmaxf(acc[kb >> 1][r] * sc + sh, 0.f), fmaxf(acc[kb >> 1][r + 1] * sc + sh, 0.f), h, l);
+                bh[p] = h; bl[p] = l;
+            }
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) acc2[rb] = mfma_hh(A2[rb][kb][1], bh, acc2[rb]);
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) acc2[rb] = mfma_hh(A2[rb][kb][0], bl, acc2[rb]);
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) acc2[rb] = mfma_hh(A2[rb][kb][0], bh, acc2[rb]);
+        }
+        // ---- output planes through the staging image [plane][q][h][kp 32][4 ch] fp16 (in the chunk buffer just consumed)
+        const float osc = HF_ASCALE / (F_SCALE * H2_ASCALE);
+        __syncthreads();                                   // every wave is done reading the coefficients of this buffer
+        char* st = cur + hsel * 256 + kp * 8 + e * 2;
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int q = 32 * rb + (r & 3) + 8 * (r >> 2) + 4 * kg;
+                const float x = acc2[rb][r] * osc;
+                top = max(top, __float_as_uint(x) & 0x7FFFFFFFu);
+                const _Float16 hh = (_Float16)x;
+                if (q < G) {
+                    *reinterpret_cast<unsigned short*>(st + q * 512) = (unsigned short)half_of(x);
+                    *reinterpret_cast<unsigned short*>(st + 30720 + q * 512) = (unsigned short)half_of(x - (float)hh);
+                }
+            }
+        __syncthreads();
+        char* dst0 = a.planes + (size_t)(c8 >> 2) * 32768 + (c8 & 3) * 4096 + (tile32 & 7) * 512;
+        const int nt = tile32 >> 3;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int idx = i * 512 + tid;                 // (plane, q, kp): 16 bytes = channels 0-3 (h = 0) | 4-7 (h = 1)
+            if (idx < 2 * G * 32) {
+                const int pl = idx >= 1920 ? 1 : 0, rem = idx - pl * 1920;
+                const int q = rem >> 5, kpp = rem & 31;
+                const char* sp = cur + pl * 30720 + q * 512 + kpp * 8;
+                const uint2 c03 = *reinterpret_cast<const uint2*>(sp);
+                const uint2 c47 = *reinterpret_cast<const uint2*>(sp + 256);
+                *reinterpret_cast<uintx4*>(dst0 + qb[q] + (long long)nt * qs[q] + kpp * 16 + pl * 16384) = uintx4{c03.x, c03.y, c47.x, c47.y};
+            }
+        }
+    }
+    note_range_bits(a.rflag, top);
+}
+
 static inline unsigned short hbits(float x) {
     const _Float16 h = (_Float16)x;
     unsigned short u;
@@ -360,6 +506,7 @@ int gft16_init() {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gft16_kernel<G16_ACTP>), hipFuncAttributeMaxDynamicSharedMemorySize, G16_LDS));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gft16_kernel<G16_INV>), hipFuncAttributeMaxDynamicSharedMemorySize, G16_LDS));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gft16_kernel<G16_INVP>), hipFuncAttributeMaxDynamicSharedMemorySize, G16_LDS));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gft16x_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, G16_LDS));
     return 0;
 }
 
@@ -380,7 +527,7 @@ static void fill_qtables(int kppad, int cin, long long* qbase, int* qstride) {
 // else bn_s != null: BN + ReLU, fp32 chunks to out32 (may alias in);
 // else: inverse transform only, out32 = group-domain values (B,32,60) (C8 must be 4)
 int launch_gft16(const float* in, float* out32, char* planes, int kppad, const void* Ffrag, const float* bn_s, const float* bn_t, int nTiles,
-                 int C8, int nCU, hipStream_t s, int B, int* rflag) {
+                 int C8, int nCU, hipStream_t s, int B, int* rflag, int variant) {
     Gft16Args a;
     a.B = B; a.res0 = nullptr; a.nTiles16 = 0; a.rflag = rflag;
     a.in = in; a.out32 = out32; a.planes = planes; a.Ffrag = reinterpret_cast<const uintx4*>(Ffrag); a.bn_s = bn_s; a.bn_t = bn_t;
@@ -392,7 +539,8 @@ int launch_gft16(const float* in, float* out32, char* planes, int kppad, const v
     }
     const int grid = a.nChunks < nCU ? a.nChunks : nCU;
     if (grid == 0) return 0;
-    if (planes) hipLaunchKernelGGL(gft16_kernel<G16_ACTP>, dim3(grid), dim3(256), G16_LDS, s, a);
+    if (planes && variant != 1) hipLaunchKernelGGL(gft16x_kernel, dim3(grid), dim3(512), G16_LDS, s, a);       // two waves per SIMD
+    else if (planes) hipLaunchKernelGGL(gft16_kernel<G16_ACTP>, dim3(grid), dim3(256), G16_LDS, s, a);
     else if (bn_s) hipLaunchKernelGGL(gft16_kernel<G16_ACT32>, dim3(grid), dim3(256), G16_LDS, s, a);
     else hipLaunchKernelGGL(gft16_kernel<G16_INV>, dim3(grid), dim3(256), G16_LDS, s, a);
     HIPCHK(hipGetLastError());

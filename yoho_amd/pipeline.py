@@ -116,7 +116,9 @@ class PairStreamer:
         self.est = make_context()
         if sd_partII is not None:
             self.est.load_partII(sd_partII)
-        self.sa, self.sb = torch.cuda.Stream(), torch.cuda.Stream()
+        # the estimator side gets the high-priority stream: its short kernels must not queue behind the thousands of workgroups of
+        # a descriptor launch, they slot in as soon as workgroups retire
+        self.sa, self.sb = torch.cuda.Stream(), torch.cuda.Stream(priority=-1)
 
     def set_modes(self, gconv=None, partII=None):
         for c in self.desc:
