@@ -18,6 +18,7 @@
  *   yoho_c_ransac_device    yohoc.ransac incl. sampling   tests/estimator.py:34-51,:119-137 (device RNG)
  *   yoho_range_status       (fp16 range guard, no counterpart: the reference computes in fp32)
  *   yoho_group_gather       60-fold FCGF feature gather   YOHO_testset.py:153-166
+ *   yoho_group_scatter      kpts_f[:, :, i] = pci_f[inds]  simple_yoho/yoho_extract.py:38-39,52
  *   yoho_set_nn_grid             (speed hint, no counterpart)    voxel size of YOHO_testset.py:39-49 / simple_yoho/fcgf_feat.py:33-43
  *   yoho_partI_forward_pair      the two PartI passes of a pair  tests/extractor.py:37-62 (one pass per fragment there)
  *   yoho_des2r_indexed           feats[match[:,0]] + Des2R       tests/extractor.py:80-103
@@ -175,6 +176,10 @@ int yoho_c_ransac_device(yoho_ctx* ctx, const double* keys0, const int64_t* i0, 
 int yoho_group_gather(yoho_ctx* ctx, const double* keys, int K, const float* pts, const float* feat,
                       int n, int g, const double* Rg_host, float* out, int64_t* nn_idx, void* stream);
 
+/* out[k, :, g] = feat[idx[k], :] for k < K: the row transfer of one group element once the nearest neighbours are known
+ * (simple_yoho/yoho_extract.py:38-39,52: kpts_f[:, :, i] = pci_f[inds]).  feat (n,32) f32, idx (K) int64, out (K,32,60) f32. */
+int yoho_group_scatter(yoho_ctx* ctx, const float* feat, int n, const int64_t* idx, int K, int g, float* out, void* stream);
+
 /* ---- training path (reference train/trainer.py on utils/network.py *_train): one (1,13) group-conv layer on
  * device-resident parameters, training layout.  weight (cout,cin,1,13), bias (cout) or NULL: device pointers.
  *   transpose = 0:  y (B,cout,60) = bias + conv(x (B,cin,60))            (utils/network.py:46-52 + Conv2d(cin,cout,(1,13)))
@@ -182,6 +187,22 @@ int yoho_group_gather(yoho_ctx* ctx, const double* keys, int K, const float* pts
  * The weight gradient is a plain contraction (dW[o,c,k] = sum_{b,g} dy[b,o,g] x[b,c,N[g,k]]) left to the caller's BLAS. */
 int yoho_gconv_layer(yoho_ctx* ctx, const float* x, int B, int cin, int cout, const float* weight, const float* bias, int transpose,
                      float* y, void* stream);
+
+/* weight (and bias) gradient of the same layer: dW (cout,cin,1,13) = sum over (b, g) of dy[b,o,g] * x[b,c,N[g,k]], db (cout) =
+ * sum of dy over (b, g) or NULL; x (B,cin,60), dy (B,cout,60) device pointers, cin and cout multiples of 32.  Together with
+ * yoho_gconv_layer(transpose = 1) this is the whole backward pass of Conv2d(cin,cout,(1,13)) on the neighbour gather
+ * (the reference's autograd of utils/network.py:46-52,18). */
+int yoho_gconv_wgrad(yoho_ctx* ctx, const float* x, const float* dy, int B, int cin, int cout, float* dW, float* db, void* stream);
+
+/* BatchNorm2d (train or eval statistics) + ReLU in front of a conv (utils/network.py:16-17,28-29,33-34), on (B,C,60) device tensors.
+ *   yoho_bn_stats          mean (C), biased var (C) over the B x 60 values of every channel (f64 sums);
+ *   yoho_bn_relu_apply     y = relu(x * scale[c] + shift[c]), scale = gamma * rsqrt(var + eps), shift = beta - mean * scale;
+ *   yoho_bn_relu_backward  dy -> dx, dgamma, dbeta through ReLU and the normalisation (batch_stats = 1: the statistics depend on x
+ *                          as in training; 0: running statistics, the normalisation is a fixed affine map). */
+int yoho_bn_stats(yoho_ctx* ctx, const float* x, int B, int C, float* mean, float* var, void* stream);
+int yoho_bn_relu_apply(yoho_ctx* ctx, const float* x, int B, int C, const float* scale, const float* shift, float* y, void* stream);
+int yoho_bn_relu_backward(yoho_ctx* ctx, const float* x, const float* y, const float* dy, int B, int C, const float* gamma,
+                          const float* mean, const float* rstd, int batch_stats, float* dx, float* dgamma, float* dbeta, void* stream);
 
 /* ---- FCGF backbone (reference fcgf_model/resunet.py ResUNet2 family, simple_yoho/fcgf_feat.py) ------------------------
  * Sparse 3-D ResUNet forward pass, fp32.  channels / tr_channels = CHANNELS / TR_CHANNELS of the model class (index 0

@@ -55,6 +55,38 @@ def test_gconv_layer_forward_and_gradients_vs_torch(hip, tables):
         assert rel(layer.weight.grad.cpu(), wr.grad.cpu()) < 1e-4 and rel(layer.bias.grad.cpu(), br.grad.cpu()) < 1e-5
 
 
+def test_fused_bn_relu_forward_and_gradients_vs_torch(hip):
+    """yoho_bn_stats / _bn_relu_apply / _bn_relu_backward (one autograd function) against torch's batch_norm + relu under
+    autograd, with batch statistics (training) and with running statistics (eval)"""
+    from yoho_amd.train.network import GroupBatchNorm
+    c = hip.get_context()
+    torch.manual_seed(1)
+    for C, B in ((32, 5), (256, 17), (512, 3)):
+        for training in (True, False):
+            m = GroupBatchNorm(C, hctx=c).cuda()
+            with torch.no_grad():
+                m.weight.uniform_(0.5, 1.5); m.bias.uniform_(-0.3, 0.3)
+                m.running_mean.uniform_(-0.2, 0.2); m.running_var.uniform_(0.5, 1.5)
+            m.train(training)
+            rm0, rv0 = m.running_mean.clone(), m.running_var.clone()
+            x = (torch.randn(B, C, 60, device="cuda") * 1.7 + 0.3).requires_grad_(True)
+            y = m(x)
+            xr = x.detach().clone().requires_grad_(True)
+            gr, br = m.weight.detach().clone().requires_grad_(True), m.bias.detach().clone().requires_grad_(True)
+            rm, rv = rm0.clone(), rv0.clone()
+            # the reference normalises the gathered (B,C,60,13) tensor: same mean / biased variance, 13x the element count
+            xg = xr[:, :, :, None].expand(B, C, 60, 13)
+            yr = torch.relu(torch.nn.functional.batch_norm(xg, rm, rv, gr, br, training, 0.1, 1e-5))[:, :, :, 0]
+            assert rel(y.detach().cpu(), yr.detach().cpu()) < 2e-6, (C, training)
+            gy = torch.randn_like(y)
+            y.backward(gy)
+            (yr * gy).sum().backward()
+            assert rel(x.grad.cpu(), xr.grad.cpu()) < 2e-5, (C, training)
+            assert rel(m.weight.grad.cpu(), gr.grad.cpu()) < 2e-5 and rel(m.bias.grad.cpu(), br.grad.cpu()) < 2e-5
+            if training:
+                assert rel(m.running_mean.cpu(), rm.cpu()) < 1e-5 and rel(m.running_var.cpu(), rv.cpu()) < 1e-5
+
+
 def test_partI_train_step_matches_reference(gold, cfg, tables):
     from yoho_amd.train import network, loss_val
     sd1 = W.synth_state_dict(W.PARTI_SPEC, 7)

@@ -40,14 +40,21 @@ def main(fd, wd, out, key="fgemm"):
         d = {"units": "KiB per dispatch as reported by rocprofv3 (FETCH_SIZE/WRITE_SIZE)",
              "correction": "gfx950: FETCH_SIZE x2 (MI355X_MICROARCH.md HBM section); WRITE_SIZE as reported", "partI_pass_gconv_bytes": {"launches_per_pass": 4}}
     d.setdefault("modes", {})[key] = rows
-    if key == "fgemm":
-        tot = sum(r["hbm_bytes_per_launch"] for r in rows if "fgemm_kernel" in r["kernel"] for _ in range(1))
-        # one pass = 4 launches: grids may coincide (L0 and L2 share a grid size): weight by dispatch counts
-        per = [r for r in rows if "fgemm_kernel" in r["kernel"]]
-        passes = min(r["dispatches"] for r in per) if per else 1
-        tot = sum(r["hbm_bytes_per_launch"] * r["dispatches"] for r in per) / max(passes, 1)
+    if key in ("fgemm", "fgemm256"):
+        # one pass = 4 GEMM launches: grids may coincide (layers 1 and 3 share a grid size): weight by dispatch counts
+        per = [r for r in rows if "fgemm" in r["kernel"]]
+        passes = max(1, min(r["dispatches"] for r in per) if per else 1)
+        tot = sum(r["hbm_bytes_per_launch"] * r["dispatches"] for r in per) / passes
+        allb = sum(r["hbm_bytes_per_launch"] * r["dispatches"] for r in rows) / passes
         d["partI_pass_gconv_bytes"][key] = tot
-        print("\nSum over the 4 fgemm launches of one PartI pass: %.2f GB (avg %.2f GB per launch)" % (tot / 1e9, tot / 4e9))
+        d.setdefault("partI_pass_total_bytes", {})[key] = allb
+        print("\nSum over the 4 GEMM launches of one PartI pass: %.2f GB (avg %.2f GB per launch); every kernel of the pass: %.2f GB"
+              % (tot / 1e9, tot / 4e9, allb / 1e9))
+    import subprocess, os
+    try:
+        d["commit"] = subprocess.check_output(["git", "rev-parse", "--short", "HEAD"], cwd=os.path.dirname(os.path.abspath(__file__))).decode().strip()
+    except Exception:
+        d["commit"] = os.environ.get("YOHO_COMMIT")
     json.dump(d, open(out, "w"), indent=1)
 
 

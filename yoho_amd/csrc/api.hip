@@ -855,4 +855,31 @@ int yoho_gconv_layer(yoho_ctx* c, const float* x, int B, int cin, int cout, cons
     return 0;
 }
 
+int yoho_bn_stats(yoho_ctx* c, const float* x, int B, int C, float* mean, float* var, void* stream) {
+    if (!c || !x || !mean || !var || B < 1 || C < 1) { set_error("yoho_bn_stats: bad argument"); return YOHO_EINVAL; }
+    HIPCHK(hipSetDevice(c->device));
+    return bn_stats(x, B, C, mean, var, (hipStream_t)stream);
+}
+
+int yoho_bn_relu_apply(yoho_ctx* c, const float* x, int B, int C, const float* scale, const float* shift, float* y, void* stream) {
+    if (!c || !x || !scale || !shift || !y || B < 1 || C < 1) { set_error("yoho_bn_relu_apply: bad argument"); return YOHO_EINVAL; }
+    HIPCHK(hipSetDevice(c->device));
+    return bn_relu_apply(x, B, C, scale, shift, y, (hipStream_t)stream);
+}
+
+int yoho_bn_relu_backward(yoho_ctx* c, const float* x, const float* y, const float* dy, int B, int C, const float* gamma, const float* mean,
+                          const float* rstd, int batch_stats, float* dx, float* dgamma, float* dbeta, void* stream) {
+    if (!c || !x || !y || !dy || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || B < 1 || C < 1) {
+        set_error("yoho_bn_relu_backward: bad argument"); return YOHO_EINVAL;
+    }
+    HIPCHK(hipSetDevice(c->device));
+    return bn_relu_backward(x, y, dy, B, C, gamma, mean, rstd, batch_stats, dx, dgamma, dbeta, (hipStream_t)stream);
+}
+
+int yoho_gconv_wgrad(yoho_ctx* c, const float* x, const float* dy, int B, int cin, int cout, float* dW, float* db, void* stream) {
+    if (!c || B < 1 || cin < 1 || cout < 1 || !x || !dy || !dW) { set_error("yoho_gconv_wgrad: bad argument"); return YOHO_EINVAL; }
+    HIPCHK(hipSetDevice(c->device));
+    return gconv_wgrad(c, x, dy, B, cin, cout, dW, db, (hipStream_t)stream);
+}
+
 }  // extern "C"

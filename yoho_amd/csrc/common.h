@@ -104,6 +104,11 @@ int launch_fgemm(const Layer& L, const char* Bplanes, int kppad, int nT32, const
 void build_gft16_frags(const FourierBasis& fb, std::vector<unsigned short>& out);
 int gconv_layer(yoho_ctx* c, const float* x, int B, int cin, int cout, const float* W, const float* bias, int transpose, float* y,
                 hipStream_t s);
+int bn_stats(const float* x, int B, int C, float* mean, float* var, hipStream_t s);
+int bn_relu_apply(const float* x, int B, int C, const float* scale, const float* shift, float* y, hipStream_t s);
+int bn_relu_backward(const float* x, const float* y, const float* dy, int B, int C, const float* gamma, const float* mean, const float* rstd,
+                     int batch_stats, float* dx, float* dgamma, float* dbeta, hipStream_t s);
+int gconv_wgrad(yoho_ctx* c, const float* x, const float* dy, int B, int cin, int cout, float* dW, float* db, hipStream_t s);
 struct FcgfNet;
 int fcgf_load(FcgfNet** out, const yoho_fcgf_config* cfg, const float* const* t, int ntensors);
 void fcgf_free(FcgfNet* n);

@@ -485,11 +485,35 @@ __global__ __launch_bounds__(256) void gather_merge_kernel(const double* __restr
     o[(size_t)(2 * sp + 1) * G] = fr[2 * sp + 1];
 }
 
+// out[row, :, g] = feat[idx[row], :]: the feature transfer of one group element once the nearest neighbours are known
+// (simple_yoho/yoho_extract.py:38-39, :52); 16 threads per row, 2 channels each
+__global__ __launch_bounds__(256) void group_scatter_kernel(const float* __restrict__ feat, const int64_t* __restrict__ idx, int K, int n, int g,
+                                                            float* __restrict__ out) {
+    const int row = blockIdx.x * 16 + (threadIdx.x >> 4), sp = threadIdx.x & 15;
+    if (row >= K) return;
+    long long bi = idx[row];
+    bi = bi < 0 ? 0 : (bi >= n ? n - 1 : bi);
+    const float2 v = *reinterpret_cast<const float2*>(feat + (size_t)bi * F + 2 * sp);
+    float* o = out + (size_t)row * F * G + g;
+    o[(size_t)(2 * sp) * G] = v.x;
+    o[(size_t)(2 * sp + 1) * G] = v.y;
+}
+
 }  // namespace yoho
 
 using namespace yoho;
 
 extern "C" {
+
+int yoho_group_scatter(yoho_ctx* c, const float* feat, int n, const int64_t* idx, int K, int g, float* out, void* stream) {
+    if (!c || K < 0 || n < 1 || g < 0 || g >= G) { set_error("yoho_group_scatter: bad argument"); return YOHO_EINVAL; }
+    if (K == 0) return 0;
+    if (!feat || !idx || !out) { set_error("yoho_group_scatter: bad argument"); return YOHO_EINVAL; }
+    HIPCHK(hipSetDevice(c->device));
+    hipLaunchKernelGGL(group_scatter_kernel, dim3((K + 15) / 16), dim3(256), 0, (hipStream_t)stream, feat, idx, K, n, g, out);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
 
 int yoho_hyp_from_quat(yoho_ctx* c, const float* quat, const int64_t* idx, const double* k0, const double* k1, int M, double* T,
                        void* stream) {

@@ -74,6 +74,161 @@ __global__ void pad_bias_kernel(const float* __restrict__ b, int n, int npad, fl
     if (i < npad) out[i] = (b && i < n) ? b[i] : 0.f;
 }
 
+// Weight gradient of the layer (the third product of its backward pass):
+//   dW[o,c,0,k] = sum_b sum_g dy[b,o,g] * x[b,c,N[g,k]]          db[o] = sum_b sum_g dy[b,o,g]
+// i.e. per tap a (cout x cin) product contracted over (batch, group element), the activations read through the neighbour
+// table instead of a materialised (B,C,60,13) gather (utils/network.py:46-52 under autograd).  One workgroup per
+// (32 output channels, 32 input channels): thread (oi = tid >> 3, cj = tid & 7) owns dW[oi][4 cj .. 4 cj + 3][0..12] - 52 fp32
+// accumulators - and walks the batch in order (deterministic sums); per sample the two 32 x 60 blocks are staged in LDS
+// ([g][channel], so the four channels of a thread are one 16-byte read and dy is a broadcast).  Training batches are a few
+// dozen keypoints (train/trainer.py), so this kernel is judged on parity, not on the roofline.
+__global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, int B, int cin, int cout,
+                                                    const int* __restrict__ nei, float* __restrict__ dW, float* __restrict__ db) {
+    __shared__ float xs[G][32];
+    __shared__ float ds[G][32];
+    __shared__ int nb[G * NTAP];
+    const int ob = blockIdx.x, cb = blockIdx.y;
+    const int tid = threadIdx.x, oi = tid >> 3, cj = tid & 7;
+    for (int i = tid; i < G * NTAP; i += 256) nb[i] = nei[i];
+    float acc[4][NTAP];
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int k = 0; k < NTAP; ++k) acc[e][k] = 0.f;
+    float bsum = 0.f;
+    for (int b = 0; b < B; ++b) {
+        __syncthreads();
+        const float* xp = x + ((size_t)b * cin + cb * 32) * G;          // 32 channels x 60 group elements, contiguous
+        const float* dp = dy + ((size_t)b * cout + ob * 32) * G;
+        for (int i = tid; i < 32 * G; i += 256) {
+            const int ch = i / G, g = i - ch * G;
+            xs[g][ch] = xp[i];
+            ds[g][ch] = dp[i];
+        }
+        __syncthreads();
+        for (int g = 0; g < G; ++g) {
+            const float d = ds[g][oi];
+            bsum += d;
+#pragma unroll
+            for (int k = 0; k < NTAP; ++k) {
+                const float4 v = *reinterpret_cast<const float4*>(&xs[nb[g * NTAP + k]][4 * cj]);
+                acc[0][k] = fmaf(d, v.x, acc[0][k]);
+                acc[1][k] = fmaf(d, v.y, acc[1][k]);
+                acc[2][k] = fmaf(d, v.z, acc[2][k]);
+                acc[3][k] = fmaf(d, v.w, acc[3][k]);
+            }
+        }
+    }
+    float* o = dW + ((size_t)(ob * 32 + oi) * cin + cb * 32 + 4 * cj) * NTAP;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int k = 0; k < NTAP; ++k) o[e * NTAP + k] = acc[e][k];
+    if (db && cb == 0 && cj == 0) db[ob * 32 + oi] = bsum;
+}
+
+// ---- BatchNorm (batch statistics) + ReLU of a (B,C,60) tensor, fused (utils/network.py:16-17: BatchNorm2d + ReLU in front of every
+// conv; on the un-gathered tensor, see train/network.py) ---------------------------------------------------------------------
+// stats: one workgroup per channel, f64 sums over the B x 60 values -> mean, biased variance
+__device__ __forceinline__ double wg_sum(double v, double* red) {
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, int B, int C, float* __restrict__ mean, float* __restrict__ var) {
+    __shared__ double red[4];
+    const int c = blockIdx.x;
+    double s = 0.0, q = 0.0;
+    for (int i = threadIdx.x; i < B * G; i += 256) {
+        const int b = i / G, g = i - b * G;
+        const double v = x[((size_t)b * C + c) * G + g];
+        s += v; q += v * v;
+    }
+    s = wg_sum(s, red);
+    q = wg_sum(q, red);
+    if (threadIdx.x == 0) {
+        const double n = (double)B * G, m = s / n;
+        mean[c] = (float)m;
+        var[c] = (float)fmax(q / n - m * m, 0.0);
+    }
+}
+
+// y = relu(x * scale[c] + shift[c])
+__global__ __launch_bounds__(256) void bn_relu_apply_kernel(const float* __restrict__ x, size_t n, int C, const float* __restrict__ scale,
+                                                            const float* __restrict__ shift, float* __restrict__ y) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int c = (int)((i / G) % C);
+    y[i] = fmaxf(fmaf(x[i], scale[c], shift[c]), 0.f);
+}
+
+// backward, reductions: dz = dy where y > 0; sum_dz[c], sum_dz_xhat[c] with xhat = (x - mean) * rstd
+__global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ dy,
+                                                                 int B, int C, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                 float* __restrict__ sum_dz, float* __restrict__ sum_dzx) {
+    __shared__ double red[4];
+    const int c = blockIdx.x;
+    const double m = mean[c], r = rstd[c];
+    double s = 0.0, q = 0.0;
+    for (int i = threadIdx.x; i < B * G; i += 256) {
+        const int b = i / G, g = i - b * G;
+        const size_t o = ((size_t)b * C + c) * G + g;
+        const double dz = y[o] > 0.f ? (double)dy[o] : 0.0;
+        s += dz; q += dz * (((double)x[o] - m) * r);
+    }
+    s = wg_sum(s, red);
+    q = wg_sum(q, red);
+    if (threadIdx.x == 0) { sum_dz[c] = (float)s; sum_dzx[c] = (float)q; }
+}
+
+// dx = gamma * rstd * (dz - sum_dz / N - xhat * sum_dzx / N)    (batch statistics);    dx = dz * gamma * rstd    (running statistics)
+__global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ dy,
+                                                                size_t n, int C, float invN, const float* __restrict__ gamma,
+                                                                const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                const float* __restrict__ sum_dz, const float* __restrict__ sum_dzx, int batch_stats,
+                                                                float* __restrict__ dx) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int c = (int)((i / G) % C);
+    const float dz = y[i] > 0.f ? dy[i] : 0.f;
+    const float gr = gamma[c] * rstd[c];
+    if (!batch_stats) { dx[i] = dz * gr; return; }
+    const float xh = (x[i] - mean[c]) * rstd[c];
+    dx[i] = gr * (dz - sum_dz[c] * invN - xh * sum_dzx[c] * invN);
+}
+
+int bn_stats(const float* x, int B, int C, float* mean, float* var, hipStream_t s) {
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(C), dim3(256), 0, s, x, B, C, mean, var);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+int bn_relu_apply(const float* x, int B, int C, const float* scale, const float* shift, float* y, hipStream_t s) {
+    const size_t n = (size_t)B * C * G;
+    hipLaunchKernelGGL(bn_relu_apply_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, n, C, scale, shift, y);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+int bn_relu_backward(const float* x, const float* y, const float* dy, int B, int C, const float* gamma, const float* mean, const float* rstd,
+                     int batch_stats, float* dx, float* dgamma, float* dbeta, hipStream_t s) {
+    // dbeta = sum dz, dgamma = sum dz * xhat: exactly the two reductions the input gradient needs
+    hipLaunchKernelGGL(bn_relu_bwd_reduce_kernel, dim3(C), dim3(256), 0, s, x, y, dy, B, C, mean, rstd, dbeta, dgamma);
+    const size_t n = (size_t)B * C * G;
+    hipLaunchKernelGGL(bn_relu_bwd_apply_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, y, dy, n, C, 1.f / ((float)B * G), gamma, mean,
+                       rstd, dbeta, dgamma, batch_stats, dx);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int gconv_wgrad(yoho_ctx* c, const float* x, const float* dy, int B, int cin, int cout, float* dW, float* db, hipStream_t s) {
+    if (cin % 32 || cout % 32) { set_error("yoho_gconv_wgrad: channel counts must be multiples of 32 (got %d -> %d)", cin, cout); return YOHO_EINVAL; }
+    hipLaunchKernelGGL(wgrad_kernel, dim3(cout / 32, cin / 32), dim3(256), 0, s, x, dy, B, cin, cout, c->dN, dW, db);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 int gconv_layer(yoho_ctx* c, const float* x, int B, int cin, int cout, const float* W, const float* bias, int transpose, float* y,
                 hipStream_t s) {
     const int ecin = transpose ? cout : cin, ecout = transpose ? cin : cout;

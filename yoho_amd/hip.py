@@ -22,7 +22,7 @@ SYMBOLS = [
     "yoho_gconv_layer", "yoho_load_fcgf", "yoho_fcgf_voxelize", "yoho_fcgf_forward", "yoho_fcgf_forward_batch", "yoho_fcgf_voxelize_rotated", "yoho_rotate_select",
     "yoho_des2r", "yoho_des2r_indexed", "yoho_partII_forward", "yoho_partII_forward_indexed", "yoho_hyp_from_quat", "yoho_o_score", "yoho_c_ransac",
     "yoho_group_gather", "yoho_set_profiling", "yoho_get_kernel_ms", "yoho_set_gconv_mode", "yoho_set_partII_mode", "yoho_set_nn_grid",
-    "yoho_range_status", "yoho_c_ransac_device",
+    "yoho_range_status", "yoho_c_ransac_device", "yoho_group_scatter", "yoho_gconv_wgrad", "yoho_bn_stats", "yoho_bn_relu_apply", "yoho_bn_relu_backward",
 ]
 
 
@@ -99,6 +99,11 @@ def load_library():
     lib.yoho_fcgf_voxelize_rotated.argtypes = [vp, vp, ci, vp, C.c_double, vp, vp, vp, vp, vp]
     lib.yoho_rotate_select.argtypes = [vp, vp, vp, vp, ci, vp, vp]
     lib.yoho_get_kernel_ms.argtypes = [vp, ci, C.POINTER(C.c_float)]
+    lib.yoho_bn_stats.argtypes = [vp, vp, ci, ci, vp, vp, vp]
+    lib.yoho_bn_relu_apply.argtypes = [vp, vp, ci, ci, vp, vp, vp, vp]
+    lib.yoho_bn_relu_backward.argtypes = [vp, vp, vp, vp, ci, ci, vp, vp, vp, ci, vp, vp, vp, vp]
+    lib.yoho_gconv_wgrad.argtypes = [vp, vp, vp, ci, ci, ci, vp, vp, vp]
+    lib.yoho_group_scatter.argtypes = [vp, vp, ci, vp, ci, ci, vp, vp]
     lib.yoho_range_status.argtypes = [vp, C.POINTER(ci), C.POINTER(ci), vp]
     lib.yoho_c_ransac_device.argtypes = [vp, vp, vp, vp, vp, ci, vp, ci, ci, C.c_uint64, C.c_double, vp, vp, vp, vp, vp]
     for s in SYMBOLS[2:]:
@@ -229,6 +234,39 @@ class Context:
                                           _dev(bias, torch.float32, "bias") if (bias is not None and not transpose) else None,
                                           1 if transpose else 0, C.c_void_p(y.data_ptr()), _stream()))
         return y
+
+    def bn_stats(self, x):
+        """per-channel mean and biased variance of a (B,C,60) tensor"""
+        B, Cn = x.shape[0], x.shape[1]
+        mean = torch.empty((Cn,), dtype=torch.float32, device=x.device)
+        var = torch.empty((Cn,), dtype=torch.float32, device=x.device)
+        _check(self._lib.yoho_bn_stats(self._h, _dev(x, torch.float32, "x"), B, Cn, C.c_void_p(mean.data_ptr()), C.c_void_p(var.data_ptr()), _stream()))
+        return mean, var
+
+    def bn_relu_apply(self, x, scale, shift):
+        y = torch.empty_like(x)
+        _check(self._lib.yoho_bn_relu_apply(self._h, _dev(x, torch.float32, "x"), x.shape[0], x.shape[1], _dev(scale, torch.float32, "scale"),
+                                            _dev(shift, torch.float32, "shift"), C.c_void_p(y.data_ptr()), _stream()))
+        return y
+
+    def bn_relu_backward(self, x, y, dy, gamma, mean, rstd, batch_stats):
+        dx = torch.empty_like(x)
+        dg = torch.empty((x.shape[1],), dtype=torch.float32, device=x.device)
+        db = torch.empty((x.shape[1],), dtype=torch.float32, device=x.device)
+        _check(self._lib.yoho_bn_relu_backward(self._h, _dev(x, torch.float32, "x"), _dev(y, torch.float32, "y"), _dev(dy, torch.float32, "dy"),
+                                               x.shape[0], x.shape[1], _dev(gamma, torch.float32, "gamma"), _dev(mean, torch.float32, "mean"),
+                                               _dev(rstd, torch.float32, "rstd"), 1 if batch_stats else 0, C.c_void_p(dx.data_ptr()),
+                                               C.c_void_p(dg.data_ptr()), C.c_void_p(db.data_ptr()), _stream()))
+        return dx, dg, db
+
+    def gconv_wgrad(self, x, dy, want_bias=True):
+        """weight / bias gradient of the (1,13) group conv: x (B,cin,60), dy (B,cout,60) -> (dW (cout,cin,1,13), db (cout) or None)"""
+        B, cin, cout = x.shape[0], int(x.shape[1]), int(dy.shape[1])
+        dW = torch.empty((cout, cin, 1, 13), dtype=torch.float32, device=x.device)
+        db = torch.empty((cout,), dtype=torch.float32, device=x.device) if want_bias else None
+        _check(self._lib.yoho_gconv_wgrad(self._h, _dev(x, torch.float32, "x"), _dev(dy, torch.float32, "dy"), B, cin, cout,
+                                          C.c_void_p(dW.data_ptr()), C.c_void_p(db.data_ptr()) if want_bias else None, _stream()))
+        return dW, db
 
     # ---- FCGF backbone ------------------------------------------------------------------------
     def load_fcgf(self, sd, channels=(0, 32, 64, 128, 256), tr_channels=(0, 64, 64, 64, 128), out_channels=32, conv1_kernel_size=7,
@@ -514,6 +552,11 @@ class Context:
                                            _dev(out, torch.float32, "out"), C.c_void_p(nn_idx.data_ptr()) if want_idx else None,
                                            _stream()))
         return nn_idx
+
+    def group_scatter(self, feat, idx, g, out):
+        """out[:, :, g] = feat[idx] (feat (n,32) f32, idx (K,) int64, out (K,32,60) f32), in place"""
+        _check(self._lib.yoho_group_scatter(self._h, _dev(feat, torch.float32, "feat"), feat.shape[0], _dev(idx, torch.int64, "idx"), idx.shape[0],
+                                            int(g), _dev(out, torch.float32, "out"), _stream()))
 
     def set_gconv_mode(self, mode):
         """'f32' (direct conv, fp32 MFMA), 'bf16x3' (direct conv, fp32-accurate 3-way bf16 split MFMA),

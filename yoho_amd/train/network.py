@@ -4,10 +4,12 @@ written here load in the reference.
 
 The reference materialises the 13-neighbour gather (`data[:, :, Nei].reshape(B, C, 60, 13)`, :46-52) and runs
 BatchNorm2d -> ReLU -> Conv2d(Cin, Cout, (1,13)) on it.  Here the gather + convolution is ONE autograd function on the HIP
-library (yoho_gconv_layer: forward and data gradient on the fp32 MFMA kernel; the weight gradient is a plain contraction
-done by torch), and BatchNorm / ReLU act on the un-gathered (B, C, 60) tensor - they are element-wise per channel, so they
-commute with the gather; the batch statistics are identical (every element appears exactly 13 times in the gathered
-tensor), only the unbiased-variance correction of running_var counts the gathered size B*60*13 as the reference does.
+library (yoho_gconv_layer: forward and data gradient on the fp32 MFMA kernel; yoho_gconv_wgrad: weight and bias gradient read
+through the neighbour table), and BatchNorm + ReLU are ONE autograd function as well (yoho_bn_stats / _bn_relu_apply /
+_bn_relu_backward) on the un-gathered (B, C, 60) tensor - they are element-wise per channel, so they commute with the gather;
+the batch statistics are identical (every element appears exactly 13 times in the gathered tensor), only the
+unbiased-variance correction of running_var counts the gathered size B*60*13 as the reference does.  torch autograd only
+chains these functions; no einsum / batch_norm / conv kernel of torch runs in a training step of the group-conv stack.
 """
 import numpy as np
 import torch
@@ -32,12 +34,8 @@ class _GroupConvFn(torch.autograd.Function):
         dx = dW = db = None
         if ctx.needs_input_grad[0]:
             dx = ctx.hctx.gconv_layer(dy, weight.contiguous(), None, transpose=True)
-        if ctx.needs_input_grad[1]:
-            B, C = x.shape[0], x.shape[1]
-            xg = x[:, :, ctx.nei].reshape(B, C, 60, 13)                  # the reference's data_process gather
-            dW = torch.einsum('bog,bcgk->ock', dy, xg).unsqueeze(2)      # (Cout, Cin, 1, 13)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = dy.sum((0, 2))
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            dW, db = ctx.hctx.gconv_wgrad(x, dy, want_bias=ctx.has_bias)   # (Cout, Cin, 1, 13), (Cout,)
         return dx, dW, db, None, None
 
 
@@ -55,13 +53,36 @@ class GroupConv2d(nn.Module):
         return _GroupConvFn.apply(x, self.weight, self.bias, self._hctx, self._nei)
 
 
-class GroupBatchNorm(nn.Module):
-    """nn.BatchNorm2d(C) of the reference's gathered (B,C,60,13) tensor, evaluated on the un-gathered (B,C,60) tensor.
-    state_dict keys = BatchNorm2d's (weight, bias, running_mean, running_var, num_batches_tracked)."""
+class _BNReLUFn(torch.autograd.Function):
+    """relu(batch_norm(x)) on the HIP library; forward returns y, backward the gradients of x, gamma, beta"""
 
-    def __init__(self, num_features, eps=1e-5, momentum=0.1):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, mean, var, eps, batch_stats, hctx):
+        x = x.contiguous()
+        rstd = torch.rsqrt(var + eps)
+        scale = (gamma * rstd).contiguous()
+        y = hctx.bn_relu_apply(x, scale, (beta - mean * scale).contiguous())
+        ctx.hctx, ctx.batch_stats = hctx, batch_stats
+        ctx.save_for_backward(x, y, gamma.detach().contiguous(), mean.contiguous(), rstd.contiguous())
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, gamma, mean, rstd = ctx.saved_tensors
+        dx, dg, db = ctx.hctx.bn_relu_backward(x, y, dy.contiguous(), gamma, mean, rstd, ctx.batch_stats)
+        return dx, dg, db, None, None, None, None, None
+
+
+class GroupBatchNorm(nn.Module):
+    """nn.BatchNorm2d(C) + nn.ReLU of the reference's gathered (B,C,60,13) tensor, evaluated on the un-gathered (B,C,60) tensor
+    (fused: the nn.ReLU that follows it in the reference's Sequential is kept as a parameter-free placeholder so that the
+    state_dict keys stay BatchNorm2d's at index 0 - weight, bias, running_mean, running_var, num_batches_tracked - and the conv's
+    at index 2; ReLU of a ReLU output is the identity)."""
+
+    def __init__(self, num_features, eps=1e-5, momentum=0.1, hctx=None):
         super().__init__()
         self.eps, self.momentum = eps, momentum
+        self._hctx = hctx
         self.weight = nn.Parameter(torch.ones(num_features))
         self.bias = nn.Parameter(torch.zeros(num_features))
         self.register_buffer('running_mean', torch.zeros(num_features))
@@ -69,6 +90,18 @@ class GroupBatchNorm(nn.Module):
         self.register_buffer('num_batches_tracked', torch.tensor(0, dtype=torch.long))
 
     def forward(self, x):                                               # (B, C, 60)
+        if self._hctx is not None:
+            x = x.contiguous()
+            if self.training:
+                with torch.no_grad():
+                    mean, var = self._hctx.bn_stats(x)
+                    n = x.shape[0] * x.shape[2] * 13                     # elements per channel of the gathered tensor
+                    self.running_mean.mul_(1 - self.momentum).add_(self.momentum * mean)
+                    self.running_var.mul_(1 - self.momentum).add_(self.momentum * var * (n / (n - 1)))
+                    self.num_batches_tracked += 1
+            else:
+                mean, var = self.running_mean, self.running_var
+            return _BNReLUFn.apply(x, self.weight, self.bias, mean, var, self.eps, self.training, self._hctx)
         if self.training:
             mean = x.mean((0, 2))
             var = x.var((0, 2), unbiased=False)
@@ -86,7 +119,7 @@ class GroupBatchNorm(nn.Module):
 class Comb_Conv(nn.Module):
     def __init__(self, in_dim, out_dim, hctx, nei):
         super().__init__()
-        self.comb_layer = nn.Sequential(GroupBatchNorm(in_dim), nn.ReLU(), GroupConv2d(in_dim, out_dim, hctx, nei))
+        self.comb_layer = nn.Sequential(GroupBatchNorm(in_dim, hctx=hctx), nn.ReLU(), GroupConv2d(in_dim, out_dim, hctx, nei))
 
     def forward(self, input):                                           # (B, in_dim, 60) -> (B, out_dim, 60)
         return self.comb_layer(input)
@@ -95,12 +128,12 @@ class Comb_Conv(nn.Module):
 class Residual_Comb_Conv(nn.Module):
     def __init__(self, in_dim, middle_dim, out_dim, hctx, nei):
         super().__init__()
-        self.comb_layer_in = nn.Sequential(GroupBatchNorm(in_dim), nn.ReLU(), GroupConv2d(in_dim, middle_dim, hctx, nei))
-        self.comb_layer_out = nn.Sequential(GroupBatchNorm(middle_dim), nn.ReLU(), GroupConv2d(middle_dim, out_dim, hctx, nei))
+        self.comb_layer_in = nn.Sequential(GroupBatchNorm(in_dim, hctx=hctx), nn.ReLU(), GroupConv2d(in_dim, middle_dim, hctx, nei))
+        self.comb_layer_out = nn.Sequential(GroupBatchNorm(middle_dim, hctx=hctx), nn.ReLU(), GroupConv2d(middle_dim, out_dim, hctx, nei))
         self.short_cut = False
         if not in_dim == out_dim:
             self.short_cut = True
-            self.short_cut_layer = nn.Sequential(GroupBatchNorm(in_dim), nn.ReLU(), GroupConv2d(in_dim, out_dim, hctx, nei))
+            self.short_cut_layer = nn.Sequential(GroupBatchNorm(in_dim, hctx=hctx), nn.ReLU(), GroupConv2d(in_dim, out_dim, hctx, nei))
 
     def forward(self, feat_input):                                      # bn*f*60
         feat = self.comb_layer_out(self.comb_layer_in(feat_input))

@@ -78,7 +78,7 @@ class yoho_extractor():
                         for j, (sel, pci_f, ds) in enumerate(res):
                             q = self.ctx.rotate_select(pc_d, Rs[j], kidx_d)
                             _, idx = self.ctx.nn_search(q, ds, want_dist=False, squared=True)
-                            kpts_f[:, :, i0 + j] = pci_f[idx]
+                            self.ctx.group_scatter(pci_f, idx, i0 + j, kpts_f)
                         continue
                     Rts = [torch.from_numpy(np.ascontiguousarray(R.T)).cuda() for R in Rs]
                     pcs = [pc_d @ Rt for Rt in Rts]
@@ -86,7 +86,7 @@ class yoho_extractor():
                     for j, (pci, (sel, pci_f)) in enumerate(zip(pcs, self.fcgf.extract_features_dev_batch(pcs, voxel_size))):
                         q = (kp_d @ Rts[j]).to(torch.float32).contiguous()
                         _, idx = self.ctx.nn_search(q, pci[sel].to(torch.float32).contiguous(), want_dist=False, squared=True)
-                        kpts_f[:, :, i0 + j] = pci_f[idx]
+                        self.ctx.group_scatter(pci_f.contiguous(), idx, i0 + j, kpts_f)
             finally:
                 self.ctx.set_nn_grid(0)
             self._last_group_feats = kpts_f
