@@ -222,6 +222,19 @@ int yoho_ctx_create(int device, const float* R, const uint8_t* N, const uint8_t*
     for (int i = 0; i < G * NTAP; ++i) if (N[i] >= G) { set_error("Nei table entry out of range"); return YOHO_EINVAL; }
     for (int i = 0; i < G * G; ++i) if (P[i] >= G) { set_error("60_60 table entry out of range"); return YOHO_EINVAL; }
     HIPCHK(hipSetDevice(device));
+    {
+        // The wave-uniform slot tables of the direct-conv kernels (gconv.hip / gconv16.hip) are __constant__ objects of the loaded
+        // code object, i.e. one copy per device for all contexts: every context of a process must be built on the same neighbour
+        // table (they always are - the table is the icosahedral group's).  A second table is refused instead of silently sharing.
+        static bool have = false;
+        static uint8_t firstN[G * NTAP], firstP[G * G];
+        if (have && (std::memcmp(firstN, N, sizeof(firstN)) || std::memcmp(firstP, P, sizeof(firstP)))) {
+            set_error("yoho_ctx_create: a context with different group tables already exists in this process (the direct-conv slot tables are per device)");
+            return YOHO_EINVAL;
+        }
+        std::memcpy(firstN, N, sizeof(firstN)); std::memcpy(firstP, P, sizeof(firstP));
+        have = true;
+    }
     yoho_ctx* c = new yoho_ctx();
     c->device = device;
     std::memcpy(c->hN, N, sizeof(c->hN));
