@@ -131,7 +131,7 @@ def main():
     ap.add_argument("--in-flight", type=int, choices=[1, 2], default=2,
                     help="pairs in flight: 2 (default) queues the descriptor pass of the next pair on a second HIP stream before waiting for "
                          "the current pair's read-backs (pipeline.PairStreamer); 1 runs the pairs strictly one after the other")
-    ap.add_argument("--gconv", choices=["f32", "bf16x3", "fourier", "fp16x2", "fgemm", "fgemm256"], default=os.environ.get("YOHO_GCONV", "fgemm"),
+    ap.add_argument("--gconv", choices=["f32", "bf16x3", "fourier", "fp16x2", "fgemm", "fgemm256", "fgemm128"], default=os.environ.get("YOHO_GCONV", "fgemm"),
                     help="PartI group conv: group-Fourier domain (fp32 MFMA), direct fp32 MFMA, direct 3-way bf16 split MFMA, "
                          "or direct 2-way fp16 split MFMA")
     ap.add_argument("--partII", choices=["f32", "bf16x3", "fp16x2"], default=os.environ.get("YOHO_PARTII", "fp16x2"),
@@ -259,7 +259,7 @@ def main():
     def add(name, ms, nbytes, note):
         hbm[name] = {"ms": round(float(ms), 4), "bytes": int(nbytes), "TBps": round(nbytes / (ms * 1e-3) / 1e12, 3) if ms > 0 else None,
                      "frac_of_8TBps": round(nbytes / (ms * 1e-3) / 8e12, 4) if ms > 0 else None, "what": note}
-    if args.gconv in ("fgemm", "fgemm256"):
+    if args.gconv in ("fgemm", "fgemm256", "fgemm128"):
         add("head16_kernel", conv_ms[4], 2 * coef(32), "x (B,32,60) f32 in, cin=32 operand planes out")
         for i, ch in ((7, 256), (8, 512), (9, 256)):
             add(f"gft16_kernel<ACTP> {ch}ch", conv_ms[i], 2 * coef(ch), "fp32 coefficients in, BN+ReLU in the group domain, fp16x2 operand planes out")
@@ -294,11 +294,11 @@ def main():
                     "note": "achieved = algorithmic fp32-equivalent FLOP/s; the 2-way fp16 split (x = hi + lo, 3 products, error "
                             "<= 3*2^-22 per product) issues 3.23 fp16 MFMA flops per algorithmic flop, so frac <= 0.31"}
             dtype = "fp16x2 split (2^-22-accurate products, fp32 accumulate)"
-        elif args.gconv in ("fgemm", "fgemm256"):
+        elif args.gconv in ("fgemm", "fgemm256", "fgemm128"):
             issued = fgemm_issued_flops(nkp) / (gconv_total_ms * 1e-3) / 1e12
             roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP16_MFMA_PEAK, "unit": "TFLOP/s",
                     "frac": round(achieved / FP16_MFMA_PEAK, 4), "traffic": pmc_traffic(args.gconv)[0], "traffic_source": pmc_traffic(args.gconv)[1],
-                    "kernel": ("fgemm2_kernel" if args.gconv == "fgemm" else "fgemm_kernel") +
+                    "kernel": {"fgemm": "fgemm3_kernel", "fgemm128": "fgemm2_kernel", "fgemm256": "fgemm_kernel"}[args.gconv] +
                               " (4 launches = 4 PartI layers over both fragments, 4.345 algorithmic TFLOP per 10000 kp)",
                     "executed_tflops": round(issued, 1), "executed_frac": round(issued / FP16_MFMA_PEAK, 4),
                     "executed_frac_per_launch": [round(f / (ms * 1e-3) / 1e12 / FP16_MFMA_PEAK, 4)

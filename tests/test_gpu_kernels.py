@@ -128,7 +128,7 @@ def test_partI_split_golden_and_vs_f32(ctx, ctx_of, mode, dmax, gold, sd1, table
     assert (ei - e16[:, :, P[17]]).abs().max().item() < 2e-5
 
 
-@pytest.mark.parametrize("fmode", ["fourier", "fgemm", "fgemm256"])
+@pytest.mark.parametrize("fmode", ["fourier", "fgemm", "fgemm256", "fgemm128"])
 def test_partI_group_fourier_mode(hip, ctx, gold, sd1, tables, fmode):
     """modes 'fourier' / 'fgemm': the conv runs on group-Fourier coefficients (244 instead of 780 slab products),
     on fp32 MFMA, or with the two large layers as irrep GEMMs on the fp16x2 split MFMA"""
@@ -152,20 +152,25 @@ def test_partI_group_fourier_mode(hip, ctx, gold, sd1, tables, fmode):
 
 
 def test_fgemm_tile_variants_are_bit_identical(hip, sd1):
-    """the two GEMM blockings of the default mode (256 x 128 tiles, two workgroups per CU | 256 x 256, one) issue the same
-    products in the same order per accumulator: identical bits, at ragged and full sizes and for a pair pass"""
-    c2, c1 = hip.Context(), hip.Context()
-    for c, m in ((c2, "fgemm"), (c1, "fgemm256")):
+    """the three GEMM blockings of the default mode (256 x 256 tile with eight waves, two per SIMD | 256 x 256 with four waves |
+    256 x 128 tiles, two workgroups per CU) and the two transform kernels (two waves per SIMD | one) issue the same products in
+    the same order per accumulator: identical bits, at ragged and full sizes and for a pair pass"""
+    cs = []
+    for m in ("fgemm", "fgemm256", "fgemm128"):
+        c = hip.Context()
         c.load_partI(sd1)
         c.set_gconv_mode(m)
+        cs.append(c)
     for B in (1, 33, 257, 1000, 5000):
         x = cu(synth.unit_features(B, seed=700 + B))
-        o2, o1 = c2.partI_forward(x, want_inv=True, want_inv_np=True), c1.partI_forward(x, want_inv=True, want_inv_np=True)
-        assert all(torch.equal(o2[k], o1[k]) for k in ("eqv", "inv", "inv_np")), B
+        outs = [c.partI_forward(x, want_inv=True, want_inv_np=True) for c in cs]
+        for o in outs[1:]:
+            assert all(torch.equal(outs[0][k], o[k]) for k in ("eqv", "inv", "inv_np")), B
     a, b = cu(synth.unit_features(5000, seed=41)), cu(synth.unit_features(4999, seed=42))
-    p2, p1 = c2.partI_forward_pair(a, b, want_inv=False, want_inv_np=True), c1.partI_forward_pair(a, b, want_inv=False, want_inv_np=True)
-    assert torch.equal(p2["eqv"], p1["eqv"]) and torch.equal(p2["inv_np"], p1["inv_np"])
-    assert torch.isfinite(p2["eqv"]).all()
+    ps = [c.partI_forward_pair(a, b, want_inv=False, want_inv_np=True) for c in cs]
+    for p in ps[1:]:
+        assert torch.equal(ps[0]["eqv"], p["eqv"]) and torch.equal(ps[0]["inv_np"], p["inv_np"])
+    assert torch.isfinite(ps[0]["eqv"]).all()
 
 
 def test_group_mean_np_bitexact(ctx):

@@ -321,7 +321,7 @@ int yoho_ctx_create(int device, const float* R, const uint8_t* N, const uint8_t*
     c->gconv_mode = 4;      // default: group-Fourier irrep GEMMs on the fp16x2 split MFMA; YOHO_GCONV=f32 | bf16x3 | fourier | fp16x2 | fgemm
     c->partII_mode = 2;     // default: fp16x2 cone layers; YOHO_PARTII=f32 | bf16x3 | fp16x2
     if (const char* m = std::getenv("YOHO_PARTII")) c->partII_mode = std::strcmp(m, "f32") == 0 ? 0 : (std::strcmp(m, "fp16x2") == 0 ? 2 : 1);
-    if (const char* m = std::getenv("YOHO_GCONV")) c->gconv_mode = std::strcmp(m, "f32") == 0 ? 0 : (std::strcmp(m, "bf16x3") == 0 ? 1 : (std::strcmp(m, "fp16x2") == 0 ? 3 : (std::strcmp(m, "fgemm") == 0 ? 4 : (std::strcmp(m, "fgemm256") == 0 ? 5 : 2))));
+    if (const char* m = std::getenv("YOHO_GCONV")) c->gconv_mode = std::strcmp(m, "f32") == 0 ? 0 : (std::strcmp(m, "bf16x3") == 0 ? 1 : (std::strcmp(m, "fp16x2") == 0 ? 3 : (std::strcmp(m, "fgemm") == 0 ? 4 : (std::strcmp(m, "fgemm256") == 0 ? 5 : (std::strcmp(m, "fgemm128") == 0 ? 6 : 2)))));
     // group-Fourier basis (irreps of the table's group)
     c->fb = new FourierBasis();
     if ((rc = build_fourier(N, P, *c->fb))) { delete c->fb; delete c; return rc; }
@@ -406,7 +406,7 @@ int yoho_load_partII(yoho_ctx* c, const yoho_partII_weights* w) {
 }
 
 int yoho_set_gconv_mode(yoho_ctx* c, int mode) {
-    if (!c || mode < 0 || mode > 5) { set_error("yoho_set_gconv_mode: mode must be 0 (fp32 MFMA), 1 (bf16x3 MFMA), 2 (group-Fourier fp32 MFMA), 3 (fp16x2 MFMA), 4 (group-Fourier irrep GEMMs, fp16x2 MFMA) or 5 (4 with 256 x 256 GEMM tiles)"); return YOHO_EINVAL; }
+    if (!c || mode < 0 || mode > 6) { set_error("yoho_set_gconv_mode: mode must be 0 (fp32 MFMA), 1 (bf16x3 MFMA), 2 (group-Fourier fp32 MFMA), 3 (fp16x2 MFMA), 4 (group-Fourier irrep GEMMs, fp16x2 MFMA), 5 or 6 (4 with the other two GEMM blockings)"); return YOHO_EINVAL; }
     c->gconv_mode = mode;
     return 0;
 }
@@ -554,7 +554,9 @@ static int partI_passF(yoho_ctx* c, const float* x, int B, float* eqv, float* in
 // group-Fourier variant: all four layers as irrep GEMMs on the fp16x2 split MFMA, fp16x2 transform kernels between them
 static int partI_passG(yoho_ctx* c, const float* x, int B, float* eqv, float* inv, float* inv_np, hipStream_t s, const float* x1 = nullptr,
                        int B0 = 0) {
-    const int gv = c->gconv_mode == 5 ? 1 : 2;        // GEMM blocking: 256 x 128 tiles, two workgroups per CU (default) | 256 x 256, one
+    // GEMM blocking: mode 4 = 256 x 256 tile, eight waves (two per SIMD) sharing the A stage | mode 5 = 256 x 256, four waves (one per SIMD) |
+    // mode 6 = 256 x 128 tiles, two four-wave workgroups per CU.  The transform kernel follows: two waves per SIMD except in mode 5.
+    const int gv = c->gconv_mode == 5 ? 1 : (c->gconv_mode == 6 ? 2 : 3);
     const int nT = (B + TILE - 1) / TILE;
     const int kppad = (B + 255) / 256 * 256;
     const size_t nX = (size_t)nT * 4, n256 = (size_t)nT * 32, n512 = (size_t)nT * 64;
@@ -599,7 +601,7 @@ static int partI_passG(yoho_ctx* c, const float* x, int B, float* eqv, float* in
 }
 
 static int partI_pass(yoho_ctx* c, const float* x, int B, float* eqv, float* inv, float* inv_np, hipStream_t s) {
-    if (c->gconv_mode == 4 || c->gconv_mode == 5) return partI_passG(c, x, B, eqv, inv, inv_np, s);
+    if (c->gconv_mode >= 4) return partI_passG(c, x, B, eqv, inv, inv_np, s);
     if (c->gconv_mode == 1 || c->gconv_mode == 3) return partI_pass16(c, x, B, eqv, inv, inv_np, s, c->gconv_mode == 1 ? 3 : 2);
     if (c->gconv_mode == 2) return partI_passF(c, x, B, eqv, inv, inv_np, s);
     const int nT = (B + TILE - 1) / TILE;
@@ -845,7 +847,7 @@ int yoho_partI_forward_pair(yoho_ctx* c, const float* x0, int B0, const float* x
                             void* stream) {
     if (!c || !x0 || !x1 || !eqv || B0 < 1 || B1 < 1) { set_error("yoho_partI_forward_pair: bad argument"); return YOHO_EINVAL; }
     if (!c->has_partI) { set_error("yoho_partI_forward_pair: PartI weights not loaded"); return YOHO_ENOWEIGHTS; }
-    if ((c->gconv_mode != 4 && c->gconv_mode != 5) || B0 + B1 > 16384) { set_error("yoho_partI_forward_pair: default arithmetic mode and at most 16384 keypoints"); return YOHO_EINVAL; }
+    if (c->gconv_mode < 4 || B0 + B1 > 16384) { set_error("yoho_partI_forward_pair: default arithmetic mode and at most 16384 keypoints"); return YOHO_EINVAL; }
     HIPCHK(hipSetDevice(c->device));
     return partI_passG(c, x0, B0 + B1, eqv, inv, inv_np, (hipStream_t)stream, x1, B0);
 }

@@ -61,6 +61,7 @@ __device__ __forceinline__ const char* uniform_ptr(const char* p) {
 
 void fgemm_fill_args(FGemmArgs& a, const Layer& L, const char* Bplanes, int kppad, int nT32, const float* res, float* out, int* rflag);
 int launch_fgemm2(const FGemmArgs& a, int flags, hipStream_t s);
+int launch_fgemm3(const FGemmArgs& a, int flags, hipStream_t s);
 int fgemm2_init();
 
 }  // namespace yoho

@@ -351,6 +351,7 @@ int launch_fgemm(const Layer& L, const char* Bplanes, int kppad, int nT32, const
                  int variant) {
     FGemmArgs a;
     fgemm_fill_args(a, L, Bplanes, kppad, nT32, res, out, rflag);
+    if (variant == 3) return launch_fgemm3(a, flags, s);
     if (variant != 1) return launch_fgemm2(a, flags, s);
     int tot = 0;
     for (int x = 0; x < 8; ++x) {

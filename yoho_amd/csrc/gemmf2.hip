@@ -273,9 +273,252 @@ __global__ __launch_bounds__(256, 2) void fgemm2_kernel(FGemmArgs a, int flags) 
     note_range_bits(a.rflag, top, FP16_MAX / HF_ASCALE);     // the consumer multiplies by HF_ASCALE and converts to fp16
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// fgemm3: the same K loop with the two 128-column halves of a 256 x 256 tile in ONE workgroup of eight waves (two per SIMD).
+// The halves share the A stage in LDS, so the L2 -> LDS traffic and the fabric traffic are those of the 256 x 256 blocking
+// (a step is 16 KiB of A + 16 KiB of B, ring of three 32 KiB buffers = 96 KiB), while every SIMD still has two waves.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int F3_BUF = 32768;                 // A 16 KiB [plane 2][k-group 2][row 256][16 B] | B 16 KiB [plane 2][k-group 2][col 256][16 B]
+constexpr int F3_LDS = 3 * F3_BUF;
+
+template <int R>
+__device__ __forceinline__ void read_frag3(const char* pa, const char* pb, Frags2& f) {
+    if constexpr (R < 4) f.al[R] = *reinterpret_cast<const uintx4*>(pa + 8192 + R * 512);
+    else if constexpr (R < 6) f.bh[R - 4] = *reinterpret_cast<const uintx4*>(pb + (R - 4) * 512);
+    else if constexpr (R < 10) f.ah[R - 6] = *reinterpret_cast<const uintx4*>(pa + (R - 6) * 512);
+    else f.bl[R - 10] = *reinterpret_cast<const uintx4*>(pb + 8192 + (R - 10) * 512);
+}
+
+// piece U (0..3) of a wave's share of a step's DMA (32 pieces of 1 KiB over 8 waves): U = 0, 1: A plane U; U = 2, 3: B plane U - 2;
+// the wave's (k-group, 64-row/column block) is folded into `la` (source) and `ldst` (destination)
+template <int U>
+__device__ __forceinline__ void dma_piece3(const char* srcA, const char* srcB, char* buf, int la, int ldst) {
+    constexpr int plane = U & 1;
+    if constexpr (U < 2) __builtin_amdgcn_global_load_lds((gptr_t)(srcA + plane * 16384 + la), (lptr_t)(buf + plane * 8192 + ldst), 16, 0, 0);
+    else __builtin_amdgcn_global_load_lds((gptr_t)(srcB + plane * 16384 + la), (lptr_t)(buf + 16384 + plane * 8192 + ldst), 16, 0, 0);
+}
+
+__device__ __forceinline__ void dma_step3(const char* srcA, const char* srcB, char* buf, int la, int lb, int w, int wkg, int wcb) {
+    const int ldst = wkg * 4096 + wcb * 1024;
+    sfor<0, 4>([&](auto uc) { dma_piece3<decltype(uc)::value>(srcA, srcB, buf, la, ldst); });
+}
+
+template <bool DMA>
+__device__ __forceinline__ void step3(const Frags2& f, floatx16 (&acc)[4][2], const char* ra, const char* rb, Frags2& nf,
+                                      const char* srcA, const char* srcB, char* dmabuf, int la, int lb, int w, int wkg, int wcb) {
+    const int ldst = wkg * 4096 + wcb * 1024;
+    sfor<0, 8>([&](auto gc) {
+        constexpr int g = decltype(gc)::value;
+        acc[g >> 1][g & 1] = mfma_h(f.al[g >> 1], f.bh[g & 1], acc[g >> 1][g & 1]);
+        read_frag3<g>(ra, rb, nf);
+        __builtin_amdgcn_sched_barrier(0);
+    });
+    sfor<0, 8>([&](auto gc) {
+        constexpr int g = decltype(gc)::value;
+        acc[g >> 1][g & 1] = mfma_h(f.ah[g >> 1], f.bl[g & 1], acc[g >> 1][g & 1]);
+        if constexpr (g < 4) read_frag3<8 + g>(ra, rb, nf);
+        else if constexpr (DMA) dma_piece3<g - 4>(srcA, srcB, dmabuf, la, ldst);
+        __builtin_amdgcn_sched_barrier(0);
+    });
+    sfor<0, 8>([&](auto gc) {
+        constexpr int g = decltype(gc)::value;
+        acc[g >> 1][g & 1] = mfma_h(f.ah[g >> 1], f.bh[g & 1], acc[g >> 1][g & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+    });
+}
+
+// work map of gemmf.hip (one workgroup per 256 x 256 tile)
+__host__ __device__ inline bool fg3_map(const FGemmArgs& a, int xcd, int slot, int& t, int& local, int& r) {
+    int start = 0;
+    for (int u = 0; u < NIR_ORD; ++u) {
+        const int ru = (xcd + a.rot[u]) & 7;
+        const int cnt = a.NT[u] > ru ? ((a.NT[u] - 1 - ru) / 8 + 1) * a.MT[u] : 0;
+        if (slot < start + cnt) { t = u; local = slot - start; r = ru; return true; }
+        start += cnt;
+    }
+    return false;
+}
+
+__global__ __launch_bounds__(512, 2) void fgemm3_kernel(FGemmArgs a, int flags) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w8 = __builtin_amdgcn_readfirstlane(tid >> 6);             // 8 waves: waves 0-3 own the left 128 columns, 4-7 the right
+    const int w = w8 & 3;
+    int t = 0, local = 0, r = 0;
+    if (!fg3_map(a, blockIdx.x & 7, blockIdx.x >> 3, t, local, r)) return;
+    const int d = a.dim[t], qbase = a.qbase[t];
+    const int MT = a.MT[t], KS = d * a.cin / 32, KT = 2 * KS;
+    const int nh = w8 >> 2, pair = local;
+    const int cg = pair / MT, mtile = pair - cg * MT;
+    const int ntile = r + 8 * cg;
+    const char* Ag = a.A + a.a_off[t] + (size_t)mtile * KS * FG_STAGE;
+    const char* Bg = a.B + a.b_off[t] + (size_t)ntile * KS * FG_STAGE;
+    const int wm = w >> 1, wn = w & 1;
+    const int wkg = w8 >> 2, wcb = w8 & 3;                               // this wave's DMA pieces: k-group, 64-row / 64-column block
+    const int la = wkg * 4096 + wcb * 1024 + lane * 16;                  // DMA source offset inside a step (same for the A and the B piece)
+    const int lb = la;
+
+    floatx16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int lane_a = (lane >> 5) * 4096 + (wm * 128 + (lane & 31)) * 16;
+    const int lane_b = 16384 + (lane >> 5) * 4096 + (nh * 128 + wn * 64 + (lane & 31)) * 16;
+
+    // prologue: steps 0, 1, 2 into the three buffers
+    dma_step3(Ag, Bg, smem, la, lb, w, wkg, wcb);
+    dma_step3(Ag + step_off(1), Bg + step_off(1), smem + F3_BUF, la, lb, w, wkg, wcb);
+    if (KT > 2) dma_step3(Ag + step_off(2), Bg + step_off(2), smem + 2 * F3_BUF, la, lb, w, wkg, wcb);
+    const bool rows_live = (mtile * 256 + wm * 128) < d * a.cout;       // else: all 128 rows of this wave are padding (cout = 32)
+    const int colbase = ntile * 256 + nh * 128 + wn * 64;
+    const int jidx = colbase / a.kppad, kp0 = colbase - jidx * a.kppad;
+    if ((flags & EPI_RES) && rows_live) {
+        // the accumulators start from the residual (x 1 / descale, a power of two): its loads fly with the first DMA stages
+        const float inv = 1.f / a.descale;
+        const int half = lane >> 5, kp32 = lane & 31, cout8 = a.cout >> 3;
+#pragma unroll
+        for (int bi = 0; bi < 2; ++bi) {
+            const int tile32 = (kp0 >> 5) + bi;
+#pragma unroll
+            for (int ai = 0; ai < 4; ++ai) {
+                const int rowb = mtile * 256 + wm * 128 + ai * 32;
+                const int iidx = rowb / a.cout, o0 = rowb - iidx * a.cout;
+                const bool ok = tile32 < a.nT32 && iidx < d;
+                const int q = qbase + iidx * d + jidx;
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const int o = o0 + q4 * 8 + half * 4;
+                    const size_t off = (((((size_t)tile32 * G + q) * cout8 + (o >> 3)) * 2 + half) * TILE + kp32) * 4;
+                    const floatx4 v = *reinterpret_cast<const floatx4*>(a.res + (ok ? off : 0)) * (ok ? inv : 0.f);     // branch-free
+                    acc[ai][bi][4 * q4 + 0] = v.x; acc[ai][bi][4 * q4 + 1] = v.y;
+                    acc[ai][bi][4 * q4 + 2] = v.z; acc[ai][bi][4 * q4 + 3] = v.w;
+                }
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    if (!rows_live) {
+        // keep this wave's share of the DMA and the barriers going (the live waves meet at one barrier per step but the last)
+        for (int s = 0; s + 1 < KT; ++s) {
+            if (s + 3 < KT) dma_step3(Ag + step_off(s + 3), Bg + step_off(s + 3), smem + (s % 3) * F3_BUF, la, lb, w, wkg, wcb);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        return;
+    }
+
+    Frags2 P, Q;
+    sfor<0, 12>([&](auto rc) { read_frag3<decltype(rc)::value>(smem + lane_a, smem + lane_b, P); });
+    // ring offsets: step s lives in buffer s % 3
+    int cur = 0, nxt = F3_BUF;                   // buffer of step s (already in registers: the target of the DMA of step s+3), of step s+1
+    int s = 0;
+    auto advance = [&]() { cur = nxt; nxt = nxt == 2 * F3_BUF ? 0 : nxt + F3_BUF; ++s; };
+    // main loop: both steps of a pair still have a DMA to issue (s + 4 < KT)
+    for (; s + 4 < KT;) {
+        step3<true>(P, acc, smem + nxt + lane_a, smem + nxt + lane_b, Q, uniform_ptr(Ag + step_off(s + 3)), uniform_ptr(Bg + step_off(s + 3)),
+                    smem + cur, la, lb, w, wkg, wcb);
+        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        advance();
+        step3<true>(Q, acc, smem + nxt + lane_a, smem + nxt + lane_b, P, uniform_ptr(Ag + step_off(s + 3)), uniform_ptr(Bg + step_off(s + 3)),
+                    smem + cur, la, lb, w, wkg, wcb);
+        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        advance();
+    }
+    // tail: the last four steps (two if KT == 2); only the first of them still has a DMA (step KT - 1) to issue
+    if (KT >= 4) {
+        step3<true>(P, acc, smem + nxt + lane_a, smem + nxt + lane_b, Q, uniform_ptr(Ag + step_off(s + 3)), uniform_ptr(Bg + step_off(s + 3)),
+                    smem + cur, la, lb, w, wkg, wcb);
+        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        advance();
+        step3<false>(Q, acc, smem + nxt + lane_a, smem + nxt + lane_b, P, nullptr, nullptr, nullptr, la, lb, w, wkg, wcb);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        advance();
+    }
+    step3<false>(P, acc, smem + nxt + lane_a, smem + nxt + lane_b, Q, nullptr, nullptr, nullptr, la, lb, w, wkg, wcb);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    advance();
+    // last step: its "next" fragments are read from a buffer that holds valid (unused) data
+    step3<false>(Q, acc, smem + cur + lane_a, smem + cur + lane_b, P, nullptr, nullptr, nullptr, la, lb, w, wkg, wcb);
+
+    // ---- epilogue: D[row][col]: lane (col = lane & 31, half = lane >> 5), reg e -> row = (e & 3) + 8 * (e >> 2) + 4 * half
+    const int half = lane >> 5, kp32 = lane & 31;
+    const int cout8 = a.cout >> 3;
+    const bool addb = (d == 1);                              // trivial irrep: coefficient 0 carries sqrt(60) * bias
+        unsigned top = 0u;                                       // largest |coefficient| written (bit pattern; inf / NaN order above)
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, 0x7FFFFFFF, 0x00020000);
+#pragma unroll
+    for (int bi = 0; bi < 2; ++bi) {
+        const int tile32 = (kp0 >> 5) + bi;
+        if (tile32 >= a.nT32) continue;
+#pragma unroll
+        for (int ai = 0; ai < 4; ++ai) {
+            const int rowb = mtile * 256 + wm * 128 + ai * 32;     // the 32 rows of an MFMA tile share i (cout is a multiple of 32)
+            const int iidx = rowb / a.cout, o0 = rowb - iidx * a.cout;
+            if (iidx >= d) continue;
+            const int q = qbase + iidx * d + jidx;
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const int o = o0 + q4 * 8 + half * 4;
+                floatx4 val;
+                val.x = acc[ai][bi][4 * q4 + 0]; val.y = acc[ai][bi][4 * q4 + 1];
+                val.z = acc[ai][bi][4 * q4 + 2]; val.w = acc[ai][bi][4 * q4 + 3];
+                val *= a.descale;
+                if (addb) val += *reinterpret_cast<const floatx4*>(a.bias + o) * 7.745966692414834f;
+                const size_t off = (((((size_t)tile32 * G + q) * cout8 + (o >> 3)) * 2 + half) * TILE + kp32) * 4;
+                if (flags & F2_ST_SC1) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uintx4, val), orsrc, (int)(off * 4), 0, 16);
+                else if (flags & F2_ST_NT) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uintx4, val), orsrc, (int)(off * 4), 0, 2);
+                else if (!(flags & F2_NOSTORE)) *reinterpret_cast<floatx4*>(a.out + off) = val;
+                top = max(max(top, __float_as_uint(val.x) & 0x7FFFFFFFu), __float_as_uint(val.y) & 0x7FFFFFFFu);
+                top = max(max(top, __float_as_uint(val.z) & 0x7FFFFFFFu), __float_as_uint(val.w) & 0x7FFFFFFFu);
+            }
+        }
+    }
+    note_range_bits(a.rflag, top, FP16_MAX / HF_ASCALE);     // the consumer multiplies by HF_ASCALE and converts to fp16
+}
+
+int fgemm3_init() {
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&fgemm3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, F3_LDS));
+    return 0;
+}
+
+int launch_fgemm3(const FGemmArgs& a, int flags, hipStream_t s) {
+    if (const char* dbg = std::getenv("YOHO_FGEMM_DEBUG")) {
+        if (std::strstr(dbg, "nostore")) flags |= F2_NOSTORE;
+    }
+    int tot = 0;
+    for (int x = 0; x < 8; ++x) {
+        int n = 0;
+        for (int t = 0; t < NIR_ORD; ++t) {
+            const int r = (x + a.rot[t]) & 7;
+            if (a.NT[t] > r) n += ((a.NT[t] - 1 - r) / 8 + 1) * a.MT[t];
+        }
+        tot = n > tot ? n : tot;
+    }
+    tot *= 8;
+    hipLaunchKernelGGL(fgemm3_kernel, dim3(tot), dim3(512), F3_LDS, s, a, flags);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 int fgemm2_init() {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&fgemm2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, F2_LDS));
-    return 0;
+    return fgemm3_init();
 }
 
 int launch_fgemm2(const FGemmArgs& a, int flags, hipStream_t s) {
