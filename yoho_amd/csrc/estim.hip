@@ -293,21 +293,30 @@ struct CStat {
 
 constexpr int CS_CHUNK = 8192;      // matches staged in LDS per round of the bucket placement
 
-__global__ __launch_bounds__(256) void cstat_kernel(const int64_t* __restrict__ dr, int M, const double* __restrict__ keys0,
+// every match in parallel: its two keypoints gathered into contiguous (M,3) arrays, its coarse rotation clamped to a byte
+__global__ __launch_bounds__(256) void cprep_kernel(const int64_t* __restrict__ dr, int M, const double* __restrict__ keys0,
                                                     const double* __restrict__ keys1, const int64_t* __restrict__ i0,
-                                                    const int64_t* __restrict__ i1, int istride, CStat* __restrict__ st,
-                                                    int* __restrict__ members, double* __restrict__ k0m, double* __restrict__ k1m) {
+                                                    const int64_t* __restrict__ i1, int istride, unsigned char* __restrict__ dr8,
+                                                    double* __restrict__ k0m, double* __restrict__ k1m) {
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= M) return;
+    long long v = dr[m];
+    dr8[m] = (unsigned char)(v < 0 ? 0 : (v > G - 1 ? G - 1 : v));
+    const size_t r0 = i0 ? (size_t)i0[(size_t)m * istride] : (size_t)m;
+    const size_t r1 = i1 ? (size_t)i1[(size_t)m * istride] : (size_t)m;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { k0m[(size_t)m * 3 + j] = keys0[r0 * 3 + j]; k1m[(size_t)m * 3 + j] = keys1[r1 * 3 + j]; }
+}
+
+// one workgroup: histogram, weights / running sum, bucket lists in ascending match order
+__global__ __launch_bounds__(256) void cstat_kernel(const unsigned char* __restrict__ dr8, int M, CStat* __restrict__ st, int* __restrict__ members) {
     __shared__ int cnt[G];
     __shared__ int pos[G];
-    __shared__ unsigned drs[CS_CHUNK / 4];        // coarse rotation of 4 matches per word
+    __shared__ unsigned char drs[CS_CHUNK];
     const int tid = threadIdx.x;
-    auto rot_of = [&](int m) -> int {
-        long long v = dr[m];
-        return (int)(v < 0 ? 0 : (v > G - 1 ? G - 1 : v));
-    };
     if (tid < G) cnt[tid] = 0;
     __syncthreads();
-    for (int m = tid; m < M; m += 256) atomicAdd(&cnt[rot_of(m)], 1);
+    for (int m = tid; m < M; m += 256) atomicAdd(&cnt[dr8[m]], 1);
     __syncthreads();
     if (tid == 0) {
         int acc = 0;
@@ -327,33 +336,17 @@ __global__ __launch_bounds__(256) void cstat_kernel(const int64_t* __restrict__ 
         }
         st->valid = run < 1e-4 ? 0 : 1;
     }
-    // bucket lists in ascending match order: thread b walks the staged chunk and appends its own matches
     for (int base = 0; base < M; base += CS_CHUNK) {
         const int n = M - base < CS_CHUNK ? M - base : CS_CHUNK;
         __syncthreads();
-        for (int w4 = tid; w4 * 4 < n; w4 += 256) {
-            unsigned pk = 0;
-            for (int e = 0; e < 4; ++e) pk |= (unsigned)(w4 * 4 + e < n ? rot_of(base + w4 * 4 + e) : 255) << (8 * e);
-            drs[w4] = pk;
-        }
+        for (int i = tid; i < n; i += 256) drs[i] = dr8[base + i];
         __syncthreads();
-        if (tid < G) {
+        if (tid < G) {                               // thread b appends its own matches, in order
             int p = pos[tid];
-            for (int w4 = 0; w4 * 4 < n; ++w4) {
-                const unsigned pk = drs[w4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (((pk >> (8 * e)) & 255u) == (unsigned)tid) members[p++] = base + w4 * 4 + e;
-            }
+            for (int i = 0; i < n; ++i)
+                if (drs[i] == (unsigned char)tid) members[p++] = base + i;
             pos[tid] = p;
         }
-    }
-    for (int i = tid; i < M * 3; i += 256) {
-        const int m = i / 3, j = i - m * 3;
-        const size_t r0 = i0 ? (size_t)i0[(size_t)m * istride] : (size_t)m;
-        const size_t r1 = i1 ? (size_t)i1[(size_t)m * istride] : (size_t)m;
-        k0m[i] = keys0[r0 * 3 + j];
-        k1m[i] = keys1[r1 * 3 + j];
     }
 }
 
@@ -580,7 +573,7 @@ int yoho_c_ransac_device(yoho_ctx* c, const double* keys0, const int64_t* i0, co
     size_t off = 0;
     auto take = [&](size_t bytes) { const size_t o = off; off = (off + bytes + 255) & ~(size_t)255; return o; };
     const size_t oT = take(sizeof(double) * 12 * I), oK0 = take(sizeof(double) * 3 * (size_t)M), oK1 = take(sizeof(double) * 3 * (size_t)M);
-    const size_t oS = take(sizeof(CStat)), oC = take(sizeof(int32_t) * I), oM = take(sizeof(int) * (size_t)M), oB = take(16);
+    const size_t oS = take(sizeof(CStat)), oC = take(sizeof(int32_t) * I), oM = take(sizeof(int) * (size_t)M), oB = take(16), oD = take((size_t)M);
     if ((rc = ensure_ws(c, off, s))) return rc;
     char* w = (char*)c->ws.p;
     double* Tall = (double*)(w + oT);
@@ -589,7 +582,9 @@ int yoho_c_ransac_device(yoho_ctx* c, const double* keys0, const int64_t* i0, co
     int32_t* cnt = (int32_t*)(w + oC);
     int* members = (int*)(w + oM);
     int* bh = (int*)(w + oB);
-    hipLaunchKernelGGL(cstat_kernel, dim3(1), dim3(256), 0, s, dr_index, M, keys0, keys1, i0, i1, istride, st, members, k0m, k1m);
+    unsigned char* dr8 = (unsigned char*)(w + oD);
+    hipLaunchKernelGGL(cprep_kernel, dim3((M + 255) / 256), dim3(256), 0, s, dr_index, M, keys0, keys1, i0, i1, istride, dr8, k0m, k1m);
+    hipLaunchKernelGGL(cstat_kernel, dim3(1), dim3(256), 0, s, dr8, M, st, members);
     HIPCHK(hipGetLastError());
     hipLaunchKernelGGL(kabsch_sample_kernel, dim3(max_iter), dim3(256), 0, s, k0m, k1m, M, st, members, (unsigned)(seed & 0xFFFFFFFFu),
                        (unsigned)(seed >> 32), d * d, Tall, cnt, triples_out);
