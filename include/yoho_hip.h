@@ -253,6 +253,12 @@ int yoho_set_gconv_mode(yoho_ctx* ctx, int mode);
  * target point within a voxel diagonal. */
 int yoho_set_nn_grid(yoho_ctx* ctx, double cell);
 
+/* yoho_mutual_nn on large sets (Na * Nb >= 2^20): 1 (default) = Gram matrix on the fp16 MFMA as a pre-filter, then the exact
+ * explicit-difference distance of every candidate within a proven error band of its row / column minimum; 0 = brute force.  The
+ * match list is identical either way (the deciding arithmetic is always utils/knn_search.py:17-20's); inputs the pre-filter
+ * cannot take (non-finite values, magnitudes beyond the fp16 range) go to the brute-force kernels by themselves. */
+int yoho_set_nn_prefilter(yoho_ctx* ctx, int enable);
+
 /* PartII group-conv layers: 0 = fp32 MFMA, 1 = bf16x3 split MFMA, 2 = fp16x2 split MFMA (default; first layer in the
  * group-Fourier domain, 13-rotation cone layer direct, last layer as one dense product at the identity). */
 int yoho_set_partII_mode(yoho_ctx* ctx, int mode);

@@ -214,6 +214,51 @@ def test_mutual_match_golden_and_full_size(ctx, gold):
     assert (np.diff(mm[:, 0]) > 0).all() and len(set(mm[:, 1])) == len(mm)
 
 
+def test_mutual_nn_prefilter_equals_brute_force(hip):
+    """yoho_mutual_nn through the fp16-MFMA pre-filter + exact candidates (matchf.hip) against the brute-force kernels: the SAME
+    match list on descriptor-like data, exact duplicates and near-duplicates (ties go to the lowest index), tiny / large / mixed
+    magnitudes, zero rows, ragged sizes, and inputs the pre-filter has to decline (NaN, inf, beyond the fp16 range)"""
+    c = hip.Context()
+    rs = np.random.RandomState(0)
+
+    def both(a, b):
+        ad, bd = cu(a), cu(b)
+        c.set_nn_prefilter(True)
+        m1 = c.mutual_nn(ad, bd).cpu().numpy()
+        c.set_nn_prefilter(False)
+        m0 = c.mutual_nn(ad, bd).cpu().numpy()
+        c.set_nn_prefilter(True)
+        return m1, m0
+
+    cases = {}
+    pr = synth.make_pair(5000, seed=2)
+    cases["descriptor-like 5000 x 5000"] = (np.mean(pr["feat0"], -1), np.mean(pr["feat1"], -1))
+    a = rs.randn(1500, 32).astype(np.float32) * 0.2
+    b = np.concatenate([a[rs.permutation(1500)[:1000]], a[:700] + rs.randn(700, 32).astype(np.float32) * 1e-6,
+                        a[300:900] + rs.randn(600, 32).astype(np.float32) * 1e-4, a[:701] + rs.randn(701, 32).astype(np.float32) * 1e-3])
+    cases["duplicates and near-duplicates 1500 x 3001"] = (a, np.ascontiguousarray(b))
+    cases["tiny magnitudes"] = (a * np.float32(1e-4), np.ascontiguousarray(b) * np.float32(1e-4))
+    cases["large magnitudes"] = (a * np.float32(50), np.ascontiguousarray(b) * np.float32(50))
+    sc = np.exp(rs.randn(1500, 1) * 2).astype(np.float32)
+    cases["mixed norms"] = (a * sc, np.ascontiguousarray(b) * np.exp(rs.randn(3001, 1) * 2).astype(np.float32))
+    z = rs.randn(1200, 32).astype(np.float32)
+    z[::7] = 0
+    cases["zero rows"] = (z, np.ascontiguousarray(z[::-1]))
+    for name, (x, y) in cases.items():
+        m1, m0 = both(x, y)
+        assert m1.shape == m0.shape and np.array_equal(m1, m0), name
+        print("mutual NN pre-filter, %s: %d matches, identical to brute force" % (name, len(m1)))
+    big = rs.randn(1100, 32).astype(np.float32)
+    for bad in (np.nan, np.inf, 7e4):
+        x = big.copy()
+        x[17, 3] = bad
+        m1, m0 = both(x, big[::-1].copy())
+        assert np.array_equal(m1, m0), bad
+    # and against the oracle on one case
+    x, y = cases["duplicates and near-duplicates 1500 x 3001"]
+    assert np.array_equal(both(x, y)[0], orc.mutual_match(x, y))
+
+
 @pytest.mark.parametrize("mode", ["f32", "bf16x3", "fp16x2"])
 def test_des2r_golden(ctx_of, mode, gold, sd1, tables):
     ctx = ctx_of[mode]

@@ -142,6 +142,9 @@ int launch_pack_partII(const float* s0, const float* s1, const float* s2, const 
                        const int* P, const float* bn_s, const float* bn_t, int M, int nTiles, float* out, hipStream_t s);
 int launch_quat_norm(const float* y, int M, float* quat, hipStream_t s);
 
+size_t mutual_prefilter_ws_bytes(int Na, int Nb);
+int launch_mutual_prefilter(const float* a, int Na, const float* b, int Nb, void* ws, unsigned long long** keysA, unsigned long long** keysB,
+                            int nCU, hipStream_t s);
 struct Workspace;
 }  // namespace yoho
 struct yoho_ctx;
@@ -185,6 +188,7 @@ struct yoho_ctx {
     int* d_tap_inv = nullptr;
     int nCU = 256;
     int* d_rflag = nullptr;      // fp16 range words (note_range): [0] PartI, [1] PartII; read and cleared by yoho_range_status
+    int nn_prefilter = 1;        // mutual NN of large sets: MFMA pre-filter + exact candidates (matchf.hip); 0 = brute force (YOHO_NN=brute)
     double nn_cell = 0.0;        // > 0: 3-D nearest-neighbour searches go through a hash grid of this cell size (gridnn.hip)
     // workspace (grown on demand)
     yoho::Workspace ws;

@@ -90,7 +90,8 @@ int launch_nn(const float* src, int Ns, const float* tgt, int Nt, int D, int dis
 // ---------------------------------------------------------------------------------------------------------------
 template <int D, bool SQUARED>
 __global__ __launch_bounds__(256) void nn32seg_kernel(const float* __restrict__ src, int Ns, const float* __restrict__ tgt, int Nt,
-                                                      unsigned long long* __restrict__ keys, int segLen) {
+                                                      unsigned long long* __restrict__ keys, int segLen, const int* __restrict__ run_if = nullptr) {
+    if (run_if && !*run_if) return;                  // fallback launch behind the MFMA pre-filter (matchf.hip): only if it declined
     __shared__ __attribute__((aligned(16))) float tile[NN_TT * D];
     __shared__ float rd[32 * NN_SPLIT];
     __shared__ int ri[32 * NN_SPLIT];
@@ -168,6 +169,20 @@ __global__ __launch_bounds__(256) void nn_unpack_kernel(const unsigned long long
     if (dist) dist[i] = __uint_as_float((unsigned)(k >> 32));
 }
 
+// the same search into keys that are ALREADY initialised, run only if *run_if is non-zero (D = 32, 'L2' distance)
+int launch_nn32seg_if(const float* src, int Ns, const float* tgt, int Nt, unsigned long long* keys, int nCU, const int* run_if, hipStream_t s) {
+    const int rb = (Ns + 31) / 32;
+    int nseg = (4 * nCU + rb - 1) / rb;
+    const int maxseg = (Nt + 63) / 64;
+    nseg = nseg < 1 ? 1 : (nseg > maxseg ? maxseg : nseg);
+    int segLen = (Nt + nseg - 1) / nseg;
+    segLen = (segLen + 15) / 16 * 16;
+    nseg = (Nt + segLen - 1) / segLen;
+    hipLaunchKernelGGL((nn32seg_kernel<32, false>), dim3(rb, nseg), dim3(256), 0, s, src, Ns, tgt, Nt, keys, segLen, run_if);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 // keys must hold Ns words; they are (re)initialised here
 int launch_nn32seg(const float* src, int Ns, const float* tgt, int Nt, bool squared, unsigned long long* keys, int nCU, hipStream_t s,
                    int D = 32) {
@@ -179,10 +194,10 @@ int launch_nn32seg(const float* src, int Ns, const float* tgt, int Nt, bool squa
     segLen = (segLen + 15) / 16 * 16;
     nseg = (Nt + segLen - 1) / segLen;
     HIPCHK(hipMemsetAsync(keys, 0xFF, sizeof(unsigned long long) * (size_t)Ns, s));
-    if (D == 3 && squared) hipLaunchKernelGGL((nn32seg_kernel<3, true>), dim3(rb, nseg), dim3(256), 0, s, src, Ns, tgt, Nt, keys, segLen);
-    else if (D == 3) hipLaunchKernelGGL((nn32seg_kernel<3, false>), dim3(rb, nseg), dim3(256), 0, s, src, Ns, tgt, Nt, keys, segLen);
-    else if (squared) hipLaunchKernelGGL((nn32seg_kernel<32, true>), dim3(rb, nseg), dim3(256), 0, s, src, Ns, tgt, Nt, keys, segLen);
-    else hipLaunchKernelGGL((nn32seg_kernel<32, false>), dim3(rb, nseg), dim3(256), 0, s, src, Ns, tgt, Nt, keys, segLen);
+    if (D == 3 && squared) hipLaunchKernelGGL((nn32seg_kernel<3, true>), dim3(rb, nseg), dim3(256), 0, s, src, Ns, tgt, Nt, keys, segLen, (const int*)nullptr);
+    else if (D == 3) hipLaunchKernelGGL((nn32seg_kernel<3, false>), dim3(rb, nseg), dim3(256), 0, s, src, Ns, tgt, Nt, keys, segLen, (const int*)nullptr);
+    else if (squared) hipLaunchKernelGGL((nn32seg_kernel<32, true>), dim3(rb, nseg), dim3(256), 0, s, src, Ns, tgt, Nt, keys, segLen, (const int*)nullptr);
+    else hipLaunchKernelGGL((nn32seg_kernel<32, false>), dim3(rb, nseg), dim3(256), 0, s, src, Ns, tgt, Nt, keys, segLen, (const int*)nullptr);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -347,6 +362,13 @@ int yoho_mutual_nn(yoho_ctx* c, const float* a, int Na, const float* b, int Nb, 
     if ((rc = ensure_ws(c, need, s))) return rc;
     int64_t* fwd = (int64_t*)c->ws.p;
     int64_t* back = fwd + Na;
+    if ((size_t)Na * Nb >= (1u << 20) && c->nn_prefilter) {
+        // MFMA pre-filter + exact evaluation of the candidates (matchf.hip): the same packed keys as the segmented search below
+        if ((rc = ensure_ws(c, mutual_prefilter_ws_bytes(Na, Nb), s))) return rc;
+        unsigned long long *kA = nullptr, *kB = nullptr;
+        if ((rc = launch_mutual_prefilter(a, Na, b, Nb, c->ws.p, &kA, &kB, c->nCU, s))) return rc;
+        return launch_mutual_compact((const int64_t*)kA, (const int64_t*)kB, Na, pairs, M_out, s, true);
+    }
     if ((size_t)Na * Nb >= (1u << 20)) {
         // segmented search: the workspace words are the packed keys, the compaction reads the index half
         if ((rc = launch_nn32seg(a, Na, b, Nb, false, (unsigned long long*)fwd, c->nCU, s))) return rc;
