@@ -47,24 +47,35 @@ __device__ __forceinline__ float ord_to(unsigned o) { return __uint_as_float((o 
 
 // squared norms, their maxima, the range check, and the initial values of minima and keys
 __global__ __launch_bounds__(256) void mf_norms_kernel(MfArgs p) {
+    __shared__ unsigned red[2][4];
     const int i = blockIdx.x * 256 + threadIdx.x;
     const int n = p.Na + p.Nb;
-    if (i >= n) return;
-    const bool isa = i < p.Na;
-    const int r = isa ? i : i - p.Na;
-    const float4* x = reinterpret_cast<const float4*>((isa ? p.a : p.b) + (size_t)r * 32);
+    const bool live = i < n, isa = i < p.Na;
+    const int r = live ? (isa ? i : i - p.Na) : 0;
     float s = 0.f, m = 0.f;
+    if (live) {
+        const float4* x = reinterpret_cast<const float4*>((isa ? p.a : p.b) + (size_t)r * 32);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const float4 v = x[k];
-        s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
-        m = fmaxf(fmaxf(fmaxf(m, fabsf(v.x)), fmaxf(fabsf(v.y), fabsf(v.z))), fabsf(v.w));
+        for (int k = 0; k < 8; ++k) {
+            const float4 v = x[k];
+            s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+            m = fmaxf(fmaxf(fmaxf(m, fabsf(v.x)), fmaxf(fabsf(v.y), fabsf(v.z))), fabsf(v.w));
+        }
+        (isa ? p.na2 : p.nb2)[r] = s;
+        (isa ? p.rowmin : p.colmin)[r] = 0xFFFFFFFFu;
+        (isa ? p.keysA : p.keysB)[r] = ~0ull;
     }
-    if (!(s <= 1e30f) || !(m <= 6.0e4f)) atomicOr(p.bad, 1);          // NaN / inf / beyond the fp16 range
-    (isa ? p.na2 : p.nb2)[r] = s;
-    atomicMax(p.maxn2 + (isa ? 0 : 1), __float_as_uint(s));          // s >= 0: integer order = float order
-    (isa ? p.rowmin : p.colmin)[r] = 0xFFFFFFFFu;
-    (isa ? p.keysA : p.keysB)[r] = ~0ull;
+    const bool bad = live && (!(s <= 1e30f) || !(m <= 6.0e4f));          // NaN / inf / beyond the fp16 range
+    if (__ballot(bad) != 0ull && (threadIdx.x & 63) == 0) atomicOr(p.bad, 1);
+    // maxima of the squared norms (s >= 0: integer order = float order): one atomic per workgroup and set
+    unsigned ma = (live && isa && !bad) ? __float_as_uint(s) : 0u, mb = (live && !isa && !bad) ? __float_as_uint(s) : 0u;
+    for (int o = 32; o >= 1; o >>= 1) { ma = max(ma, (unsigned)__shfl_xor((int)ma, o)); mb = max(mb, (unsigned)__shfl_xor((int)mb, o)); }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = ma; red[1][threadIdx.x >> 6] = mb; }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        const unsigned v = max(max(red[threadIdx.x][0], red[threadIdx.x][1]), max(red[threadIdx.x][2], red[threadIdx.x][3]));
+        if (v) atomicMax(p.maxn2 + threadIdx.x, v);
+    }
 }
 
 __global__ __launch_bounds__(256) void mf_band_kernel(MfArgs p) {
@@ -215,7 +226,7 @@ int launch_mutual_prefilter(const float* a, int Na, const float* b, int Nb, void
     hipLaunchKernelGGL(mf_norms_kernel, dim3((n + 255) / 256), dim3(256), 0, s, p);
     hipLaunchKernelGGL(mf_band_kernel, dim3((n + 255) / 256), dim3(256), 0, s, p);
     const int cb = (Nb + 127) / 128;
-    int segs = (4 * nCU + cb - 1) / cb;                         // a few workgroups per CU
+    int segs = (2 * nCU + cb - 1) / cb;                         // about two workgroups per CU: the column fragments are loaded once per workgroup
     const int maxsegs = (Na + 127) / 128;
     segs = segs < 1 ? 1 : (segs > maxsegs ? maxsegs : segs);
     p.segRows = ((Na + segs - 1) / segs + 127) / 128 * 128;
