@@ -98,6 +98,19 @@ def test_batched_clouds_equal_separate_passes(fctx):
     assert (two[0] - sep[0]).abs().max().item() < 2e-5 and torch.equal(two[0], two[1])
 
 
+def test_parity_sorted_transposed_convs_are_bit_identical(fctx):
+    """the row order and the skipped kernel offsets of the transposed convolutions change no bit of the output"""
+    clouds = [torch.from_numpy(fo.voxelize(synth.surface_cloud(n, seed=sd), 0.025)[1]).cuda() for n, sd in ((6000, 5), (37, 6), (2500, 7))]
+    try:
+        fctx.set_fcgf_parity_sort(False)
+        ref = [fctx.fcgf_forward(c) for c in clouds] + list(fctx.fcgf_forward_batch(clouds))
+    finally:
+        fctx.set_fcgf_parity_sort(True)
+    got = [fctx.fcgf_forward(c) for c in clouds] + list(fctx.fcgf_forward_batch(clouds))
+    for a, b in zip(ref, got):
+        assert torch.equal(a, b)
+
+
 def test_other_model_configs_and_tiny_clouds(hip):
     """ResUNetBN2B channels, conv1 kernel 5, normalize_feature off; clouds of 1 and 2 voxels, negative coordinates"""
     spec = W.fcgf_spec((None, 32, 64, 128, 256), (None, 64, 64, 64, 64), 32, 5)

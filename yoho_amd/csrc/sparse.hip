@@ -241,6 +241,46 @@ __global__ void coords4_kernel(const int* c3, int n, const int* off, int nb, int
     reinterpret_cast<int4*>(c4)[i] = make_int4(c3[3 * (size_t)i], c3[3 * (size_t)i + 1], c3[3 * (size_t)i + 2], b);
 }
 
+// Rows of a level sorted by the parity class of their coordinates on the next coarser stride (8 classes, each padded with
+// -1 to a multiple of 128 slots = one workgroup of the fine-level kernel).  A transposed convolution reaches a fine row
+// from 1, 2, 4 or 8 of the 27 offsets - per axis: offset 0 if the coordinate is even on the coarse stride, +-1 if odd -
+// and the set is the same for the whole class, so class-pure tiles skip the other offsets (sp_next_offset).  The order
+// inside a class follows the atomics and does not matter: every row's sum is taken in kernel-offset order.
+constexpr int PAR_PAD = 128;
+__device__ __forceinline__ int parity_class(int4 c, int sh) { return ((c.x >> sh) & 1) | (((c.y >> sh) & 1) << 1) | (((c.z >> sh) & 1) << 2); }
+
+__global__ __launch_bounds__(256) void parity_count_kernel(const int* __restrict__ coords, int n, int sh, int* __restrict__ cnt) {
+    __shared__ int lc[8];
+    if (threadIdx.x < 8) lc[threadIdx.x] = 0;
+    __syncthreads();
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) atomicAdd(&lc[parity_class(reinterpret_cast<const int4*>(coords)[i], sh)], 1);
+    __syncthreads();
+    if (threadIdx.x < 8 && lc[threadIdx.x]) atomicAdd(&cnt[threadIdx.x], lc[threadIdx.x]);
+}
+
+// cnt[0..7]: class sizes, cnt[8..15]: cursors (zeroed); perm: n + 8 * PAR_PAD slots preset to -1
+__global__ __launch_bounds__(256) void parity_scatter_kernel(const int* __restrict__ coords, int n, int sh, int* __restrict__ cnt,
+                                                             int* __restrict__ perm) {
+    __shared__ int lc[8], lbase[8];
+    if (threadIdx.x < 8) lc[threadIdx.x] = 0;
+    __syncthreads();
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    int cls = 0, pos = 0;
+    if (i < n) {
+        cls = parity_class(reinterpret_cast<const int4*>(coords)[i], sh);
+        pos = atomicAdd(&lc[cls], 1);
+    }
+    __syncthreads();
+    if (threadIdx.x < 8) {
+        int base = 0;
+        for (int c = 0; c < (int)threadIdx.x; ++c) base += (cnt[c] + PAR_PAD - 1) / PAR_PAD * PAR_PAD;
+        lbase[threadIdx.x] = base + (lc[threadIdx.x] ? atomicAdd(&cnt[8 + threadIdx.x], lc[threadIdx.x]) : 0);
+    }
+    __syncthreads();
+    if (i < n) perm[lbase[cls] + pos] = i;
+}
+
 struct SpConvArgs {
     const float* in; int ldin, cin;
     const int* map;          // [K][nout] or null (K = 1, identity)
@@ -254,7 +294,17 @@ struct SpConvArgs {
     const float* aff_t;      // shift / bias or null
     const float* res; int ldres, rcoff;    // residual added after the affine, or null
     int relu;
+    const int* rowperm;      // fp16x2 kernels: tile slot -> output row (-1 = padding), or null (slot = row)
+    int nslots;              // tile slots (= nout without a permutation)
 };
+
+// Offsets that no row of a tile reaches are skipped (their rows of the A operand are all zero: the skipped MFMAs would add
+// exact zeros, so the sums are bit-identical).  The mask has one bit per kernel offset; iteration is in ascending order.
+__device__ __forceinline__ int sp_next_offset(unsigned& mask) {
+    const int k = __builtin_ctz(mask);
+    mask &= mask - 1;
+    return k;
+}
 
 constexpr int SP_MAXK = 27;
 
@@ -402,14 +452,26 @@ template <int NCB, int ND>
 __global__ __launch_bounds__(256) void spconv16s_kernel(SpConvArgs a) {
     __shared__ int srcl[4][SP_MAXK * 32];
     __shared__ float red[3 * NCB * 16 * 64];
+    __shared__ int prow[32];
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int li = lane & 31, h = lane >> 5;
     const int rbase = blockIdx.x * 32;
     const int cb0 = blockIdx.y * NCB;
-    const int row = rbase + li;
-    const bool valid = row < a.nout;
+    const int slot = rbase + li;
+    int row = -1;
+    if (slot < a.nslots) row = a.rowperm ? a.rowperm[slot] : slot;
+    const bool valid = row >= 0;
+    if (w == 0 && h == 0) prow[li] = row;
     int* sl = srcl[w];
-    for (int k = h; k < a.K; k += 2) sl[k * 32 + li] = valid ? (a.map ? a.map[(size_t)k * a.nout + row] : row) : -1;
+    unsigned actl = 0u;                                                   // offsets reached by any row of the tile (every wave computes it)
+    for (int k = h; k < a.K; k += 2) {
+        const int v = valid ? (a.map ? a.map[(size_t)k * a.nout + row] : row) : -1;
+        sl[k * 32 + li] = v;
+        const unsigned long long b = __ballot(v >= 0);
+        if ((unsigned)b) actl |= 1u << (k - h);
+        if (b >> 32) actl |= 2u << (k - h);
+    }
+    const unsigned act = __builtin_amdgcn_readfirstlane(actl) | __builtin_amdgcn_readlane(actl, 32);
     __builtin_amdgcn_wave_barrier();
 
     floatx16s acc[NCB];
@@ -424,8 +486,18 @@ __global__ __launch_bounds__(256) void spconv16s_kernel(SpConvArgs a) {
 
     // Loads are branch-free (empty cells: out-of-range buffer offset; steps past the end re-read the last one): the
     // compiler's vmcnt bookkeeping only keeps loads in flight across straight-line code.
-    const int nit = it1 - it0;
-    int ik = it0 / nchunk, icc = it0 - ik * nchunk, issued = 0;          // wave-uniform position of the load pointer
+    // this wave's steps: those of [it0, it1) whose offset is active, in ascending order (the fixed ranges keep the order
+    // in which the partial sums meet independent of what the tile skips)
+    int nit = 0, ik = 0, icc = 0, issued = 0;                            // wave-uniform position of the load pointer
+    for (unsigned m = act; m;) {
+        const int k = sp_next_offset(m);
+        const int lo = max(it0, k * nchunk), hi = min(it1, (k + 1) * nchunk);
+        if (hi > lo) {
+            if (nit == 0) { ik = k; icc = lo - k * nchunk; }
+            nit += hi - lo;
+        }
+    }
+    auto next_active = [&](int k) { return __builtin_ctz(act & ~((2u << k) - 1u)); };
     const __amdgpu_buffer_rsrc_t rs = sp_rsrc(a.in);
     auto issue = [&](float (&av)[16], uintx4s (&bv)[4 * NCB]) {
         const int src = sl[ik * 32 + li];
@@ -435,7 +507,7 @@ __global__ __launch_bounds__(256) void spconv16s_kernel(SpConvArgs a) {
         for (int sp = 0; sp < 4; ++sp)
 #pragma unroll
             for (int cb = 0; cb < NCB; ++cb) bv[sp * NCB + cb] = wp[((size_t)sp * ncbt + cb) * 64];
-        if (++issued < nit && ++icc == nchunk) { icc = 0; ++ik; }
+        if (++issued < nit && ++icc == nchunk) { icc = 0; ik = next_active(ik); }
     };
     auto mma = [&](const float (&av)[16], const uintx4s (&bv)[4 * NCB]) {
 #pragma unroll
@@ -494,8 +566,8 @@ __global__ __launch_bounds__(256) void spconv16s_kernel(SpConvArgs a) {
         const float s = (a.aff_s ? a.aff_s[co] : 1.f) * a.descale, t = a.aff_t ? a.aff_t[co] : 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int orow = rbase + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (orow < a.nout) {
+            const int orow = prow[(r & 3) + 8 * (r >> 2) + 4 * h];
+            if (orow >= 0) {
                 float v = acc[cb][r] * s + t;
                 if (a.res) v += a.res[(size_t)orow * a.ldres + a.rcoff + co];
                 if (a.relu) v = fmaxf(v, 0.f);
@@ -513,16 +585,35 @@ __global__ __launch_bounds__(256) void spconv16s_kernel(SpConvArgs a) {
 template <int NCB>
 __global__ __launch_bounds__(256) void spconv16w_kernel(SpConvArgs a) {
     __shared__ int srcl[4][SP_MAXK * 32];
+    __shared__ int prow[4][32];
+    __shared__ unsigned actm;
     __shared__ __attribute__((aligned(16))) uintx4s bst[2][4 * NCB * 64];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int li = lane & 31, h = lane >> 5;
     const int rbase = (blockIdx.x * 4 + w) * 32;
     const int cb0 = blockIdx.y * NCB;
-    const int row = rbase + li;
-    const bool valid = row < a.nout;
+    const int slot = rbase + li;
+    int row = -1;
+    if (slot < a.nslots) row = a.rowperm ? a.rowperm[slot] : slot;
+    const bool valid = row >= 0;
     int* sl = srcl[w];
-    for (int k = h; k < a.K; k += 2) sl[k * 32 + li] = valid ? (a.map ? a.map[(size_t)k * a.nout + row] : row) : -1;
-    __builtin_amdgcn_wave_barrier();
+    if (tid == 0) actm = 0u;
+    if (h == 0) prow[w][li] = row;
+    __syncthreads();
+    {
+        unsigned m = 0u;
+        for (int k = h; k < a.K; k += 2) {
+            const int v = valid ? (a.map ? a.map[(size_t)k * a.nout + row] : row) : -1;
+            sl[k * 32 + li] = v;
+            const unsigned long long b = __ballot(v >= 0);           // low half: offset k - h, high half: the next one
+            if ((unsigned)b) m |= 1u << (k - h);
+            if (b >> 32) m |= 2u << (k - h);
+        }
+        if (m && li == 0) atomicOr(&actm, m);
+    }
+    __syncthreads();
+    const unsigned act = __builtin_amdgcn_readfirstlane(actm);        // offsets reached by any of the workgroup's 128 rows
+    if (act == 0u && __syncthreads_or(valid) == 0) return;            // padding only
 
     floatx16s acc[NCB];
 #pragma unroll
@@ -530,80 +621,84 @@ __global__ __launch_bounds__(256) void spconv16w_kernel(SpConvArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[cb][r] = 0.f;
     const int nchunk = a.cin / 32, ncbt = a.cout / 32;
-    const int total = a.K * nchunk;
+    const int total = __builtin_popcount(act) * nchunk;
     const uintx4s* Wh = reinterpret_cast<const uintx4s*>(a.Wh);
 
-    // branch-free loads, see spconv16_kernel
-    int ak = 0, acc_ = 0, aissued = 0, bissued = 0;                       // wave-uniform load pointers
-    const __amdgpu_buffer_rsrc_t rs = sp_rsrc(a.in);
-    auto loadA = [&](float (&av)[16]) {
-        const int src = sl[ak * 32 + li];
-        sp_gather16(rs, src < 0 ? SP_OOB : ((unsigned)src * (unsigned)a.ldin + acc_ * 32 + h * 8) * 4u, av);
-        if (++aissued < total && ++acc_ == nchunk) { acc_ = 0; ++ak; }
-    };
-    // stage image = [step-plane 4][cb NCB][lane 64] fragments; piece j of this thread = image index j * 256 + tid
-    auto loadB = [&](uintx4s (&br)[NCB]) {
-        const int it = bissued < total ? bissued : total - 1;
+    if (total > 0) {
+        // branch-free loads, see spconv16_kernel
+        unsigned amask = act, bmask = act;                                    // wave-uniform load pointers
+        int ak = sp_next_offset(amask), acc_ = 0, aissued = 0;
+        int bk = sp_next_offset(bmask), bcc = 0, bissued = 0;
+        const __amdgpu_buffer_rsrc_t rs = sp_rsrc(a.in);
+        auto loadA = [&](float (&av)[16]) {
+            const int src = sl[ak * 32 + li];
+            sp_gather16(rs, src < 0 ? SP_OOB : ((unsigned)src * (unsigned)a.ldin + acc_ * 32 + h * 8) * 4u, av);
+            if (++aissued < total && ++acc_ == nchunk) { acc_ = 0; ak = sp_next_offset(amask); }
+        };
+        // stage image = [step-plane 4][cb NCB][lane 64] fragments; piece j of this thread = image index j * 256 + tid
+        auto loadB = [&](uintx4s (&br)[NCB]) {
+            const int it = bk * nchunk + bcc;                                 // past the end: the last step again
 #pragma unroll
-        for (int j = 0; j < NCB; ++j) {
-            const int idx = j * 256 + tid, sp = idx / (NCB * 64), within = idx - sp * (NCB * 64);
-            br[j] = Wh[(((size_t)it * 4 + sp) * ncbt + cb0) * 64 + within];
-        }
-        ++bissued;
-    };
-    auto storeB = [&](int buf, const uintx4s (&br)[NCB]) {
-#pragma unroll
-        for (int j = 0; j < NCB; ++j) bst[buf][j * 256 + tid] = br[j];
-    };
-    auto mma = [&](const float (&av)[16], int buf) {
-        const uintx4s* bl = &bst[buf][lane];
-#pragma unroll
-        for (int st = 0; st < 2; ++st) {
-            uintx4s ah, al, bh[NCB], bw[NCB];
-#pragma unroll
-            for (int cb = 0; cb < NCB; ++cb) { bh[cb] = bl[((2 * st + 0) * NCB + cb) * 64]; bw[cb] = bl[((2 * st + 1) * NCB + cb) * 64]; }
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                unsigned hh, ll;
-                split_pair_sp(av[8 * st + 2 * p], av[8 * st + 2 * p + 1], hh, ll);
-                ah[p] = hh; al[p] = ll;
+            for (int j = 0; j < NCB; ++j) {
+                const int idx = j * 256 + tid, sp = idx / (NCB * 64), within = idx - sp * (NCB * 64);
+                br[j] = Wh[(((size_t)it * 4 + sp) * ncbt + cb0) * 64 + within];
             }
+            if (++bissued < total && ++bcc == nchunk) { bcc = 0; bk = sp_next_offset(bmask); }
+        };
+        auto storeB = [&](int buf, const uintx4s (&br)[NCB]) {
 #pragma unroll
-            for (int cb = 0; cb < NCB; ++cb) acc[cb] = mfma_sp16(al, bh[cb], acc[cb]);
+            for (int j = 0; j < NCB; ++j) bst[buf][j * 256 + tid] = br[j];
+        };
+        auto mma = [&](const float (&av)[16], int buf) {
+            const uintx4s* bl = &bst[buf][lane];
 #pragma unroll
-            for (int cb = 0; cb < NCB; ++cb) acc[cb] = mfma_sp16(ah, bw[cb], acc[cb]);
+            for (int st = 0; st < 2; ++st) {
+                uintx4s ah, al, bh[NCB], bw[NCB];
 #pragma unroll
-            for (int cb = 0; cb < NCB; ++cb) acc[cb] = mfma_sp16(ah, bh[cb], acc[cb]);
+                for (int cb = 0; cb < NCB; ++cb) { bh[cb] = bl[((2 * st + 0) * NCB + cb) * 64]; bw[cb] = bl[((2 * st + 1) * NCB + cb) * 64]; }
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    unsigned hh, ll;
+                    split_pair_sp(av[8 * st + 2 * p], av[8 * st + 2 * p + 1], hh, ll);
+                    ah[p] = hh; al[p] = ll;
+                }
+#pragma unroll
+                for (int cb = 0; cb < NCB; ++cb) acc[cb] = mfma_sp16(al, bh[cb], acc[cb]);
+#pragma unroll
+                for (int cb = 0; cb < NCB; ++cb) acc[cb] = mfma_sp16(ah, bw[cb], acc[cb]);
+#pragma unroll
+                for (int cb = 0; cb < NCB; ++cb) acc[cb] = mfma_sp16(ah, bh[cb], acc[cb]);
+            }
+        };
+        constexpr int NA = 4;                                                 // even: the stage parity of ring slot j is j & 1
+        float av[NA][16];
+        uintx4s br[2][NCB];
+        loadB(br[0]);
+        loadB(br[1]);
+#pragma unroll
+        for (int j = 0; j < NA - 1; ++j) loadA(av[j]);
+        storeB(0, br[0]);
+        // step s: barrier (stage s & 1 complete, the other one free) -> weights of s + 1 into the free stage, fetch the
+        // weights of s + 2 and the rows of s + NA - 1, MFMAs of s
+        const int nmain = (total / NA) * NA;
+        for (int it = 0; it < nmain; it += NA) {
+#pragma unroll
+            for (int j = 0; j < NA; ++j) {
+                __syncthreads();
+                storeB((j + 1) & 1, br[(j + 1) & 1]);
+                loadB(br[j & 1]);
+                loadA(av[(j + NA - 1) % NA]);
+                mma(av[j], j & 1);
+            }
         }
-    };
-    constexpr int NA = 4;                                                 // even: the stage parity of ring slot j is j & 1
-    float av[NA][16];
-    uintx4s br[2][NCB];
-    loadB(br[0]);
-    loadB(br[1]);
 #pragma unroll
-    for (int j = 0; j < NA - 1; ++j) loadA(av[j]);
-    storeB(0, br[0]);
-    // step s: barrier (stage s & 1 complete, the other one free) -> weights of s + 1 into the free stage, fetch the
-    // weights of s + 2 and the rows of s + NA - 1, MFMAs of s
-    const int nmain = (total / NA) * NA;
-    for (int it = 0; it < nmain; it += NA) {
-#pragma unroll
-        for (int j = 0; j < NA; ++j) {
-            __syncthreads();
-            storeB((j + 1) & 1, br[(j + 1) & 1]);
-            loadB(br[j & 1]);
-            loadA(av[(j + NA - 1) % NA]);
-            mma(av[j], j & 1);
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < NA - 1; ++j) {
-        if (nmain + j < total) {                                          // uniform over the workgroup
-            __syncthreads();
-            storeB((j + 1) & 1, br[(j + 1) & 1]);
-            loadB(br[j & 1]);
-            mma(av[j], j & 1);
+        for (int j = 0; j < NA - 1; ++j) {
+            if (nmain + j < total) {                                          // uniform over the workgroup
+                __syncthreads();
+                storeB((j + 1) & 1, br[(j + 1) & 1]);
+                loadB(br[j & 1]);
+                mma(av[j], j & 1);
+            }
         }
     }
 #pragma unroll
@@ -612,8 +707,8 @@ __global__ __launch_bounds__(256) void spconv16w_kernel(SpConvArgs a) {
         const float s = (a.aff_s ? a.aff_s[co] : 1.f) * a.descale, t = a.aff_t ? a.aff_t[co] : 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int orow = rbase + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (orow < a.nout) {
+            const int orow = prow[w][(r & 3) + 8 * (r >> 2) + 4 * h];
+            if (orow >= 0) {
                 float v = acc[cb][r] * s + t;
                 if (a.res) v += a.res[(size_t)orow * a.ldres + a.rcoff + co];
                 if (a.relu) v = fmaxf(v, 0.f);
@@ -804,12 +899,14 @@ __global__ __launch_bounds__(256) void conv1_bitmap_kernel(const int* __restrict
     }
 }
 
-static int launch_spconv(const SpConvArgs& a, hipStream_t s) {
-    if (a.nout == 0) return 0;
+static int launch_spconv(const SpConvArgs& a_in, hipStream_t s) {
+    if (a_in.nout == 0) return 0;
+    SpConvArgs a = a_in;
+    if (!a.Wh || !a.rowperm) { a.rowperm = nullptr; a.nslots = a.nout; }     // the permutation is an optimisation of the fp16x2 kernels
     if (a.cin % 32 == 0 && a.cout % 32 == 0 && a.cout <= 256 && a.ldin % 4 == 0 && a.K <= SP_MAXK) {
         // Two 32-channel output blocks per wave where possible (halves the gather traffic).  Levels with fewer than ~1024
         // (row tile, channel group) units run the split variant: one unit per workgroup, the K loop over its 4 waves.
-        const int ncbt = a.cout / 32, rowtiles = (a.nout + 31) / 32;
+        const int ncbt = a.cout / 32, rowtiles = (a.nslots + 31) / 32;
         const int ncb = (ncbt % 2 == 0 && (long long)rowtiles * (ncbt / 2) >= 1024) ? 2 : 1;
         const bool split = (long long)rowtiles * (ncbt / ncb) < 1024;
         const dim3 blk(256);
@@ -820,7 +917,7 @@ static int launch_spconv(const SpConvArgs& a, hipStream_t s) {
             else if (ncb == 2) hipLaunchKernelGGL((spconv_kernel<2, true>), grid, blk, 0, s, a);
             else hipLaunchKernelGGL((spconv_kernel<1, true>), grid, blk, 0, s, a);
         } else {
-            const dim3 grid((a.nout + 127) / 128, ncbt / ncb);
+            const dim3 grid((a.nslots + 127) / 128, ncbt / ncb);
             if (a.Wh && ncb == 2) hipLaunchKernelGGL((spconv16w_kernel<2>), grid, blk, 0, s, a);
             else if (a.Wh) hipLaunchKernelGGL((spconv16w_kernel<1>), grid, blk, 0, s, a);
             else if (ncb == 2) hipLaunchKernelGGL((spconv_kernel<2, false>), grid, blk, 0, s, a);
@@ -1042,6 +1139,7 @@ size_t fcgf_workspace_bytes(const FcgfNet* net, int n0) {
     size_t b = 0;
     b += 4 * (N * 4 * 4 + (size_t)table_cap(n0) * 12) + 8192;                 // coords + tables
     b += ((size_t)k1 + 27 * 10) * N * 4;                                      // kernel maps
+    b += 3 * (N + 8 * 128 + 256) * 4;                                         // parity-sorted row orders
     const int* C = net->C; const int* T = net->T;
     size_t feat = 1 + 2 * C[1] + (T[2] + C[1]) + 2 * T[2] + T[1] + net->out_ch;
     feat += 2 * C[2] + (T[3] + C[2]) + 2 * T[3] + 2 * C[3] + (T[4] + C[3]) + 2 * T[4] + 3 * C[4];
@@ -1170,6 +1268,19 @@ int fcgf_forward(yoho_ctx* ctx, const FcgfNet* net, const int* coords0, int n0, 
         Mdown[l] = make_map(L[l + 1], L[l], 3, L[l].ts, +1);           // strided conv: offsets on the input (finer) stride
         Mup[l] = make_map(L[l], L[l + 1], 3, L[l].ts, -1);             // transposed: coarse row at coord(fine) - offset
     }
+    // parity-sorted row orders of levels 0..2 for the transposed convolutions
+    int* perm[3]; int nperm[3];
+    for (int l = 0; l < 3; ++l) {
+        nperm[l] = L[l].n + 8 * PAR_PAD;
+        perm[l] = ar.take<int>((size_t)nperm[l]);
+        int* pc = ar.take<int>(16);
+        if (ar.off > ar.cap) { set_error("fcgf_forward: workspace estimate too small"); return YOHO_ENOMEM; }
+        if (L[l].n == 0) continue;
+        HIPCHK(hipMemsetAsync(perm[l], 0xFF, sizeof(int) * (size_t)nperm[l], s));
+        HIPCHK(hipMemsetAsync(pc, 0, sizeof(int) * 16, s));
+        hipLaunchKernelGGL(parity_count_kernel, dim3((L[l].n + 255) / 256), dim3(256), 0, s, L[l].coords, L[l].n, l, pc);
+        hipLaunchKernelGGL(parity_scatter_kernel, dim3((L[l].n + 255) / 256), dim3(256), 0, s, L[l].coords, L[l].n, l, pc, perm[l]);
+    }
     HIPCHK(hipGetLastError());
     // ---- features
     float* ones = ar.take<float>((size_t)n0 * net->in_ch);
@@ -1185,8 +1296,10 @@ int fcgf_forward(yoho_ctx* ctx, const FcgfNet* net, const int* coords0, int n0, 
     if (ar.off > ar.cap) { set_error("fcgf_forward: workspace estimate too small (%zu > %zu)", ar.off, ar.cap); return YOHO_ENOMEM; }
 
     auto conv = [&](const float* in, int ldin, int cin, const int* map, int K, int nout, const ConvW& W, int cout, float* o, int ldout,
-                    int ocoff, const BnAff* bn, const float* bias, const float* res, int ldres, int rcoff, int relu) -> int {
+                    int ocoff, const BnAff* bn, const float* bias, const float* res, int ldres, int rcoff, int relu,
+                    const int* rowperm = nullptr, int nslots = 0) -> int {
         SpConvArgs a;
+        a.rowperm = rowperm; a.nslots = rowperm ? nslots : nout;
         a.in = in; a.ldin = ldin; a.cin = cin; a.map = map; a.K = K; a.nout = nout; a.W = W.w; a.Wh = W.wh; a.descale = W.descale; a.cout = cout;
         a.out = o; a.ldout = ldout; a.ocoff = ocoff; a.aff_s = bn ? bn->s : nullptr; a.aff_t = bn ? bn->t : bias;
         a.res = res; a.ldres = ldres; a.rcoff = rcoff; a.relu = relu;
@@ -1227,7 +1340,8 @@ int fcgf_forward(yoho_ctx* ctx, const FcgfNet* net, const int* coords0, int n0, 
         float* u = ar.take<float>((size_t)L[l].n * co);
         float* sc = ar.take<float>((size_t)L[l].n * co);
         if (ar.off > ar.cap) { set_error("fcgf_forward: workspace estimate too small"); return YOHO_ENOMEM; }
-        if ((rc = conv(din, dld, dcin, Mup[l], 27, L[l].n, net->conv_tr[j], co, u, co, 0, &net->norm_tr[j], nullptr, nullptr, 0, 0, 0))) return rc;
+        if ((rc = conv(din, dld, dcin, Mup[l], 27, L[l].n, net->conv_tr[j], co, u, co, 0, &net->norm_tr[j], nullptr, nullptr, 0, 0, 0,
+                       ctx->fcgf_parity_sort ? perm[l] : nullptr, nperm[l]))) return rc;
         if ((rc = block(l, u, co, net->bconv_tr[j], net->bnorm_tr[j], sc, cat[l], catw[l], 0))) return rc;
         din = cat[l]; dld = catw[l]; dcin = catw[l];
     }
