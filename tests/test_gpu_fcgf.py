@@ -98,17 +98,23 @@ def test_batched_clouds_equal_separate_passes(fctx):
     assert (two[0] - sep[0]).abs().max().item() < 2e-5 and torch.equal(two[0], two[1])
 
 
-def test_parity_sorted_transposed_convs_are_bit_identical(fctx):
-    """the row order and the skipped kernel offsets of the transposed convolutions change no bit of the output"""
+def test_internal_row_orders_are_bit_identical(fctx):
+    """cell-sorted level-0 rows, parity-sorted rows and skipped kernel offsets of the transposed convolutions change no bit
+    of the output, and rows come back in the caller's order"""
     clouds = [torch.from_numpy(fo.voxelize(synth.surface_cloud(n, seed=sd), 0.025)[1]).cuda() for n, sd in ((6000, 5), (37, 6), (2500, 7))]
+    clouds.append(torch.from_numpy(fo.voxelize(synth.surface_cloud(20000, seed=8, extent=6.0), 0.025)[1]).cuda())    # wider than the 128-voxel cell wrap
     try:
-        fctx.set_fcgf_parity_sort(False)
+        fctx.set_fcgf_sort(False, False)
         ref = [fctx.fcgf_forward(c) for c in clouds] + list(fctx.fcgf_forward_batch(clouds))
+        outs = []
+        for par, cells in ((True, False), (False, True), (True, True)):
+            fctx.set_fcgf_sort(par, cells)
+            outs.append([fctx.fcgf_forward(c) for c in clouds] + list(fctx.fcgf_forward_batch(clouds)))
     finally:
-        fctx.set_fcgf_parity_sort(True)
-    got = [fctx.fcgf_forward(c) for c in clouds] + list(fctx.fcgf_forward_batch(clouds))
-    for a, b in zip(ref, got):
-        assert torch.equal(a, b)
+        fctx.set_fcgf_sort(True, True)
+    for got in outs:
+        for a, b in zip(ref, got):
+            assert torch.equal(a, b)
 
 
 def test_other_model_configs_and_tiny_clouds(hip):

@@ -20,6 +20,8 @@ SOURCES = ["api.hip", "gconv.hip", "gconv16.hip", "fourier.hip", "gemmf.hip", "g
 # FMA contraction (hipcc defaults to -ffp-contract=fast and __fmul_rn/__fadd_rn are plain operators
 # in this ROCm, so they would fuse); explicit fma()/fmaf() calls are unaffected.
 EXTRA = {"layout.hip": ["-ffp-contract=off"], "match.hip": ["-ffp-contract=off"], "matchf.hip": ["-ffp-contract=off"], "gridnn.hip": ["-ffp-contract=off"], "estim.hip": ["-ffp-contract=off"]}
+if os.environ.get("YOHO_SPCONV_ABLATE"):          # timing experiments: compile-time ablations of the fine-level sparse conv (YOHO_SPCONV_DEBUG)
+    EXTRA["sparse.hip"] = ["-DYOHO_SPCONV_ABLATE"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-I" + os.path.join(REPO, "include"), "-I" + CSRC]
 

@@ -281,6 +281,49 @@ __global__ __launch_bounds__(256) void parity_scatter_kernel(const int* __restri
     if (i < n) perm[lbase[cls] + pos] = i;
 }
 
+// Level-0 rows grouped by the 8^3-voxel cell they lie in (cells in Morton order inside a cloud, 16 cells per axis with
+// wrap-around): the rows a workgroup's 128 output rows gather are then mostly shared (a surface patch and its one-voxel
+// halo) and hit in the L2 instead of each coming from the MALL / HBM, and the coarser levels - compacted in first-occurrence
+// order - inherit the grouping.  Counting sort: cell histogram, scan (in-block + block totals), scatter; the order inside a
+// cell follows the atomics and does not matter: a row's result does not depend on where the row sits, and the final kernel
+// writes through the permutation, so the caller's row order is kept.
+constexpr int CELL_SH = 3, CELL_PER_CLOUD = 4096;
+__device__ __forceinline__ int cell_of(int4 c) {
+    auto spread = [](unsigned v) { v &= 15u; v = (v | (v << 4)) & 0x0C3u; v = (v | (v << 2)) & 0x249u; return v; };     // abcd -> a00b00c00d
+    return c.w * CELL_PER_CLOUD + (int)(spread(c.x >> CELL_SH) | (spread(c.y >> CELL_SH) << 1) | (spread(c.z >> CELL_SH) << 2));
+}
+
+__global__ void cell_count_kernel(const int* __restrict__ coords, int n, int* __restrict__ cnt) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) atomicAdd(&cnt[cell_of(reinterpret_cast<const int4*>(coords)[i])], 1);
+}
+
+// cnt[1024 b .. 1024 b + 1023] -> exclusive prefix inside the block, block total -> btot[b]
+__global__ __launch_bounds__(1024) void cell_scan_kernel(int* __restrict__ cnt, int* __restrict__ btot) {
+    __shared__ int wsum[16];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int v = cnt[blockIdx.x * 1024 + tid];
+    int s = v;
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(s, o); if (lane >= o) s += t; }
+    if (lane == 63) wsum[wv] = s;
+    __syncthreads();
+    int off = 0;
+    for (int k = 0; k < wv; ++k) off += wsum[k];
+    cnt[blockIdx.x * 1024 + tid] = off + s - v;
+    if (tid == 1023) btot[blockIdx.x] = off + s;
+}
+
+__global__ void cell_scatter_kernel(const int* __restrict__ coords, int n, const int* __restrict__ pre, const int* __restrict__ btot,
+                                    int* __restrict__ cursor, int* __restrict__ perm, int* __restrict__ sorted) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int4 c = reinterpret_cast<const int4*>(coords)[i];
+    const int cell = cell_of(c);
+    const int r = btot[cell >> 10] + pre[cell] + atomicAdd(&cursor[cell], 1);
+    perm[r] = i;
+    reinterpret_cast<int4*>(sorted)[r] = c;
+}
+
 struct SpConvArgs {
     const float* in; int ldin, cin;
     const int* map;          // [K][nout] or null (K = 1, identity)
@@ -296,6 +339,7 @@ struct SpConvArgs {
     int relu;
     const int* rowperm;      // fp16x2 kernels: tile slot -> output row (-1 = padding), or null (slot = row)
     int nslots;              // tile slots (= nout without a permutation)
+    int debug;               // timing experiments only (YOHO_SPCONV_DEBUG): 1 = no (offset, chunk) loop, 2 = no epilogue
 };
 
 // Offsets that no row of a tile reaches are skipped (their rows of the A operand are all zero: the skipped MFMAs would add
@@ -582,12 +626,16 @@ __global__ __launch_bounds__(256) void spconv16s_kernel(SpConvArgs a) {
 // ahead, they go through a double-buffered LDS stage (one barrier per step) and each wave reads its fragments from
 // there - the vector-memory pipe only carries the gathers (a quarter of the bytes of the per-wave weight loads).
 // The gathered rows run NA - 1 steps ahead in a register ring.
-template <int NCB>
+template <int NCB, int DBG = 0>
 __global__ __launch_bounds__(256) void spconv16w_kernel(SpConvArgs a) {
-    __shared__ int srcl[4][SP_MAXK * 32];
+    // one LDS block: region rows of the four waves | double-buffered weight stage; the epilogue lays its output tiles over it
+    constexpr int SRCL_INTS = 4 * SP_MAXK * 32, BST_FRAGS = 2 * 4 * NCB * 64, EPI_LD = 36;       // EPI_LD: padded row of 32 floats
+    static_assert(SRCL_INTS * 4 + BST_FRAGS * 16 >= 4 * 32 * EPI_LD * 4, "epilogue tiles must fit");
+    __shared__ __attribute__((aligned(16))) char smem[SRCL_INTS * 4 + BST_FRAGS * 16];
     __shared__ int prow[4][32];
     __shared__ unsigned actm;
-    __shared__ __attribute__((aligned(16))) uintx4s bst[2][4 * NCB * 64];
+    int (*srcl)[SP_MAXK * 32] = reinterpret_cast<int (*)[SP_MAXK * 32]>(smem);
+    uintx4s (*bst)[4 * NCB * 64] = reinterpret_cast<uintx4s (*)[4 * NCB * 64]>(smem + SRCL_INTS * 4);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int li = lane & 31, h = lane >> 5;
     const int rbase = (blockIdx.x * 4 + w) * 32;
@@ -601,13 +649,22 @@ __global__ __launch_bounds__(256) void spconv16w_kernel(SpConvArgs a) {
     if (h == 0) prow[w][li] = row;
     __syncthreads();
     {
+        // all map reads of the tile in flight at once (half h holds offsets h, h + 2, ...), then the LDS copies and the ballots
+        constexpr int NV = (SP_MAXK + 1) / 2;
+        int v[NV];
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int k = 2 * j + h;
+            v[j] = (valid && k < a.K) ? (a.map ? a.map[(size_t)k * a.nout + row] : row) : -1;
+        }
         unsigned m = 0u;
-        for (int k = h; k < a.K; k += 2) {
-            const int v = valid ? (a.map ? a.map[(size_t)k * a.nout + row] : row) : -1;
-            sl[k * 32 + li] = v;
-            const unsigned long long b = __ballot(v >= 0);           // low half: offset k - h, high half: the next one
-            if ((unsigned)b) m |= 1u << (k - h);
-            if (b >> 32) m |= 2u << (k - h);
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int k = 2 * j + h;
+            if (k < SP_MAXK) sl[k * 32 + li] = v[j];
+            const unsigned long long b = __ballot(v[j] >= 0);        // low half: offset 2 j, high half: 2 j + 1
+            if ((unsigned)b) m |= 1u << (2 * j);
+            if (b >> 32) m |= 2u << (2 * j);
         }
         if (m && li == 0) atomicOr(&actm, m);
     }
@@ -624,14 +681,20 @@ __global__ __launch_bounds__(256) void spconv16w_kernel(SpConvArgs a) {
     const int total = __builtin_popcount(act) * nchunk;
     const uintx4s* Wh = reinterpret_cast<const uintx4s*>(a.Wh);
 
-    if (total > 0) {
+    if (total > 0 && !(a.debug & 1)) {
         // branch-free loads, see spconv16_kernel
         unsigned amask = act, bmask = act;                                    // wave-uniform load pointers
         int ak = sp_next_offset(amask), acc_ = 0, aissued = 0;
         int bk = sp_next_offset(bmask), bcc = 0, bissued = 0;
         const __amdgpu_buffer_rsrc_t rs = sp_rsrc(a.in);
         auto loadA = [&](float (&av)[16]) {
-            const int src = sl[ak * 32 + li];
+            int src = sl[ak * 32 + li];
+            if constexpr (DBG & 32) src = min(rbase + li, a.nout - 1);          // sequential rows instead of the neighbours
+            if constexpr (DBG & 64) src = (rbase >> 5) & 1023;                  // one row for the whole wave
+            if constexpr (DBG & 4) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) av[e] = __int_as_float(src + e);
+            } else
             sp_gather16(rs, src < 0 ? SP_OOB : ((unsigned)src * (unsigned)a.ldin + acc_ * 32 + h * 8) * 4u, av);
             if (++aissued < total && ++acc_ == nchunk) { acc_ = 0; ak = sp_next_offset(amask); }
         };
@@ -641,6 +704,8 @@ __global__ __launch_bounds__(256) void spconv16w_kernel(SpConvArgs a) {
 #pragma unroll
             for (int j = 0; j < NCB; ++j) {
                 const int idx = j * 256 + tid, sp = idx / (NCB * 64), within = idx - sp * (NCB * 64);
+                if constexpr (DBG & 16) { br[j][0] = it + idx; br[j][1] = sp; br[j][2] = within; br[j][3] = it; }
+                else
                 br[j] = Wh[(((size_t)it * 4 + sp) * ncbt + cb0) * 64 + within];
             }
             if (++bissued < total && ++bcc == nchunk) { bcc = 0; bk = sp_next_offset(bmask); }
@@ -662,12 +727,17 @@ __global__ __launch_bounds__(256) void spconv16w_kernel(SpConvArgs a) {
                     split_pair_sp(av[8 * st + 2 * p], av[8 * st + 2 * p + 1], hh, ll);
                     ah[p] = hh; al[p] = ll;
                 }
+                if constexpr (DBG & 8) {
+#pragma unroll
+                    for (int cb = 0; cb < NCB; ++cb) { acc[cb][0] += __uint_as_float(al[0] ^ bh[cb][0] ^ ah[1] ^ bw[cb][1] ^ al[2] ^ ah[3] ^ bh[cb][2] ^ bw[cb][3] ^ al[1] ^ al[3] ^ ah[0] ^ ah[2]); }
+                } else {
 #pragma unroll
                 for (int cb = 0; cb < NCB; ++cb) acc[cb] = mfma_sp16(al, bh[cb], acc[cb]);
 #pragma unroll
                 for (int cb = 0; cb < NCB; ++cb) acc[cb] = mfma_sp16(ah, bw[cb], acc[cb]);
 #pragma unroll
                 for (int cb = 0; cb < NCB; ++cb) acc[cb] = mfma_sp16(ah, bh[cb], acc[cb]);
+                }
             }
         };
         constexpr int NA = 4;                                                 // even: the stage parity of ring slot j is j & 1
@@ -701,18 +771,34 @@ __global__ __launch_bounds__(256) void spconv16w_kernel(SpConvArgs a) {
             }
         }
     }
+    if (a.debug & 2) return;
+    // Epilogue through LDS: the accumulator tile (a lane holds one channel of 16 rows) is turned into rows of 32 channels, so
+    // that eight lanes move one row's 128 bytes with 16-byte accesses (residual read, affine, ReLU, store).
+    __syncthreads();                                                      // every wave is done with the stage buffers
+    float* et = reinterpret_cast<float*>(smem) + w * 32 * EPI_LD;
+    const int er = lane >> 3, ep = lane & 7;                              // row within a group of eight, 4-channel piece
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb) {
-        const int co = (cb0 + cb) * 32 + li;
-        const float s = (a.aff_s ? a.aff_s[co] : 1.f) * a.descale, t = a.aff_t ? a.aff_t[co] : 0.f;
+        if (cb) __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int orow = prow[w][(r & 3) + 8 * (r >> 2) + 4 * h];
+        for (int r = 0; r < 16; ++r) et[((r & 3) + 8 * (r >> 2) + 4 * h) * EPI_LD + li] = acc[cb][r];
+        __builtin_amdgcn_wave_barrier();
+        const int co = (cb0 + cb) * 32 + 4 * ep;
+        float4 sc = make_float4(a.descale, a.descale, a.descale, a.descale), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a.aff_s) { const float4 t = *reinterpret_cast<const float4*>(a.aff_s + co); sc.x *= t.x; sc.y *= t.y; sc.z *= t.z; sc.w *= t.w; }
+        if (a.aff_t) sh = *reinterpret_cast<const float4*>(a.aff_t + co);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int orow = prow[w][8 * g + er];
             if (orow >= 0) {
-                float v = acc[cb][r] * s + t;
-                if (a.res) v += a.res[(size_t)orow * a.ldres + a.rcoff + co];
-                if (a.relu) v = fmaxf(v, 0.f);
-                a.out[(size_t)orow * a.ldout + a.ocoff + co] = v;
+                float4 v = *reinterpret_cast<const float4*>(et + (8 * g + er) * EPI_LD + 4 * ep);
+                v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+                if (a.res) {
+                    const float4 rr = *reinterpret_cast<const float4*>(a.res + (size_t)orow * a.ldres + a.rcoff + co);
+                    v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+                }
+                if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                *reinterpret_cast<float4*>(a.out + (size_t)orow * a.ldout + a.ocoff + co) = v;
             }
         }
     }
@@ -902,8 +988,11 @@ __global__ __launch_bounds__(256) void conv1_bitmap_kernel(const int* __restrict
 static int launch_spconv(const SpConvArgs& a_in, hipStream_t s) {
     if (a_in.nout == 0) return 0;
     SpConvArgs a = a_in;
+    static const int dbg = [] { const char* e = std::getenv("YOHO_SPCONV_DEBUG"); return e ? std::atoi(e) : 0; }();
+    a.debug = dbg;
     if (!a.Wh || !a.rowperm) { a.rowperm = nullptr; a.nslots = a.nout; }     // the permutation is an optimisation of the fp16x2 kernels
-    if (a.cin % 32 == 0 && a.cout % 32 == 0 && a.cout <= 256 && a.ldin % 4 == 0 && a.K <= SP_MAXK) {
+    const bool vec_ok = a.ldout % 4 == 0 && a.ocoff % 4 == 0 && (!a.res || (a.ldres % 4 == 0 && a.rcoff % 4 == 0));      // 16-byte epilogue accesses
+    if (a.cin % 32 == 0 && a.cout % 32 == 0 && a.cout <= 256 && a.ldin % 4 == 0 && a.K <= SP_MAXK && vec_ok) {
         // Two 32-channel output blocks per wave where possible (halves the gather traffic).  Levels with fewer than ~1024
         // (row tile, channel group) units run the split variant: one unit per workgroup, the K loop over its 4 waves.
         const int ncbt = a.cout / 32, rowtiles = (a.nslots + 31) / 32;
@@ -918,6 +1007,15 @@ static int launch_spconv(const SpConvArgs& a_in, hipStream_t s) {
             else hipLaunchKernelGGL((spconv_kernel<1, true>), grid, blk, 0, s, a);
         } else {
             const dim3 grid((a.nslots + 127) / 128, ncbt / ncb);
+#ifdef YOHO_SPCONV_ABLATE
+            if (a.Wh && ncb == 2 && (dbg & 4) && (dbg & 8) && (dbg & 16)) hipLaunchKernelGGL((spconv16w_kernel<2, 28>), grid, blk, 0, s, a);
+            else if (a.Wh && ncb == 2 && (dbg & 32)) hipLaunchKernelGGL((spconv16w_kernel<2, 32>), grid, blk, 0, s, a);
+            else if (a.Wh && ncb == 2 && (dbg & 64)) hipLaunchKernelGGL((spconv16w_kernel<2, 64>), grid, blk, 0, s, a);
+            else if (a.Wh && ncb == 2 && (dbg & 4)) hipLaunchKernelGGL((spconv16w_kernel<2, 4>), grid, blk, 0, s, a);
+            else if (a.Wh && ncb == 2 && (dbg & 8)) hipLaunchKernelGGL((spconv16w_kernel<2, 8>), grid, blk, 0, s, a);
+            else if (a.Wh && ncb == 2 && (dbg & 16)) hipLaunchKernelGGL((spconv16w_kernel<2, 16>), grid, blk, 0, s, a);
+            else
+#endif
             if (a.Wh && ncb == 2) hipLaunchKernelGGL((spconv16w_kernel<2>), grid, blk, 0, s, a);
             else if (a.Wh) hipLaunchKernelGGL((spconv16w_kernel<1>), grid, blk, 0, s, a);
             else if (ncb == 2) hipLaunchKernelGGL((spconv_kernel<2, false>), grid, blk, 0, s, a);
@@ -939,7 +1037,7 @@ __global__ void fill_ones_kernel(float* p, int n) {
 
 // rows /= |row| (resunet.py:183-187), then once more (fcgf_feat.py:48).  c <= 32: a half-wave per row (the xor tree over
 // 32 lanes gives the same sum as the 64-lane tree with zeros in the upper half), 8 rows per wave; else one wave per row.
-__global__ __launch_bounds__(256) void row_normalize_kernel(const float* in, int n, int c, float* out, int twice) {
+__global__ __launch_bounds__(256) void row_normalize_kernel(const float* in, int n, int c, float* out, int twice, const int* __restrict__ operm) {
     const int lane = threadIdx.x & 63, wave = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (c <= 32) {
         const int l32 = lane & 31;
@@ -953,7 +1051,7 @@ __global__ __launch_bounds__(256) void row_normalize_kernel(const float* in, int
                 for (int o = 16; o >= 1; o >>= 1) s += __shfl_xor(s, o);
                 v = v / sqrtf(s);
             }
-            if (ok) out[(size_t)row * c + l32] = v;
+            if (ok) out[(size_t)(operm ? operm[row] : row) * c + l32] = v;
         }
         return;
     }
@@ -965,7 +1063,7 @@ __global__ __launch_bounds__(256) void row_normalize_kernel(const float* in, int
         for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
         v = v / sqrtf(s);
     }
-    if (lane < c) out[(size_t)row * c + lane] = v;
+    if (lane < c) out[(size_t)(operm ? operm[row] : row) * c + lane] = v;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1140,6 +1238,7 @@ size_t fcgf_workspace_bytes(const FcgfNet* net, int n0) {
     b += 4 * (N * 4 * 4 + (size_t)table_cap(n0) * 12) + 8192;                 // coords + tables
     b += ((size_t)k1 + 27 * 10) * N * 4;                                      // kernel maps
     b += 3 * (N + 8 * 128 + 256) * 4;                                         // parity-sorted row orders
+    b += N * 20 + (size_t)64 * 4096 * 8 + 8192;                               // cell-sorted level-0 rows
     const int* C = net->C; const int* T = net->T;
     size_t feat = 1 + 2 * C[1] + (T[2] + C[1]) + 2 * T[2] + T[1] + net->out_ch;
     feat += 2 * C[2] + (T[3] + C[2]) + 2 * T[3] + 2 * C[3] + (T[4] + C[3]) + 2 * T[4] + 3 * C[4];
@@ -1173,6 +1272,22 @@ int fcgf_forward(yoho_ctx* ctx, const FcgfNet* net, const int* coords0, int n0, 
         HIPCHK(hipMemcpyAsync(doff, hoff, sizeof(int) * (nb + 1), hipMemcpyHostToDevice, s));
         HIPCHK(hipStreamSynchronize(s));                     // hoff lives on this stack frame
         hipLaunchKernelGGL(coords4_kernel, dim3((n0 + 255) / 256), dim3(256), 0, s, coords0, n0, doff, nb, L[0].coords);
+    }
+    int* operm = nullptr;                          // internal level-0 row -> caller's row (null: same order)
+    if (ctx->fcgf_cell_sort) {
+        const int ncell = nb * CELL_PER_CLOUD, nblk = ncell / 1024;
+        int* cnt = ar.take<int>((size_t)2 * ncell);            // histogram -> in-block prefix | cursors
+        int* btot = ar.take<int>(nblk + 1);
+        int* sorted = ar.take<int>((size_t)n0 * 4);
+        operm = ar.take<int>((size_t)n0);
+        if (ar.off > ar.cap) { set_error("fcgf_forward: workspace estimate too small"); return YOHO_ENOMEM; }
+        HIPCHK(hipMemsetAsync(cnt, 0, sizeof(int) * 2 * (size_t)ncell, s));
+        hipLaunchKernelGGL(cell_count_kernel, dim3((n0 + 255) / 256), dim3(256), 0, s, L[0].coords, n0, cnt);
+        hipLaunchKernelGGL(cell_scan_kernel, dim3(nblk), dim3(1024), 0, s, cnt, btot);
+        hipLaunchKernelGGL(block_scan_kernel, dim3(1), dim3(1024), 0, s, btot, nblk, btot + nblk);
+        hipLaunchKernelGGL(cell_scatter_kernel, dim3((n0 + 255) / 256), dim3(256), 0, s, L[0].coords, n0, cnt, btot, cnt + ncell, operm, sorted);
+        HIPCHK(hipGetLastError());
+        L[0].coords = sorted;
     }
     const bool conv1_fused = net->in_ch == 1 && C[1] == 32 && net->k1 * net->k1 * net->k1 <= C1O_MAXK;
     int* dbb = ar.take<int>(64 * 6);
@@ -1351,7 +1466,7 @@ int fcgf_forward(yoho_ctx* ctx, const FcgfNet* net, const int* coords0, int n0, 
     if ((rc = conv(cat[0], catw[0], catw[0], nullptr, 1, n0, net->conv1_tr, T[1], f1, T[1], 0, nullptr, nullptr, nullptr, 0, 0, 1))) return rc;
     if ((rc = conv(f1, T[1], T[1], nullptr, 1, n0, net->final_k, net->out_ch, f2, net->out_ch, 0, nullptr, net->final_b, nullptr, 0, 0, 0))) return rc;
     hipLaunchKernelGGL(row_normalize_kernel, dim3(net->out_ch <= 32 ? (n0 + 31) / 32 : (n0 + 3) / 4), dim3(256), 0, s, f2, n0, net->out_ch, out,
-                       net->normalize ? 1 : 0);
+                       net->normalize ? 1 : 0, operm);
     HIPCHK(hipGetLastError());
     return 0;
 }

@@ -22,7 +22,7 @@ SYMBOLS = [
     "yoho_gconv_layer", "yoho_load_fcgf", "yoho_fcgf_voxelize", "yoho_fcgf_forward", "yoho_fcgf_forward_batch", "yoho_fcgf_voxelize_rotated", "yoho_rotate_select",
     "yoho_des2r", "yoho_des2r_indexed", "yoho_partII_forward", "yoho_partII_forward_indexed", "yoho_hyp_from_quat", "yoho_o_score", "yoho_c_ransac",
     "yoho_group_gather", "yoho_set_profiling", "yoho_get_kernel_ms", "yoho_set_gconv_mode", "yoho_set_partII_mode", "yoho_set_nn_grid",
-    "yoho_range_status", "yoho_c_ransac_device", "yoho_group_scatter", "yoho_set_nn_prefilter", "yoho_set_fcgf_parity_sort", "yoho_gconv_wgrad", "yoho_bn_stats", "yoho_bn_relu_apply", "yoho_bn_relu_backward",
+    "yoho_range_status", "yoho_c_ransac_device", "yoho_group_scatter", "yoho_set_nn_prefilter", "yoho_set_fcgf_sort", "yoho_gconv_wgrad", "yoho_bn_stats", "yoho_bn_relu_apply", "yoho_bn_relu_backward",
 ]
 
 
@@ -97,7 +97,7 @@ def load_library():
     lib.yoho_set_partII_mode.argtypes = [vp, ci]
     lib.yoho_set_nn_grid.argtypes = [vp, C.c_double]
     lib.yoho_set_nn_prefilter.argtypes = [vp, ci]
-    lib.yoho_set_fcgf_parity_sort.argtypes = [vp, ci]
+    lib.yoho_set_fcgf_sort.argtypes = [vp, ci, ci]
     lib.yoho_fcgf_voxelize_rotated.argtypes = [vp, vp, ci, vp, C.c_double, vp, vp, vp, vp, vp]
     lib.yoho_rotate_select.argtypes = [vp, vp, vp, vp, ci, vp, vp]
     lib.yoho_get_kernel_ms.argtypes = [vp, ci, C.POINTER(C.c_float)]
@@ -575,9 +575,10 @@ class Context:
         """mutual_nn on large sets through the MFMA pre-filter (default) or by brute force; identical match lists"""
         _check(self._lib.yoho_set_nn_prefilter(self._h, 1 if on else 0))
 
-    def set_fcgf_parity_sort(self, on=True):
-        """transposed convolutions of the FCGF backbone over parity-sorted rows (default) or rows in order; identical outputs"""
-        _check(self._lib.yoho_set_fcgf_parity_sort(self._h, 1 if on else 0))
+    def set_fcgf_sort(self, parity=True, cells=True):
+        """internal row orders of the FCGF backbone: transposed convolutions over parity-sorted rows, level-0 rows grouped by
+        8^3-voxel cell (both default on; identical outputs in the caller's row order either way)"""
+        _check(self._lib.yoho_set_fcgf_sort(self._h, 1 if parity else 0, 1 if cells else 0))
 
     def set_nn_grid(self, cell):
         """3-D nearest-neighbour searches (nn_search with 3 columns, group_gather) through a hash grid with this cell size
