@@ -259,11 +259,11 @@ int yoho_set_nn_grid(yoho_ctx* ctx, double cell);
  * cannot take (non-finite values, magnitudes beyond the fp16 range) go to the brute-force kernels by themselves. */
 int yoho_set_nn_prefilter(yoho_ctx* ctx, int enable);
 
-/* FCGF backbone, internal row orders (both on by default; outputs are bit-identical either way, rows come back in the
- * caller's order):
- *   cell_sort   - the level-0 rows of a pass are grouped by 8^3-voxel cell (Morton order of the cells), so the rows a
- *                 workgroup gathers are shared by its output rows and stay in the L2;
- *   parity_sort - the transposed convolutions walk the rows of their output level sorted by the parity class of the
+/* FCGF backbone, internal row orders (outputs are bit-identical either way, rows come back in the caller's order):
+ *   cell_sort   - 0 never, 1 (default) for passes of at least 2^18 voxels, 2 always: the level-0 rows of a pass are grouped
+ *                 by 8^3-voxel cell (Morton order of the cells), so the rows a workgroup gathers are shared by its output
+ *                 rows and stay in the L2 (the sort pays for itself only on large passes);
+ *   parity_sort - (default on) the transposed convolutions walk the rows of their output level sorted by the parity class of the
  *                 coordinates (a row is reached from 1, 2, 4 or 8 of the 27 offsets, the same for a whole class) and every
  *                 tile skips the offsets none of its rows reaches (skipped terms are exact zeros). */
 int yoho_set_fcgf_sort(yoho_ctx* ctx, int parity_sort, int cell_sort);

@@ -104,14 +104,14 @@ def test_internal_row_orders_are_bit_identical(fctx):
     clouds = [torch.from_numpy(fo.voxelize(synth.surface_cloud(n, seed=sd), 0.025)[1]).cuda() for n, sd in ((6000, 5), (37, 6), (2500, 7))]
     clouds.append(torch.from_numpy(fo.voxelize(synth.surface_cloud(20000, seed=8, extent=6.0), 0.025)[1]).cuda())    # wider than the 128-voxel cell wrap
     try:
-        fctx.set_fcgf_sort(False, False)
+        fctx.set_fcgf_sort(False, 0)
         ref = [fctx.fcgf_forward(c) for c in clouds] + list(fctx.fcgf_forward_batch(clouds))
         outs = []
-        for par, cells in ((True, False), (False, True), (True, True)):
+        for par, cells in ((True, 0), (False, 2), (True, 2)):
             fctx.set_fcgf_sort(par, cells)
             outs.append([fctx.fcgf_forward(c) for c in clouds] + list(fctx.fcgf_forward_batch(clouds)))
     finally:
-        fctx.set_fcgf_sort(True, True)
+        fctx.set_fcgf_sort(True, 1)                           # the defaults
     for got in outs:
         for a, b in zip(ref, got):
             assert torch.equal(a, b)

@@ -188,7 +188,7 @@ struct yoho_ctx {
     int* d_tap_inv = nullptr;
     int nCU = 256;
     int* d_rflag = nullptr;      // fp16 range words (note_range): [0] PartI, [1] PartII; read and cleared by yoho_range_status
-    int fcgf_cell_sort = 1;      // FCGF backbone: level-0 rows grouped by 8^3-voxel cell inside the pass (gather locality); 0: YOHO_FCGF_CELLS=0
+    int fcgf_cell_sort = 1;      // FCGF backbone: level-0 rows grouped by 8^3-voxel cell inside the pass (gather locality): 0 never, 1 passes of >= 2^18 rows, 2 always
     int fcgf_parity_sort = 1;    // transposed convolutions of the FCGF backbone walk parity-sorted rows (sparse.hip); 0: YOHO_FCGF_SORT=0
     int nn_prefilter = 1;        // mutual NN of large sets: MFMA pre-filter + exact candidates (matchf.hip); 0 = brute force (YOHO_NN=brute)
     double nn_cell = 0.0;        // > 0: 3-D nearest-neighbour searches go through a hash grid of this cell size (gridnn.hip)

@@ -288,6 +288,7 @@ __global__ __launch_bounds__(256) void parity_scatter_kernel(const int* __restri
 // cell follows the atomics and does not matter: a row's result does not depend on where the row sits, and the final kernel
 // writes through the permutation, so the caller's row order is kept.
 constexpr int CELL_SH = 3, CELL_PER_CLOUD = 4096;
+constexpr int CELL_SORT_MIN_ROWS = 1 << 18;      // measured: -0.2 ms on a 1.3 M-row pass (sort included), +0.06 ms on an 88 k-row pass
 __device__ __forceinline__ int cell_of(int4 c) {
     auto spread = [](unsigned v) { v &= 15u; v = (v | (v << 4)) & 0x0C3u; v = (v | (v << 2)) & 0x249u; return v; };     // abcd -> a00b00c00d
     return c.w * CELL_PER_CLOUD + (int)(spread(c.x >> CELL_SH) | (spread(c.y >> CELL_SH) << 1) | (spread(c.z >> CELL_SH) << 2));
@@ -985,6 +986,73 @@ __global__ __launch_bounds__(256) void conv1_bitmap_kernel(const int* __restrict
     }
 }
 
+// The first convolution as a matrix product on the fp16 MFMA: out[row][32] = occ[row][K^3] * W[K^3][32] with the occupancy
+// bits of the row's K^3 region as a 0 / 1 operand (exact in fp16) and the weights as fp16 hi + lo planes (W * 2^s = hi + lo,
+// fp32 accumulation; |error| <= 2^-22 |w| per term).  The reduction axis is ordered (z, y, x) with x padded to 8: the eight
+// x-neighbours of one (y, z) line are one lane's share of a 32x32x16 step, i.e. one unaligned 8-bit run of one bitmap row,
+// so a step is two (y, z) lines (one per lane half) and K = 7 takes 25 steps of two MFMAs for 32 rows.  Persistent
+// workgroups keep the weight planes (50 KiB for K = 7) in LDS; a wave's 2 x 25 bitmap words are requested before the first
+// step.  Replaces the per-row bit scan of conv1_bitmap_kernel (1.3 ms -> see DESIGN 3.5 for 1.3 M rows).
+constexpr int C1M_MAXSTEPS = 25;                                     // (7 * 7 + 1) / 2
+__global__ __launch_bounds__(256) void conv1_mfma_kernel(const int* __restrict__ coords, int n, const BmDesc* __restrict__ desc,
+                                                         const unsigned* __restrict__ bm, const unsigned* __restrict__ zero2, int ksize,
+                                                         const uintx4s* __restrict__ planes, float descale, const float* __restrict__ aff_s, const float* __restrict__ aff_t,
+                                                         float* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) uintx4s pl[C1M_MAXSTEPS * 2 * 64];
+    const int nsteps = (ksize * ksize + 1) / 2, hk = ksize / 2;
+    for (int i = threadIdx.x; i < nsteps * 128; i += 256) pl[i] = planes[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5;
+    const unsigned runmask = (1u << ksize) - 1u;
+    const float sc = (aff_s ? aff_s[li] : 1.f) * descale, sh = aff_t ? aff_t[li] : 0.f;
+    const int ntiles = (n + 31) / 32;
+    for (int tile = blockIdx.x * 4 + (threadIdx.x >> 6); tile < ntiles; tile += gridDim.x * 4) {
+        const int row = tile * 32 + li;
+        const bool valid = row < n;
+        const int4 c = valid ? reinterpret_cast<const int4*>(coords)[row] : make_int4(0, 0, 0, 0);
+        const BmDesc d = desc[c.w];
+        const unsigned* bmc = bm + d.base;
+        const int bx = c.x - d.x0 - hk, by = c.y - d.y0 - hk, bz = c.z - d.z0 - hk;      // >= 0 by construction of the margin
+        const int wcol = bx >> 5, shift = bx & 31;
+        // this lane's (y, z) lines: 2 s + h, s = 0 .. nsteps - 1
+        unsigned w0[C1M_MAXSTEPS], w1[C1M_MAXSTEPS];
+        {
+            int dy = h, dz = 0;
+#pragma unroll
+            for (int st = 0; st < C1M_MAXSTEPS; ++st) {
+                const bool use = valid && st < nsteps && dz < ksize;
+                const unsigned* wp = use ? bmc + (((bz + dz) * d.ny + (by + dy)) * d.wx + wcol) : zero2;      // a cloud's bitmap has < 2^24 words
+                w0[st] = wp[0];
+                w1[st] = wp[1];                                                               // (two spare words behind the last bitmap)
+                dy += 2;
+                if (dy >= ksize) { dy -= ksize; ++dz; }
+            }
+        }
+        floatx16s acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int st = 0; st < C1M_MAXSTEPS; ++st) {
+            if (st < nsteps) {                                                                // uniform
+                const unsigned run = (unsigned)((((unsigned long long)w1[st] << 32) | w0[st]) >> shift) & runmask;
+                uintx4s af;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int b0 = __builtin_amdgcn_sbfe(run, 2 * j, 1), b1 = __builtin_amdgcn_sbfe(run, 2 * j + 1, 1);   // 0 / -1
+                    af[j] = ((unsigned)b0 & 0x00003C00u) | ((unsigned)b1 & 0x3C000000u);                                   // 1.0 in fp16
+                }
+                acc = mfma_sp16(af, pl[(2 * st + 0) * 64 + lane], acc);
+                acc = mfma_sp16(af, pl[(2 * st + 1) * 64 + lane], acc);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int orow = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (orow < n) out[(size_t)orow * 32 + li] = acc[r] * sc + sh;
+        }
+    }
+}
+
 static int launch_spconv(const SpConvArgs& a_in, hipStream_t s) {
     if (a_in.nout == 0) return 0;
     SpConvArgs a = a_in;
@@ -1087,6 +1155,7 @@ struct FcgfNet {
     ConvW conv1_tr;
     ConvW final_k;
     float* final_b = nullptr;
+    void* c1planes = nullptr; float c1descale = 1.f;             // first convolution as an MFMA product (conv1_mfma_kernel)
     std::vector<void*> owned;
 };
 
@@ -1188,6 +1257,33 @@ int fcgf_load(FcgfNet** out, const yoho_fcgf_config* cfg, const float* const* t,
         }
     }
     if (rc) return fail(rc);
+    if (use16 && n->in_ch == 1 && C[1] == 32 && n->k1 <= 7) {
+        // weight planes of the first convolution in the order conv1_mfma_kernel walks: step s, lane half kg -> (y, z) line
+        // 2 s + kg, element e -> x offset e (zero for e >= k1 and for the line past the end)
+        const float* w = t[0];                                       // (k1^3, 1, 32), kernel index x fastest
+        const int k1 = n->k1, kv = k1 * k1 * k1, nsteps = (k1 * k1 + 1) / 2;
+        float wmax = 0.f;
+        for (int i = 0; i < kv * 32; ++i) wmax = std::fmax(wmax, std::fabs(w[i]));
+        int ex = 0;
+        if (wmax > 0.f && std::isfinite(wmax)) (void)std::frexp(wmax, &ex);
+        const float wscale = std::ldexp(1.f, 10 - ex);
+        n->c1descale = 1.f / wscale;
+        std::vector<unsigned short> pl((size_t)nsteps * 2 * 64 * 8, 0);
+        for (int st = 0; st < nsteps; ++st)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int line = 2 * st + (lane >> 5), ch = lane & 31;
+                if (line >= k1 * k1) continue;
+                for (int e = 0; e < k1; ++e) {
+                    const float x = w[((size_t)line * k1 + e) * 32 + ch] * wscale;          // line = z * k1 + y
+                    const _Float16 hi = (_Float16)x;
+                    pl[(((size_t)st * 2 + 0) * 64 + lane) * 8 + e] = f16bits(x);
+                    pl[(((size_t)st * 2 + 1) * 64 + lane) * 8 + e] = f16bits(x - (float)hi);
+                }
+            }
+        HIPCHK(hipMalloc(&n->c1planes, pl.size() * 2));
+        n->owned.push_back(n->c1planes);
+        HIPCHK(hipMemcpy(n->c1planes, pl.data(), pl.size() * 2, hipMemcpyHostToDevice));
+    }
     if ((rc = up_conv(n, t[ti], 1, C[1] + T[2], T[1], &n->conv1_tr, use16))) return fail(rc);
     ti += 1;
     if ((rc = up_conv(n, t[ti], 1, T[1], n->out_ch, &n->final_k, use16))) return fail(rc);
@@ -1274,7 +1370,7 @@ int fcgf_forward(yoho_ctx* ctx, const FcgfNet* net, const int* coords0, int n0, 
         hipLaunchKernelGGL(coords4_kernel, dim3((n0 + 255) / 256), dim3(256), 0, s, coords0, n0, doff, nb, L[0].coords);
     }
     int* operm = nullptr;                          // internal level-0 row -> caller's row (null: same order)
-    if (ctx->fcgf_cell_sort) {
+    if (ctx->fcgf_cell_sort > 1 || (ctx->fcgf_cell_sort == 1 && n0 >= CELL_SORT_MIN_ROWS)) {
         const int ncell = nb * CELL_PER_CLOUD, nblk = ncell / 1024;
         int* cnt = ar.take<int>((size_t)2 * ncell);            // histogram -> in-block prefix | cursors
         int* btot = ar.take<int>(nblk + 1);
@@ -1353,6 +1449,7 @@ int fcgf_forward(yoho_ctx* ctx, const FcgfNet* net, const int* coords0, int n0, 
     BmDesc hdesc[64];
     BmDesc* ddesc = nullptr;
     unsigned* dbm = nullptr;
+    long long dbm_words = 0;
     if (conv1_fused) {
         const int hk = net->k1 / 2;
         long long words = 0;
@@ -1368,9 +1465,10 @@ int fcgf_forward(yoho_ctx* ctx, const FcgfNet* net, const int* coords0, int n0, 
             words += wx * dy * dz;
         }
         if (ok && words > 0 && ar.off + (size_t)words * 4 + 8192 < ar.cap) {
-            dbm = ar.take<unsigned>((size_t)words);
+            dbm_words = words;
+            dbm = ar.take<unsigned>((size_t)words + 2);            // + spare words: conv1_mfma_kernel reads word pairs
             ddesc = reinterpret_cast<BmDesc*>(ar.take<char>(sizeof(BmDesc) * 64));
-            HIPCHK(hipMemsetAsync(dbm, 0, (size_t)words * 4, s));
+            HIPCHK(hipMemsetAsync(dbm, 0, ((size_t)words + 2) * 4, s));
             HIPCHK(hipMemcpyAsync(ddesc, hdesc, sizeof(BmDesc) * nb, hipMemcpyHostToDevice, s));
             hipLaunchKernelGGL(bitmap_fill_kernel, dim3((n0 + 255) / 256), dim3(256), 0, s, L[0].coords, n0, ddesc, dbm);
             HIPCHK(hipStreamSynchronize(s));                  // hdesc lives on this frame
@@ -1430,7 +1528,10 @@ int fcgf_forward(yoho_ctx* ctx, const FcgfNet* net, const int* coords0, int n0, 
     // encoder (resunet.py:142-160).  The block outputs land in the decoder's concatenation buffers (right-hand columns).
     const int k1v = net->k1 * net->k1 * net->k1;
     if (conv1_fused) {
-        if (dbm)
+        if (dbm && net->c1planes)
+            hipLaunchKernelGGL(conv1_mfma_kernel, dim3(std::min((n0 + 127) / 128, 3 * (ctx->nCU > 0 ? ctx->nCU : 256))), dim3(256), 0, s, L[0].coords, n0, ddesc, dbm,
+                               dbm + dbm_words, net->k1, reinterpret_cast<const uintx4s*>(net->c1planes), net->c1descale, net->norm[0].s, net->norm[0].t, x[0]);
+        else if (dbm)
             hipLaunchKernelGGL(conv1_bitmap_kernel, dim3(std::min((n0 + 7) / 8, 3 * (ctx->nCU > 0 ? ctx->nCU : 256))), dim3(256), 0, s, L[0].coords, n0, ddesc, dbm, net->k1, net->conv[0].w,
                                net->norm[0].s, net->norm[0].t, x[0]);
         else

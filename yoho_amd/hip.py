@@ -575,10 +575,11 @@ class Context:
         """mutual_nn on large sets through the MFMA pre-filter (default) or by brute force; identical match lists"""
         _check(self._lib.yoho_set_nn_prefilter(self._h, 1 if on else 0))
 
-    def set_fcgf_sort(self, parity=True, cells=True):
-        """internal row orders of the FCGF backbone: transposed convolutions over parity-sorted rows, level-0 rows grouped by
-        8^3-voxel cell (both default on; identical outputs in the caller's row order either way)"""
-        _check(self._lib.yoho_set_fcgf_sort(self._h, 1 if parity else 0, 1 if cells else 0))
+    def set_fcgf_sort(self, parity=True, cells=1):
+        """internal row orders of the FCGF backbone: transposed convolutions over parity-sorted rows (default on), level-0 rows
+        grouped by 8^3-voxel cell (0 never, 1 = default: passes of >= 2^18 voxels, 2 always); identical outputs in the
+        caller's row order either way"""
+        _check(self._lib.yoho_set_fcgf_sort(self._h, 1 if parity else 0, int(cells)))
 
     def set_nn_grid(self, cell):
         """3-D nearest-neighbour searches (nn_search with 3 columns, group_gather) through a hash grid with this cell size
