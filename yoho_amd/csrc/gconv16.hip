@@ -193,8 +193,7 @@ __global__ __launch_bounds__(256, 1) void gconv16_kernel(Conv16Args a, int flags
         for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
 
     const char* Xt = a.X + (size_t)tile * a.cin8 * CHB;
-    const int total = a.cin8 * NTP;
-    const uintx4* Wb = reinterpret_cast<const uintx4*>(a.Wp) + (size_t)ob * total * (64 * NPL) + lane;   // NPL planes x 64 lanes per step
+    const uintx4* Wb = reinterpret_cast<const uintx4*>(a.Wp) + (size_t)ob * a.cin8 * NTP * (64 * NPL) + lane;   // NPL planes x 64 lanes per step
 
     const int laneoff = (lane & 15) * 16;
 
@@ -213,9 +212,13 @@ __global__ __launch_bounds__(256, 1) void gconv16_kernel(Conv16Args a, int flags
     const int* tabl = tab + cls;
 
     stage_chunk16<NPL>(Xt, smem, w, lane);
-    uintx4 wn[3];
+    // A planes (weights) run a whole channel chunk ahead: ring slot tp holds tap pair tp of the current chunk and is
+    // refilled with the next chunk's right after use, 7 steps (~2 us of MFMAs) before it is needed - an L2 / MALL round trip
+    uintx4 wr[NTP][NPL];
 #pragma unroll
-    for (int pl = 0; pl < NPL; ++pl) wn[pl] = Wb[64 * pl];
+    for (int tp = 0; tp < NTP; ++tp)
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) wr[tp][pl] = Wb[(size_t)tp * (64 * NPL) + 64 * pl];
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -223,19 +226,19 @@ __global__ __launch_bounds__(256, 1) void gconv16_kernel(Conv16Args a, int flags
 #pragma unroll
     for (int j = 0; j < UPW; ++j) soff[j] = tabl[j * 4];
 
-    int it = 0;
     for (int c8 = 0; c8 < a.cin8; ++c8) {
-        if (c8 + 1 < a.cin8) stage_chunk16<NPL>(Xt + (size_t)(c8 + 1) * CHB, smem + ((c8 + 1) & 1) * CHB, w, lane);
+        const bool more = c8 + 1 < a.cin8;
+        if (more) stage_chunk16<NPL>(Xt + (size_t)(c8 + 1) * CHB, smem + ((c8 + 1) & 1) * CHB, w, lane);
         const char* xb = smem + (c8 & 1) * CHB + laneoff;
-        for (int tp = 0; tp < NTP; ++tp) {
+        static_for<0, NTP>([&](auto tpc) {
+            constexpr int tp = decltype(tpc)::value;
             uintx4 wa[3];                                            // A planes of this tap pair: [0] = hi .. [NPL-1] = lo
 #pragma unroll
-            for (int pl = 0; pl < NPL; ++pl) wa[pl] = wn[pl];
-            ++it;
-            if (it < total) {
-                const uintx4* wp = Wb + (size_t)it * (64 * NPL);
+            for (int pl = 0; pl < NPL; ++pl) wa[pl] = wr[tp][pl];
+            if (more) {
+                const uintx4* wp = Wb + ((size_t)(c8 + 1) * NTP + tp) * (64 * NPL);
 #pragma unroll
-                for (int pl = 0; pl < NPL; ++pl) wn[pl] = wp[64 * pl];
+                for (int pl = 0; pl < NPL; ++pl) wr[tp][pl] = wp[64 * pl];
             }
             const int* tabn = tabl + (tp + 1) * (UPW * 4);          // offsets of the next tap pair (tp 7 == tp 0)
             int soffn[UPW];
@@ -279,8 +282,14 @@ __global__ __launch_bounds__(256, 1) void gconv16_kernel(Conv16Args a, int flags
             });
 #pragma unroll
             for (int j = 0; j < UPW; ++j) soff[j] = soffn[j];
+        });
+        // the next chunk's DMA (issued first) must have landed; the 7 x NPL weight loads issued after it may stay in flight
+        if (more) {
+            if constexpr (NPL == 3) asm volatile("s_waitcnt vmcnt(21)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
 
