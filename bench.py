@@ -265,8 +265,14 @@ def main():
             add(f"gft16_kernel<ACTP> {ch}ch", conv_ms[i], 2 * coef(ch), "fp32 coefficients in, BN+ReLU in the group domain, fp16x2 operand planes out")
         add("gft16_kernel<INV>", conv_ms[10], 2 * coef(32), "fp32 coefficients in, group-domain fp32 out")
         add("finalize_partI_kernel", conv_ms[11], 3 * coef(32) + 128 * nkp, "y + x in, eqv + inv_np out")
-    add("nn32seg + mutual_compact (both directions)", nn_ms, 4 * KP * 128 + 16 * M,
-        "vector-fp32-bound, not HBM-bound: 2 x 5000 x 5000 x 32 x 3 flop = %.1f TFLOP/s of the 157.3 fp32 peak" % (2 * KP * KP * 32 * 3 / (nn_ms * 1e-3) / 1e12))
+    if os.environ.get("YOHO_NN") == "brute":
+        add("nn32seg + mutual_compact (both directions, brute force)", nn_ms, 4 * KP * 128 + 16 * M,
+            "vector-fp32-bound, not HBM-bound: 2 x 5000 x 5000 x 32 x 3 flop = %.1f TFLOP/s of the 157.3 fp32 peak" % (2 * KP * KP * 32 * 3 / (nn_ms * 1e-3) / 1e12))
+    else:
+        add("mutual NN: mf_norms + 2 x mf_gram (fp16-MFMA Gram pre-filter, exact fp32 distance of the candidates in the error band) + mutual_compact",
+            nn_ms, 4 * KP * 128 + 16 * M,
+            "latency / issue-bound, not HBM-bound: the %d x %d Gram matrix is formed twice on the matrix cores (row minima, then candidates), "
+            "%.1f us per pass; brute force (YOHO_NN=brute) evaluates 2 x 5000 x 5000 explicit differences on the vector pipes" % (KP, KP, nn_ms * 500))
     add("des2r_kernel", des_ms, M * (2 * 7680 + 8), "two (32,60) descriptors per match in, index out")
 
     if rank == 0:
