@@ -31,6 +31,8 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 constexpr int GB = 65536;                       // one chunk buffer: 64 rows x 1 KiB (rows 60..63 stay zero)
 constexpr int G16_LDS = 2 * GB + 1024;          // + per-coefficient output offsets
+constexpr int G16X_MAXC = 512;                  // gft16x keeps the BN scale / shift of every channel in LDS
+constexpr int G16X_LDS = G16_LDS + 2 * G16X_MAXC * 4;
 constexpr float F_SCALE = 1024.f;               // |F| <= sqrt(5/60): planes of F * 2^10
 
 struct Gft16Args {
@@ -347,6 +349,10 @@ __global__ __launch_bounds__(512, 2) void gft16x_kernel(Gft16Args a) {
     long long* qb = reinterpret_cast<long long*>(smem + 2 * GB);
     int* qs = reinterpret_cast<int*>(smem + 2 * GB + 512);
     if (tid < G) { qb[tid] = a.qbase[tid]; qs[tid] = a.qstride[tid]; }
+    // BN scale / shift of all channels in LDS: an ordinary global load inside the loop would make the compiler drain the
+    // vector-memory counter (vmcnt(0)) at its use - with it the LDS DMA of the next chunk and the stores of the last one
+    float* bnl = reinterpret_cast<float*>(smem + G16_LDS);
+    for (int i = tid; i < a.C8 * 8; i += 512) { bnl[i] = a.bn_s[i]; bnl[G16X_MAXC + i] = a.bn_t[i]; }
 
     uintx4 A1[2][4][2], A2[2][4][2];
 #pragma unroll
@@ -358,6 +364,13 @@ __global__ __launch_bounds__(512, 2) void gft16x_kernel(Gft16Args a) {
                 A1[rb][kb][pl] = a.Ffrag[(((0 * 2 + rb) * 4 + kb) * 2 + pl) * 64 + lane];
                 A2[rb][kb][pl] = a.Ffrag[(((1 * 2 + rb) * 4 + kb) * 2 + pl) * 64 + lane];
             }
+    // workgroup barrier that does not touch the vector-memory counter (__syncthreads() would wait vmcnt(0) while an LDS DMA
+    // is pending): LDS traffic of this wave drained, then the raw barrier
+    auto lds_barrier = [] {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
     auto stage = [&](int chunk, char* dst) {
         const int c8 = chunk % a.C8, tile32 = chunk / a.C8;
         const char* src = reinterpret_cast<const char*>(a.in) + ((size_t)tile32 * G * a.C8 + c8) * 1024;
@@ -368,10 +381,18 @@ __global__ __launch_bounds__(512, 2) void gft16x_kernel(Gft16Args a) {
     unsigned top = 0u;
     int chunk = blockIdx.x;
     if (chunk < a.nChunks) stage(chunk, smem);
+    // first chunk, tables, transform fragments: a wait the compiler's own scoreboard sees (vmcnt(0) expcnt(7) lgkmcnt(15)) - behind
+    // an opaque asm wait it would put a vmcnt(0) in front of the first use of the fragments, inside the loop
+    __builtin_amdgcn_s_waitcnt(0x0F70);
     for (int it = 0; chunk < a.nChunks; chunk += gridDim.x, ++it) {
         char* cur = smem + (it & 1) * GB;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        // vector-memory operations complete in issue order: behind this chunk's DMA (issued one iteration ago) are only the
+        // plane stores of the previous chunk - 8 per thread in waves 0-3, 7 in waves 4-7 - which may stay in flight
+        if (it > 0) {
+            if (w8 < 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+        }
+        lds_barrier();
         const int next = chunk + gridDim.x;
         if (next < a.nChunks) stage(next, smem + ((it + 1) & 1) * GB);
         const int c8 = chunk % a.C8, tile32 = chunk / a.C8;
@@ -405,7 +426,7 @@ __global__ __launch_bounds__(512, 2) void gft16x_kernel(Gft16Args a) {
         // ---- BN + ReLU in registers, product 2: coefficients = F * activated (K order of A2 = accumulator register order)
         const int ch = c8 * 8 + hsel * 4 + e;
         const float dscale1 = 1.f / (F_SCALE * HF_ASCALE);
-        const float sc = a.bn_s[ch] * dscale1 * H2_ASCALE, sh = a.bn_t[ch] * H2_ASCALE;
+        const float sc = bnl[ch] * dscale1 * H2_ASCALE, sh = bnl[G16X_MAXC + ch] * H2_ASCALE;
         floatx16 acc2[2];
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb)
@@ -430,7 +451,7 @@ __global__ __launch_bounds__(512, 2) void gft16x_kernel(Gft16Args a) {
         }
         // ---- output planes through the staging image [plane][q][h][kp 32][4 ch] fp16 (in the chunk buffer just consumed)
         const float osc = HF_ASCALE / (F_SCALE * H2_ASCALE);
-        __syncthreads();                                   // every wave is done reading the coefficients of this buffer
+        lds_barrier();                                     // every wave is done reading the coefficients of this buffer
         char* st = cur + hsel * 256 + kp * 8 + e * 2;
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb)
@@ -445,7 +466,7 @@ __global__ __launch_bounds__(512, 2) void gft16x_kernel(Gft16Args a) {
                     *reinterpret_cast<unsigned short*>(st + 30720 + q * 512) = (unsigned short)half_of(x - (float)hh);
                 }
             }
-        __syncthreads();
+        lds_barrier();
         char* dst0 = a.planes + (size_t)(c8 >> 2) * 32768 + (c8 & 3) * 4096 + (tile32 & 7) * 512;
         const int nt = tile32 >> 3;
 #pragma unroll
@@ -455,8 +476,11 @@ __global__ __launch_bounds__(512, 2) void gft16x_kernel(Gft16Args a) {
                 const int pl = idx >= 1920 ? 1 : 0, rem = idx - pl * 1920;
                 const int q = rem >> 5, kpp = rem & 31;
                 const char* sp = cur + pl * 30720 + q * 512 + kpp * 8;
-                const uint2 c03 = *reinterpret_cast<const uint2*>(sp);
-                const uint2 c47 = *reinterpret_cast<const uint2*>(sp + 256);
+                // read through asm: in front of a C++ LDS load the compiler waits for every pending LDS DMA - a vmcnt(0) that
+                // would also drain the next chunk's DMA issued at the top of this iteration
+                uint2 c03, c47;
+                asm volatile("ds_read_b64 %0, %2\n\tds_read_b64 %1, %2 offset:256\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&v"(c03), "=&v"(c47) : "v"((unsigned)(size_t)sp) : "memory");
                 *reinterpret_cast<uintx4*>(dst0 + qb[q] + (long long)nt * qs[q] + kpp * 16 + pl * 16384) = uintx4{c03.x, c03.y, c47.x, c47.y};
             }
         }
@@ -506,7 +530,7 @@ int gft16_init() {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gft16_kernel<G16_ACTP>), hipFuncAttributeMaxDynamicSharedMemorySize, G16_LDS));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gft16_kernel<G16_INV>), hipFuncAttributeMaxDynamicSharedMemorySize, G16_LDS));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gft16_kernel<G16_INVP>), hipFuncAttributeMaxDynamicSharedMemorySize, G16_LDS));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gft16x_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, G16_LDS));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gft16x_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, G16X_LDS));
     return 0;
 }
 
@@ -539,7 +563,7 @@ int launch_gft16(const float* in, float* out32, char* planes, int kppad, const v
     }
     const int grid = a.nChunks < nCU ? a.nChunks : nCU;
     if (grid == 0) return 0;
-    if (planes && variant != 1) hipLaunchKernelGGL(gft16x_kernel, dim3(grid), dim3(512), G16_LDS, s, a);       // two waves per SIMD
+    if (planes && variant != 1 && a.C8 * 8 <= G16X_MAXC) hipLaunchKernelGGL(gft16x_kernel, dim3(grid), dim3(512), G16X_LDS, s, a);       // two waves per SIMD
     else if (planes) hipLaunchKernelGGL(gft16_kernel<G16_ACTP>, dim3(grid), dim3(256), G16_LDS, s, a);
     else if (bn_s) hipLaunchKernelGGL(gft16_kernel<G16_ACT32>, dim3(grid), dim3(256), G16_LDS, s, a);
     else hipLaunchKernelGGL(gft16_kernel<G16_INV>, dim3(grid), dim3(256), G16_LDS, s, a);
