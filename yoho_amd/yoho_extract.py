@@ -14,6 +14,8 @@ Differences from the reference (all deliberate):
     (:37) and would index the features with distances;
   * any number of keypoints works (no "avoid B == 1" last-batch merge needed, :55-58).
 """
+import os
+
 import numpy as np
 import torch
 
@@ -36,6 +38,7 @@ class yoho_extractor():
         self._load_model()
         self.bs = 500
         self.rot_batch = 15            # rotated copies of the cloud per backbone pass (HBM-resident path; split further by voxel count)
+        self.overlap_keypoint_draw = os.environ.get("YOHO_OVERLAP_DRAW", "1") != "0"   # keypoint permutation drawn while the first backbone pass runs
 
     def _load_model(self):
         sd = self.yoho_ckpt if isinstance(self.yoho_ckpt, dict) else W.load_checkpoint(self.yoho_ckpt)[0]
@@ -56,9 +59,44 @@ class yoho_extractor():
         dist, idx = self.ctx.nn_search(q, s, want_dist=False, squared=True)
         return f[idx]
 
+    def _transfer(self, res, pc_d, Rs, kidx_d, g0, kpts_f):
+        """NN feature transfer of one backbone pass: kpts_f[:, :, g0 + j] = F_j[nn(R_j keypoints, down-sampled points of copy j)]"""
+        for j, (sel, pci_f, ds) in enumerate(res):
+            q = self.ctx.rotate_select(pc_d, Rs[j], kidx_d)
+            _, idx = self.ctx.nn_search(q, ds, want_dist=False, squared=True)
+            self.ctx.group_scatter(pci_f, idx, g0 + j, kpts_f)
+
+    def _extract_features_overlapped(self, pc, voxel_size, nkpts):
+        """extract_features' HBM-resident path with the keypoint draw off the critical path.  The reference's
+        np.random.permutation(len(pc))[0:nkpts] on the global generator costs 5 ms of host time for 300 k points, and nothing on
+        the device depends on it until the first NN transfer: it is taken after the first backbone pass has been queued (the
+        library call returns once the last level size is known, with most of the pass still running on the device), so the
+        device works while the host shuffles.  It is the only draw in this method, so the generator is consumed exactly as in
+        the reference (same keypoints for the same seed)."""
+        pc_d = torch.from_numpy(np.ascontiguousarray(np.asarray(pc, dtype=np.float64))).cuda()
+        G, nb = self.grs.shape[0], self.rot_batch
+        batches = [[self.grs[i] for i in range(i0, min(i0 + nb, G))] for i0 in range(0, G, nb)]
+        first = self.fcgf.extract_rotated_batch(pc_d, batches[0], voxel_size)
+        kpts_index = np.random.permutation(len(pc))[0:nkpts]
+        kpts = pc[kpts_index]
+        kpts_f = torch.empty((kpts.shape[0], 32, 60), dtype=torch.float32, device="cuda")
+        kidx_d = torch.from_numpy(kpts_index.astype(np.int64)).cuda()
+        self.ctx.set_nn_grid(voxel_size)           # the NN targets are one point per voxel: grid search, same winners
+        try:
+            for b, Rs in enumerate(batches):
+                res = first if b == 0 else self.fcgf.extract_rotated_batch(pc_d, Rs, voxel_size)
+                self._transfer(res, pc_d, Rs, kidx_d, b * nb, kpts_f)
+        finally:
+            self.ctx.set_nn_grid(0)
+        self._last_group_feats = kpts_f
+        out = self._partI(kpts_f)
+        return kpts, out["inv"].cpu(), out["eqv"].cpu()
+
     def extract_features(self, pc, voxel_size, nkpts=5000):
         if self.fcgf is None:
             raise NotImplementedError("no FCGF backbone: pass fcgf_ckpt=<FCGF checkpoint> or fcgf=<object with run(pc, voxel_size)>")
+        if hasattr(self.fcgf, "extract_features_dev") and hasattr(self.fcgf, "extract_rotated_batch") and self.overlap_keypoint_draw:
+            return self._extract_features_overlapped(pc, voxel_size, nkpts)
         kpts_index = np.random.permutation(len(pc))[0:nkpts]
         kpts = pc[kpts_index]
         kpts_f = torch.empty((kpts.shape[0], 32, 60), dtype=torch.float32, device="cuda")
@@ -75,10 +113,7 @@ class yoho_extractor():
                     if hasattr(self.fcgf, "extract_rotated_batch"):
                         # rotated copies never materialised: rotation + voxelisation + down-sampled points in one pass
                         res = self.fcgf.extract_rotated_batch(pc_d, Rs, voxel_size)
-                        for j, (sel, pci_f, ds) in enumerate(res):
-                            q = self.ctx.rotate_select(pc_d, Rs[j], kidx_d)
-                            _, idx = self.ctx.nn_search(q, ds, want_dist=False, squared=True)
-                            self.ctx.group_scatter(pci_f, idx, i0 + j, kpts_f)
+                        self._transfer(res, pc_d, Rs, kidx_d, i0, kpts_f)
                         continue
                     Rts = [torch.from_numpy(np.ascontiguousarray(R.T)).cuda() for R in Rs]
                     pcs = [pc_d @ Rt for Rt in Rts]
