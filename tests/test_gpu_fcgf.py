@@ -11,7 +11,7 @@ import fcgf_oracle as fo  # noqa: E402
 from yoho_amd import synth, weights as W  # noqa: E402
 
 pytestmark = pytest.mark.gpu
-TOL = 1e-4
+TOL = 1e-5        # measured 4e-7 .. 1.1e-6 (fp16x2 split products, fp32 accumulation)
 
 
 def rel(a, b):
