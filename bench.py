@@ -40,22 +40,25 @@ FOURIER_EXEC_PER_ALG = 244.0 / 780.0      # slab products per 8-channel chunk: s
 FP16_MFMA_PEAK = 2500.0         # TFLOP/s dense (v_mfma_f32_32x32x16_f16, same rate as bf16)
 
 
-def fgemm_issued_flops(nkp):
-    """fp16 MFMA flops the four irrep-GEMM launches of one PartI pass over nkp keypoints issue, padding included:
-    per irrep (d = 1,3,3,4,5) an (M = ceil(d*Cout/256)*256) x (N = d*kppad) x (K = d*Cin) product, 3 split products."""
-    kppad = (nkp + 255) // 256 * 256
-    tot = 0
-    for cin, cout in ((32, 256), (256, 512), (512, 256), (256, 32)):
-        for d in (1, 3, 3, 4, 5):
-            m = (d * cout + 255) // 256 * 256
-            tot += 2 * 3 * m * (d * kppad) * (d * cin)
-    return tot
+def _issued_rows(d, cout, mode):
+    """MFMA rows the GEMM kernel of `mode` issues for an irrep of dimension d: the live rows are d * cout; 256 x 256 tiles issue
+    them in 128-row wave halves (a half made of padding only is skipped); the default mode's small-M kernel (fgemm3s, 32 output
+    channels) issues exactly the 32 d live rows."""
+    if mode == "fgemm" and cout == 32:
+        return 32 * d
+    return (d * cout + 127) // 128 * 128
 
 
-def fgemm_issued_flops_per_layer(nkp):
+def fgemm_issued_flops_per_layer(nkp, mode="fgemm"):
+    """fp16 MFMA flops each of the four irrep-GEMM launches of one PartI pass over nkp keypoints issues, padding included:
+    per irrep (d = 1,3,3,4,5) an (issued rows) x (N = d*kppad) x (K = d*Cin) product, 3 split products."""
     kppad = (nkp + 255) // 256 * 256
-    return [sum(2 * 3 * ((d * cout + 255) // 256 * 256) * (d * kppad) * (d * cin) for d in (1, 3, 3, 4, 5))
+    return [sum(2 * 3 * _issued_rows(d, cout, mode) * (d * kppad) * (d * cin) for d in (1, 3, 3, 4, 5))
             for cin, cout in ((32, 256), (256, 512), (512, 256), (256, 32))]
+
+
+def fgemm_issued_flops(nkp, mode="fgemm"):
+    return sum(fgemm_issued_flops_per_layer(nkp, mode))
 
 
 PMC_FILES = ("r02_pmc_traffic.json", "r01_pmc_traffic.json")     # newest first
@@ -301,14 +304,14 @@ def main():
                             "<= 3*2^-22 per product) issues 3.23 fp16 MFMA flops per algorithmic flop, so frac <= 0.31"}
             dtype = "fp16x2 split (2^-22-accurate products, fp32 accumulate)"
         elif args.gconv in ("fgemm", "fgemm256", "fgemm128"):
-            issued = fgemm_issued_flops(nkp) / (gconv_total_ms * 1e-3) / 1e12
+            issued = fgemm_issued_flops(nkp, args.gconv) / (gconv_total_ms * 1e-3) / 1e12
             roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP16_MFMA_PEAK, "unit": "TFLOP/s",
                     "frac": round(achieved / FP16_MFMA_PEAK, 4), "traffic": pmc_traffic(args.gconv)[0], "traffic_source": pmc_traffic(args.gconv)[1],
-                    "kernel": {"fgemm": "fgemm3_kernel", "fgemm128": "fgemm2_kernel", "fgemm256": "fgemm_kernel"}[args.gconv] +
+                    "kernel": {"fgemm": "fgemm3_kernel (fgemm3s_kernel for the 32-channel layer)", "fgemm128": "fgemm2_kernel", "fgemm256": "fgemm_kernel"}[args.gconv] +
                               " (4 launches = 4 PartI layers over both fragments, 4.345 algorithmic TFLOP per 10000 kp)",
                     "executed_tflops": round(issued, 1), "executed_frac": round(issued / FP16_MFMA_PEAK, 4),
                     "executed_frac_per_launch": [round(f / (ms * 1e-3) / 1e12 / FP16_MFMA_PEAK, 4)
-                                                 for f, ms in zip(fgemm_issued_flops_per_layer(nkp), conv_ms[:4])],
+                                                 for f, ms in zip(fgemm_issued_flops_per_layer(nkp, args.gconv), conv_ms[:4])],
                     "conv_total_frac": round(FLOP_PER_KP * nkp / (conv_total_ms * 1e-3) / 1e12 / FP16_MFMA_PEAK, 4),
                     "conv_total_ms": round(conv_total_ms, 3),
                     "note": "achieved = algorithmic FLOP/s of the reference's direct 13-tap formulation (SURVEY 8d) over the 4 "

@@ -492,8 +492,181 @@ __global__ __launch_bounds__(512, 2) void fgemm3_kernel(FGemmArgs a, int flags) 
     note_range_bits(a.rflag, top, FP16_MAX / HF_ASCALE);     // the consumer multiplies by HF_ASCALE and converts to fp16
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// fgemm3s: fgemm3's staging and K loop for layers with 32 output channels (32 d <= 160 live rows of the 256-row A tile).  In
+// fgemm3 the waves are arranged 2 (rows) x 4 (columns): the lower row half is padding, so half the waves - two of the four
+// SIMDs - idle and the other two issue 24 MFMAs per step on 128 rows of which 32 d are real.  Here the eight waves split the
+// 256 columns (32 each) and every wave holds the d live 32-row tiles: 3 d MFMAs per wave and step on all four SIMDs, the same
+// products in the same order per accumulator (bit-identical coefficients).
+// ---------------------------------------------------------------------------------------------------------------
+struct Frags3s {
+    uintx4 ah[5], al[5], bh, bl;
+};
+
+// fragment read R (0..11) of a step, in the order of use: A lo x5, B hi, A hi x5, B lo
+template <int R>
+__device__ __forceinline__ void read_frag3s(const char* pa, const char* pb, Frags3s& f) {
+    if constexpr (R < 5) f.al[R] = *reinterpret_cast<const uintx4*>(pa + 8192 + R * 512);
+    else if constexpr (R == 5) f.bh = *reinterpret_cast<const uintx4*>(pb);
+    else if constexpr (R < 11) f.ah[R - 6] = *reinterpret_cast<const uintx4*>(pa + (R - 6) * 512);
+    else f.bl = *reinterpret_cast<const uintx4*>(pb + 8192);
+}
+
+// One K16 step: 3 d MFMAs on `f` (lo.hi, hi.lo, hi.hi per accumulator, as fgemm3); behind them the 12 fragment reads of the next
+// step (rows beyond 32 d are padding: read, never used) and the wave's four DMA pieces of the step three ahead.
+template <bool DMA, int D>
+__device__ __forceinline__ void step3s(const Frags3s& f, floatx16 (&acc)[5], const char* ra, const char* rb, Frags3s& nf,
+                                       const char* srcA, const char* srcB, char* dmabuf, int la, int ldst) {
+    sfor<0, 5>([&](auto gc) {
+        constexpr int g = decltype(gc)::value;
+        if constexpr (g < D) acc[g] = mfma_h(f.al[g], f.bh, acc[g]);
+        if constexpr (g < D) read_frag3s<g>(ra, rb, nf);
+        if constexpr (g == 4) read_frag3s<5>(ra, rb, nf);
+        __builtin_amdgcn_sched_barrier(0);
+    });
+    sfor<0, 5>([&](auto gc) {
+        constexpr int g = decltype(gc)::value;
+        if constexpr (g < D) acc[g] = mfma_h(f.ah[g], f.bl, acc[g]);
+        if constexpr (g < D) read_frag3s<6 + g>(ra, rb, nf);
+        if constexpr (g == 4) read_frag3s<11>(ra, rb, nf);
+        __builtin_amdgcn_sched_barrier(0);
+    });
+    sfor<0, 5>([&](auto gc) {
+        constexpr int g = decltype(gc)::value;
+        if constexpr (g < D) acc[g] = mfma_h(f.ah[g], f.bh, acc[g]);
+        if constexpr (DMA && g < 4) dma_piece3<g>(srcA, srcB, dmabuf, la, ldst);
+        __builtin_amdgcn_sched_barrier(0);
+    });
+}
+
+// K loop of fgemm3s for an irrep of dimension D (compile time: no branches around the MFMAs, no reads of padding rows)
+template <int D>
+__device__ __forceinline__ void fgemm3s_kloop(floatx16 (&acc)[5], char* smem, const char* Ag, const char* Bg, int KT, int la, int ldst,
+                                              int lane_a, int lane_b) {
+    Frags3s P, Q;
+    sfor<0, 12>([&](auto rc) {
+        constexpr int R = decltype(rc)::value;
+        if constexpr (R == 5 || R == 11 || (R < 5 && R < D) || (R > 5 && R < 11 && R - 6 < D)) read_frag3s<R>(smem + lane_a, smem + lane_b, P);
+    });
+    int cur = 0, nxt = F3_BUF;                   // ring offsets: step s lives in buffer s % 3
+    int s = 0;
+    auto advance = [&]() { cur = nxt; nxt = nxt == 2 * F3_BUF ? 0 : nxt + F3_BUF; ++s; };
+    auto sync4 = [] {
+        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto sync0 = [] {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // main loop: both steps of a pair still have a DMA to issue (s + 4 < KT)
+    while (s + 4 < KT) {
+        step3s<true, D>(P, acc, smem + nxt + lane_a, smem + nxt + lane_b, Q, uniform_ptr(Ag + step_off(s + 3)), uniform_ptr(Bg + step_off(s + 3)),
+                     smem + cur, la, ldst);
+        sync4();
+        advance();
+        step3s<true, D>(Q, acc, smem + nxt + lane_a, smem + nxt + lane_b, P, uniform_ptr(Ag + step_off(s + 3)), uniform_ptr(Bg + step_off(s + 3)),
+                     smem + cur, la, ldst);
+        sync4();
+        advance();
+    }
+    // tail: the last four steps (two if KT == 2); only the first of them still has a DMA (step KT - 1) to issue
+    if (KT >= 4) {
+        step3s<true, D>(P, acc, smem + nxt + lane_a, smem + nxt + lane_b, Q, uniform_ptr(Ag + step_off(s + 3)), uniform_ptr(Bg + step_off(s + 3)),
+                     smem + cur, la, ldst);
+        sync4();
+        advance();
+        step3s<false, D>(Q, acc, smem + nxt + lane_a, smem + nxt + lane_b, P, nullptr, nullptr, nullptr, la, ldst);
+        sync0();
+        advance();
+    }
+    step3s<false, D>(P, acc, smem + nxt + lane_a, smem + nxt + lane_b, Q, nullptr, nullptr, nullptr, la, ldst);
+    sync0();
+    advance();
+    // last step: its "next" fragments are read from a buffer that holds valid (unused) data
+    step3s<false, D>(Q, acc, smem + cur + lane_a, smem + cur + lane_b, P, nullptr, nullptr, nullptr, la, ldst);
+
+}
+
+__global__ __launch_bounds__(512, 2) void fgemm3s_kernel(FGemmArgs a, int flags) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int t = 0, local = 0, r = 0;
+    if (!fg3_map(a, blockIdx.x & 7, blockIdx.x >> 3, t, local, r)) return;
+    const int d = a.dim[t], qbase = a.qbase[t];
+    const int KS = d * a.cin / 32, KT = 2 * KS;                        // MT = 1: the tile holds all 32 d rows
+    const int ntile = r + 8 * local;
+    const char* Ag = a.A + a.a_off[t];
+    const char* Bg = a.B + a.b_off[t] + (size_t)ntile * KS * FG_STAGE;
+    const int wkg = w8 >> 2, wcb = w8 & 3;                               // this wave's DMA pieces: k-group, 64-row / 64-column block
+    const int la = wkg * 4096 + wcb * 1024 + lane * 16;
+    const int ldst = wkg * 4096 + wcb * 1024;
+
+    floatx16 acc[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+
+    const int lane_a = (lane >> 5) * 4096 + (lane & 31) * 16;
+    const int lane_b = 16384 + (lane >> 5) * 4096 + (w8 * 32 + (lane & 31)) * 16;
+
+    auto dma = [&](int st, char* buf) {
+        const char* sa = uniform_ptr(Ag + step_off(st));
+        const char* sb = uniform_ptr(Bg + step_off(st));
+        sfor<0, 4>([&](auto uc) { dma_piece3<decltype(uc)::value>(sa, sb, buf, la, ldst); });
+    };
+    dma(0, smem);
+    dma(1, smem + F3_BUF);
+    if (KT > 2) dma(2, smem + 2 * F3_BUF);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    switch (d) {
+        case 1: fgemm3s_kloop<1>(acc, smem, Ag, Bg, KT, la, ldst, lane_a, lane_b); break;
+        case 3: fgemm3s_kloop<3>(acc, smem, Ag, Bg, KT, la, ldst, lane_a, lane_b); break;
+        case 4: fgemm3s_kloop<4>(acc, smem, Ag, Bg, KT, la, ldst, lane_a, lane_b); break;
+        default: fgemm3s_kloop<5>(acc, smem, Ag, Bg, KT, la, ldst, lane_a, lane_b); break;
+    }
+
+    // ---- epilogue: D[row][col]: lane (col = lane & 31, half = lane >> 5), reg e -> row = (e & 3) + 8 * (e >> 2) + 4 * half
+    const int half = lane >> 5, kp32 = lane & 31;
+    const int cout8 = a.cout >> 3;                                       // = 4: row tile ai is coefficient row i = ai
+    const bool addb = (d == 1);                                          // trivial irrep: coefficient 0 carries sqrt(60) * bias
+    const int colbase = ntile * 256 + w8 * 32;
+    const int jidx = colbase / a.kppad, kp0 = colbase - jidx * a.kppad;
+    const int tile32 = kp0 >> 5;
+    unsigned top = 0u;
+    if (tile32 < a.nT32) {
+#pragma unroll
+        for (int ai = 0; ai < 5; ++ai) {
+            if (ai >= d) continue;
+            const int q = qbase + ai * d + jidx;
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const int o = q4 * 8 + half * 4;
+                floatx4 val;
+                val.x = acc[ai][4 * q4 + 0]; val.y = acc[ai][4 * q4 + 1];
+                val.z = acc[ai][4 * q4 + 2]; val.w = acc[ai][4 * q4 + 3];
+                val *= a.descale;
+                if (addb) val += *reinterpret_cast<const floatx4*>(a.bias + o) * 7.745966692414834f;
+                const size_t off = (((((size_t)tile32 * G + q) * cout8 + (o >> 3)) * 2 + half) * TILE + kp32) * 4;
+                if (!(flags & F2_NOSTORE)) *reinterpret_cast<floatx4*>(a.out + off) = val;
+                top = max(max(top, __float_as_uint(val.x) & 0x7FFFFFFFu), __float_as_uint(val.y) & 0x7FFFFFFFu);
+                top = max(max(top, __float_as_uint(val.z) & 0x7FFFFFFFu), __float_as_uint(val.w) & 0x7FFFFFFFu);
+            }
+        }
+    }
+    note_range_bits(a.rflag, top, FP16_MAX / HF_ASCALE);
+}
+
 int fgemm3_init() {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&fgemm3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, F3_LDS));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&fgemm3s_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, F3_LDS));
     return 0;
 }
 
@@ -511,7 +684,10 @@ int launch_fgemm3(const FGemmArgs& a, int flags, hipStream_t s) {
         tot = n > tot ? n : tot;
     }
     tot *= 8;
-    hipLaunchKernelGGL(fgemm3_kernel, dim3(tot), dim3(512), F3_LDS, s, a, flags);
+    // 32 output channels, no residual: all 32 d live rows in every wave (fgemm3s); YOHO_FGEMM_DEBUG=nosmall keeps fgemm3
+    static const bool small_ok = [] { const char* e = std::getenv("YOHO_FGEMM_DEBUG"); return !(e && std::strstr(e, "nosmall")); }();
+    if (small_ok && a.cout == 32 && !(flags & EPI_RES)) hipLaunchKernelGGL(fgemm3s_kernel, dim3(tot), dim3(512), F3_LDS, s, a, flags);
+    else hipLaunchKernelGGL(fgemm3_kernel, dim3(tot), dim3(512), F3_LDS, s, a, flags);
     HIPCHK(hipGetLastError());
     return 0;
 }
