@@ -139,6 +139,21 @@ def test_other_model_configs_and_tiny_clouds(hip):
         hip.Context().fcgf_forward(torch.zeros((4, 3), dtype=torch.int32, device="cuda"))      # weights not loaded
 
 
+def test_fp16x2_kernels_against_the_fp32_mfma_variant(hip, fsd, monkeypatch):
+    """YOHO_FCGF=f32 (fp32-MFMA sparse convolutions, exact per-bit first convolution; read when the weights are loaded) against
+    the default fp16x2 kernels with the first convolution as an MFMA product over the occupancy bits"""
+    coords = torch.from_numpy(fo.voxelize(synth.surface_cloud(5000, seed=11), 0.025)[1]).cuda()
+    monkeypatch.setenv("YOHO_FCGF", "f32")
+    c32 = hip.Context()
+    c32.load_fcgf(fsd)
+    monkeypatch.delenv("YOHO_FCGF")
+    c16 = hip.Context()
+    c16.load_fcgf(fsd)
+    F32, F16 = c32.fcgf_forward(coords), c16.fcgf_forward(coords)
+    assert not torch.equal(F32, F16)                                  # two different arithmetic paths ...
+    assert rel(F16.cpu().numpy(), F32.cpu().numpy()) < TOL            # ... that agree to fp32 level
+
+
 def test_reloading_weights_keeps_every_network_intact(hip, fsd, tables):
     """regression: a second yoho_load_fcgf released a buffer it did not own; later loads then overwrote live weights"""
     c = hip.Context()
