@@ -228,6 +228,13 @@ int yoho_fcgf_voxelize(yoho_ctx* ctx, const double* pts, int n, double voxel_siz
  * (may be NULL) receives the rotated selected points, i.e. pcd[sel] cast to float (YOHO_testset.py:92). */
 int yoho_fcgf_voxelize_rotated(yoho_ctx* ctx, const double* pts, int n, const double* R, double voxel_size, int64_t* sel,
                                int32_t* coords, float* pts_sel, int* count, void* stream);
+/* yoho_fcgf_voxelize_rotated for nb (1..64) rotations of the same cloud in one call: R_host holds nb row-major 3x3 matrices, the
+ * outputs hold n rows per copy - sel (nb, n), coords (nb, n, 3), pts_sel (nb, n, 3) or NULL - of which the first counts[b] of copy b
+ * are valid.  The copies' stages are queued back to back and the counts come back with one read-back (the 60-rotation loops of
+ * YOHO_testset.py:143-147 / simple_yoho/yoho_extract.py:46-53 in groups). */
+int yoho_fcgf_voxelize_rotated_batch(yoho_ctx* ctx, const double* pts, int n, const double* R_host, int nb, double voxel_size,
+                                     int64_t* sel, int32_t* coords, float* pts_sel, int* counts, void* stream);
+
 /* out (m,3) f32 = (float)(R pts[sel[i]]) with the arithmetic of yoho_fcgf_voxelize_rotated (R may be NULL: plain gather + cast):
  * the rotated keypoints of the feature transfer. */
 int yoho_rotate_select(yoho_ctx* ctx, const double* pts, const double* R, const int64_t* sel, int m, float* out, void* stream);

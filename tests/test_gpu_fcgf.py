@@ -62,6 +62,19 @@ def test_voxelize_rotated_equals_voxelising_the_rotated_copy(fctx, tables):
     assert np.array_equal(fctx.rotate_select(pc_d, None, kidx).cpu().numpy(), pc[::7].astype(np.float32))
 
 
+def test_voxelize_rotated_batch_equals_single_calls(fctx, tables):
+    """yoho_fcgf_voxelize_rotated_batch (one read-back for all copies) against one call per rotation"""
+    pc_d = torch.from_numpy(synth.surface_cloud(7000, seed=12)).cuda()
+    Rs = [tables.R64[g] for g in (0, 7, 33, 59)]
+    bat = fctx.fcgf_voxelize_rotated_batch(pc_d, Rs, 0.025)
+    for R, (sel, coords, ps) in zip(Rs, bat):
+        s1, c1, p1 = fctx.fcgf_voxelize_rotated(pc_d, R, 0.025)
+        assert torch.equal(sel, s1) and torch.equal(coords, c1) and torch.equal(ps, p1)
+    sel, coords = fctx.fcgf_voxelize_rotated_batch(pc_d, Rs[:1], 0.025, want_points=False)[0]
+    assert torch.equal(sel, bat[0][0]) and torch.equal(coords, bat[0][1])
+    assert fctx.fcgf_voxelize_rotated_batch(pc_d[:0], Rs, 0.025)[2][0].shape[0] == 0      # empty cloud
+
+
 @pytest.mark.parametrize("n,seed", [(1500, 1), (6000, 2)])
 def test_backbone_vs_oracle(fctx, fsd, n, seed):
     pc = synth.surface_cloud(n, seed=seed)

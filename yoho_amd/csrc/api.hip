@@ -830,6 +830,14 @@ int yoho_fcgf_voxelize_rotated(yoho_ctx* c, const double* pts, int n, const doub
     return fcgf_voxelize(c, pts, n, R_host, voxel_size, sel, coords, pts_sel, count, (hipStream_t)stream);
 }
 
+int yoho_fcgf_voxelize_rotated_batch(yoho_ctx* c, const double* pts, int n, const double* R_host, int nb, double voxel_size, int64_t* sel,
+                                     int32_t* coords, float* pts_sel, int* counts, void* stream) {
+    if (!c || !counts || !R_host || n < 0 || nb < 1 || !(voxel_size > 0)) { set_error("yoho_fcgf_voxelize_rotated_batch: bad argument"); return YOHO_EINVAL; }
+    if (n > 0 && (!pts || !sel || !coords)) { set_error("yoho_fcgf_voxelize_rotated_batch: bad argument"); return YOHO_EINVAL; }
+    HIPCHK(hipSetDevice(c->device));
+    return fcgf_voxelize_batch(c, pts, n, R_host, nb, voxel_size, sel, coords, pts_sel, counts, (hipStream_t)stream);
+}
+
 int yoho_rotate_select(yoho_ctx* c, const double* pts, const double* R_host, const int64_t* sel, int m, float* out, void* stream) {
     if (!c || m < 0) { set_error("yoho_rotate_select: bad argument"); return YOHO_EINVAL; }
     if (m == 0) return 0;

@@ -116,6 +116,8 @@ int fcgf_forward(yoho_ctx* ctx, const FcgfNet* net, const int* coords0, int n0, 
 int fcgf_voxelize(yoho_ctx* ctx, const double* pts, int n, const double* R_host, double voxel, int64_t* sel, int* coords, float* pts_sel,
                   int* count_host, hipStream_t s);
 int fcgf_rotate_select(const double* pts, const double* R_host, const int64_t* sel, int m, float* out, hipStream_t s);
+int fcgf_voxelize_batch(yoho_ctx* ctx, const double* pts, int n, const double* R_host, int nb, double voxel, int64_t* sel, int* coords,
+                        float* pts_sel, int* counts_host, hipStream_t s);
 int launch_cone1(const Layer& L, const char* X, int nTiles32, int nTiles16, const float* res, float* out, const int* n0, hipStream_t s);
 int gft16_init();
 int launch_gft16(const float* in, float* out32, char* planes, int kppad, const void* Ffrag, const float* bn_s, const float* bn_t, int nTiles,

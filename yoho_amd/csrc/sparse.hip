@@ -1574,9 +1574,10 @@ int fcgf_forward(yoho_ctx* ctx, const FcgfNet* net, const int* coords0, int n0, 
 
 // voxelisation (fcgf_feat.py:33-43): first point of every voxel in input order -> sel (ascending), integer coordinates
 // the selected points, rotated like the voxelisation saw them, as fp32 (the reference's pcd[sel].float())
-__global__ void rotate_sel_kernel(CoordSrc src, const int64_t* __restrict__ sel, int m, float* __restrict__ out) {
+// m_dev (or null): the row count lives on the device (batched voxelisation: no host round trip between its stages)
+__global__ void rotate_sel_kernel(CoordSrc src, const int64_t* __restrict__ sel, int m, float* __restrict__ out, const int* __restrict__ m_dev) {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= m) return;
+    if (i >= (m_dev ? *m_dev : m)) return;
     double p0, p1, p2;
     point_of(src, (int)sel[i], p0, p1, p2);
     out[3 * (size_t)i] = (float)p0; out[3 * (size_t)i + 1] = (float)p1; out[3 * (size_t)i + 2] = (float)p2;
@@ -1586,7 +1587,7 @@ int fcgf_rotate_select(const double* pts, const double* R_host, const int64_t* s
     if (m == 0) return 0;
     CoordSrc src{nullptr, pts, 1.0, 1, R_host ? 1 : 0, {0}};
     if (R_host) for (int i = 0; i < 9; ++i) src.R[i] = R_host[i];
-    hipLaunchKernelGGL(rotate_sel_kernel, dim3((m + 255) / 256), dim3(256), 0, s, src, sel, m, out);
+    hipLaunchKernelGGL(rotate_sel_kernel, dim3((m + 255) / 256), dim3(256), 0, s, src, sel, m, out, (const int*)nullptr);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -1620,6 +1621,51 @@ int fcgf_voxelize(yoho_ctx* ctx, const double* pts, int n, const double* R_host,
         return YOHO_EINVAL;
     }
     if (pts_sel) return fcgf_rotate_select(pts, R_host, sel, *count_host, pts_sel, s);
+    return 0;
+}
+
+// nb rotated copies of one cloud in one call: the stages of all copies are queued back to back (one hash table, block sums and
+// counters per copy in the workspace) and the nb voxel counts come back with ONE read-back.  Outputs are laid out with n rows per
+// copy: sel (nb, n), coords (nb, n, 3), pts_sel (nb, n, 3) or null; counts_host (nb).
+int fcgf_voxelize_batch(yoho_ctx* ctx, const double* pts, int n, const double* R_host, int nb, double voxel, int64_t* sel, int* coords,
+                        float* pts_sel, int* counts_host, hipStream_t s) {
+    if (nb < 1 || nb > 64) { set_error("fcgf_voxelize_batch: 1..64 copies per call"); return YOHO_EINVAL; }
+    for (int b = 0; b < nb; ++b) counts_host[b] = 0;
+    if (n == 0) return 0;
+    int rc;
+    const unsigned cap = table_cap(n);
+    const size_t per = (size_t)cap * 12 + ((size_t)(n + 1023) / 1024 + 1) * 4 + 1024;
+    if ((rc = ensure_ws(ctx, per * nb + 8192, s))) return rc;
+    Arena ar{(char*)ctx->ws.p, 0, ctx->ws.bytes};
+    int* dcount = ar.take<int>(2 * (size_t)nb);          // per copy: [0] number of voxels, [1] out-of-range flag
+    HIPCHK(hipMemsetAsync(dcount, 0, 2 * sizeof(int) * nb, s));
+    for (int b = 0; b < nb; ++b) {
+        Level L;
+        L.mask = cap - 1; L.keys = ar.take<u64>(cap); L.vals = ar.take<int>(cap);
+        int* bsum = ar.take<int>((size_t)(n + 1023) / 1024 + 1);
+        if (ar.off > ar.cap) { set_error("fcgf_voxelize_batch: workspace estimate too small"); return YOHO_ENOMEM; }
+        CoordSrc src{nullptr, pts, voxel, 1, 1, {0}, dcount + 2 * b + 1};
+        for (int i = 0; i < 9; ++i) src.R[i] = R_host[9 * b + i];
+        if ((rc = build_table(src, n, L, s))) return rc;
+        if ((rc = launch_first_compact(src, n, L.keys, L.vals, L.mask, bsum, coords + (size_t)b * n * 3, 3, sel + (size_t)b * n, dcount + 2 * b, s))) return rc;
+        if (pts_sel) {
+            CoordSrc rs{nullptr, pts, 1.0, 1, 1, {0}};
+            for (int i = 0; i < 9; ++i) rs.R[i] = R_host[9 * b + i];
+            hipLaunchKernelGGL(rotate_sel_kernel, dim3((n + 255) / 256), dim3(256), 0, s, rs, sel + (size_t)b * n, n, pts_sel + (size_t)b * n * 3,
+                               (const int*)(dcount + 2 * b));
+        }
+    }
+    HIPCHK(hipGetLastError());
+    int hc[128];
+    HIPCHK(hipMemcpyAsync(hc, dcount, 2 * sizeof(int) * nb, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    for (int b = 0; b < nb; ++b) {
+        if (hc[2 * b + 1]) {
+            set_error("voxelisation: a point's voxel index is outside +-%d in rotated copy %d (cloud extent / voxel size too large, or a non-finite point)", VOX_LIM, b);
+            return YOHO_EINVAL;
+        }
+        counts_host[b] = hc[2 * b];
+    }
     return 0;
 }
 

@@ -89,7 +89,9 @@ class fcgf_extractor():
         list of (sel, F, rotated selected points (m,3) f32).  The copies are never materialised: rotation, voxelisation and
         the down-sampled points come from one pass over pts (yoho_fcgf_voxelize_rotated)."""
         self._resident()
-        vox = [self.ctx.fcgf_voxelize_rotated(pts, R, voxel_size) for R in rotations]
+        vox = []
+        for b0 in range(0, len(rotations), 64):        # one library call (one count read-back) per 64 copies
+            vox += self.ctx.fcgf_voxelize_rotated_batch(pts, rotations[b0:b0 + 64], voxel_size)
         feats, group, rows = [], [], 0
         for _, c, _ in vox:
             if group and (rows + c.shape[0] > self.MAX_VOXELS_PER_PASS or len(group) == 64):

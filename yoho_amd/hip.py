@@ -22,7 +22,7 @@ SYMBOLS = [
     "yoho_gconv_layer", "yoho_load_fcgf", "yoho_fcgf_voxelize", "yoho_fcgf_forward", "yoho_fcgf_forward_batch", "yoho_fcgf_voxelize_rotated", "yoho_rotate_select",
     "yoho_des2r", "yoho_des2r_indexed", "yoho_partII_forward", "yoho_partII_forward_indexed", "yoho_hyp_from_quat", "yoho_o_score", "yoho_c_ransac",
     "yoho_group_gather", "yoho_set_profiling", "yoho_get_kernel_ms", "yoho_set_gconv_mode", "yoho_set_partII_mode", "yoho_set_nn_grid",
-    "yoho_range_status", "yoho_c_ransac_device", "yoho_group_scatter", "yoho_set_nn_prefilter", "yoho_set_fcgf_sort", "yoho_gconv_wgrad", "yoho_bn_stats", "yoho_bn_relu_apply", "yoho_bn_relu_backward",
+    "yoho_range_status", "yoho_c_ransac_device", "yoho_group_scatter", "yoho_set_nn_prefilter", "yoho_set_fcgf_sort", "yoho_fcgf_voxelize_rotated_batch", "yoho_gconv_wgrad", "yoho_bn_stats", "yoho_bn_relu_apply", "yoho_bn_relu_backward",
 ]
 
 
@@ -100,6 +100,7 @@ def load_library():
     lib.yoho_set_fcgf_sort.argtypes = [vp, ci, ci]
     lib.yoho_fcgf_voxelize_rotated.argtypes = [vp, vp, ci, vp, C.c_double, vp, vp, vp, vp, vp]
     lib.yoho_rotate_select.argtypes = [vp, vp, vp, vp, ci, vp, vp]
+    lib.yoho_fcgf_voxelize_rotated_batch.argtypes = [vp, vp, ci, vp, ci, C.c_double, vp, vp, vp, vp, vp]
     lib.yoho_get_kernel_ms.argtypes = [vp, ci, C.POINTER(C.c_float)]
     lib.yoho_bn_stats.argtypes = [vp, vp, ci, ci, vp, vp, vp]
     lib.yoho_bn_relu_apply.argtypes = [vp, vp, ci, ci, vp, vp, vp, vp]
@@ -310,6 +311,24 @@ class Context:
                                                     C.c_void_p(ps.data_ptr()) if want_points else None, C.byref(cnt), _stream()))
         m = cnt.value
         return (sel[:m], coords[:m], ps[:m]) if want_points else (sel[:m], coords[:m])
+
+    def fcgf_voxelize_rotated_batch(self, pts, Rs, voxel_size, want_points=True):
+        """fcgf_voxelize_rotated for a list of rotations of the same cloud in one library call (one count read-back for all):
+        -> list of (sel, coords[, rotated selected points]) views into shared (nb, n, ...) buffers."""
+        n, nb = pts.shape[0], len(Rs)
+        Rh = np.ascontiguousarray(np.stack([np.asarray(R, dtype=np.float64).reshape(3, 3) for R in Rs]))
+        sel = torch.empty((nb, n), dtype=torch.int64, device=pts.device)
+        coords = torch.empty((nb, n, 3), dtype=torch.int32, device=pts.device)
+        ps = torch.empty((nb, n, 3), dtype=torch.float32, device=pts.device) if want_points else None
+        cnt = (C.c_int * nb)()
+        _check(self._lib.yoho_fcgf_voxelize_rotated_batch(self._h, _dev(pts, torch.float64, "pts"), n, _np_ptr(Rh), nb, float(voxel_size),
+                                                          C.c_void_p(sel.data_ptr()), C.c_void_p(coords.data_ptr()),
+                                                          C.c_void_p(ps.data_ptr()) if want_points else None, cnt, _stream()))
+        out = []
+        for b in range(nb):
+            m = cnt[b]
+            out.append((sel[b, :m], coords[b, :m], ps[b, :m]) if want_points else (sel[b, :m], coords[b, :m]))
+        return out
 
     def rotate_select(self, pts, R, sel):
         """(float32)(R pts[sel]) for pts (n,3) f64 cuda, sel (m,) int64 cuda; R (3,3) or None."""
