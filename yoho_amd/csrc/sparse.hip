@@ -1084,7 +1084,11 @@ static int launch_spconv(const SpConvArgs& a_in, hipStream_t s) {
             else if (a.Wh && ncb == 2 && (dbg & 16)) hipLaunchKernelGGL((spconv16w_kernel<2, 16>), grid, blk, 0, s, a);
             else
 #endif
-            if (a.Wh && ncb == 2) hipLaunchKernelGGL((spconv16w_kernel<2>), grid, blk, 0, s, a);
+            // 128 output channels: all four channel blocks in one wave, so every row is gathered once instead of twice (the gathers'
+            // lane requests are what bounds these kernels; measured -0.25 ms on a 1.3 M-voxel pass, no gain at 256 channels)
+            if (a.Wh && ncb == 2 && ncbt == 4 && rowtiles >= 1024)
+                hipLaunchKernelGGL((spconv16w_kernel<4>), dim3(grid.x, 1), blk, 0, s, a);
+            else if (a.Wh && ncb == 2) hipLaunchKernelGGL((spconv16w_kernel<2>), grid, blk, 0, s, a);
             else if (a.Wh) hipLaunchKernelGGL((spconv16w_kernel<1>), grid, blk, 0, s, a);
             else if (ncb == 2) hipLaunchKernelGGL((spconv_kernel<2, false>), grid, blk, 0, s, a);
             else hipLaunchKernelGGL((spconv_kernel<1, false>), grid, blk, 0, s, a);
