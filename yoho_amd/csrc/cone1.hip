@@ -41,8 +41,14 @@ __device__ __forceinline__ floatx16 mfma_c1(uintx4 a, uintx4 b, floatx16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(ca.h, cb.h, c, 0, 0, 0);
 }
 
-__global__ __launch_bounds__(256, 2) void cone1_kernel(Cone1Args a) {
-    __shared__ __attribute__((aligned(16))) char smem[2 * C1_STAGE];
+// compile-time loop
+template <int I, int N, typename Fn>
+__device__ __forceinline__ void sfor_c1(Fn&& fn) {
+    if constexpr (I < N) { fn(std::integral_constant<int, I>{}); sfor_c1<I + 1, N>(fn); }
+}
+
+__global__ __launch_bounds__(256, 1) void cone1_kernel(Cone1Args a) {       // <= 204 workgroups for 3233 matches: one per CU
+    __shared__ __attribute__((aligned(16))) char smem[3 * C1_STAGE];
     __shared__ int n0s[16];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -56,8 +62,8 @@ __global__ __launch_bounds__(256, 2) void cone1_kernel(Cone1Args a) {
     long long soff[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int u = w + 4 * i;
-        const int slot = (u < C1_UNITS ? u : 0) * 4 + (lane >> 4);
+        const int u = w + 4 * i < C1_UNITS ? w + 4 * i : w + 4 * (i - 1);      // waves 2, 3 own three units: the fourth piece repeats the third
+        const int slot = u * 4 + (lane >> 4);
         const int pl = slot / 28, r = slot - pl * 28, ht = r / 14, k = r - ht * 14;
         int t16 = 2 * tile32 + ht;
         t16 = t16 < a.nTiles16 ? t16 : a.nTiles16 - 1;
@@ -66,9 +72,10 @@ __global__ __launch_bounds__(256, 2) void cone1_kernel(Cone1Args a) {
     auto stage = [&](int c8, char* dst) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int u = w + 4 * i;
-            if (u < C1_UNITS)
-                __builtin_amdgcn_global_load_lds((gptr_t)(a.X + soff[i] + (long long)c8 * C1_CHUNK), (lptr_t)(dst + u * 1024), 16, 0, 0);
+            // (same bytes to the same place for the repeated piece: every wave issues four, so the wait counts are uniform and the
+            // loop body has no branch)
+            const int u = w + 4 * i < C1_UNITS ? w + 4 * i : w + 4 * (i - 1);
+            __builtin_amdgcn_global_load_lds((gptr_t)(a.X + soff[i] + (long long)c8 * C1_CHUNK), (lptr_t)(dst + u * 1024), 16, 0, 0);
         }
     };
 
@@ -82,30 +89,73 @@ __global__ __launch_bounds__(256, 2) void cone1_kernel(Cone1Args a) {
     const int lane_b = ((lane >> 4) & 1) * (14 * 256) + (lane >> 5) * 256 + (lane & 15) * 16;
     const uintx4* Wl = reinterpret_cast<const uintx4*>(a.Wp) + (size_t)ob * a.cin8 * (7 * 2 * 64) + lane;
 
-    uintx4 wcur[7][2], wnxt[7][2];
+    // Pipeline.  A workgroup walks 64 channel chunks of 21 MFMAs (0.3 us) each, and it is alone on its CU (<= 204 workgroups per
+    // pair), so what it waits for is latency: the X slabs (LDS-DMA, from HBM) and the weight planes (registers, from the L2) are
+    // requested TWO chunks ahead (rings of three).  In iteration c the wave issues W(c+2) and then DMA(c+2); at the top of
+    // iteration c everything older than the requests of chunk c+1 has to have landed: a counted wait (vector-memory
+    // operations complete in issue order), through the builtin so that the compiler's scoreboard sees it.  The B fragments are
+    // read through asm: in front of a C++ LDS load the compiler waits for every pending LDS DMA (vmcnt(0)), which serialised
+    // this loop before (128 us -> see DESIGN 3.1b).
+    constexpr int RING = 3;
+    uintx4 wreg[RING][7][2];
+    auto loadW = [&](int c8, uintx4 (&wr)[7][2]) {
+        const uintx4* Wn = Wl + (size_t)c8 * (7 * 2 * 64);
 #pragma unroll
-    for (int tp = 0; tp < 7; ++tp) { wcur[tp][0] = Wl[(tp * 2) * 64]; wcur[tp][1] = Wl[(tp * 2 + 1) * 64]; }
-    stage(0, smem);
-    for (int c8 = 0; c8 < a.cin8; ++c8) {
-        char* cur = smem + (c8 & 1) * C1_STAGE;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        const int cn = c8 + 1 < a.cin8 ? c8 + 1 : c8;
-        stage(cn, smem + ((c8 + 1) & 1) * C1_STAGE);
-        const uintx4* Wn = Wl + (size_t)cn * (7 * 2 * 64);
+        for (int tp = 0; tp < 7; ++tp) { wr[tp][0] = Wn[(tp * 2) * 64]; wr[tp][1] = Wn[(tp * 2 + 1) * 64]; }
+    };
+    auto compute = [&](const char* cur, const uintx4 (&wr)[7][2]) {
+        // all 14 B fragments of the chunk are requested at once, one wait (tied to the registers, so no MFMA is scheduled in front
+        // of it), then the 21 MFMAs
+        const unsigned base = (unsigned)(size_t)(cur + lane_b);
+        uintx4 bh[7], bl[7];
 #pragma unroll
-        for (int tp = 0; tp < 7; ++tp) { wnxt[tp][0] = Wn[(tp * 2) * 64]; wnxt[tp][1] = Wn[(tp * 2 + 1) * 64]; }
+        for (int tp = 0; tp < 7; ++tp)
+            asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4"
+                         : "=&v"(bh[tp]), "=&v"(bl[tp]) : "v"(base), "n"(tp * 512), "n"(tp * 512 + 2 * 14 * 256) : "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(bh[0]), "+v"(bh[1]), "+v"(bh[2]), "+v"(bh[3]), "+v"(bh[4]), "+v"(bh[5]), "+v"(bh[6]),
+                       "+v"(bl[0]), "+v"(bl[1]), "+v"(bl[2]), "+v"(bl[3]), "+v"(bl[4]), "+v"(bl[5]), "+v"(bl[6]) :: "memory");
 #pragma unroll
         for (int tp = 0; tp < 7; ++tp) {
-            const uintx4 bh = *reinterpret_cast<const uintx4*>(cur + lane_b + tp * 512);
-            const uintx4 bl = *reinterpret_cast<const uintx4*>(cur + lane_b + tp * 512 + 2 * 14 * 256);
-            acc[0] = mfma_c1(wcur[tp][1], bh, acc[0]);      // three independent accumulation chains
-            acc[1] = mfma_c1(wcur[tp][0], bl, acc[1]);
-            acc[2] = mfma_c1(wcur[tp][0], bh, acc[2]);
+            acc[0] = mfma_c1(wr[tp][1], bh[tp], acc[0]);  // three independent accumulation chains
+            acc[1] = mfma_c1(wr[tp][0], bl[tp], acc[1]);
+            acc[2] = mfma_c1(wr[tp][0], bh[tp], acc[2]);
         }
-#pragma unroll
-        for (int tp = 0; tp < 7; ++tp) { wcur[tp][0] = wnxt[tp][0]; wcur[tp][1] = wnxt[tp][1]; }
+    };
+    // the requests of one chunk stay in flight: 14 weight loads + 4 DMA pieces
+    auto top = [&]() {
+        __builtin_amdgcn_s_waitcnt(0x4F72);                              // vmcnt(18) = 0b010010: low nibble 2, bits 15:14 = 1
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto stage_of = [&](int c8) { return smem + (c8 % RING) * C1_STAGE; };
+    const int last = a.cin8 - 1;
+    auto clamp = [&](int c8) { return c8 <= last ? c8 : last; };
+    // prologue: chunks 0, 1, 2 (in the order the loop keeps: W then DMA)
+    loadW(clamp(0), wreg[0]); stage(clamp(0), stage_of(0));
+    loadW(clamp(1), wreg[1]); stage(clamp(1), stage_of(1));
+    const int nmain = (a.cin8 / RING) * RING;
+    for (int c8 = 0; c8 < nmain; c8 += RING) {
+        sfor_c1<0, RING>([&](auto jc) {
+            constexpr int jj = decltype(jc)::value;
+            const int c = c8 + jj;                                       // no branch in here: the compiler's wait bookkeeping stays
+            top();                                                       // exact on straight-line code
+            loadW(clamp(c + RING - 1), wreg[(jj + RING - 1) % RING]);
+            stage(clamp(c + RING - 1), stage_of(c + RING - 1));
+            compute(stage_of(c), wreg[jj]);
+        });
     }
+    // the cin8 % RING chunks left (their requests are already in flight; the extra requests keep the wait counts valid)
+    sfor_c1<0, RING - 1>([&](auto jc) {
+        constexpr int jj = decltype(jc)::value;
+        if (nmain + jj <= last) {
+            top();
+            loadW(last, wreg[(jj + RING - 1) % RING]);
+            stage(last, stage_of(nmain + jj + RING - 1));
+            compute(stage_of(nmain + jj), wreg[jj]);
+        }
+    });
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     // epilogue: D[o][col]: lane (col = lane & 31 = match within the 32-tile, half = lane >> 5), reg r -> o = (r&3) + 8 (r>>2) + 4 half
@@ -127,7 +177,7 @@ __global__ __launch_bounds__(256, 2) void cone1_kernel(Cone1Args a) {
 }
 
 int launch_cone1(const Layer& L, const char* X, int nTiles32, int nTiles16, const float* res, float* out, const int* n0, hipStream_t s) {
-    if (L.cout_pad % 128 || !L.wph) { set_error("cone1: needs cout %% 128 == 0 and fp16x2 weights"); return YOHO_EINVAL; }
+    if (L.cout_pad % 128 || !L.wph || L.cin % 32) { set_error("cone1: needs cout %% 128 == 0, cin %% 32 == 0 and fp16x2 weights"); return YOHO_EINVAL; }
     Cone1Args a;
     a.X = X; a.Wp = reinterpret_cast<const char*>(L.wph); a.bias = L.bias; a.res = res; a.out = out;
     a.nTiles32 = nTiles32; a.nTiles16 = nTiles16; a.cin8 = L.cin / 8; a.cout8 = L.cout_pad / 8; a.descale = L.wph_descale;
