@@ -37,6 +37,8 @@ struct MfArgs {
     unsigned* maxn2;                     // [0] max |a_i|^2 bits, [1] max |b_j|^2 bits
     int* bad;                            // non-finite / out-of-range input: brute force instead
     int segRows;                         // a rows per workgroup of the Gram passes
+    unsigned long long* cand;            // pass 2: candidate pairs (i << 34 | j << 4 | for_row << 1 | for_col), evaluated exactly by mf_exact_kernel
+    unsigned* ncand; unsigned cap;       // their number (may exceed cap: then `bad` is raised and brute force answers)
 };
 
 __device__ __forceinline__ unsigned ord_of(float f) {          // monotone map float -> unsigned
@@ -98,18 +100,27 @@ __device__ __forceinline__ halfx8 frag_of(const float* row) {      // 8 consecut
     return h;
 }
 
-__device__ __noinline__ void mf_exact(const MfArgs& p, int i, int j, bool for_row, bool for_col) {
-    float av[32], bv[32];
+// exact distances of the candidates of pass 2, one thread per pair, merged as packed keys (distance bits << 32 | index) like the
+// brute-force kernels do.  In pass 2 a candidate used to be evaluated on the spot: one ~150-instruction divergent call per
+// (column slab, register) slot with any candidate in the wave - that was most of the pass.
+__global__ __launch_bounds__(256) void mf_exact_kernel(MfArgs p) {
+    if (*p.bad) return;
+    const unsigned n = *p.ncand < p.cap ? *p.ncand : p.cap;
+    for (unsigned c = blockIdx.x * 256 + threadIdx.x; c < n; c += gridDim.x * 256) {
+        const unsigned long long e = p.cand[c];
+        const int i = (int)(e >> 34), j = (int)((e >> 4) & 0x3FFFFFFFull);
+        float av[32], bv[32];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const float4 x = reinterpret_cast<const float4*>(p.a + (size_t)i * 32)[k], y = reinterpret_cast<const float4*>(p.b + (size_t)j * 32)[k];
-        av[4 * k] = x.x; av[4 * k + 1] = x.y; av[4 * k + 2] = x.z; av[4 * k + 3] = x.w;
-        bv[4 * k] = y.x; bv[4 * k + 1] = y.y; bv[4 * k + 2] = y.z; bv[4 * k + 3] = y.w;
+        for (int k = 0; k < 8; ++k) {
+            const float4 x = reinterpret_cast<const float4*>(p.a + (size_t)i * 32)[k], y = reinterpret_cast<const float4*>(p.b + (size_t)j * 32)[k];
+            av[4 * k] = x.x; av[4 * k + 1] = x.y; av[4 * k + 2] = x.z; av[4 * k + 3] = x.w;
+            bv[4 * k] = y.x; bv[4 * k + 1] = y.y; bv[4 * k + 2] = y.z; bv[4 * k + 3] = y.w;
+        }
+        // (a - b)^2 and (b - a)^2 are the same floats, so one evaluation serves both search directions
+        const unsigned long long d = (unsigned long long)__float_as_uint(dist_of_f32(dist2_f32<32>(av, bv))) << 32;
+        if (e & 2ull) atomicMin(p.keysA + i, d | (unsigned)j);
+        if (e & 1ull) atomicMin(p.keysB + j, d | (unsigned)i);
     }
-    // (a - b)^2 and (b - a)^2 are the same floats, so one evaluation serves both search directions
-    const unsigned long long d = (unsigned long long)__float_as_uint(dist_of_f32(dist2_f32<32>(av, bv))) << 32;
-    if (for_row) atomicMin(p.keysA + i, d | (unsigned)j);
-    if (for_col) atomicMin(p.keysB + j, d | (unsigned)i);
 }
 
 // One workgroup: 128 b rows (columns of G, fragments kept in registers) x segRows a rows, 32 a rows per wave and step.
@@ -118,7 +129,19 @@ __device__ __noinline__ void mf_exact(const MfArgs& p, int i, int j, bool for_ro
 template <int PASS>
 __global__ __launch_bounds__(256) void mf_gram_kernel(MfArgs p) {
     if (*p.bad) return;
+    constexpr int WL = PASS == 2 ? 1024 : 1;                 // pass 2: per-wave list of the candidates found since the last flush
+    __shared__ unsigned long long wl[4][WL];
+    int wcnt = 0;                                            // wave-uniform
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    auto flush = [&]() {
+        if (wcnt == 0) return;
+        unsigned base = 0;
+        if (lane == 0) base = atomicAdd(p.ncand, (unsigned)wcnt);
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (base + (unsigned)wcnt > p.cap) { if (lane == 0) *p.bad = 1; }       // list full: brute force answers instead
+        else for (int k = lane; k < wcnt; k += 64) p.cand[base + k] = wl[w][k];
+        wcnt = 0;
+    };
     const int l31 = lane & 31, half = lane >> 5;
     const int col0 = blockIdx.x * 128;
     halfx8 Bf[4][2];
@@ -170,9 +193,17 @@ __global__ __launch_bounds__(256) void mf_gram_kernel(MfArgs p) {
                 const float s = nbj[t] - 2.f * g[e], tt = na[e] - 2.f * g[e];
                 if (PASS == 1) {
                     if (ok) { rth[e] = fminf(rth[e], s); cbest[t] = fminf(cbest[t], tt); }
-                } else if (ok) {
-                    const bool cr = s <= rth[e], cc = tt <= cbest[t] + cband[t];
-                    if (cr || cc) mf_exact(p, i, jcol[t], cr, cc);
+                } else {
+                    const bool cr = ok && s <= rth[e], cc = ok && tt <= cbest[t] + cband[t];
+                    const unsigned long long m = __ballot(cr || cc);
+                    if (m) {                                              // uniform
+                        const int add = __popcll(m);
+                        if (wcnt + add > WL) flush();
+                        if (cr || cc)
+                            wl[w][wcnt + __popcll(m & ((1ull << lane) - 1ull))] =
+                                ((unsigned long long)i << 34) | ((unsigned long long)jcol[t] << 4) | (cr ? 2ull : 0ull) | (cc ? 1ull : 0ull);
+                        wcnt += add;
+                    }
                 }
             }
         }
@@ -187,6 +218,7 @@ __global__ __launch_bounds__(256) void mf_gram_kernel(MfArgs p) {
                 if (l31 == 0 && i < rhi && v < __builtin_inff()) atomicMin(p.rowmin + i, ord_of(v));
             }
         }
+        if (PASS == 2) flush();
     }
     if (PASS == 1) {
 #pragma unroll
@@ -201,7 +233,7 @@ int launch_nn32seg_if(const float* src, int Ns, const float* tgt, int Nt, unsign
 
 size_t mutual_prefilter_ws_bytes(int Na, int Nb) {
     const size_t n = (size_t)Na + Nb;
-    return n * (sizeof(unsigned long long) + 3 * sizeof(float) + sizeof(unsigned)) + 256;
+    return n * (sizeof(unsigned long long) + 3 * sizeof(float) + sizeof(unsigned)) + 256 + (16 * n + 4096) * sizeof(unsigned long long);
 }
 
 // keysA (Na) / keysB (Nb) receive the packed winners (the layout launch_mutual_compact<PACKED> reads); ws as sized above
@@ -219,9 +251,12 @@ int launch_mutual_prefilter(const float* a, int Na, const float* b, int Nb, void
     p.rowmin = (unsigned*)w; w += sizeof(unsigned) * (size_t)Na;
     p.colmin = (unsigned*)w; w += sizeof(unsigned) * (size_t)Nb;
     p.maxn2 = (unsigned*)w; w += 2 * sizeof(unsigned);
-    p.bad = (int*)w;
+    p.bad = (int*)w; w += sizeof(int);
+    p.ncand = (unsigned*)w; w += sizeof(unsigned);
+    p.cand = (unsigned long long*)(((size_t)w + 15) & ~(size_t)15);
+    p.cap = 16u * (unsigned)(Na + Nb) + 4000u;
     *keysA = p.keysA; *keysB = p.keysB;
-    HIPCHK(hipMemsetAsync(p.maxn2, 0, 16, s));
+    HIPCHK(hipMemsetAsync(p.maxn2, 0, 16, s));                  // maxima, `bad`, candidate count
     const int n = Na + Nb;
     hipLaunchKernelGGL(mf_norms_kernel, dim3((n + 255) / 256), dim3(256), 0, s, p);
     hipLaunchKernelGGL(mf_band_kernel, dim3((n + 255) / 256), dim3(256), 0, s, p);
@@ -233,6 +268,7 @@ int launch_mutual_prefilter(const float* a, int Na, const float* b, int Nb, void
     segs = (Na + p.segRows - 1) / p.segRows;
     hipLaunchKernelGGL(mf_gram_kernel<1>, dim3(cb, segs), dim3(256), 0, s, p);
     hipLaunchKernelGGL(mf_gram_kernel<2>, dim3(cb, segs), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(mf_exact_kernel, dim3(nCU > 0 ? 2 * nCU : 512), dim3(256), 0, s, p);
     HIPCHK(hipGetLastError());
     // inputs the pre-filter cannot take: the brute-force kernels run (they return at once otherwise)
     int rc;
