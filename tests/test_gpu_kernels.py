@@ -244,6 +244,11 @@ def test_mutual_nn_prefilter_equals_brute_force(hip):
     z = rs.randn(1200, 32).astype(np.float32)
     z[::7] = 0
     cases["zero rows"] = (z, np.ascontiguousarray(z[::-1]))
+    # every pair a candidate: the candidate list overflows and the brute-force kernels take over (ties -> lowest index)
+    one = rs.randn(1, 32).astype(np.float32)
+    cases["all rows identical 1100 x 1300 (candidate list full)"] = (np.repeat(one, 1100, 0), np.repeat(one, 1300, 0))
+    few = rs.randn(5, 32).astype(np.float32)
+    cases["five distinct rows repeated 1500 x 1500"] = (few[rs.randint(0, 5, 1500)], few[rs.randint(0, 5, 1500)])
     for name, (x, y) in cases.items():
         m1, m0 = both(x, y)
         assert m1.shape == m0.shape and np.array_equal(m1, m0), name
