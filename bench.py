@@ -30,8 +30,10 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 from yoho_amd import hip, synth, weights as W, pipeline, dist as ydist  # noqa: E402
+from yoho_amd.power import PowerMonitor, ClockProbe  # noqa: E402
 
 KP = 5000                       # keypoints per fragment (BASELINE.json configs[1])
+DEFAULT_SCHEDULE = "0"          # PartI schedule of the timed steps (profiles/r03_chunk_sweep.md)
 FLOP_PER_KP = 434_503_680       # 2 * 60 * (416*256 + 3328*512 + 6656*256 + 3328*32)  
 FP32_MFMA_PEAK = 157.3          # TFLOP/s, MI355X_MICROARCH.md (v_mfma_f32_32x32x2_f32 = vector rate)
 BF16_MFMA_PEAK = 2500.0         # TFLOP/s dense, MI355X_MICROARCH.md (v_mfma_f32_32x32x16_bf16)
@@ -61,7 +63,7 @@ def fgemm_issued_flops(nkp, mode="fgemm"):
     return sum(fgemm_issued_flops_per_layer(nkp, mode))
 
 
-PMC_FILES = ("r02_pmc_traffic.json", "r01_pmc_traffic.json")     # newest first
+PMC_FILES = ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")     # newest first
 
 
 def pmc_traffic(mode):
@@ -139,7 +141,14 @@ def main():
                          "or direct 2-way fp16 split MFMA")
     ap.add_argument("--partII", choices=["f32", "bf16x3", "fp16x2"], default=os.environ.get("YOHO_PARTII", "fp16x2"),
                     help="arithmetic of the two PartII cone layers")
+    ap.add_argument("--repeats", type=int, default=3, help="the timed region (exactly --steps steps) is run this many times; ms_per_step / value are "
+                                                           "the median repeat, min / max are reported beside it")
+    ap.add_argument("--partI-schedule", default=os.environ.get("YOHO_PARTI_CHUNK", DEFAULT_SCHEDULE),
+                    help="PartI pass: '0' breadth-first, 'C' or 'CxS' depth-first over chunks of C keypoints on S (1 or 2) streams")
+    ap.add_argument("--no-dataset", action="store_true", help="skip the dataset-scale leg (tools/bench_dataset.py: 60 fragments from disk, ~500 pairs)")
     args = ap.parse_args()
+    sched = [int(v) for v in str(args.partI_schedule).lower().split("x")] + [1]
+    sched_chunk, sched_streams = sched[0], sched[1]
 
     rank, world, local = ydist.init_from_env("nccl" if args.gpus > 1 else None)
     if args.gpus > 1 and world != args.gpus:
@@ -156,6 +165,7 @@ def main():
     ctx.load_partII(sd2)
     ctx.set_gconv_mode(args.gconv)
     ctx.set_partII_mode(args.partII)
+    ctx.set_partI_schedule(sched_chunk, sched_streams)
 
     cu = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
     rng = np.random.RandomState(1234 + rank)
@@ -185,6 +195,8 @@ def main():
     if args.in_flight == 2:
         streamer = pipeline.PairStreamer(lambda: hip.Context(dev), sd1, sd2)
         streamer.set_modes(args.gconv, args.partII)
+        for c_ in streamer.desc:
+            c_.set_partI_schedule(sched_chunk, sched_streams)
 
     def run_steps(n, estimator="yohoo", seed0=0):
         """n steps = n sweeps over this rank's pair list, all inside one call so that consecutive steps can overlap"""
@@ -198,20 +210,37 @@ def main():
             r = pipeline.run_pair(ctx, a0, a1, b0, b1, inlier_dist=dist, max_iter=1000, order_rng=rng, estimator=estimator, seed=seed0 + i)
         return r
 
-    def timed(estimator, steps, warmup):
-        r = run_steps(warmup, estimator, 1)
-        ydist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        r = run_steps(steps, estimator, 1000)
-        torch.cuda.synchronize()
-        ydist.barrier()
-        return ydist.max_over_ranks(time.perf_counter() - t0), r
+    mon = PowerMonitor(dev)
+    probe = ClockProbe(ctx, us=1000)
 
-    dt, res = timed("yohoo", args.steps, max(args.warmup, 1))
+    def timed(estimator, steps, warmup, repeats=1):
+        """warmup steps, then `repeats` timed regions of exactly `steps` steps each (barrier + synchronize on both sides, max over
+        ranks) -> (median region time, all region times, per-rank times of the median region, last result, clock / power during
+        the regions)"""
+        r = run_steps(warmup, estimator, 1)
+        times, per_rank = [], []
+        mon.start()
+        for rep in range(max(1, repeats)):
+            ydist.barrier()
+            torch.cuda.synchronize()
+            probe.queue(max(1, int(steps * 6)))            # ~1 ms probes covering the region, on their own high-priority stream
+            t0 = time.perf_counter()
+            r = run_steps(steps, estimator, 1000 + 100000 * rep)
+            torch.cuda.synchronize()
+            mine_dt = time.perf_counter() - t0
+            ydist.barrier()
+            times.append(ydist.max_over_ranks(time.perf_counter() - t0))
+            per_rank.append(ydist.all_ranks(mine_dt))
+        power = mon.stop()
+        power["clock_probe"] = probe.summary()
+        order = sorted(range(len(times)), key=lambda i: times[i])
+        med = order[len(order) // 2]
+        return times[med], times, per_rank[med], r, power
+
+    dt, dts, rank_dts, res, power_steps = timed("yohoo", args.steps, max(args.warmup, 1), args.repeats)
     yohoc = None
     if not args.no_yohoc:
-        dtc, resc = timed("yohoc", args.steps, max(min(args.warmup, 2), 1))
+        dtc, _, _, resc, _ = timed("yohoc", args.steps, max(min(args.warmup, 2), 1))
         # host time per pair of the estimator call alone (launches only: nothing is read back inside the call)
         m_, dr_ = res.match, res.dr_index
         torch.cuda.synchronize()
@@ -229,13 +258,33 @@ def main():
     # timed step (both fragments in one pass)
     fboth = torch.cat([f0, f1])
     nkp = fboth.shape[0]
+    # (with two chunk streams the launches of neighbouring chunks overlap and their event times would count the overlap twice, so
+    # the per-launch figures come from the same chunks on ONE stream; the whole-pass time of the schedule as timed is reported too)
+    ctx.set_partI_schedule(sched_chunk, 1)
     ctx.set_profiling(True)
     conv_ms = []
+    for _ in range(8):                                       # a few passes so that clock and power settle as in the timed steps
+        ctx.partI_forward(fboth, want_inv=False, want_inv_np=True, check_range=False)
+    torch.cuda.synchronize()
+    mon.start()
     for _ in range(3):
+        probe.queue(4)
         ctx.partI_forward(fboth, want_inv=False, want_inv_np=True, check_range=False)
         torch.cuda.synchronize()
-        conv_ms.append([ctx.kernel_ms(i) for i in range(12)])
+        conv_ms.append([ctx.kernel_ms(i) for i in range(13)])
+    power_prof = mon.stop()
+    power_prof["clock_probe"] = probe.summary()
+    pass_ms_timed_schedule = None
+    if sched_streams == 2:
+        ctx.set_partI_schedule(sched_chunk, 2)
+        t_ = []
+        for _ in range(3):
+            ctx.partI_forward(fboth, want_inv=False, want_inv_np=True, check_range=False)
+            torch.cuda.synchronize()
+            t_.append(ctx.kernel_ms(12))
+        pass_ms_timed_schedule = float(np.mean(t_))
     ctx.set_profiling(False)
+    ctx.set_partI_schedule(sched_chunk, sched_streams)
     conv_ms = np.array(conv_ms).mean(0)
     gconv_total_ms = float(conv_ms[:4].sum())
     achieved = FLOP_PER_KP * nkp / (gconv_total_ms * 1e-3) / 1e12      # algorithmic (direct 13-tap) FLOP/s
@@ -339,6 +388,12 @@ def main():
             "unit": "keypoints/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "ms_per_step_repeats": {"n": len(dts), "min": round(min(dts) / args.steps * 1e3, 3), "median": round(dt / args.steps * 1e3, 3),
+                                    "max": round(max(dts) / args.steps * 1e3, 3),
+                                    "note": "every repeat times exactly --steps steps between barriers; value / ms_per_step are the median repeat"},
+            "ranks": {"world_size_seen": world, "backend": (torch.distributed.get_backend() if world > 1 else None),
+                      "ms_per_step_per_rank": {"min": round(min(rank_dts) / args.steps * 1e3, 3), "mean": round(float(np.mean(rank_dts)) / args.steps * 1e3, 3),
+                                               "max": round(max(rank_dts) / args.steps * 1e3, 3), "all": [round(v / args.steps * 1e3, 3) for v in rank_dts]}},
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": dtype, "data": "synthetic",
             "config": {"workload": "one synthetic scene pair per step per GPU: 2 fragments x 5000 keypoints x 60 rotations x 32-D "
@@ -346,17 +401,40 @@ def main():
                                    "random-init weights (seeded), inputs resident in HBM",
                        "keypoints_per_fragment": KP, "partI_batch": nkp, "matches": M, "hypotheses": min(1000, M), "gconv": args.gconv, "partII": args.partII,
                        "pairs_per_step": pairs_per_step, "pairs_in_flight": args.in_flight,
+                       "partI_schedule": ("breadth-first (every layer over the whole pass)" if sched_chunk == 0 else
+                                          f"depth-first, chunks of {sched_chunk} keypoints on {sched_streams} stream(s)"),
                        "parallelism": (f"one pair per GPU per step, {world} GPU(s), no data-path collective" if args.scaling == "weak" else
                                        f"64 pairs (8 scenes x 8) per step dealt to {world} rank(s) by run_dataset.plan_shards, no data-path collective")},
             "roofline": roof,
             "roofline_extra": {"launch_ms": [round(float(v), 3) for v in conv_ms[:4]], "head_ms": round(float(conv_ms[4]), 3),
                                "tail_ms": round(float(conv_ms[5]), 3), "transform_ms": round(float(conv_ms[6]), 3), "hbm": hbm,
+                               "pass_ms_one_stream": round(float(conv_ms[12]), 3),
+                               "pass_ms_timed_schedule": round(pass_ms_timed_schedule, 3) if pass_ms_timed_schedule else round(float(conv_ms[12]), 3),
+                               "power": {"timed_steps": power_steps, "profiled_partI_passes": power_prof,
+                                         "note": "SMU samples (amdsmi, side thread) and the library's one-wave clock probe (shader cycles per "
+                                                 "constant-rate wall tick, own high-priority stream) taken while the timed steps / the profiled "
+                                                 "PartI passes ran; nominal maximum 2400 MHz"},
                                "range_repeats": int(ctx.range_fallbacks + (sum(c.range_fallbacks for c in streamer.desc + [streamer.est]) if streamer else 0))},
         }
         if yohoc is not None:
             out["yohoc"] = yohoc
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
+    # dataset-scale leg (BASELINE configs 3 / 5): 60 fragments x 5000 keypoints from .npy files on disk, ~500 pairs, through the
+    # dataset driver; with N ranks the scene's pairs are dealt to them by run_dataset.plan_shards.  Never part of `value`.
+    dataset = None
+    if not args.no_dataset:
+        streamer = None
+        torch.cuda.empty_cache()
+        try:
+            sys.path.insert(0, os.path.join(REPO, "tools"))
+            import bench_dataset
+            dataset = bench_dataset.run(nfrag=60, kp=KP, span=9, estimator="yohoo", workdir=os.environ.get("YOHO_DS_WORKDIR", "/tmp/yoho_ds"), runs=2)
+        except Exception as e:           # the headline must survive a failure of this leg
+            dataset = {"error": f"{type(e).__name__}: {e}"}
+    if rank == 0:
+        if dataset is not None:
+            out["dataset"] = dataset
         print(json.dumps(out), flush=True)
     ydist.barrier()
 

@@ -279,9 +279,6 @@ int yoho_set_fcgf_sort(yoho_ctx* ctx, int parity_sort, int cell_sort);
  * group-Fourier domain, 13-rotation cone layer direct, last layer as one dense product at the identity). */
 int yoho_set_partII_mode(yoho_ctx* ctx, int mode);
 
-/* timing hook for bench.py: device time (ms) of the stages of the last yoho_partI_forward pass, measured with hipEvents
- * on the call's own stream.  which 0..3: the four group-conv launches; 4: head; 5: tail (inverse transform + finalize);
- * 6: the three inter-layer transform launches together, 7 / 8 / 9 each of them; 10: inverse transform; 11: finalize. */
 /* fp16 range guard.  The default arithmetic (PartI mode 4, PartII mode 2; also PartI mode 3) keeps activations and
  * Fourier coefficients as fixed power-of-two multiples in fp16 planes (|activation| < 4094, |coefficient| < 16376).
  * Every kernel that writes such planes raises a device-side flag when a value falls outside; nothing else in the
@@ -292,8 +289,27 @@ int yoho_set_partII_mode(yoho_ctx* ctx, int mode);
  * The reference computes in fp32 throughout (utils/network.py:12-105, 259-278), so it has no counterpart. */
 int yoho_range_status(yoho_ctx* ctx, int* partI_overflow, int* partII_overflow, void* stream);
 
+/* Schedule of the PartI pass in the default arithmetic mode (no counterpart in the reference, whose extractor walks batches of
+ * test_batch_size keypoints breadth-first, tests/extractor.py:51-59).  chunk_kp = 0 (default): every layer sweeps all keypoints of
+ * the pass.  chunk_kp > 0 (rounded up to a multiple of 256): depth-first - the pass is cut into chunks of chunk_kp keypoints, each
+ * running head -> 4 irrep GEMMs + 3 transforms -> tail on its own workspace slice, so a chunk's intermediates (0.5 MB per
+ * keypoint) can stay in the 256 MB Infinity Cache between layers.  streams = 2: chunks alternate between the caller's stream and
+ * a stream owned by the context, forked from / joined into the caller's stream with events, so the call keeps its contract
+ * (asynchronous, ordered on the caller's stream).  Results are bit-identical for every schedule. */
+int yoho_set_partI_schedule(yoho_ctx* ctx, int chunk_kp, int streams);
+
+/* timing hook for bench.py: device time (ms) of the stages of the last yoho_partI_forward pass, measured with hipEvents
+ * on the launch streams.  which 0..3: the four group-conv launches; 4: head; 5: tail (inverse transform + finalize);
+ * 6: the three inter-layer transform launches together, 7 / 8 / 9 each of them; 10: inverse transform; 11: finalize
+ * (a chunked pass reports the sums over its chunks); 12: the whole pass, first launch to last. */
 int yoho_set_profiling(yoho_ctx* ctx, int enable);
 int yoho_get_kernel_ms(yoho_ctx* ctx, int which, float* ms);
+
+/* measurement hook for bench.py: the shader clock the part actually sustains while other streams are loaded.  One wave spins for
+ * `microseconds` of the constant-rate wall counter and writes out[0] = shader cycles elapsed (s_memtime), out[1] = wall-counter
+ * ticks elapsed, out[2] = the wall counter's rate in kHz (device int64[3]); shader MHz = out[0] / out[1] * out[2] / 1000.  Launch
+ * it on a stream of its own beside the kernels under test. */
+int yoho_clock_probe(yoho_ctx* ctx, int microseconds, long long* out3, void* stream);
 
 #ifdef __cplusplus
 }

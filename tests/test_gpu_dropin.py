@@ -373,3 +373,70 @@ def test_testset_create_from_point_clouds(tmp_path, tables):
             sel, Fg = fo.extract_features(pcg, 0.025, fsd)
             ref = orc.group_gather_one(kps[pid], pcg[sel].astype(np.float32), Fg, tables.R64[g])[0]
             assert rel(got[:, :, g], ref) < 1e-4, (pid, g)
+
+
+@pytest.mark.parametrize("estimator,part,it", [("yohoo", "PartII", 1000), ("yohoc", "PartI", 100)])
+def test_eval_sharded_world1_on_scene6(gold, tmp_path, sd1, sd2, tables, estimator, part, it):
+    """The dataset driver's GPU worker (run_dataset.eval_sharded: load + describe every fragment once, HBM-resident pairs, pre.log,
+    RR) at world = 1 on the scene6 files.  YOHO-O: the reference's per-pair success flags and Registration Recall (0.6) from
+    tests/evaluator.py + utils/RR_cal.py; YOHO-C with the sampling on the device (its own Philox stream): the same success flags as
+    the reference's np.random YOHO-C (statistical parity: every pair registers, RR 1.0).  Every pair's result equals a plain
+    pipeline.run_pair on separately described fragments with the same pair seed, and fragments are released after their last pair."""
+    from yoho_amd import run_dataset, store, RR_cal, pipeline, hip
+    from yoho_amd.dataset import ThrDMatchPartDataset
+    store.clear()
+    g = gold("scene6.npz")
+    sd2i = W.identity_head(sd2)
+    nfrag = int(g["nfrag"])
+    sc = synth.make_scene(nfrag, int(g["K"]), seed=int(g["seed"]), res_deg=[float(v) for v in g["res_deg"]])
+    sroot = tmp_path / "origin" / "synth4" / "room"
+    cache = tmp_path / "cache"
+    synth.write_scene_files(sc, str(sroot), str(cache / "Testset" / "synth4/room"))
+    model_fn = tmp_path / "model"
+    for sub, sd in (("PartI_train", sd1), ("PartII_train", sd2i)):
+        os.makedirs(model_fn / sub)
+        W.save_checkpoint(str(model_fn / sub / "model_best.pth"), sd, 0.5)
+    ds = ThrDMatchPartDataset(str(sroot), nfrag)
+    ds.name = "synth4/room"
+    datasets = {"wholesetname": "synth4", "room": ds}
+    cfg = types.SimpleNamespace(SO3_related_files=None, model_fn=str(model_fn), output_cache_fn=str(cache), origin_data_dir=str(tmp_path / "origin"),
+                                ransac_c_inlinerdist=0.07, ransac_o_inlinerdist=0.09, RR_dist_threshold=0.2, testset_name="synth4")
+    stats = {}
+    rr = run_dataset.eval_sharded(cfg, max_iter=it, estimator=estimator, datasets=datasets, base_seed=3, results_log=str(tmp_path / "results.log"),
+                                  stats_out=stats)
+    sign = "YOHO_O" if estimator == "yohoo" else "YOHO_C"
+    _, flags, _ = RR_cal.benchmark(cfg, datasets, it, yoho_sign=sign)
+    assert np.array_equal(np.asarray(flags[ds.name]), g[f"{part}_flags"]), (flags[ds.name], g[f"{part}_flags"])
+    assert rr == float(g[f"{part}_RR"])
+    assert stats["fragments"] == nfrag and stats["pairs"] == len(ds.pair_ids) and stats["peak_resident_fragments"] == nfrag
+    # the files the reference's estimator leaves: one npz per pair + pre.log in pair order
+    sdir = cache / "Testset" / "synth4/room" / "Match" / sign / f"{it}iters"
+    est_pairs, est = RR_cal.read_pre_trajectory(str(sdir / "pre.log"))
+    assert [tuple(int(v) for v in p[:2]) for p in est_pairs] == [(int(a), int(b)) for a, b in ds.pair_ids]
+    # pair by pair against pipeline.run_pair on separately described fragments
+    ctx = hip.get_context()
+    cu = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    desc = {}
+    for k in range(nfrag):
+        o = ctx.partI_forward(cu(sc["feats"][k]), want_inv=False, want_inv_np=True)
+        desc[str(k)] = (cu(sc["feats"][k]), cu(sc["keys"][k]), {"eqv": o["eqv"], "inv_np": o["inv_np"]})
+    for (a, b), res in zip(ds.pair_ids, stats["results"]["room"]):
+        seed = run_dataset.pair_seed(3, ds.name, a, b)
+        fa, ka, oa = desc[str(a)]
+        fb, kb, ob = desc[str(b)]
+        r = pipeline.run_pair(ctx, fa, fb, ka, kb, inlier_dist=0.09 if estimator == "yohoo" else 0.07, max_iter=it,
+                              order_rng=np.random.RandomState(seed & 0xFFFFFFFF), eqv=(oa, ob), estimator=estimator, seed=seed)
+        assert np.array_equal(np.asarray(r.trans, np.float64), res["trans"]) and int(r.best_h) == res["recalltime"], (a, b)
+        assert np.array_equal(r.match.cpu().numpy(), g[f"match_{a}_{b}"])
+        z = np.load(sdir / f"{a}-{b}.npz")
+        assert np.array_equal(z["trans"], res["trans"]) and int(z["recalltime"]) == res["recalltime"]
+    # every fragment was released after its last pair
+    runner = run_dataset.ScenePairRunner(cfg, ctx, estimator=estimator, max_iter=it, base_seed=3)
+    pairs = [tuple(p) for p in ds.pair_ids]
+    runner.setup_scene(ds, pairs[:5])                       # pairs (0,1) ... (0,5): fragment 0 five times, the others once
+    assert set(runner.frag) == {"0", "1", "2", "3", "4", "5"}
+    runner.run_pair(ds, pairs[0])
+    assert set(runner.frag) == {"0", "2", "3", "4", "5"}
+    for p in pairs[1:5]:
+        runner.run_pair(ds, p)
+    assert runner.frag == {} and runner.uses == {}

@@ -173,6 +173,42 @@ def test_fgemm_tile_variants_are_bit_identical(hip, sd1):
     assert torch.isfinite(ps[0]["eqv"]).all()
 
 
+def test_partI_depth_first_schedule_is_bit_identical(hip, sd1):
+    """yoho_set_partI_schedule: the pass cut into chunks (one stream, or alternating over the caller's and the context's own
+    stream) gives the bits of the breadth-first pass - ragged sizes, chunks that straddle the fragment boundary of a pair pass,
+    work queued on the caller's stream before and after the call - and the profiling hook sums over the chunks"""
+    c = hip.Context()
+    c.load_partI(sd1)
+    x = cu(synth.unit_features(1500, seed=51))
+    a, b = cu(synth.unit_features(1100, seed=52)), cu(synth.unit_features(700, seed=53))
+    ref = c.partI_forward(x, want_inv=True, want_inv_np=True)
+    refp = c.partI_forward_pair(a, b, want_inv=True, want_inv_np=True)
+    for chunk, ns in ((256, 1), (256, 2), (512, 2), (1000, 1), (1024, 2), (4096, 2)):
+        c.set_partI_schedule(chunk, ns)
+        o = c.partI_forward(x.clone(), want_inv=True, want_inv_np=True)
+        p = c.partI_forward_pair(a, b, want_inv=True, want_inv_np=True)
+        s = p["eqv"].sum()                                   # consumer on the caller's stream right behind the call
+        assert all(torch.equal(ref[k], o[k]) for k in ("eqv", "inv", "inv_np")), (chunk, ns)
+        assert all(torch.equal(refp[k], p[k]) for k in ("eqv", "inv", "inv_np")), (chunk, ns)
+        assert torch.isfinite(s)
+    c.set_partI_schedule(512, 2)
+    c.set_profiling(True)
+    c.partI_forward(x, want_inv=False, want_inv_np=True)
+    ms = [c.kernel_ms(i) for i in range(13)]
+    c.set_profiling(False)
+    assert all(m > 0 for m in ms[:4]) and ms[12] > 0 and ms[6] > 0
+    c.set_partI_schedule(0, 1)
+    with pytest.raises(RuntimeError):
+        c.set_partI_schedule(1024, 3)
+    # the clock probe (bench.py's power section): a plausible shader clock
+    t = c.clock_probe(2000)
+    torch.cuda.synchronize()
+    cyc, ticks, khz = (int(v) for v in t.cpu())
+    mhz = cyc / ticks * khz / 1000.0
+    print("clock probe: %.0f MHz (%d cycles / %d ticks of a %d kHz counter)" % (mhz, cyc, ticks, khz))
+    assert ticks > 0 and 100.0 < mhz < 3000.0
+
+
 def test_group_mean_np_bitexact(ctx):
     x = synth.unit_features(333, seed=5) * np.float32(1.7)
     out = ctx.group_mean_np(cu(x)).cpu().numpy()

@@ -212,7 +212,29 @@ static ConvArgs conv_args(const Layer& L, const float* X, int nTiles, const floa
 
 using namespace yoho;
 
+namespace yoho {
+__global__ void clock_probe_kernel(long long* out, long long wall_ticks, long long wall_khz) {
+    if (threadIdx.x != 0) return;
+    const long long w0 = wall_clock64(), c0 = clock64();
+    long long w1 = w0;
+    while (w1 - w0 < wall_ticks) { __builtin_amdgcn_s_sleep(16); w1 = wall_clock64(); }
+    const long long c1 = clock64();
+    out[0] = c1 - c0; out[1] = w1 - w0; out[2] = wall_khz;
+}
+}  // namespace yoho
+
 extern "C" {
+
+int yoho_clock_probe(yoho_ctx* c, int microseconds, long long* out3, void* stream) {
+    if (!c || !out3 || microseconds < 1 || microseconds > 1000000) { set_error("yoho_clock_probe: bad argument"); return YOHO_EINVAL; }
+    HIPCHK(hipSetDevice(c->device));
+    int khz = 0;
+    HIPCHK(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, c->device));
+    if (khz <= 0) { set_error("yoho_clock_probe: the device reports no wall-clock rate"); return YOHO_EHIP; }
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, out3, (long long)microseconds * khz / 1000, (long long)khz);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
 
 const char* yoho_last_error(void) { return g_err; }
 const char* yoho_version(void) { return "yoho_hip 0.1.0 (gfx950)"; }
@@ -324,6 +346,10 @@ int yoho_ctx_create(int device, const float* R, const uint8_t* N, const uint8_t*
     if (const char* m = std::getenv("YOHO_FCGF_SORT")) c->fcgf_parity_sort = std::strcmp(m, "0") == 0 ? 0 : 1;
     if (const char* m = std::getenv("YOHO_NN")) c->nn_prefilter = std::strcmp(m, "brute") == 0 ? 0 : 1;
     if (const char* m = std::getenv("YOHO_PARTII")) c->partII_mode = std::strcmp(m, "f32") == 0 ? 0 : (std::strcmp(m, "fp16x2") == 0 ? 2 : 1);
+    if (const char* m = std::getenv("YOHO_PARTI_CHUNK")) {       // "1024" or "1024x2" (chunk keypoints x streams), see yoho_set_partI_schedule
+        int ck = 0, ns = 1;
+        if (std::sscanf(m, "%dx%d", &ck, &ns) >= 1 && ck >= 0 && (ns == 1 || ns == 2)) { c->partI_chunk = (ck + 255) / 256 * 256; c->partI_streams = ns; }
+    }
     if (const char* m = std::getenv("YOHO_GCONV")) c->gconv_mode = std::strcmp(m, "f32") == 0 ? 0 : (std::strcmp(m, "bf16x3") == 0 ? 1 : (std::strcmp(m, "fp16x2") == 0 ? 3 : (std::strcmp(m, "fgemm") == 0 ? 4 : (std::strcmp(m, "fgemm256") == 0 ? 5 : (std::strcmp(m, "fgemm128") == 0 ? 6 : 2)))));
     // group-Fourier basis (irreps of the table's group)
     c->fb = new FourierBasis();
@@ -367,7 +393,11 @@ int yoho_ctx_destroy(yoho_ctx* c) {
     if (c->d_tap_inv) (void)hipFree(c->d_tap_inv);
     if (c->d_rflag) (void)hipFree(c->d_rflag);
     delete c->fb;
-    if (c->ev_created) for (auto& e : c->ev) (void)hipEventDestroy(e);
+    for (auto& e : c->ev) (void)hipEventDestroy(e);
+    for (auto& e : c->ev_pass) if (e) (void)hipEventDestroy(e);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
     delete c;
     return 0;
 }
@@ -414,6 +444,13 @@ int yoho_set_gconv_mode(yoho_ctx* c, int mode) {
     return 0;
 }
 
+int yoho_set_partI_schedule(yoho_ctx* c, int chunk_kp, int streams) {
+    if (!c || chunk_kp < 0 || streams < 1 || streams > 2) { set_error("yoho_set_partI_schedule: chunk_kp >= 0 and streams 1 or 2"); return YOHO_EINVAL; }
+    c->partI_chunk = (chunk_kp + 255) / 256 * 256;
+    c->partI_streams = streams;
+    return 0;
+}
+
 int yoho_set_partII_mode(yoho_ctx* c, int mode) {
     if (!c || mode < 0 || mode > 2) { set_error("yoho_set_partII_mode: mode must be 0 (fp32 MFMA), 1 (bf16x3) or 2 (fp16x2 MFMA for the cone layers)"); return YOHO_EINVAL; }
     c->partII_mode = mode;
@@ -457,14 +494,24 @@ int yoho_range_status(yoho_ctx* c, int* partI_overflow, int* partII_overflow, vo
     return 0;
 }
 
+// events of a profiled pass: EV_PER_PASS per chunk, grown on demand
+static int ensure_events(yoho_ctx* c, int nchunks) {
+    while ((int)c->ev.size() < nchunks * EV_PER_PASS) {
+        hipEvent_t e;
+        HIPCHK(hipEventCreate(&e));
+        c->ev.push_back(e);
+    }
+    for (auto& e : c->ev_pass) if (!e) HIPCHK(hipEventCreate(&e));
+    c->ev_created = true;
+    return 0;
+}
+
 int yoho_set_profiling(yoho_ctx* c, int enable) {
     if (!c) { set_error("null ctx"); return YOHO_EINVAL; }
     HIPCHK(hipSetDevice(c->device));
-    if (enable && !c->ev_created) {
-        for (auto& e : c->ev) HIPCHK(hipEventCreate(&e));
-        c->ev_created = true;
-    }
+    if (enable) { int rc = ensure_events(c, 1); if (rc) return rc; }
     c->profiling = enable != 0;
+    c->ev_chunks = 0;
     for (auto& m : c->kernel_ms) m = -1.f;
     return 0;
 }
@@ -472,24 +519,29 @@ int yoho_set_profiling(yoho_ctx* c, int enable) {
 // which: 0..3 = PartI group-conv launches (conv_in, res_in, res_out, conv_out) of the last profiled
 // yoho_partI_forward pass; 4 = head (pack [+ forward transform]), 5 = tail ([inverse transform +] finalize),
 // 6 = the inter-layer transform kernels together (group-Fourier modes), 7 / 8 / 9 = each of them, 10 = the inverse
-// transform of the tail, 11 = finalize alone.  Synchronises on the recorded events.
+// transform of the tail, 11 = finalize alone, 12 = the whole pass (first launch to last, on the caller's stream).
+// A chunked pass (yoho_set_partI_schedule) reports the sums over its chunks.  Synchronises on the recorded events.
 int yoho_get_kernel_ms(yoho_ctx* c, int which, float* ms) {
-    if (!c || !ms || which < 0 || which > 11) { set_error("yoho_get_kernel_ms: bad argument"); return YOHO_EINVAL; }
-    if (!c->ev_created) { set_error("profiling was not enabled"); return YOHO_EINVAL; }
+    if (!c || !ms || which < 0 || which > 12) { set_error("yoho_get_kernel_ms: bad argument"); return YOHO_EINVAL; }
+    if (!c->ev_created || c->ev_chunks < 1) { set_error("no profiled PartI pass (yoho_set_profiling, then yoho_partI_forward)"); return YOHO_EINVAL; }
     // event order: e0 head e1 conv0 e2 xf e3 conv1 e4 xf e5 conv2 e6 xf e7 conv3 e8 inverse transform e10 finalize e9
     static const int first[6] = {1, 3, 5, 7, 0, 8};
-    HIPCHK(hipEventSynchronize(c->ev[9]));
-    if (which >= 7 && which <= 9) { HIPCHK(hipEventElapsedTime(ms, c->ev[2 * (which - 6)], c->ev[2 * (which - 6) + 1])); return 0; }
-    if (which == 10) { HIPCHK(hipEventElapsedTime(ms, c->ev[8], c->ev[10])); return 0; }
-    if (which == 11) { HIPCHK(hipEventElapsedTime(ms, c->ev[10], c->ev[9])); return 0; }
-    if (which == 5) { HIPCHK(hipEventElapsedTime(ms, c->ev[8], c->ev[9])); return 0; }
-    if (which == 6) {            // the three inter-layer transform kernels (group-Fourier mode; ~0 otherwise)
-        float t = 0.f, d = 0.f;
-        for (int i = 2; i <= 6; i += 2) { HIPCHK(hipEventElapsedTime(&d, c->ev[i], c->ev[i + 1])); t += d; }
-        *ms = t;
-        return 0;
+    HIPCHK(hipEventSynchronize(c->ev_pass[1]));
+    if (which == 12) { HIPCHK(hipEventElapsedTime(ms, c->ev_pass[0], c->ev_pass[1])); return 0; }
+    float tot = 0.f;
+    for (int k = 0; k < c->ev_chunks; ++k) {
+        hipEvent_t* ev = c->ev.data() + (size_t)k * EV_PER_PASS;
+        auto el = [&](int a, int b) -> int { float d = 0.f; HIPCHK(hipEventElapsedTime(&d, ev[a], ev[b])); tot += d; return 0; };
+        int rc = 0;
+        if (which >= 7 && which <= 9) rc = el(2 * (which - 6), 2 * (which - 6) + 1);
+        else if (which == 10) rc = el(8, 10);
+        else if (which == 11) rc = el(10, 9);
+        else if (which == 5) rc = el(8, 9);
+        else if (which == 6) { for (int i = 2; i <= 6 && !rc; i += 2) rc = el(i, i + 1); }      // the three inter-layer transform kernels (group-Fourier modes; ~0 otherwise)
+        else rc = el(first[which], first[which] + 1);
+        if (rc) return rc;
     }
-    HIPCHK(hipEventElapsedTime(ms, c->ev[first[which]], c->ev[first[which] + 1]));
+    *ms = tot;
     return 0;
 }
 
@@ -509,6 +561,7 @@ static int partI_pass16(yoho_ctx* c, const float* x, int B, float* eqv, float* i
     float* bY = (float*)((char*)bH0 + szH0);
     const bool prof = c->profiling && c->ev_created;
     auto mark = [&](int i) { if (prof) (void)hipEventRecord(c->ev[i], s); };
+    if (prof) { c->ev_chunks = 1; (void)hipEventRecord(c->ev_pass[0], s); }
     mark(0);
     int* rf = c->d_rflag;
     if ((rc = launch_pack16_partI(x, B, nT, bX, s, npl, rf))) return rc;
@@ -523,6 +576,7 @@ static int partI_pass16(yoho_ctx* c, const float* x, int B, float* eqv, float* i
     mark(8); mark(10);
     if ((rc = launch_finalize_partI(bY, x, B, eqv, inv, inv_np, 1, s))) return rc;
     mark(9);
+    if (prof) (void)hipEventRecord(c->ev_pass[1], s);
     return 0;
 }
 
@@ -542,6 +596,7 @@ static int partI_passF(yoho_ctx* c, const float* x, int B, float* eqv, float* in
     const bool prof = c->profiling && c->ev_created;
     auto mark = [&](int i) { if (prof) (void)hipEventRecord(c->ev[i], s); };
     const Layer* L = c->p1;
+    if (prof) { c->ev_chunks = 1; (void)hipEventRecord(c->ev_pass[0], s); }
     mark(0);
     if ((rc = launch_pack_partI(x, B, nT, bS, s))) return rc;
     if ((rc = launch_gft(0, bS, bX, c->dFpad, nullptr, nullptr, nT, 4, s))) return rc;
@@ -564,22 +619,33 @@ static int partI_passF(yoho_ctx* c, const float* x, int B, float* eqv, float* in
     mark(10);
     if ((rc = launch_finalize_partI(bYs, x, B, eqv, inv, inv_np, 0, s))) return rc;
     mark(9);
+    if (prof) (void)hipEventRecord(c->ev_pass[1], s);
     return 0;
 }
 
 // group-Fourier variant: all four layers as irrep GEMMs on the fp16x2 split MFMA, fp16x2 transform kernels between them
-static int partI_passG(yoho_ctx* c, const float* x, int B, float* eqv, float* inv, float* inv_np, hipStream_t s, const float* x1 = nullptr,
-                       int B0 = 0) {
+static size_t partI_G_ws_bytes(int B) {
+    const int nT = (B + TILE - 1) / TILE;
+    const int kppad = (B + 255) / 256 * 256;
+    const size_t nX = (size_t)nT * 4, n256 = (size_t)nT * 32, n512 = (size_t)nT * 64;
+    const size_t sz = (nX * 2 + n256 * 2 + n512) * CHUNK_FLOATS * sizeof(float) + fgemm_planes_bytes(kppad, 32) + fgemm_planes_bytes(kppad, 256) +
+                      fgemm_planes_bytes(kppad, 512);
+    return (sz + 4095) / 4096 * 4096;
+}
+
+// one chunk of the pass: B keypoints through head -> 4 GEMMs + 3 transforms -> tail on the workspace slice at `ws`; rows >= B0 of
+// the chunk come from x1 (when set).  evbase: first of this chunk's EV_PER_PASS profiling events.
+static int partI_passG_chunk(yoho_ctx* c, char* ws, int evbase, const float* x, int B, float* eqv, float* inv, float* inv_np, hipStream_t s,
+                             const float* x1, int B0) {
     // GEMM blocking: mode 4 = 256 x 256 tile, eight waves (two per SIMD) sharing the A stage | mode 5 = 256 x 256, four waves (one per SIMD) |
     // mode 6 = 256 x 128 tiles, two four-wave workgroups per CU.  The transform kernel follows: two waves per SIMD except in mode 5.
     const int gv = c->gconv_mode == 5 ? 1 : (c->gconv_mode == 6 ? 2 : 3);
     const int nT = (B + TILE - 1) / TILE;
     const int kppad = (B + 255) / 256 * 256;
     const size_t nX = (size_t)nT * 4, n256 = (size_t)nT * 32, n512 = (size_t)nT * 64;
-    const size_t szP32 = fgemm_planes_bytes(kppad, 32), szP256 = fgemm_planes_bytes(kppad, 256), szP512 = fgemm_planes_bytes(kppad, 512);
+    const size_t szP32 = fgemm_planes_bytes(kppad, 32), szP256 = fgemm_planes_bytes(kppad, 256);
     int rc;
-    if ((rc = ensure_ws(c, (nX * 2 + n256 * 2 + n512) * CHUNK_FLOATS * sizeof(float) + szP32 + szP256 + szP512, s))) return rc;
-    float* bH0 = (float*)c->ws.p;                 // raw h0 (Fourier), kept for the residual
+    float* bH0 = (float*)ws;                      // raw h0 (Fourier), kept for the residual
     float* bA = bH0 + n256 * CHUNK_FLOATS;        // raw h2
     float* bM = bA + n256 * CHUNK_FLOATS;         // raw mid 512
     float* bY = bM + n512 * CHUNK_FLOATS;         // conv_out raw (Fourier)
@@ -588,9 +654,8 @@ static int partI_passG(yoho_ctx* c, const float* x, int B, float* eqv, float* in
     char* bP256 = bP32 + szP32;                       // act(h0), later act(h2)
     char* bP512 = bP256 + szP256;                     // act(mid)
     const bool prof = c->profiling && c->ev_created;
-    auto mark = [&](int i) { if (prof) (void)hipEventRecord(c->ev[i], s); };
+    auto mark = [&](int i) { if (prof) (void)hipEventRecord(c->ev[evbase + i], s); };
     const Layer* L = c->p1;
-    for (int i = 0; i < 4; ++i) if (!L[i].wpg) { set_error("irrep-GEMM weights missing"); return YOHO_ENOWEIGHTS; }
     mark(0);
     int* rf = c->d_rflag;
     if ((rc = launch_head16(x, B, nT, bP32, kppad, c->dF16, s, x1, B0, rf))) return rc;
@@ -616,6 +681,55 @@ static int partI_passG(yoho_ctx* c, const float* x, int B, float* eqv, float* in
     return 0;
 }
 
+// The pass over B keypoints (rows >= B0 from x1 when set).  Breadth-first (one chunk) unless yoho_set_partI_schedule asked for the
+// depth-first schedule: chunks of partI_chunk keypoints, each with its own workspace slice per stream, results bit-identical
+// (a keypoint's arithmetic does not depend on which other keypoints share its launch).
+static int partI_passG(yoho_ctx* c, const float* x, int B, float* eqv, float* inv, float* inv_np, hipStream_t s, const float* x1 = nullptr,
+                       int B0 = 0) {
+    for (int i = 0; i < 4; ++i) if (!c->p1[i].wpg) { set_error("irrep-GEMM weights missing"); return YOHO_ENOWEIGHTS; }
+    const int chunk = c->partI_chunk > 0 ? c->partI_chunk : B;
+    const int nch = (B + chunk - 1) / chunk;
+    const int nstr = (nch > 1 && c->partI_streams == 2) ? 2 : 1;
+    const size_t slice = partI_G_ws_bytes(nch > 1 ? chunk : B);
+    int rc;
+    if ((rc = ensure_ws(c, slice * nstr, s))) return rc;
+    const bool prof = c->profiling && c->ev_created;
+    if (prof) {
+        if ((rc = ensure_events(c, nch))) return rc;
+        c->ev_chunks = nch;
+        (void)hipEventRecord(c->ev_pass[0], s);
+    }
+    if (nstr == 2) {
+        if (!c->side_stream) {
+            HIPCHK(hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
+            HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+        }
+        HIPCHK(hipEventRecord(c->ev_fork, s));                      // the side stream starts behind everything queued on the caller's
+        HIPCHK(hipStreamWaitEvent(c->side_stream, c->ev_fork, 0));
+    }
+    for (int k = 0; k < nch; ++k) {
+        const int off = k * chunk, n = B - off < chunk ? B - off : chunk;
+        const float *xc, *x1c = nullptr;
+        int B0c = 0;
+        if (x1 && off >= B0) xc = x1 + (size_t)(off - B0) * F * G;
+        else {
+            xc = x + (size_t)off * F * G;
+            if (x1 && off + n > B0) { x1c = x1; B0c = B0 - off; }
+        }
+        hipStream_t sk = (nstr == 2 && (k & 1)) ? c->side_stream : s;
+        char* ws = (char*)c->ws.p + (nstr == 2 && (k & 1) ? slice : 0);
+        if ((rc = partI_passG_chunk(c, ws, k * EV_PER_PASS, xc, n, eqv + (size_t)off * F * G, inv ? inv + (size_t)off * F : nullptr,
+                                    inv_np ? inv_np + (size_t)off * F : nullptr, sk, x1c, B0c))) return rc;
+    }
+    if (nstr == 2) {
+        HIPCHK(hipEventRecord(c->ev_join, c->side_stream));          // the caller's stream continues behind the side stream's last chunk
+        HIPCHK(hipStreamWaitEvent(s, c->ev_join, 0));
+    }
+    if (prof) (void)hipEventRecord(c->ev_pass[1], s);
+    return 0;
+}
+
 static int partI_pass(yoho_ctx* c, const float* x, int B, float* eqv, float* inv, float* inv_np, hipStream_t s) {
     if (c->gconv_mode >= 4) return partI_passG(c, x, B, eqv, inv, inv_np, s);
     if (c->gconv_mode == 1 || c->gconv_mode == 3) return partI_pass16(c, x, B, eqv, inv, inv_np, s, c->gconv_mode == 1 ? 3 : 2);
@@ -632,6 +746,7 @@ static int partI_pass(yoho_ctx* c, const float* x, int B, float* eqv, float* inv
     float* bY = bA1 + n512 * CHUNK_FLOATS;
     const bool prof = c->profiling && c->ev_created;
     auto mark = [&](int i) { if (prof) (void)hipEventRecord(c->ev[i], s); };
+    if (prof) { c->ev_chunks = 1; (void)hipEventRecord(c->ev_pass[0], s); }
     mark(0);
     if ((rc = launch_pack_partI(x, B, nT, bX, s))) return rc;
     mark(1);
@@ -645,6 +760,7 @@ static int partI_pass(yoho_ctx* c, const float* x, int B, float* eqv, float* inv
     mark(8); mark(10);
     if ((rc = launch_finalize_partI(bY, x, B, eqv, inv, inv_np, 0, s))) return rc;
     mark(9);
+    if (prof) (void)hipEventRecord(c->ev_pass[1], s);
     return 0;
 }
 

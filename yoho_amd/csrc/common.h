@@ -196,9 +196,20 @@ struct yoho_ctx {
     double nn_cell = 0.0;        // > 0: 3-D nearest-neighbour searches go through a hash grid of this cell size (gridnn.hip)
     // workspace (grown on demand)
     yoho::Workspace ws;
-    // profiling
+    // depth-first PartI schedule (default mode): the pass is cut into chunks of partI_chunk keypoints (a multiple of 256; 0 = one
+    // breadth-first pass), each chunk running head -> 4 GEMMs + 3 transforms -> tail on its own slice of the workspace so that
+    // the intermediates of a chunk stay in the 256 MB Infinity Cache; with partI_streams == 2 the chunks alternate between the
+    // caller's stream and an internal one (forked / joined with events), so one chunk's transforms overlap the other's GEMMs
+    int partI_chunk = 0;
+    int partI_streams = 1;
+    hipStream_t side_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // profiling: EV_PER_PASS events per chunk of the last profiled PartI pass
     bool profiling = false;
-    hipEvent_t ev[16];
+    std::vector<hipEvent_t> ev;
+    int ev_chunks = 0;           // chunks of the last profiled pass
+    hipEvent_t ev_pass[2] = {nullptr, nullptr};   // around the whole pass on the caller's stream
     bool ev_created = false;
     float kernel_ms[8];
 };
+namespace yoho { constexpr int EV_PER_PASS = 11; }

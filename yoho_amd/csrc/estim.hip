@@ -291,8 +291,6 @@ struct CStat {
     int pad;
 };
 
-constexpr int CS_CHUNK = 8192;      // matches staged in LDS per round of the bucket placement
-
 // every match in parallel: its two keypoints gathered into contiguous (M,3) arrays, its coarse rotation clamped to a byte
 __global__ __launch_bounds__(256) void cprep_kernel(const int64_t* __restrict__ dr, int M, const double* __restrict__ keys0,
                                                     const double* __restrict__ keys1, const int64_t* __restrict__ i0,
@@ -308,27 +306,62 @@ __global__ __launch_bounds__(256) void cprep_kernel(const int64_t* __restrict__ 
     for (int j = 0; j < 3; ++j) { k0m[(size_t)m * 3 + j] = keys0[r0 * 3 + j]; k1m[(size_t)m * 3 + j] = keys1[r1 * 3 + j]; }
 }
 
-// one workgroup: histogram, weights / running sum, bucket lists in ascending match order
-__global__ __launch_bounds__(256) void cstat_kernel(const unsigned char* __restrict__ dr8, int M, CStat* __restrict__ st, int* __restrict__ members) {
-    __shared__ int cnt[G];
-    __shared__ int pos[G];
-    __shared__ unsigned char drs[CS_CHUNK];
-    const int tid = threadIdx.x;
-    if (tid < G) cnt[tid] = 0;
+// one workgroup of 16 waves: histogram, weights / running sum, bucket lists in ascending match order (a stable counting sort).
+// Wave w owns the contiguous segment [w * seg, (w + 1) * seg) of the matches.  Pass 1: per-wave bucket counts (the lanes of a
+// 64-match step that share a bucket find each other with six ballots; the lowest of them adds their number to the wave's own
+// LDS row - no atomics).  Then 60 threads turn the counts into per-wave cursors (bucket start + the counts of the waves before),
+// thread 0 into the weights and their running sum.  Pass 2: every wave walks its segment again and places match m at
+// cursor[bucket] + (number of lower lanes of the step in the same bucket): ascending match order inside every bucket, exactly
+// the order of the reference's R_index_pre_statistic lists (tests/estimator.py:34-51).
+constexpr int CS_WAVES = 16;
+
+__device__ __forceinline__ unsigned long long same_bucket_lanes(int b, bool valid) {
+    unsigned long long same = __ballot(valid);
+#pragma unroll
+    for (int bit = 0; bit < 6; ++bit) {
+        const bool on = (b >> bit) & 1;
+        const unsigned long long bal = __ballot(on);
+        same &= on ? bal : ~bal;
+    }
+    return valid ? same : 0ull;
+}
+
+__global__ __launch_bounds__(64 * CS_WAVES) void cstat_kernel(const unsigned char* __restrict__ dr8, int M, CStat* __restrict__ st, int* __restrict__ members) {
+    __shared__ volatile int wcnt[CS_WAVES][64];      // pass 1: counts of wave w; pass 2: its cursors
+    __shared__ int tot[G];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int seg = ((M + CS_WAVES - 1) / CS_WAVES + 63) / 64 * 64;
+    const int m0 = w * seg, m1 = min(M, m0 + seg);
+    wcnt[w][lane] = 0;
+    __builtin_amdgcn_wave_barrier();
+    const unsigned long long below = (1ull << lane) - 1ull;
+    for (int base = m0; base < m1; base += 64) {
+        const int m = base + lane;
+        const bool valid = m < m1;
+        const int b = valid ? dr8[m] : 0;
+        const unsigned long long same = same_bucket_lanes(b, valid);
+        if (valid && (same & below) == 0ull) wcnt[w][b] += __popcll(same);       // one writer per bucket and wave
+        __builtin_amdgcn_wave_barrier();
+    }
     __syncthreads();
-    for (int m = tid; m < M; m += 256) atomicAdd(&cnt[dr8[m]], 1);
+    if (tid < G) {
+        int n = 0;
+        for (int k = 0; k < CS_WAVES; ++k) n += wcnt[k][tid];
+        tot[tid] = n;
+    }
     __syncthreads();
     if (tid == 0) {
         int acc = 0;
         double run = 0.0;
         for (int j = 0; j < G; ++j) {
-            pos[j] = acc;
+            const int n = tot[j];
             st->start[j] = acc;
-            st->count[j] = cnt[j];
-            acc += cnt[j];
+            st->count[j] = n;
+            tot[j] = acc;
+            acc += n;
             double p = 0.0;
-            if (cnt[j] >= 2) {
-                const double num = (double)cnt[j] / 100.0;
+            if (n >= 2) {
+                const double num = (double)n / 100.0;
                 p = __dmul_rn(__dmul_rn(num, __dsub_rn(num, 0.01)), __dsub_rn(num, 0.02));
             }
             run = __dadd_rn(run, p);
@@ -336,17 +369,25 @@ __global__ __launch_bounds__(256) void cstat_kernel(const unsigned char* __restr
         }
         st->valid = run < 1e-4 ? 0 : 1;
     }
-    for (int base = 0; base < M; base += CS_CHUNK) {
-        const int n = M - base < CS_CHUNK ? M - base : CS_CHUNK;
-        __syncthreads();
-        for (int i = tid; i < n; i += 256) drs[i] = dr8[base + i];
-        __syncthreads();
-        if (tid < G) {                               // thread b appends its own matches, in order
-            int p = pos[tid];
-            for (int i = 0; i < n; ++i)
-                if (drs[i] == (unsigned char)tid) members[p++] = base + i;
-            pos[tid] = p;
+    __syncthreads();
+    if (tid < G) {                                   // counts -> cursors: bucket start + the counts of the waves before
+        int acc = tot[tid];
+        for (int k = 0; k < CS_WAVES; ++k) { const int n = wcnt[k][tid]; wcnt[k][tid] = acc; acc += n; }
+    }
+    __syncthreads();
+    for (int base = m0; base < m1; base += 64) {
+        const int m = base + lane;
+        const bool valid = m < m1;
+        const int b = valid ? dr8[m] : 0;
+        const unsigned long long same = same_bucket_lanes(b, valid);
+        int cur = 0;
+        if (valid) cur = wcnt[w][b];
+        __builtin_amdgcn_wave_barrier();
+        if (valid) {
+            members[cur + __popcll(same & below)] = m;
+            if ((same & below) == 0ull) wcnt[w][b] = cur + __popcll(same);
         }
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -584,7 +625,7 @@ int yoho_c_ransac_device(yoho_ctx* c, const double* keys0, const int64_t* i0, co
     int* bh = (int*)(w + oB);
     unsigned char* dr8 = (unsigned char*)(w + oD);
     hipLaunchKernelGGL(cprep_kernel, dim3((M + 255) / 256), dim3(256), 0, s, dr_index, M, keys0, keys1, i0, i1, istride, dr8, k0m, k1m);
-    hipLaunchKernelGGL(cstat_kernel, dim3(1), dim3(256), 0, s, dr8, M, st, members);
+    hipLaunchKernelGGL(cstat_kernel, dim3(1), dim3(64 * CS_WAVES), 0, s, dr8, M, st, members);
     HIPCHK(hipGetLastError());
     hipLaunchKernelGGL(kabsch_sample_kernel, dim3(max_iter), dim3(256), 0, s, k0m, k1m, M, st, members, (unsigned)(seed & 0xFFFFFFFFu),
                        (unsigned)(seed >> 32), d * d, Tall, cnt, triples_out);

@@ -78,6 +78,18 @@ def barrier():
         dist.barrier()
 
 
+def all_ranks(x, device=None):
+    """the value every rank holds, as a list in rank order (on every rank)"""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return [float(x)]
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    t = torch.tensor([float(x)], dtype=torch.float64, device=device)
+    out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [float(v.item()) for v in out]
+
+
 def max_over_ranks(x, device=None):
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return float(x)

@@ -22,7 +22,7 @@ SYMBOLS = [
     "yoho_gconv_layer", "yoho_load_fcgf", "yoho_fcgf_voxelize", "yoho_fcgf_forward", "yoho_fcgf_forward_batch", "yoho_fcgf_voxelize_rotated", "yoho_rotate_select",
     "yoho_des2r", "yoho_des2r_indexed", "yoho_partII_forward", "yoho_partII_forward_indexed", "yoho_hyp_from_quat", "yoho_o_score", "yoho_c_ransac",
     "yoho_group_gather", "yoho_set_profiling", "yoho_get_kernel_ms", "yoho_set_gconv_mode", "yoho_set_partII_mode", "yoho_set_nn_grid",
-    "yoho_range_status", "yoho_c_ransac_device", "yoho_group_scatter", "yoho_set_nn_prefilter", "yoho_set_fcgf_sort", "yoho_fcgf_voxelize_rotated_batch", "yoho_gconv_wgrad", "yoho_bn_stats", "yoho_bn_relu_apply", "yoho_bn_relu_backward",
+    "yoho_range_status", "yoho_c_ransac_device", "yoho_group_scatter", "yoho_set_nn_prefilter", "yoho_set_fcgf_sort", "yoho_fcgf_voxelize_rotated_batch", "yoho_gconv_wgrad", "yoho_bn_stats", "yoho_bn_relu_apply", "yoho_bn_relu_backward", "yoho_set_partI_schedule", "yoho_clock_probe",
 ]
 
 
@@ -95,6 +95,8 @@ def load_library():
     lib.yoho_set_profiling.argtypes = [vp, ci]
     lib.yoho_set_gconv_mode.argtypes = [vp, ci]
     lib.yoho_set_partII_mode.argtypes = [vp, ci]
+    lib.yoho_set_partI_schedule.argtypes = [vp, ci, ci]
+    lib.yoho_clock_probe.argtypes = [vp, ci, vp, vp]
     lib.yoho_set_nn_grid.argtypes = [vp, C.c_double]
     lib.yoho_set_nn_prefilter.argtypes = [vp, ci]
     lib.yoho_set_fcgf_sort.argtypes = [vp, ci, ci]
@@ -585,6 +587,11 @@ class Context:
         _check(self._lib.yoho_set_gconv_mode(self._h, GCONV_MODES[mode]))
         self.gconv_mode = mode
 
+    def set_partI_schedule(self, chunk_kp=0, streams=1):
+        """PartI pass of the default mode breadth-first (chunk_kp = 0) or depth-first over chunks of chunk_kp keypoints, the
+        chunks on one stream or alternating over two (include/yoho_hip.h); bit-identical results."""
+        _check(self._lib.yoho_set_partI_schedule(self._h, int(chunk_kp), int(streams)))
+
     def set_partII_mode(self, mode):
         """'f32', 'bf16x3' or 'fp16x2' for the two large cone layers of PartII."""
         _check(self._lib.yoho_set_partII_mode(self._h, PARTII_MODES[mode]))
@@ -604,6 +611,14 @@ class Context:
         """3-D nearest-neighbour searches (nn_search with 3 columns, group_gather) through a hash grid with this cell size
         (0 = brute force).  Same answers for any cell; pass the voxel size the target cloud was down-sampled with."""
         _check(self._lib.yoho_set_nn_grid(self._h, float(cell)))
+
+    def clock_probe(self, microseconds, stream=None):
+        """queue the one-wave clock probe (include/yoho_hip.h) on `stream` (a torch stream; default: the current one);
+        returns the (3,) int64 device tensor it fills - shader MHz = t[0] / t[1] * t[2] / 1000 once the stream has run"""
+        out = torch.zeros(3, dtype=torch.int64, device=f"cuda:{self.device}")
+        st = stream.cuda_stream if stream is not None else _stream()
+        _check(self._lib.yoho_clock_probe(self._h, int(microseconds), out.data_ptr(), st))
+        return out
 
     # ---- profiling hook (bench.py) ------------------------------------------------------------
     def set_profiling(self, on=True):

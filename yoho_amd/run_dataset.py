@@ -32,25 +32,112 @@ from .estimator import format_log_entry, NO_ESTIMATE  # noqa: F401  (re-exported
 # ---------------------------------------------------------------------------------------------------------------
 # work plan
 # ---------------------------------------------------------------------------------------------------------------
-def plan_shards(scene_sizes, world):
-    """scene_sizes: {scene key: number of pairs}.  Returns plan[rank] = list of (scene key, [pair positions]), the
-    positions indexing dataset.pair_ids.  Deterministic; every (scene, position) appears exactly once."""
-    world = max(1, int(world))
-    total = sum(int(n) for n in scene_sizes.values())
-    share = max(1, -(-total // world))
-    load = [0] * world
+FRAG_COST = 4.0       # cost of loading + describing one fragment in units of one pair (disk + H2D + PartI ~ 6 ms against ~1.5 ms per pair;
+                      # tools/bench_dataset.py measures both)
+MIN_PART = 8          # a scene is not cut into parts of fewer pairs than this (except its last remainder)
+
+
+def part_cost(n_pairs, n_frags=None, frag_cost=FRAG_COST):
+    """cost model of one (rank, scene part): its pairs + the fragments it has to load and describe - at most all of the scene's, at
+    most two per pair (upper bound; contiguous pairs of a sorted gt.log share fragments)"""
+    n_pairs = int(n_pairs)
+    if n_pairs <= 0:
+        return 0.0
+    touched = 2 * n_pairs if n_frags is None else min(int(n_frags), 2 * n_pairs)
+    return n_pairs + frag_cost * touched
+
+
+def _fit_pairs(room, n_frags, frag_cost):
+    """largest k with part_cost(k) <= room"""
+    if room <= 0:
+        return 0
+    if n_frags is not None and room >= part_cost(-(-int(n_frags) // 2), n_frags, frag_cost):
+        return int(room - frag_cost * int(n_frags))
+    return int(room / (1.0 + 2.0 * frag_cost))
+
+
+def _plan_wrap(order, frags, frag_cost, world, T):
+    """fill rank 0, 1, ... up to cost T each, a scene that does not fit spilling its remaining pairs into the next rank
+    (McNaughton's wrap-around rule with a per-part overhead); None if `world` ranks of capacity T do not hold everything"""
     plan = [[] for _ in range(world)]
-    for scene, n in sorted(scene_sizes.items(), key=lambda kv: (-int(kv[1]), str(kv[0]))):
-        n = int(n)
-        if n == 0:
-            continue
-        parts = min(world, -(-n // share))
-        ranks = sorted(range(world), key=lambda r: (load[r], r))[:parts]
-        for j, r in enumerate(ranks):
-            pos = list(range(j, n, parts))
-            plan[r].append((scene, pos))
-            load[r] += len(pos)
+    r, load = 0, 0.0
+    for scene, n in order:
+        f = frags.get(scene)
+        start = 0
+        while start < n:
+            if r >= world:
+                return None
+            rest = n - start
+            if load + part_cost(rest, f, frag_cost) <= T:
+                take = rest
+            else:
+                take = min(_fit_pairs(T - load, f, frag_cost), rest - MIN_PART)      # leave a sensible remainder
+                if take < MIN_PART:                                                  # this rank is full
+                    r, load = r + 1, 0.0
+                    continue
+            plan[r].append((scene, list(range(start, start + take))))
+            load += part_cost(take, f, frag_cost)
+            start += take
     return plan
+
+
+def _plan_lpt(order, frags, frag_cost, world, target):
+    """scenes whole, largest first onto the least loaded rank; only a scene that costs more than the per-rank target is cut, into
+    the fewest equal contiguous blocks that fit under it"""
+    plan = [[] for _ in range(world)]
+    load = [0.0] * world
+    for scene, n in order:
+        f = frags.get(scene)
+        parts = 1
+        while parts < min(world, max(1, n // MIN_PART)) and part_cost(-(-n // parts), f, frag_cost) > target:
+            parts += 1
+        bounds = [n * j // parts for j in range(parts + 1)]
+        ranks = sorted(range(world), key=lambda q: (load[q], q))[:parts]
+        for j, r in enumerate(ranks):
+            pos = list(range(bounds[j], bounds[j + 1]))
+            if pos:
+                plan[r].append((scene, pos))
+                load[r] += part_cost(len(pos), f, frag_cost)
+    return plan
+
+
+def plan_shards(scene_sizes, world, scene_frags=None, frag_cost=FRAG_COST):
+    """scene_sizes: {scene key: number of pairs}; scene_frags: {scene key: number of fragments} (optional: without it a part is
+    charged two fragments per pair).  Returns plan[rank] = list of (scene key, [pair positions]), the positions indexing
+    dataset.pair_ids.  Deterministic; every (scene, position) appears exactly once.
+
+    A part is a CONTIGUOUS block of a scene's pairs (neighbouring pairs of a gt.log share fragments, so a block loads fewer
+    fragments than a strided subset).  Two candidate plans under the cost model of part_cost, the one with the smaller maximum
+    rank load wins: (a) scenes whole, largest first onto the least loaded rank, only scenes above the per-rank target cut;
+    (b) wrap-around filling at the smallest per-rank capacity that holds everything (binary search), which cuts a scene at every
+    rank boundary and pays the fragments of both parts for it."""
+    world = max(1, int(world))
+    frags = scene_frags or {}
+    order = sorted(((k, int(n)) for k, n in scene_sizes.items() if int(n) > 0), key=lambda kv: (-kv[1], str(kv[0])))
+    if not order:
+        return [[] for _ in range(world)]
+    total = sum(part_cost(n, frags.get(k), frag_cost) for k, n in order)
+    if world == 1:
+        return [[(k, list(range(n))) for k, n in order]]
+    best = _plan_lpt(order, frags, frag_cost, world, total / world)
+    lo, hi = total / world, total
+    wrap = None
+    for _ in range(40):
+        mid = 0.5 * (lo + hi)
+        p = _plan_wrap(order, frags, frag_cost, world, mid)
+        if p is None:
+            lo = mid
+        else:
+            wrap, hi = p, mid
+    if wrap is not None and max(plan_loads(wrap, frags, frag_cost)) < max(plan_loads(best, frags, frag_cost)) - 1e-9:
+        best = wrap
+    return best
+
+
+def plan_loads(plan, scene_frags=None, frag_cost=FRAG_COST):
+    """cost of every rank's share under part_cost (tests, bench: the max / mean ratio is the planned imbalance)"""
+    frags = scene_frags or {}
+    return [sum(part_cost(len(pos), frags.get(s), frag_cost) for s, pos in part) for part in plan]
 
 
 def pair_seed(base_seed, scene_name, id0, id1):
@@ -73,17 +160,26 @@ def run_sharded(datasets, pair_fn, rank=0, world=1, scene_fn=None, gather=None):
     scene_fn(dataset, pairs) is called once per (rank, scene part) before its pairs (descriptor extraction).
     Returns on EVERY rank {scene key: [result per pair, in dataset.pair_ids order]} (gathered on the host)."""
     items = scene_items(datasets)
-    plan = plan_shards({k: len(d.pair_ids) for k, d in items}, world)
+    plan = plan_shards({k: len(d.pair_ids) for k, d in items}, world, {k: len(d.pc_ids) for k, d in items})
     by_key = dict(items)
     mine = {}
-    for key, positions in plan[rank]:
-        ds = by_key[key]
-        pairs = [tuple(ds.pair_ids[p]) for p in positions]
-        if scene_fn is not None:
-            scene_fn(ds, pairs)
-        for p, pair in zip(positions, pairs):
-            mine[(key, p)] = pair_fn(ds, pair)
+    try:
+        for key, positions in plan[rank]:
+            ds = by_key[key]
+            pairs = [tuple(ds.pair_ids[p]) for p in positions]
+            if scene_fn is not None:
+                scene_fn(ds, pairs)
+            for p, pair in zip(positions, pairs):
+                mine[(key, p)] = pair_fn(ds, pair)
+    except Exception as e:
+        # a rank that fails must still reach the gather, or the other ranks would wait for it forever: the error travels with
+        # the results and is raised on EVERY rank
+        import traceback
+        mine = {("__error__", rank): f"rank {rank}: {type(e).__name__}: {e}\n{traceback.format_exc()}"}
     parts = (gather or ydist.gather_results)(mine)
+    errors = [v for part in parts for kp, v in part.items() if kp[0] == "__error__"]
+    if errors:
+        raise RuntimeError("sharded run failed:\n" + "\n".join(errors))
     merged = {}
     for part in parts:
         for kp, v in part.items():
@@ -116,9 +212,14 @@ def write_scene_results(cfg, dataset, results, yoho_sign, max_iter):
 # the GPU worker of one rank
 # ---------------------------------------------------------------------------------------------------------------
 class ScenePairRunner:
-    """HBM-resident execution of the pairs one rank owns.  estimator 'yohoo' (needs the PartII weights) or 'yohoc'."""
+    """HBM-resident execution of the pairs one rank owns.  estimator 'yohoo' (needs the PartII weights) or 'yohoc'.
 
-    def __init__(self, cfg, ctx, estimator="yohoo", max_iter=1000, base_seed=0):
+    A fragment stays resident (FCGF group feature, PartI descriptor, keypoints: 77 MB at 5000 keypoints) exactly as long as a
+    pair of the current scene part still needs it: setup_scene counts the uses, run_pair releases a fragment after its last
+    pair, so a rank's footprint is bounded by one scene part whatever the number of parts it walks.
+    `stats` accumulates where the time goes (seconds; device work is timed with a synchronise only when timing=True)."""
+
+    def __init__(self, cfg, ctx, estimator="yohoo", max_iter=1000, base_seed=0, timing=False):
         import torch
         from . import pipeline
         self.torch, self.pipeline = torch, pipeline
@@ -127,41 +228,107 @@ class ScenePairRunner:
         self.inlier_dist = cfg.ransac_o_inlinerdist if estimator == "yohoo" else cfg.ransac_c_inlinerdist
         self.scene = None
         self.frag = {}
+        self.uses = {}
+        self.timing = bool(timing)
+        self.stats = {"fragments": 0, "pairs": 0, "load_s": 0.0, "load_wait_s": 0.0, "h2d_describe_s": 0.0, "setup_s": 0.0, "pairs_s": 0.0,
+                      "bytes_read": 0, "peak_resident_fragments": 0}
 
     def _feature_dir(self, dataset):
         from .utils import dataset_feature_name
         return f'{self.cfg.output_cache_fn}/Testset/{dataset_feature_name(dataset.name)}/FCGF_Input_Group_feature'
 
-    def setup_scene(self, dataset, pairs):
-        """load + describe every fragment the pairs touch (tests/extractor.py:37-62 without the .npy round trip);
-        up to 3 fragments of 5000 keypoints go through one PartI pass"""
+    def _load_fragment(self, dataset, fdir, fid):
+        """disk -> page-locked host tensors (the .npy is read straight into the pinned buffer, one copy)"""
+        import time
         torch = self.torch
+        t0 = time.perf_counter()
+        src = np.load(f'{fdir}/{fid}.npy', mmap_mode='r')
+        x = torch.empty(src.shape, dtype=torch.float32).pin_memory()
+        np.copyto(x.numpy(), src, casting='same_kind')
+        keys = torch.from_numpy(np.ascontiguousarray(dataset.get_kps(fid), dtype=np.float64)).pin_memory()
+        return fid, x, keys, time.perf_counter() - t0
+
+    def setup_scene(self, dataset, pairs):
+        """load + describe every fragment the pairs touch (tests/extractor.py:37-62 without the .npy round trip): a loader
+        thread reads the cache files into pinned memory while the device describes the fragments already there; up to 16384
+        keypoints (3 fragments of 5000) go through one PartI pass"""
+        import queue
+        import threading
+        import time
+        torch = self.torch
+        t_setup = time.perf_counter()
         if self.scene != dataset.name:
-            self.scene, self.frag = dataset.name, {}
+            self.scene, self.frag, self.uses = dataset.name, {}, {}
+        for p in pairs:
+            for i in p:
+                self.uses[i] = self.uses.get(i, 0) + 1
         need = sorted({i for p in pairs for i in p if i not in self.frag}, key=lambda v: int(v))
         fdir = self._feature_dir(dataset)
-        loaded = []
-        for fid in need:
-            x = torch.from_numpy(np.ascontiguousarray(np.load(f'{fdir}/{fid}.npy'), dtype=np.float32)).cuda()
-            keys = torch.from_numpy(np.ascontiguousarray(dataset.get_kps(fid), dtype=np.float64)).cuda()
-            loaded.append((fid, x, keys))
+        q = queue.Queue(maxsize=6)
+
+        def loader():
+            try:
+                for fid in need:
+                    q.put(self._load_fragment(dataset, fdir, fid))
+            except BaseException as e:          # surfaced in the consumer
+                q.put(e)
+            q.put(None)
+        th = threading.Thread(target=loader, daemon=True)
+        th.start()
+
+        def describe(group):
+            t0 = time.perf_counter()
+            dev = [(fid, x.cuda(non_blocking=True), keys.cuda(non_blocking=True)) for fid, x, keys in group]
+            xs = torch.cat([g[1] for g in dev]) if len(dev) > 1 else dev[0][1]
+            out = self.ctx.partI_forward(xs.contiguous(), want_inv=False, want_inv_np=True)
+            o = 0
+            for fid, x, keys in dev:
+                n = x.shape[0]
+                # own storage per fragment, so that releasing one fragment frees its memory (slices would pin the whole pass)
+                self.frag[fid] = dict(feat=x, keys=keys, eqv=out["eqv"][o:o + n].clone(), inv_np=out["inv_np"][o:o + n].clone())
+                o += n
+            if self.timing:
+                torch.cuda.synchronize()
+            self.stats["h2d_describe_s"] += time.perf_counter() - t0
+            self.stats["fragments"] += len(group)
+
         group, rows = [], 0
-        for item in loaded + [None]:
-            if item is None or (group and rows + item[1].shape[0] > 16384):
-                if group:
-                    xs = torch.cat([g[1] for g in group]) if len(group) > 1 else group[0][1]
-                    out = self.ctx.partI_forward(xs.contiguous(), want_inv=False, want_inv_np=True)
-                    o = 0
-                    for fid, x, keys in group:
-                        n = x.shape[0]
-                        self.frag[fid] = dict(feat=x, keys=keys, eqv=out["eqv"][o:o + n], inv_np=out["inv_np"][o:o + n])
-                        o += n
-                group, rows = [], 0
+        while True:
+            t0 = time.perf_counter()
+            item = q.get()
+            self.stats["load_wait_s"] += time.perf_counter() - t0
+            if isinstance(item, BaseException):
+                raise item
             if item is not None:
-                group.append(item)
-                rows += item[1].shape[0]
+                self.stats["load_s"] += item[3]
+                self.stats["bytes_read"] += item[1].numel() * 4 + item[2].numel() * 8
+                item = item[:3]
+            # a pass is flushed when full, when the input ends, or when the loader has nothing ready (do not idle the device)
+            if group and (item is None or rows + item[1].shape[0] > 16384):
+                describe(group)
+                group, rows = [], 0
+            if item is None:
+                break
+            group.append(item)
+            rows += item[1].shape[0]
+            if q.empty() and group and rows >= 4096:
+                describe(group)
+                group, rows = [], 0
+        th.join()
+        self.stats["peak_resident_fragments"] = max(self.stats["peak_resident_fragments"], len(self.frag))
+        self.stats["setup_s"] += time.perf_counter() - t_setup
+
+    def _release(self, fid):
+        n = self.uses.get(fid, 0) - 1
+        if n <= 0:
+            self.uses.pop(fid, None)
+            self.frag.pop(fid, None)
+        else:
+            self.uses[fid] = n
 
     def run_pair(self, dataset, pair):
+        import time
+        t0 = time.perf_counter()
         id0, id1 = pair
         a, b = self.frag[id0], self.frag[id1]
         seed = pair_seed(self.base_seed, dataset.name, id0, id1)
@@ -170,7 +337,12 @@ class ScenePairRunner:
                                    eqv=({"eqv": a["eqv"], "inv_np": a["inv_np"]}, {"eqv": b["eqv"], "inv_np": b["inv_np"]}),
                                    estimator=self.estimator, seed=seed)
         trans = np.asarray(r.trans, dtype=np.float64)
-        return {"trans": trans, "recalltime": int(r.best_h), "matches": int(r.match.shape[0]), "inliers": int(r.best_count)}
+        out = {"trans": trans, "recalltime": int(r.best_h), "matches": int(r.match.shape[0]), "inliers": int(r.best_count)}
+        self._release(id0)
+        self._release(id1)
+        self.stats["pairs"] += 1
+        self.stats["pairs_s"] += time.perf_counter() - t0
+        return out
 
 
 def load_and_broadcast_weights(cfg, ctx, need_partII):
@@ -190,33 +362,46 @@ def load_and_broadcast_weights(cfg, ctx, need_partII):
         ctx.load_partII(ydist.broadcast_state_dict(sd2, W.PARTII_SPEC))
 
 
-def eval_sharded(cfg, max_iter=1000, estimator="yohoo", datasets=None, base_seed=0, results_log=None):
+def eval_sharded(cfg, max_iter=1000, estimator="yohoo", datasets=None, base_seed=0, results_log=None, ctx=None, state_dicts=None,
+                 stats_out=None):
     """The sharded counterpart of Evaluator_PartI/II.eval (tests/evaluator.py:75-101,146-173): run every pair of the
     test set over the initialised process group (one rank per GPU), write npz / pre.log on rank 0 and return the
     Registration Recall there (None on the other ranks).  FCGF group features and keypoints are read from the
-    reference's cache layout; descriptors, matches and hypotheses never touch the disk."""
+    reference's cache layout; descriptors, matches and hypotheses never touch the disk.  stats_out: a dict that receives the
+    rank's ScenePairRunner.stats and the gathered per-pair results (tools/bench_dataset.py, tests)."""
     import torch
     from . import hip, RR_cal
     from .dataset import get_dataset
     if datasets is None:
         datasets = get_dataset(cfg, False)
     rank, world, local = ydist.init_from_env()
-    ctx = hip.get_context(so3_dir=getattr(cfg, "SO3_related_files", None))
-    load_and_broadcast_weights(cfg, ctx, need_partII=(estimator == "yohoo"))
-    runner = ScenePairRunner(cfg, ctx, estimator=estimator, max_iter=max_iter, base_seed=base_seed)
+    if ctx is None:
+        ctx = hip.get_context(so3_dir=getattr(cfg, "SO3_related_files", None))
+    if state_dicts is None:
+        load_and_broadcast_weights(cfg, ctx, need_partII=(estimator == "yohoo"))
+    else:                                        # already loaded by the caller (bench / tests): (PartI, PartII or None)
+        ctx.load_partI(state_dicts[0])
+        if estimator == "yohoo":
+            ctx.load_partII(state_dicts[1])
+    runner = ScenePairRunner(cfg, ctx, estimator=estimator, max_iter=max_iter, base_seed=base_seed, timing=stats_out is not None)
     results = run_sharded(datasets, runner.run_pair, rank=rank, world=world, scene_fn=runner.setup_scene)
     torch.cuda.synchronize()
+    if stats_out is not None:
+        stats_out.update(runner.stats)
+        stats_out["results"] = results
     if rank != 0:
         ydist.barrier()
         return None
-    sign = 'YOHO_O' if estimator == "yohoo" else 'YOHO_C'
-    for key, ds in scene_items(datasets):
-        write_scene_results(cfg, ds, results[key], sign, max_iter)
-    rr, flags, errors = RR_cal.benchmark(cfg, datasets, max_iter, yoho_sign=sign)
-    if results_log:
-        if os.path.dirname(results_log):
-            os.makedirs(os.path.dirname(results_log), exist_ok=True)
-        with open(results_log, 'a') as f:
-            f.write(f"{datasets['wholesetname']}-{estimator}-{max_iter}iterations-{world}ranks\nMean_Registration_Recall {rr}\n\n")
-    ydist.barrier()
+    try:
+        sign = 'YOHO_O' if estimator == "yohoo" else 'YOHO_C'
+        for key, ds in scene_items(datasets):
+            write_scene_results(cfg, ds, results[key], sign, max_iter)
+        rr, flags, errors = RR_cal.benchmark(cfg, datasets, max_iter, yoho_sign=sign)
+        if results_log:
+            if os.path.dirname(results_log):
+                os.makedirs(os.path.dirname(results_log), exist_ok=True)
+            with open(results_log, 'a') as f:
+                f.write(f"{datasets['wholesetname']}-{estimator}-{max_iter}iterations-{world}ranks\nMean_Registration_Recall {rr}\n\n")
+    finally:
+        ydist.barrier()                          # the other ranks wait here whatever happened to rank 0's files
     return rr
