@@ -283,8 +283,8 @@ int yoho_set_partII_mode(yoho_ctx* ctx, int mode);
  * Fourier coefficients as fixed power-of-two multiples in fp16 planes (|activation| < 4094, |coefficient| < 16376).
  * Every kernel that writes such planes raises a device-side flag when a value falls outside; nothing else in the
  * forward calls changes (they stay asynchronous, and their outputs are then not to be trusted).
- * yoho_range_status waits for `stream`, reports and clears the flags (out pointers may be NULL) and returns
- * YOHO_ERANGE if either was set, 0 otherwise; the caller then repeats the pass after yoho_set_gconv_mode(ctx, 1) /
+ * yoho_range_status waits for `stream`, reports and clears the flag of every network whose out pointer is given (a NULL out
+ * pointer leaves that network's flag pending for a later call) and returns YOHO_ERANGE if a reported flag was set, 0 otherwise; the caller then repeats the pass after yoho_set_gconv_mode(ctx, 1) /
  * yoho_set_partII_mode(ctx, 1) (bf16x3 planes carry the fp32 exponent range) - yoho_amd/hip.py does exactly that.
  * The reference computes in fp32 throughout (utils/network.py:12-105, 259-278), so it has no counterpart. */
 int yoho_range_status(yoho_ctx* ctx, int* partI_overflow, int* partII_overflow, void* stream);

@@ -167,8 +167,16 @@ def test_fp16_range_guard_partI(hip, sd1, tables):
     assert rel(o1["eqv"].cpu().numpy(), orc.partI_forward(x1, sdx, tables.N)[0]) < TOL
     # the C ABI reports YOHO_ERANGE (-5) with a message when polled after an overflowing pass
     c.partI_forward(xd, check_range=False)
-    rc = c._lib.yoho_range_status(c._h, None, None, None)
-    assert rc == -5 and b"fp16 range" in c._lib.yoho_last_error()
+    import ctypes
+    a, b = ctypes.c_int(0), ctypes.c_int(0)
+    assert c._lib.yoho_range_status(c._h, None, None, None) == 0                  # nobody asked: nothing reported, nothing cleared
+    assert c._lib.yoho_range_status(c._h, None, ctypes.byref(b), None) == 0 and b.value == 0     # a PartII check leaves the PartI flag pending
+    rc = c._lib.yoho_range_status(c._h, ctypes.byref(a), None, None)
+    assert rc == -5 and a.value == 1 and b"fp16 range" in c._lib.yoho_last_error()
+    assert c._lib.yoho_range_status(c._h, ctypes.byref(a), ctypes.byref(b), None) == 0 and a.value == 0      # reported once, then cleared
+    # the wrapper keeps a flag pending until the caller that owns that network consumes it
+    c.partI_forward(xd, check_range=False)
+    assert c.partII_overflow() is False and c.partI_overflow() is True and c.partI_overflow() is False
 
 
 def test_fp16_range_guard_partII_and_pipeline(hip, sd1, sd2, tables):

@@ -483,7 +483,11 @@ int yoho_range_status(yoho_ctx* c, int* partI_overflow, int* partII_overflow, vo
     int h[2] = {0, 0};
     HIPCHK(hipMemcpyAsync(h, c->d_rflag, sizeof(h), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
-    if (h[0] || h[1]) HIPCHK(hipMemsetAsync(c->d_rflag, 0, sizeof(h), s));
+    // only a word the caller asked for is reported and cleared: a flag nobody has looked at yet stays pending
+    if (!partI_overflow) h[0] = 0;
+    if (!partII_overflow) h[1] = 0;
+    if (h[0]) HIPCHK(hipMemsetAsync(c->d_rflag, 0, sizeof(int), s));
+    if (h[1]) HIPCHK(hipMemsetAsync(c->d_rflag + 1, 0, sizeof(int), s));
     if (partI_overflow) *partI_overflow = h[0];
     if (partII_overflow) *partII_overflow = h[1];
     if (h[0] || h[1]) {
@@ -708,6 +712,10 @@ static int partI_passG(yoho_ctx* c, const float* x, int B, float* eqv, float* in
         HIPCHK(hipEventRecord(c->ev_fork, s));                      // the side stream starts behind everything queued on the caller's
         HIPCHK(hipStreamWaitEvent(c->side_stream, c->ev_fork, 0));
     }
+    static const char* dbg = std::getenv("YOHO_PARTI_DEBUG");      // experiments: "serial" = wait after every chunk, "sideonly" = all chunks on the side stream
+    const bool dbg_serial = dbg && std::strstr(dbg, "serial"), dbg_side = dbg && std::strstr(dbg, "sideonly");
+    const bool dbg_own = dbg && std::strstr(dbg, "ownslice");      // every chunk on its own workspace slice (no address is reused inside a pass)
+    if (dbg_own && (rc = ensure_ws(c, slice * (size_t)nch, s))) return rc;
     for (int k = 0; k < nch; ++k) {
         const int off = k * chunk, n = B - off < chunk ? B - off : chunk;
         const float *xc, *x1c = nullptr;
@@ -717,10 +725,12 @@ static int partI_passG(yoho_ctx* c, const float* x, int B, float* eqv, float* in
             xc = x + (size_t)off * F * G;
             if (x1 && off + n > B0) { x1c = x1; B0c = B0 - off; }
         }
-        hipStream_t sk = (nstr == 2 && (k & 1)) ? c->side_stream : s;
-        char* ws = (char*)c->ws.p + (nstr == 2 && (k & 1) ? slice : 0);
+        const bool on_side = nstr == 2 && ((k & 1) || dbg_side);
+        hipStream_t sk = on_side ? c->side_stream : s;
+        char* ws = (char*)c->ws.p + (dbg_own ? slice * (size_t)k : (on_side ? slice : 0));
         if ((rc = partI_passG_chunk(c, ws, k * EV_PER_PASS, xc, n, eqv + (size_t)off * F * G, inv ? inv + (size_t)off * F : nullptr,
                                     inv_np ? inv_np + (size_t)off * F : nullptr, sk, x1c, B0c))) return rc;
+        if (dbg_serial) HIPCHK(hipStreamSynchronize(sk));
     }
     if (nstr == 2) {
         HIPCHK(hipEventRecord(c->ev_join, c->side_stream));          // the caller's stream continues behind the side stream's last chunk

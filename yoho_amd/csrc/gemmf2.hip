@@ -184,6 +184,7 @@ __global__ __launch_bounds__(256, 2) void fgemm2_kernel(FGemmArgs a, int flags) 
 
     if (!rows_live) {
         // keep this wave's share of the DMA and the barriers going (the live waves meet at one barrier per step but the last)
+        __builtin_amdgcn_s_barrier();                          // the live waves' barrier behind their reads of step 0 (below)
         for (int s = 0; s + 1 < KT; ++s) {
             if (s + 3 < KT) dma_step(Ag + step_off(s + 3), Bg + step_off(s + 3), smem + (s % 3) * F2_BUF, la, lb, w, wkg, wcb);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -194,6 +195,10 @@ __global__ __launch_bounds__(256, 2) void fgemm2_kernel(FGemmArgs a, int flags) 
 
     Frags2 P, Q;
     sfor<0, 12>([&](auto rc) { read_frag2<decltype(rc)::value>(smem + lane_a, smem + lane_b, P); });
+    // every wave has step 0 in registers before any wave's first DMA (step 3) lands in buffer 0 (see fgemm3s_kloop)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
     // ring offsets: step s lives in buffer s % 3
     int cur = 0, nxt = F2_BUF;                   // buffer of step s (already in registers: the target of the DMA of step s+3), of step s+1
     int s = 0;
@@ -405,6 +410,7 @@ __global__ __launch_bounds__(512, 2) void fgemm3_kernel(FGemmArgs a, int flags) 
 
     if (!rows_live) {
         // keep this wave's share of the DMA and the barriers going (the live waves meet at one barrier per step but the last)
+        __builtin_amdgcn_s_barrier();                          // the live waves' barrier behind their reads of step 0 (below)
         for (int s = 0; s + 1 < KT; ++s) {
             if (s + 3 < KT) dma_step3(Ag + step_off(s + 3), Bg + step_off(s + 3), smem + (s % 3) * F3_BUF, la, lb, w, wkg, wcb);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -415,6 +421,10 @@ __global__ __launch_bounds__(512, 2) void fgemm3_kernel(FGemmArgs a, int flags) 
 
     Frags2 P, Q;
     sfor<0, 12>([&](auto rc) { read_frag3<decltype(rc)::value>(smem + lane_a, smem + lane_b, P); });
+    // every wave has step 0 in registers before any wave's first DMA (step 3) lands in buffer 0 (see fgemm3s_kloop)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
     // ring offsets: step s lives in buffer s % 3
     int cur = 0, nxt = F3_BUF;                   // buffer of step s (already in registers: the target of the DMA of step s+3), of step s+1
     int s = 0;
@@ -549,6 +559,14 @@ __device__ __forceinline__ void fgemm3s_kloop(floatx16 (&acc)[5], char* smem, co
         constexpr int R = decltype(rc)::value;
         if constexpr (R == 5 || R == 11 || (R < 5 && R < D) || (R > 5 && R < 11 && R - 6 < D)) read_frag3s<R>(smem + lane_a, smem + lane_b, P);
     });
+    // Every wave must have step 0 in registers before ANY wave overwrites buffer 0 with step 3 (the first DMA of the loop below):
+    // inside the loop the barrier at the end of step s - 1 orders the reads of step s before the DMA of step s + 3, but between
+    // the prologue's barrier and the first step there was nothing - a wave delayed by a few hundred cycles (cold instruction
+    // cache at the head of a launch) read step 3's rows in place of step 0's.  Found in round 3 by the depth-first schedule
+    // (many short launches), whose outputs differed from the breadth-first pass in whole 32-keypoint wave tiles.
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
     int cur = 0, nxt = F3_BUF;                   // ring offsets: step s lives in buffer s % 3
     int s = 0;
     auto advance = [&]() { cur = nxt; nxt = nxt == 2 * F3_BUF ? 0 : nxt + F3_BUF; ++s; };

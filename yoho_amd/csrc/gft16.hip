@@ -48,6 +48,7 @@ struct Gft16Args {
     long long qbase[G];       // byte offset of coefficient q inside the operand planes (irrep pack + j and m terms)
     int qstride[G];           // bytes per 256-column tile of q's irrep (= K stages * 32 KiB)
     int* rflag;               // fp16 range flag of the context (note_range)
+    int drain;                // experiment (YOHO_PARTI_DEBUG=drain): wait for every outstanding vector-memory operation instead of the counted wait
 };
 
 __device__ __forceinline__ floatx16 mfma_hh(uintx4 a, uintx4 b, floatx16 c) {
@@ -389,7 +390,8 @@ __global__ __launch_bounds__(512, 2) void gft16x_kernel(Gft16Args a) {
         // vector-memory operations complete in issue order: behind this chunk's DMA (issued one iteration ago) are only the
         // plane stores of the previous chunk - 8 per thread in waves 0-3, 7 in waves 4-7 - which may stay in flight
         if (it > 0) {
-            if (w8 < 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            if (a.drain) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (w8 < 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
         }
         lds_barrier();
@@ -556,6 +558,10 @@ int launch_gft16(const float* in, float* out32, char* planes, int kppad, const v
     a.B = B; a.res0 = nullptr; a.nTiles16 = 0; a.rflag = rflag;
     a.in = in; a.out32 = out32; a.planes = planes; a.Ffrag = reinterpret_cast<const uintx4*>(Ffrag); a.bn_s = bn_s; a.bn_t = bn_t;
     a.nChunks = nTiles * C8; a.C8 = C8;
+    static const int dbg_drain = [] { const char* e = std::getenv("YOHO_PARTI_DEBUG"); return (e && std::strstr(e, "drain")) ? 1 : 0; }();
+    static const int dbg_xf1 = [] { const char* e = std::getenv("YOHO_PARTI_DEBUG"); return (e && std::strstr(e, "xf1")) ? 1 : 0; }();
+    a.drain = dbg_drain;
+    if (dbg_xf1) variant = 1;
     if (planes) {
         fill_qtables(kppad, C8 * 8, a.qbase, a.qstride);
     } else {
@@ -681,7 +687,7 @@ int launch_head16(const float* x, int B, int nTiles, char* planes, int kppad, co
 int launch_gft16_invp(const float* in, float* res0, char* planes16, int nTiles16, const void* Ffrag, const float* bn_s, const float* bn_t,
                       int nTiles, int C8, int nCU, hipStream_t s, int* rflag) {
     Gft16Args a;
-    a.rflag = rflag;
+    a.rflag = rflag; a.drain = 0;
     a.in = in; a.out32 = nullptr; a.planes = planes16; a.Ffrag = reinterpret_cast<const uintx4*>(Ffrag); a.bn_s = bn_s; a.bn_t = bn_t;
     a.nChunks = nTiles * C8; a.C8 = C8; a.B = 0; a.res0 = res0; a.nTiles16 = nTiles16;
     for (int q = 0; q < G; ++q) { a.qbase[q] = 0; a.qstride[q] = 0; }

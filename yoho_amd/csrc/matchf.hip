@@ -135,6 +135,11 @@ __global__ __launch_bounds__(256) void mf_gram_kernel(MfArgs p) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     auto flush = [&]() {
         if (wcnt == 0) return;
+        // the list was written by other lanes of this wave: all their LDS stores are issued and complete before the cross-lane
+        // reads below (a wave's LDS operations retire in order; the fence keeps the compiler from moving the loads above the stores)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         unsigned base = 0;
         if (lane == 0) base = atomicAdd(p.ncand, (unsigned)wcnt);
         base = __builtin_amdgcn_readfirstlane(base);

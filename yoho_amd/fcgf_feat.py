@@ -48,12 +48,13 @@ class fcgf_extractor():
         ch, tr = MODEL_CHANNELS[name]
         if name == "ResUNet2":
             raise ValueError("ResUNet2 has no normalisation layers (NORM_TYPE None); use a BN variant")
-        # simple_yoho/fcgf_feat.py:48-49 normalises the rows once more whatever config.normalize_feature says, so the
-        # features this class returns are always unit rows
+        # config.normalize_feature goes to the library as it is: when it is set the model normalises (fcgf_model/resunet.py:187-190)
+        # and simple_yoho/fcgf_feat.py:48-49 normalises once more (the library's row kernel then runs both passes); when it is not,
+        # only the second normalisation happens - one pass, the same roundings as the reference.  Unit rows either way.
         self._load_args = dict(sd=checkpoint['state_dict'], channels=ch, tr_channels=tr,
                                out_channels=int(_cfg_get(config, 'model_n_out', 32)),
                                conv1_kernel_size=int(_cfg_get(config, 'conv1_kernel_size', 7)), in_channels=1,
-                               normalize_feature=True)
+                               normalize_feature=bool(_cfg_get(config, 'normalize_feature', True)))
         self.ctx.load_fcgf(owner=self, **self._load_args)
 
     def _resident(self):

@@ -173,6 +173,7 @@ class Context:
         self.set_gconv_mode(self.gconv_mode)
         self.set_partII_mode(self.partII_mode)
         self.range_fallbacks = 0            # passes repeated in bf16x3 because a value left the fp16 range
+        self._range_pending = [False, False]  # flags read from the device but not yet consumed by a caller (range_status)
         self.partI_owner = self.partII_owner = self.fcgf_owner = None      # whose weights are resident (network objects)
 
     def close(self):
@@ -361,14 +362,28 @@ class Context:
 
     # ---- descriptor path -------------------------------------------------------------------
     # ---- fp16 range guard -------------------------------------------------------------------
-    def range_status(self):
-        """(partI_overflow, partII_overflow) since the last call: waits for the current stream, reads and clears the
-        device flags the fp16x2 kernels raise when a value does not fit an fp16 plane (include/yoho_hip.h)."""
+    def range_status(self, consume=(True, True)):
+        """(partI_overflow, partII_overflow): waits for the current stream and reads the device flags the fp16x2 kernels raise when
+        a value does not fit an fp16 plane (include/yoho_hip.h).  A raised flag stays pending until a call CONSUMES that
+        component: a caller that looks at one network only passes consume=(True, False) / (False, True), so a PartI overflow left
+        behind by an unchecked pass is not wiped by a PartII check (and vice versa)."""
         a, b = C.c_int(0), C.c_int(0)
         rc = self._lib.yoho_range_status(self._h, C.byref(a), C.byref(b), _stream())
         if rc not in (0, -5):                      # YOHO_ERANGE is the report itself
             _check(rc)
-        return bool(a.value), bool(b.value)
+        self._range_pending[0] |= bool(a.value)
+        self._range_pending[1] |= bool(b.value)
+        out = tuple(self._range_pending)
+        for i in (0, 1):
+            if consume[i]:
+                self._range_pending[i] = False
+        return out
+
+    def partI_overflow(self):
+        return self.range_status(consume=(True, False))[0]
+
+    def partII_overflow(self):
+        return self.range_status(consume=(False, True))[1]
 
     def _repeat_wider(self, which, fn):
         """repeat fn() with `which` ('gconv' / 'partII') switched to the bf16x3 planes (fp32 exponent range)"""
@@ -396,7 +411,7 @@ class Context:
         range_status() themselves (pipeline.run_pair does, at its first host read-back)."""
         if check_range and self.gconv_mode in FP16_GCONV_MODES:
             out = self.partI_forward(x, want_inv, want_inv_np, check_range=False)
-            if self.range_status()[0]:
+            if self.partI_overflow():
                 out = self._repeat_wider("gconv", lambda: self.partI_forward(x, want_inv, want_inv_np, check_range=False))
             return out
         B = x.shape[0]
@@ -420,7 +435,7 @@ class Context:
         (supports_pair)."""
         if check_range:
             out = self.partI_forward_pair(x0, x1, want_inv, want_inv_np, check_range=False)
-            if self.range_status()[0]:
+            if self.partI_overflow():
                 xc = torch.cat([x0, x1])
                 out = self._repeat_wider("gconv", lambda: self.partI_forward(xc, want_inv, want_inv_np, check_range=False))
             return out
@@ -486,7 +501,7 @@ class Context:
         in place.  Default PartII arithmetic mode only (supports_matched)."""
         if check_range:
             q = self.partII_forward_matched(feat0, feat1, eqv0, eqv1, match, pre_idx, check_range=False)
-            if self.range_status()[1]:
+            if self.partII_overflow():
                 m0, m1 = match[:, 0], match[:, 1]
                 q = self._repeat_wider("partII", lambda: self.partII_forward(feat1[m1], feat0[m0], eqv1[m1], eqv0[m0], pre_idx, check_range=False))
             return q
@@ -503,7 +518,7 @@ class Context:
         if check_range and self.partII_mode == "fp16x2":
             args = (before_eqv0, before_eqv1, after_eqv0, after_eqv1, pre_idx)
             q = self.partII_forward(*args, check_range=False)
-            if self.range_status()[1]:
+            if self.partII_overflow():
                 q = self._repeat_wider("partII", lambda: self.partII_forward(*args, check_range=False))
             return q
         M = before_eqv0.shape[0]
@@ -578,6 +593,10 @@ class Context:
 
     def group_scatter(self, feat, idx, g, out):
         """out[:, :, g] = feat[idx] (feat (n,32) f32, idx (K,) int64, out (K,32,60) f32), in place"""
+        if feat.dim() != 2 or feat.shape[1] != 32:
+            raise ValueError(f"group_scatter: feat must be (n, 32) (the group feature's width, YOHO_testset.py:153-166), got {tuple(feat.shape)}")
+        if idx.dim() != 1 or tuple(out.shape) != (idx.shape[0], 32, 60) or not 0 <= int(g) < 60:
+            raise ValueError(f"group_scatter: idx (K,), out (K, 32, 60), 0 <= g < 60; got idx {tuple(idx.shape)}, out {tuple(out.shape)}, g {g}")
         _check(self._lib.yoho_group_scatter(self._h, _dev(feat, torch.float32, "feat"), feat.shape[0], _dev(idx, torch.int64, "idx"), idx.shape[0],
                                             int(g), _dev(out, torch.float32, "out"), _stream()))
 
@@ -612,10 +631,12 @@ class Context:
         (0 = brute force).  Same answers for any cell; pass the voxel size the target cloud was down-sampled with."""
         _check(self._lib.yoho_set_nn_grid(self._h, float(cell)))
 
-    def clock_probe(self, microseconds, stream=None):
+    def clock_probe(self, microseconds, stream=None, out=None):
         """queue the one-wave clock probe (include/yoho_hip.h) on `stream` (a torch stream; default: the current one);
         returns the (3,) int64 device tensor it fills - shader MHz = t[0] / t[1] * t[2] / 1000 once the stream has run"""
-        out = torch.zeros(3, dtype=torch.int64, device=f"cuda:{self.device}")
+        if out is None:
+            out = torch.zeros(3, dtype=torch.int64, device=f"cuda:{self.device}")
+            torch.cuda.current_stream().synchronize()        # the fill must not run after the probe (it is on another stream)
         st = stream.cuda_stream if stream is not None else _stream()
         _check(self._lib.yoho_clock_probe(self._h, int(microseconds), out.data_ptr(), st))
         return out

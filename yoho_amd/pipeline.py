@@ -44,7 +44,7 @@ def run_pair(ctx, feat0, feat1, keys0, keys1, inlier_dist=0.09, max_iter=1000, o
         o0, o1 = eqv
     # tests/matcher.py:35-48 (the match count is read back here: first host wait of the pair)
     match = ctx.mutual_nn(o0["inv_np"], o1["inv_np"])
-    if eqv is None and ctx.range_status()[0]:
+    if eqv is None and ctx.partI_overflow():
         r.range_repeats += 1
         wide = ctx._repeat_wider("gconv", lambda: describe_pair(ctx, feat0, feat1, check_range=False))
         o0, o1 = wide
@@ -86,7 +86,7 @@ def run_pair(ctx, feat0, feat1, keys0, keys1, inlier_dist=0.09, max_iter=1000, o
         return res.cpu().numpy()                           # second host wait: the winner
 
     bh, bc = (int(v) for v in head_and_vote())
-    if ctx.range_status()[1]:
+    if ctx.partII_overflow():
         r.range_repeats += 1
         bh, bc = (int(v) for v in ctx._repeat_wider("partII", head_and_vote))
     r.best_h, r.best_count = bh, bc
@@ -154,14 +154,18 @@ class PairStreamer:
                 nxt = self._describe(i + 1, pairs[i + 1])           # queued before this pair's read-backs block the host
             with torch.cuda.stream(self.sb):
                 self.sb.wait_event(ev)
+                d = self.desc[i & 1]
+                repeats = 0
+                # the descriptor pass's range flag BEFORE the pair runs, read on this stream (it waits for the pass, as the match
+                # count's read-back would a moment later; the next pair's pass is already queued on the other stream): a pass that
+                # left the fp16 range is repeated in bf16x3 first, so the pair runs once and consumes the RNG once, as run_pair does
+                if d.partI_overflow():
+                    o0, o1 = d._repeat_wider("gconv", lambda: describe_pair(d, pair[0], pair[1], check_range=False))
+                    torch.cuda.current_stream().synchronize()        # d's next pass is queued on the other stream
+                    repeats = 1
                 r = run_pair(self.est, pair[0], pair[1], pair[2], pair[3], inlier_dist=inlier_dist, max_iter=max_iter, order_rng=order_rng,
                              eqv=(o0, o1), estimator=estimator, seed=(seeds[i] if seeds is not None else 0))
-                d = self.desc[i & 1]
-                if d.range_status()[0]:                    # the descriptor pass left the fp16 range: descriptors again in bf16x3, then the rest
-                    o0, o1 = d._repeat_wider("gconv", lambda: describe_pair(d, pair[0], pair[1], check_range=False))
-                    r = run_pair(self.est, pair[0], pair[1], pair[2], pair[3], inlier_dist=inlier_dist, max_iter=max_iter, order_rng=order_rng,
-                                 eqv=(o0, o1), estimator=estimator, seed=(seeds[i] if seeds is not None else 0))
-                    r.range_repeats += 1
+                r.range_repeats += repeats
             out.append(r)
         cur.wait_stream(self.sa)
         cur.wait_stream(self.sb)

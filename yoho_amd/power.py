@@ -148,25 +148,37 @@ class ClockProbe:
     """Shader clock under load from the device itself: probes of `us` microseconds queued back to back on a high-priority stream
     while the caller's work runs on other streams.  mhz() waits for them and returns the per-probe clocks."""
 
-    def __init__(self, ctx, us=200):
+    def __init__(self, ctx, us=200, capacity=4096):
         import torch
         self.ctx, self.us = ctx, int(us)
         self.stream = torch.cuda.Stream(priority=-1)
+        # one result buffer, zeroed once and synchronised: a per-probe torch.zeros would put a fill kernel on the CALLER's stream,
+        # behind the kernels under test, and wipe the probe's answer when it finally runs
+        self.buf = torch.zeros((capacity, 3), dtype=torch.int64, device=f"cuda:{ctx.device}")
+        torch.cuda.synchronize()
+        self.n = 0
         self.out = []
 
     def queue(self, n=1):
         for _ in range(n):
-            self.out.append(self.ctx.clock_probe(self.us, self.stream))
+            if self.n >= self.buf.shape[0]:
+                return
+            row = self.buf[self.n]
+            self.ctx.clock_probe(self.us, self.stream, out=row)
+            self.out.append(row)
+            self.n += 1
 
     def mhz(self):
         import torch
         self.stream.synchronize()
         vals = []
-        for t in self.out:
-            c, w, khz = (int(v) for v in t.cpu())
+        for c, w, khz in self.buf[:self.n].cpu().tolist():
             if w > 0:
                 vals.append(c / w * khz / 1000.0)
         self.out = []
+        self.n = 0
+        self.buf.zero_()
+        torch.cuda.synchronize()
         return vals
 
     def summary(self):
