@@ -235,3 +235,29 @@ def test_pair_streamer_equals_sequential_run_pair(hip, dctx, sd1, sd2):
                 assert torch.equal(g.quat, ref.quat) and torch.equal(g.trans_pre, ref.trans_pre)
             assert g.range_repeats == 0
     assert st.run([]) == []
+
+
+def test_partI_many_short_launches_equal_one_long_launch(hip, sd1):
+    """Regression for the round-3 race in the ring-buffered irrep GEMMs (a wave could overwrite LDS buffer 0 with K step 3 before
+    a slower wave had read step 0: whole 32-keypoint wave tiles of a launch came out wrong, about one pass in five under the
+    depth-first schedule, whose launches are short and start on a cold instruction cache).  10000 keypoints cut into chunks of
+    1024 / 2048 (one stream and two) must reproduce the bits of the single breadth-first pass, pass after pass."""
+    c = hip.Context()
+    c.load_partI(sd1)
+    x = cu(synth.unit_features(10000, seed=77))
+    ref = c.partI_forward(x, want_inv=False, want_inv_np=True)
+    ref = {k: v.clone() for k, v in ref.items()}
+    bad = []
+    for chunk, ns in ((1024, 1), (2048, 1), (1024, 2)):
+        c.set_partI_schedule(chunk, ns)
+        for rep in range(12):
+            o = c.partI_forward(x, want_inv=False, want_inv_np=True, check_range=False)
+            if not (torch.equal(o["eqv"], ref["eqv"]) and torch.equal(o["inv_np"], ref["inv_np"])):
+                rows = (o["eqv"] != ref["eqv"]).reshape(10000, -1).any(1).nonzero().flatten()
+                bad.append((chunk, ns, rep, int(rows.numel()), int(rows[0]), int(rows[-1])))
+    assert not bad, bad
+    # and the breadth-first pass itself, repeated on the same context
+    c.set_partI_schedule(0, 1)
+    for rep in range(6):
+        o = c.partI_forward(x, want_inv=False, want_inv_np=True, check_range=False)
+        assert torch.equal(o["eqv"], ref["eqv"]), rep

@@ -229,6 +229,9 @@ class ScenePairRunner:
         self.scene = None
         self.frag = {}
         self.uses = {}
+        self._pin_pool = {}
+        import threading
+        self._pin_lock = threading.Lock()
         self.timing = bool(timing)
         self.stats = {"fragments": 0, "pairs": 0, "load_s": 0.0, "load_wait_s": 0.0, "h2d_describe_s": 0.0, "setup_s": 0.0, "pairs_s": 0.0,
                       "bytes_read": 0, "peak_resident_fragments": 0}
@@ -237,15 +240,43 @@ class ScenePairRunner:
         from .utils import dataset_feature_name
         return f'{self.cfg.output_cache_fn}/Testset/{dataset_feature_name(dataset.name)}/FCGF_Input_Group_feature'
 
+    def _pinned(self, shape, dtype):
+        """a page-locked staging tensor from a small pool (allocating pinned memory per fragment costs more than reading the file)"""
+        torch = self.torch
+        key = (tuple(shape), dtype)
+        with self._pin_lock:
+            pool = self._pin_pool.setdefault(key, [])
+            for i, (buf, ev) in enumerate(pool):
+                if ev is None or ev.query():                 # its last upload has completed
+                    pool.pop(i)
+                    return buf
+        return torch.empty(shape, dtype=dtype).pin_memory()
+
+    def _recycle(self, buf, event):
+        with self._pin_lock:
+            self._pin_pool.setdefault((tuple(buf.shape), buf.dtype), []).append((buf, event))
+
     def _load_fragment(self, dataset, fdir, fid):
-        """disk -> page-locked host tensors (the .npy is read straight into the pinned buffer, one copy)"""
+        """disk -> page-locked host tensors: the .npy payload is read straight into a pinned buffer (header parsed with numpy's own
+        reader, then one readinto: no intermediate array, no page-fault-driven mmap copy)"""
         import time
         torch = self.torch
         t0 = time.perf_counter()
-        src = np.load(f'{fdir}/{fid}.npy', mmap_mode='r')
-        x = torch.empty(src.shape, dtype=torch.float32).pin_memory()
-        np.copyto(x.numpy(), src, casting='same_kind')
-        keys = torch.from_numpy(np.ascontiguousarray(dataset.get_kps(fid), dtype=np.float64)).pin_memory()
+        with open(f'{fdir}/{fid}.npy', 'rb') as f:
+            major, minor = np.lib.format.read_magic(f)
+            shape, fortran, dt = (np.lib.format.read_array_header_1_0 if major == 1 else np.lib.format.read_array_header_2_0)(f)
+            if fortran or dt != np.dtype('<f4'):
+                x = torch.from_numpy(np.ascontiguousarray(np.load(f'{fdir}/{fid}.npy'), dtype=np.float32)).pin_memory()
+            else:
+                x = self._pinned(shape, torch.float32)
+                view = memoryview(x.numpy()).cast('B')
+                got = 0
+                while got < len(view):
+                    n = f.readinto(view[got:])
+                    if not n:
+                        raise IOError(f'{fdir}/{fid}.npy: file shorter than its header says')
+                    got += n
+        keys = torch.from_numpy(np.ascontiguousarray(dataset.get_kps(fid), dtype=np.float64))
         return fid, x, keys, time.perf_counter() - t0
 
     def setup_scene(self, dataset, pairs):
@@ -265,11 +296,20 @@ class ScenePairRunner:
         need = sorted({i for p in pairs for i in p if i not in self.frag}, key=lambda v: int(v))
         fdir = self._feature_dir(dataset)
         q = queue.Queue(maxsize=6)
+        NLOAD = 3                                       # loader threads (file reads release the GIL); results are consumed in order
 
         def loader():
+            from concurrent.futures import ThreadPoolExecutor
             try:
-                for fid in need:
-                    q.put(self._load_fragment(dataset, fdir, fid))
+                with ThreadPoolExecutor(NLOAD) as ex:
+                    pending = []
+                    it = iter(need)
+                    for fid in it:
+                        pending.append(ex.submit(self._load_fragment, dataset, fdir, fid))
+                        if len(pending) >= NLOAD + 1:
+                            q.put(pending.pop(0).result())
+                    for fut in pending:
+                        q.put(fut.result())
             except BaseException as e:          # surfaced in the consumer
                 q.put(e)
             q.put(None)
@@ -278,7 +318,12 @@ class ScenePairRunner:
 
         def describe(group):
             t0 = time.perf_counter()
-            dev = [(fid, x.cuda(non_blocking=True), keys.cuda(non_blocking=True)) for fid, x, keys in group]
+            dev = [(fid, x.cuda(non_blocking=True), keys.cuda()) for fid, x, keys in group]
+            up = torch.cuda.Event()
+            up.record()
+            for _, x, _ in group:
+                if x.is_pinned():
+                    self._recycle(x, up)
             xs = torch.cat([g[1] for g in dev]) if len(dev) > 1 else dev[0][1]
             out = self.ctx.partI_forward(xs.contiguous(), want_inv=False, want_inv_np=True)
             o = 0
