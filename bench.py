@@ -226,9 +226,12 @@ def main():
         """warmup steps, then `repeats` timed regions of exactly `steps` steps each (barrier + synchronize on both sides, max over
         ranks) -> (median region time, all region times, per-rank times of the median region, last result, clock / power during
         the regions)"""
+        mon.start()                                        # the sampler's first SMU calls and the probe stream's creation are slow:
+        probe.queue(1)                                     # both happen during the warm-up, not inside a timed region
         r = run_steps(warmup, estimator, 1)
+        probe.summary()
+        del mon.samples[:]
         times, per_rank = [], []
-        mon.start()
         for rep in range(max(1, repeats)):
             ydist.barrier()
             torch.cuda.synchronize()

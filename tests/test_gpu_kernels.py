@@ -209,6 +209,34 @@ def test_partI_depth_first_schedule_is_bit_identical(hip, sd1):
     assert ticks > 0 and 100.0 < mhz < 3000.0
 
 
+def test_contexts_with_different_group_tables_coexist(hip, sd1, tables, tmp_path):
+    """The slot tables of the direct-conv kernels travel in the launch arguments (device memory of the context), so a second
+    context on a RELABELLED copy of the group (element a <-> pi[a], identity fixed) lives beside the default one: its PartI on the
+    relabelled input is the default context's output relabelled, in the direct fp32 mode and in the default Fourier mode, and the
+    default context still answers as before (round 2 refused the second table set)."""
+    rs = np.random.RandomState(5)
+    pi = np.concatenate([[0], 1 + rs.permutation(59)])
+    inv = np.argsort(pi)
+    d = tmp_path / "so3"
+    os.makedirs(d)
+    np.save(d / "Rotation.npy", tables.R64[pi])
+    np.save(d / "Nei_Index_in_SO3_ordered_13.npy", inv[tables.N[pi]].astype(np.float64))
+    np.save(d / "60_60.npy", inv[tables.P[pi][:, pi]].astype(np.float64))
+    x = synth.unit_features(70, seed=91)
+    for mode, tol in (("f32", 2e-5), ("fgemm", 2e-5)):
+        a = hip.Context()
+        a.load_partI(sd1); a.set_gconv_mode(mode)
+        ref = a.partI_forward(cu(x), want_inv=True)
+        b = hip.Context(so3_dir=str(d))
+        b.load_partI(sd1); b.set_gconv_mode(mode)
+        ob = b.partI_forward(cu(np.ascontiguousarray(x[:, :, pi])), want_inv=True)
+        again = a.partI_forward(cu(x), want_inv=True)
+        assert torch.equal(again["eqv"], ref["eqv"]), mode                      # the first context is undisturbed
+        e = ref["eqv"].cpu().numpy()
+        assert np.abs(ob["eqv"].cpu().numpy() - e[:, :, pi]).max() < tol, mode  # relabelled group, relabelled answer
+        assert np.abs(ob["inv"].cpu().numpy() - ref["inv"].cpu().numpy()).max() < tol, mode
+
+
 def test_group_mean_np_bitexact(ctx):
     x = synth.unit_features(333, seed=5) * np.float32(1.7)
     out = ctx.group_mean_np(cu(x)).cpu().numpy()

@@ -1,18 +1,18 @@
 #!/bin/bash
 # Round-end profile collection on the GPU box (run through gpurun from the repo root):
-#   bash tools/collect_profiles.sh <commit>        -> gpurun_out/r02/*   (copy the summaries into profiles/ afterwards)
+#   bash tools/collect_profiles.sh <commit>        -> gpurun_out/r03p/*   (copy the summaries into profiles/ afterwards)
 # rocprofv3 counter passes are separate runs with --kernel-trace only (no --stats / sys-trace next to --pmc).
 set -x
 export YOHO_COMMIT=${1:-unknown}
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r02
+O=$R/gpurun_out/r03p
 rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 # 1. kernel trace of the bench command (pairs strictly one after the other, so that per-kernel durations are not inflated by overlap)
-rocprofv3 --kernel-trace --stats -d $O/prof_bench_seq -- python $R/bench.py --no-cpu-baseline --steps 10 --in-flight 1 > $O/bench_seq.json 2> $O/bench_seq.err
+rocprofv3 --kernel-trace --stats -d $O/prof_bench_seq -- python $R/bench.py --no-cpu-baseline --no-dataset --repeats 1 --steps 10 --in-flight 1 > $O/bench_seq.json 2> $O/bench_seq.err
 python $R/tools/rocpd_stats.py $O/prof_bench_seq > $O/kernel_trace_bench_seq.md 2>&1
 # 2. the same with the default two pairs in flight
-rocprofv3 --kernel-trace --stats -d $O/prof_bench -- python $R/bench.py --no-cpu-baseline --steps 10 > $O/bench.json 2> $O/bench.err
+rocprofv3 --kernel-trace --stats -d $O/prof_bench -- python $R/bench.py --no-cpu-baseline --no-dataset --repeats 1 --steps 10 > $O/bench.json 2> $O/bench.err
 python $R/tools/rocpd_stats.py $O/prof_bench > $O/kernel_trace_bench.md 2>&1
 # 3. HBM traffic of one PartI pass over 10000 keypoints: FETCH_SIZE and WRITE_SIZE in separate passes
 for cnt in FETCH_SIZE WRITE_SIZE; do
@@ -22,7 +22,7 @@ cd $R
 python tools/pmc_traffic.py $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_traffic.json fgemm > $O/pmc_traffic.md 2>&1
 cd /tmp
 # 4. SQ counters: matrix-pipe utilisation and effective clock, with and without the coefficient stores (the power experiment)
-for d in plain nostore; do
+for d in plain; do
   YOHO_FGEMM_DEBUG=$d PMC_B=10000 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_ANY --output-format csv -d $O/pmc_sq_$d -- python $R/tools/pmc_partI.py fgemm > $O/pmc_sq_$d.log 2>&1
   (echo "== YOHO_FGEMM_DEBUG=$d"; python $R/tools/pmc_report.py $O/pmc_sq_$d) >> $O/pmc_sq.md 2>&1
 done

@@ -205,6 +205,7 @@ static ConvArgs conv_args(const Layer& L, const float* X, int nTiles, const floa
     a.nTiles = nTiles; a.cin8 = L.cin / 8; a.cout8 = L.cout_pad / 8;
     a.nOB = osplit ? L.cout_pad / 128 : L.cout_pad / 32;
     a.ntaps = L.ntaps;
+    a.slabtab = L.tabs ? L.tabs->slabtab : nullptr; a.outg = L.tabs ? L.tabs->outg : nullptr;
     return a;
 }
 
@@ -244,19 +245,6 @@ int yoho_ctx_create(int device, const float* R, const uint8_t* N, const uint8_t*
     for (int i = 0; i < G * NTAP; ++i) if (N[i] >= G) { set_error("Nei table entry out of range"); return YOHO_EINVAL; }
     for (int i = 0; i < G * G; ++i) if (P[i] >= G) { set_error("60_60 table entry out of range"); return YOHO_EINVAL; }
     HIPCHK(hipSetDevice(device));
-    {
-        // The wave-uniform slot tables of the direct-conv kernels (gconv.hip / gconv16.hip) are __constant__ objects of the loaded
-        // code object, i.e. one copy per device for all contexts: every context of a process must be built on the same neighbour
-        // table (they always are - the table is the icosahedral group's).  A second table is refused instead of silently sharing.
-        static bool have = false;
-        static uint8_t firstN[G * NTAP], firstP[G * G];
-        if (have && (std::memcmp(firstN, N, sizeof(firstN)) || std::memcmp(firstP, P, sizeof(firstP)))) {
-            set_error("yoho_ctx_create: a context with different group tables already exists in this process (the direct-conv slot tables are per device)");
-            return YOHO_EINVAL;
-        }
-        std::memcpy(firstN, N, sizeof(firstN)); std::memcpy(firstP, P, sizeof(firstP));
-        have = true;
-    }
     yoho_ctx* c = new yoho_ctx();
     c->device = device;
     std::memcpy(c->hN, N, sizeof(c->hN));
@@ -318,7 +306,7 @@ int yoho_ctx_create(int device, const float* R, const uint8_t* N, const uint8_t*
     fill(CFG_C45, two, 12, false);
     fill(CFG_C13, one, 4, false);
     fill(CFG_C1, std::vector<int>{0}, 1, true);
-    if ((rc = upload_slot_tables(slab.data(), outg.data())) || (rc = gconv_init())) { delete c; return rc; }
+    if ((rc = upload_slot_tables(slab.data(), outg.data(), c->tabs)) || (rc = gconv_init())) { delete c; return rc; }
     // bf16x3 variant: unit u = output group elements (2u, 2u+1); tap pair tp = taps (2tp, 2tp+1), tap 13 = zero weights
     {
         std::vector<int> slab4(3 * 7 * 32, 0), unitg(3 * 32 * 2, -1);
@@ -338,7 +326,7 @@ int yoho_ctx_create(int device, const float* R, const uint8_t* N, const uint8_t*
                             slab4[(cfg * 7 + tp) * 32 + u] |= (g < 0 ? 0 : (int)N[g * NTAP + tap]) << (8 * (2 * gs + h));
                         }
         }
-        if ((rc = upload_slot_tables16(slab4.data(), unitg.data())) || (rc = gconv16_init())) { delete c; return rc; }
+        if ((rc = upload_slot_tables16(slab4.data(), unitg.data(), c->tabs)) || (rc = gconv16_init())) { delete c; return rc; }
     }
     c->gconv_mode = 4;      // default: group-Fourier irrep GEMMs on the fp16x2 split MFMA; YOHO_GCONV=f32 | bf16x3 | fourier | fp16x2 | fgemm
     c->partII_mode = 2;     // default: fp16x2 cone layers; YOHO_PARTII=f32 | bf16x3 | fp16x2
@@ -392,6 +380,7 @@ int yoho_ctx_destroy(yoho_ctx* c) {
     if (c->fcgf) fcgf_free(c->fcgf);
     if (c->d_tap_inv) (void)hipFree(c->d_tap_inv);
     if (c->d_rflag) (void)hipFree(c->d_rflag);
+    for (int* t : {c->tabs.slabtab, c->tabs.outg, c->tabs.slab4, c->tabs.unitg}) if (t) (void)hipFree(t);
     delete c->fb;
     for (auto& e : c->ev) (void)hipEventDestroy(e);
     for (auto& e : c->ev_pass) if (e) (void)hipEventDestroy(e);
@@ -412,6 +401,7 @@ int yoho_load_partI(yoho_ctx* c, const yoho_partI_weights* w) {
     if ((rc = build_layer(c->p1[1], w->res_in, 256, 512, NTAP, &w->res_out_bn, c->fb))) return rc;
     if ((rc = build_layer(c->p1[2], w->res_out, 512, 256, NTAP, &w->out_bn, c->fb))) return rc;
     if ((rc = build_layer(c->p1[3], w->conv_out, 256, 32, NTAP, nullptr, c->fb))) return rc;
+    for (auto& L : c->p1) L.tabs = &c->tabs;
     c->has_partI = true;
     return 0;
 }
@@ -434,6 +424,7 @@ int yoho_load_partII(yoho_ctx* c, const yoho_partII_weights* w) {
     if ((rc = build_layer(c->p2[3], w->fc0, 256, 512, 1, &w->fc0_bn))) return rc;
     if ((rc = build_layer(c->p2[4], w->fc1, 512, 128, 1, &w->fc1_bn))) return rc;
     if ((rc = build_layer(c->p2[5], w->fc2, 128, 4, 1, nullptr))) return rc;
+    for (auto& L : c->p2) L.tabs = &c->tabs;
     c->has_partII = true;
     return 0;
 }

@@ -44,7 +44,18 @@ __device__ __forceinline__ void note_range_bits(int* flag, unsigned top, float l
     if (flag && top > __float_as_uint(limit)) atomicOr(flag, 1);
 }
 
+// wave-uniform slot tables of the direct-conv kernels (gconv.hip / gconv16.hip): device memory owned by the context, handed to the
+// kernels in their arguments and read there through the constant address space (scalar loads), so that contexts built on
+// different group tables can coexist in one process (round 2 kept them in __constant__ objects of the code object)
+struct SlotTables {
+    int* slabtab = nullptr;   // [NCFG][13 * 60]  LDS byte offset of input slab N[g(slot), tap]
+    int* outg = nullptr;      // [NCFG][60]       output group element of a slot, -1 = unused
+    int* slab4 = nullptr;     // [3][7 * 32]      gconv16: four slab indices of a (tap pair, unit), one per byte
+    int* unitg = nullptr;     // [3][32 * 2]      gconv16: output group elements (ga, gb) of a unit, -1 = unused
+};
+
 struct Layer {
+    const SlotTables* tabs = nullptr;   // the owning context's slot tables (set by build_layer)
     int cin = 0, cout = 0, cout_pad = 0, ntaps = 0;
     float* wp = nullptr;      // packed MFMA A-fragments [ob][c8][tap][lane64][4]
     void* wp16 = nullptr;     // bf16x3 planes [ob][c8][tap-pair 7][plane 3][lane64][8] (13-tap layers only)
@@ -71,11 +82,13 @@ struct ConvArgs {
     float* out_raw;        // EPI_RAW
     float* out_act;        // EPI_ACT: relu(v*bn_s + bn_t)
     int nTiles, cin8, cout8, nOB, ntaps;
+    const int* slabtab;    // SlotTables::slabtab / outg of the context
+    const int* outg;
 };
 
 // slot-table configurations (constant memory, see gconv.hip)
 enum { CFG_FULL = 0, CFG_C45 = 1, CFG_C13 = 2, CFG_C1 = 3, NCFG = 4 };
-int upload_slot_tables(const int* slab_h /*[NCFG][13*60]*/, const int* outg_h /*[NCFG][60]*/);
+int upload_slot_tables(const int* slab_h /*[NCFG][13*60]*/, const int* outg_h /*[NCFG][60]*/, SlotTables& t);
 int launch_gconv(const ConvArgs& a, int gpw, int flags, hipStream_t s);
 int gconv_init();   // sets the dynamic-LDS attribute of every instantiation
 
@@ -132,7 +145,7 @@ int launch_head16(const float* x, int B, int nTiles, char* planes, int kppad, co
 int launch_gconvf(const Layer& L, const float* X, int nTiles, const float* res, float* out, int flags, hipStream_t s);
 int launch_gft(int mode, const float* in, float* out, const float* Fpad, const float* bn_s, const float* bn_t, int nTiles, int C8, hipStream_t s);
 // bf16x3 variant (gconv16.hip)
-int upload_slot_tables16(const int* slab4_h, const int* unitg_h);
+int upload_slot_tables16(const int* slab4_h, const int* unitg_h, SlotTables& t);
 int gconv16_init();
 int launch_gconv16(const Layer& L, const char* X, int nTiles, const float* res, float* out_raw, char* out_act, int flags, hipStream_t s,
                    int cfg = 0, float* out_raw32 = nullptr, float* out_act32 = nullptr, int npl = 3, int* rflag = nullptr);
@@ -189,6 +202,7 @@ struct yoho_ctx {
     int tap_inv[13] = {0};       // inv[k]: the tap whose group element is the inverse of tap k's (train.hip)
     int* d_tap_inv = nullptr;
     int nCU = 256;
+    yoho::SlotTables tabs;       // direct-conv slot tables (device)
     int* d_rflag = nullptr;      // fp16 range words (note_range): [0] PartI, [1] PartII; read and cleared by yoho_range_status
     int fcgf_cell_sort = 1;      // FCGF backbone: level-0 rows grouped by 8^3-voxel cell inside the pass (gather locality): 0 never, 1 passes of >= 2^18 rows, 2 always
     int fcgf_parity_sort = 1;    // transposed convolutions of the FCGF backbone walk parity-sorted rows (sparse.hip); 0: YOHO_FCGF_SORT=0

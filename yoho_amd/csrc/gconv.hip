@@ -29,15 +29,16 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 constexpr int CHUNK_BYTES = CHUNK_FLOATS * 4;         // 61440
 constexpr int LDS_BYTES = 2 * CHUNK_BYTES;            // 122880
 
-// Slot tables live in constant memory so that the wave-uniform lookups are scalar (s_load) and
-// never touch the vector-memory counter the LDS DMA and the weight prefetch depend on.
-//   c_slabtab[cfg][tap][slot] = LDS byte offset of input slab N[g(slot), tap];  c_outg[cfg][slot] = g or -1
-__constant__ int c_slabtab[NCFG][NTAP * G];
-__constant__ int c_outg[NCFG][G];
+// Slot tables: device memory of the context, addressed through the constant address space so that the wave-uniform lookups are
+// scalar (s_load) and never touch the vector-memory counter the LDS DMA and the weight prefetch depend on.
+//   slabtab[cfg][tap][slot] = LDS byte offset of input slab N[g(slot), tap];  outg[cfg][slot] = g or -1
+typedef const __attribute__((address_space(4))) int* cint_p;
 
-int upload_slot_tables(const int* slab_h, const int* outg_h) {
-    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_slabtab), slab_h, sizeof(int) * NCFG * NTAP * G));
-    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_outg), outg_h, sizeof(int) * NCFG * G));
+int upload_slot_tables(const int* slab_h, const int* outg_h, SlotTables& t) {
+    HIPCHK(hipMalloc((void**)&t.slabtab, sizeof(int) * NCFG * NTAP * G));
+    HIPCHK(hipMalloc((void**)&t.outg, sizeof(int) * NCFG * G));
+    HIPCHK(hipMemcpy(t.slabtab, slab_h, sizeof(int) * NCFG * NTAP * G, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(t.outg, outg_h, sizeof(int) * NCFG * G, hipMemcpyHostToDevice));
     return 0;
 }
 
@@ -95,7 +96,7 @@ __global__ __launch_bounds__(256, 1) void gconv_kernel(ConvArgs a, int flags, in
             const floatx4 wc = wnext;
             ++it;
             if (it < total) wnext = Wb[(size_t)it * 64];
-            const int* st = &c_slabtab[cfg][(tap * 4 + ws) * GPW];
+            cint_p st = (cint_p)a.slabtab + cfg * (NTAP * G) + (tap * 4 + ws) * GPW;
 #pragma unroll
             for (int j = 0; j < GPW; ++j) {
                 const int so = st[j];                                   // wave-uniform (scalar load)
@@ -112,7 +113,7 @@ __global__ __launch_bounds__(256, 1) void gconv_kernel(ConvArgs a, int flags, in
 
     // ---- epilogue: D[i=o][j=kp]; lane (kp = lane&31, half = lane>>5), reg r -> o = (r&3) + 8*(r>>2) + 4*half
     const int kp = lane & 31, half = lane >> 5;
-    const int* og = &c_outg[cfg][ws * GPW];
+    cint_p og = (cint_p)a.outg + cfg * G + ws * GPW;
 #pragma unroll
     for (int j = 0; j < GPW; ++j) {
         const int g = og[j];
@@ -165,6 +166,7 @@ int gconv_init() {
 
 // gpw: 15 / 12 / 4 / 1; gpw == -1 selects the o-split single-group-element variant.
 int launch_gconv(const ConvArgs& a, int gpw, int flags, hipStream_t s) {
+    if (!a.slabtab || !a.outg) { set_error("launch_gconv: the layer carries no slot tables"); return YOHO_EINVAL; }
     int nstage = G;
     switch (gpw) {
         case 15: return launch_t<15, false>(a, flags, nstage, CFG_FULL, s);

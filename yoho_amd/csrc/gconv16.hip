@@ -49,12 +49,11 @@ constexpr int NUNIT = 32;                             // unit slots per configur
 // cfg: 0 = all 60 group elements (30 units), 1 = the 45-element 2-hop cone of element 0 (23 units),
 //      2 = its 13-element 1-hop cone (7 units)   [PartII only needs group element 0 of its last feature map]
 constexpr int NCFG16 = 3;
-__constant__ int c_slab4[NCFG16][NTP * NUNIT];
-__constant__ int c_unitg[NCFG16][NUNIT * 2];
-
-int upload_slot_tables16(const int* slab4_h, const int* unitg_h) {
-    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_slab4), slab4_h, sizeof(int) * NCFG16 * NTP * NUNIT));
-    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_unitg), unitg_h, sizeof(int) * NCFG16 * NUNIT * 2));
+int upload_slot_tables16(const int* slab4_h, const int* unitg_h, SlotTables& t) {
+    HIPCHK(hipMalloc((void**)&t.slab4, sizeof(int) * NCFG16 * NTP * NUNIT));
+    HIPCHK(hipMalloc((void**)&t.unitg, sizeof(int) * NCFG16 * NUNIT * 2));
+    HIPCHK(hipMemcpy(t.slab4, slab4_h, sizeof(int) * NCFG16 * NTP * NUNIT, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(t.unitg, unitg_h, sizeof(int) * NCFG16 * NUNIT * 2, hipMemcpyHostToDevice));
     return 0;
 }
 
@@ -165,6 +164,8 @@ struct Conv16Args {
     int nTiles, cin8, cout8, nOBgrid, cfg;
     float descale;         // fp16x2: 1 / (weight scale * H2_ASCALE), a power of two; bf16x3: unused
     int* rflag;            // fp16 range flag (note_range)
+    const int* slab4;      // SlotTables::slab4 / unitg of the context
+    const int* unitg;
 };
 
 template <int UPW, int NOB, int NPL>
@@ -204,7 +205,7 @@ __global__ __launch_bounds__(256, 1) void gconv16_kernel(Conv16Args a, int flags
     int* tab = reinterpret_cast<int*>(smem + 2 * CHB) + w * (8 * UPW * 4);
     for (int i = lane; i < 8 * UPW * 4; i += 64) {
         const int cls = i & 3, j = (i >> 2) % UPW, tp = (i >> 2) / UPW;
-        const unsigned packed = (unsigned)c_slab4[cfg][(tp == NTP ? 0 : tp) * NUNIT + ubase + j];
+        const unsigned packed = (unsigned)a.slab4[cfg * (NTP * NUNIT) + (tp == NTP ? 0 : tp) * NUNIT + ubase + j];
         tab[i] = (int)(((packed >> (8 * cls)) & 0xFFu) << 8);
     }
     // lane class: 2 * (column belongs to the unit's second group element) + (second tap of the pair)
@@ -295,7 +296,7 @@ __global__ __launch_bounds__(256, 1) void gconv16_kernel(Conv16Args a, int flags
 
     // ---- epilogue.  D[i = o][j = col]: lane (col = lane&31, half = lane>>5), reg r -> o = (r&3) + 8*(r>>2) + 4*half
     const int kp = lane & 15, half = lane >> 5, gsel = (lane >> 4) & 1;
-    const int* ug = &c_unitg[cfg][ubase * 2];
+    const int* ug = a.unitg + cfg * (NUNIT * 2) + ubase * 2;
     float amax = 0.f;
 #pragma unroll
     for (int j = 0; j < UPW; ++j) {
@@ -390,6 +391,8 @@ int launch_gconv16(const Layer& L, const char* X, int nTiles, const float* res, 
                    int cfg, float* out_raw32, float* out_act32, int npl, int* rflag) {
     Conv16Args a;
     a.rflag = rflag;
+    if (!L.tabs || !L.tabs->slab4) { set_error("launch_gconv16: the layer carries no slot tables"); return YOHO_EINVAL; }
+    a.slab4 = L.tabs->slab4; a.unitg = L.tabs->unitg;
     a.X = X; a.Wp = reinterpret_cast<const char*>(npl == 2 ? L.wph : L.wp16); a.bias = L.bias; a.bn_s = L.bn_s; a.bn_t = L.bn_t;
     a.res = res; a.out_raw = out_raw; a.out_act = out_act; a.out_raw32 = out_raw32; a.out_act32 = out_act32;
     a.nTiles = nTiles; a.cin8 = L.cin / 8; a.cout8 = L.cout_pad / 8; a.cfg = cfg; a.nOBgrid = 1;

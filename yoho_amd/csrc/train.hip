@@ -253,6 +253,7 @@ int gconv_layer(yoho_ctx* c, const float* x, int B, int cin, int cout, const flo
     ConvArgs a;
     a.X = bX; a.Wp = L.wp; a.bias = L.bias; a.bn_s = nullptr; a.bn_t = nullptr; a.res = nullptr; a.out_raw = bY; a.out_act = nullptr;
     a.nTiles = nT; a.cin8 = ecin / 8; a.cout8 = cpad / 8; a.nOB = nob; a.ntaps = NTAP;
+    a.slabtab = c->tabs.slabtab; a.outg = c->tabs.outg;
     if ((rc = launch_gconv(a, 15, EPI_RAW, s))) return rc;
     hipLaunchKernelGGL(unpack_bcg_kernel, dim3(nT * (cpad / 8)), dim3(256), 0, s, bY, B, cpad / 8, ecout, y);
     HIPCHK(hipGetLastError());
