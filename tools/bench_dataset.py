@@ -23,7 +23,7 @@ if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
 
-def build_scene(root, cache_scene_dir, nfrag, kp, span, seed=0, device=None):
+def build_scene(root, cache_scene_dir, nfrag, kp, span, seed=0, device=None, npairs=None):
     """A scene in the shape of a 3DMatch test scene: every fragment is a moved, row-shuffled, group-permuted, noisy copy of one base
     fragment (30 % of the rows replaced by outliers); pairs (i, j) with 0 < j - i <= span.  Generated with torch on `device` (the
     GPU when there is one: a throughput workload, not a fixture).  Writes gt.log / gt.info / keypoints / FCGF_Input_Group_feature
@@ -64,6 +64,10 @@ def build_scene(root, cache_scene_dir, nfrag, kp, span, seed=0, device=None):
         np.save(f"{root}/Keypoints_PC/cloud_bin_{f}Keypoints.npy", np.ascontiguousarray(kk))
         poses.append((R, t))
     pairs = [(i, j) for i in range(nfrag) for j in range(i + 1, min(nfrag, i + span + 1))]
+    if npairs is not None:
+        # exactly npairs pairs, nearest fragments first (a gt.log lists the overlapping pairs, which are mostly close in scan order)
+        allp = sorted(((i, j) for i in range(nfrag) for j in range(i + 1, nfrag)), key=lambda p: (p[1] - p[0], p[0]))
+        pairs = sorted(allp[:npairs])
     with open(f"{root}/PointCloud/gt.log", "w") as fl, open(f"{root}/PointCloud/gt.info", "w") as fi:
         for (i, j) in pairs:                       # keys_i = Ri Rj^T (keys_j - tj) + ti
             (Ri, ti), (Rj, tj) = poses[i], poses[j]
@@ -85,14 +89,19 @@ def drop_page_cache():
         return False
 
 
-def run(nfrag=60, kp=5000, span=9, estimator="yohoo", workdir="/tmp/yoho_ds", runs=2, max_iter=1000, keep=False):
-    """-> dict for the bench line.  Every rank of an initialised process group calls this; rank 0 builds the files."""
+# the 3DMatch test set's shape: fragments per scene (utils/dataset.py:163-167) and pairs per scene as its gt.log files list them (1623)
+PRESET_3DMATCH = [("kitchen", 60, 506), ("home1", 60, 156), ("home2", 60, 208), ("hotel1", 55, 226), ("hotel2", 57, 104), ("hotel3", 37, 54),
+                  ("study", 66, 292), ("lab", 38, 77)]
+
+
+def run(nfrag=60, kp=5000, span=9, estimator="yohoo", workdir="/tmp/yoho_ds", runs=2, max_iter=1000, keep=False, preset=None):
+    """-> dict for the bench line.  Every rank of an initialised process group calls this; rank 0 builds the files.
+    preset="3dmatch": eight scenes with the fragment and pair counts of the 3DMatch test set instead of one scene."""
     import torch
     from yoho_amd import hip, weights as W, run_dataset, dist as ydist
     from yoho_amd.dataset import ThrDMatchPartDataset
     rank, world, local = ydist.init_from_env()
-    name = "synthds/scene0"
-    sroot = f"{workdir}/origin/{name}"
+    scenes = [("scene0", nfrag, None)] if preset is None else PRESET_3DMATCH
     cache = f"{workdir}/cache"
     def all_ok(ok, what):
         """every rank learns whether any rank failed (a failure on one rank must not leave the others waiting at a barrier)"""
@@ -104,22 +113,29 @@ def run(nfrag=60, kp=5000, span=9, estimator="yohoo", workdir="/tmp/yoho_ds", ru
     if rank == 0:
         try:
             shutil.rmtree(workdir, ignore_errors=True)
-            build_scene(sroot, f"{cache}/Testset/{name}", nfrag, kp, span)
+            for si, (sn, nf, npairs) in enumerate(scenes):
+                build_scene(f"{workdir}/origin/synthds/{sn}", f"{cache}/Testset/synthds/{sn}", nf, kp, span, seed=si, npairs=npairs)
         except Exception as e:
             ok, err[0] = False, f"{type(e).__name__}: {e}"
     all_ok(ok, "building the scene files")
     t_build = time.perf_counter() - t0
-    ds = ThrDMatchPartDataset(sroot, nfrag)
-    ds.name = name
-    datasets = {"wholesetname": "synthds", "scene0": ds}
+    datasets = {"wholesetname": "synthds"}
+    for sn, nf, _ in scenes:
+        ds = ThrDMatchPartDataset(f"{workdir}/origin/synthds/{sn}", nf)
+        ds.name = f"synthds/{sn}"
+        datasets[sn] = ds
+    nfrag_all = sum(nf for _, nf, _ in scenes)
+    npairs_all = sum(len(datasets[sn].pair_ids) for sn, _, _ in scenes)
     cfg = types.SimpleNamespace(SO3_related_files=None, model_fn=f"{workdir}/model", output_cache_fn=cache, origin_data_dir=f"{workdir}/origin",
                                 ransac_c_inlinerdist=0.07, ransac_o_inlinerdist=0.09, RR_dist_threshold=0.2, testset_name="synthds")
     sd1 = W.synth_state_dict(W.PARTI_SPEC, 7)
     sd2 = W.identity_head(W.synth_state_dict(W.PARTII_SPEC, 8))
     ctx = hip.Context(local if world > 1 else torch.cuda.current_device())
-    out = {"workload": f"synthetic scene, {nfrag} fragments x {kp} keypoints ({nfrag * kp * 7680 / 1e9:.2f} GB of FCGF group features as .npy on disk), "
-                       f"{len(ds.pair_ids)} pairs (fragments at most {span} apart), estimator {estimator}, {world} rank(s)",
-           "fragments": nfrag, "keypoints_per_fragment": kp, "pairs": len(ds.pair_ids), "ranks": world, "estimator": estimator,
+    out = {"workload": (f"synthetic scene, {nfrag} fragments x {kp} keypoints" if preset is None else
+                        f"synthetic test set in the shape of 3DMatch's: 8 scenes, {nfrag_all} fragments x {kp} keypoints") +
+                       f" ({nfrag_all * kp * 7680 / 1e9:.2f} GB of FCGF group features as .npy on disk), {npairs_all} pairs, estimator {estimator}, {world} rank(s)",
+           "fragments": nfrag_all, "keypoints_per_fragment": kp, "pairs": npairs_all, "ranks": world, "estimator": estimator,
+           "scenes": {sn: {"fragments": nf, "pairs": len(datasets[sn].pair_ids)} for sn, nf, _ in scenes},
            "scene_build_s": round(t_build, 2), "runs": []}
     for r in range(runs):
         cold = drop_page_cache() if (r == 0 and rank == 0) else False
@@ -138,10 +154,10 @@ def run(nfrag=60, kp=5000, span=9, estimator="yohoo", workdir="/tmp/yoho_ds", ru
         dt = ydist.max_over_ranks(time.perf_counter() - t0)
         res = stats.pop("results")
         if rank == 0:
-            inl = [p["inliers"] for p in res["scene0"]]
-            mt = [p["matches"] for p in res["scene0"]]
+            inl = [p["inliers"] for sn, _, _ in scenes for p in res[sn]]
+            mt = [p["matches"] for sn, _, _ in scenes for p in res[sn]]
             row = {"page_cache": "dropped before the run" if cold else "warm", "total_s": round(dt, 3),
-                   "keypoints_per_s_end_to_end": round(nfrag * kp / dt, 1), "pairs_per_s_end_to_end": round(len(ds.pair_ids) / dt, 1),
+                   "keypoints_per_s_end_to_end": round(nfrag_all * kp / dt, 1), "pairs_per_s_end_to_end": round(npairs_all / dt, 1),
                    "rank0": {"fragments": stats["fragments"], "pairs": stats["pairs"],
                              "setup_s (load + H2D + PartI, overlapped)": round(stats["setup_s"], 3),
                              "disk_read_s (loader thread)": round(stats["load_s"], 3), "disk_GBps": round(stats["bytes_read"] / max(stats["load_s"], 1e-9) / 1e9, 2),
@@ -166,7 +182,8 @@ if __name__ == "__main__":
     ap.add_argument("--estimator", default="yohoo")
     ap.add_argument("--workdir", default="/tmp/yoho_ds")
     ap.add_argument("--runs", type=int, default=2)
+    ap.add_argument("--preset", default=None, choices=[None, "3dmatch"])
     a = ap.parse_args()
-    o = run(a.nfrag, a.kp, a.span, a.estimator, a.workdir, a.runs)
+    o = run(a.nfrag, a.kp, a.span, a.estimator, a.workdir, a.runs, preset=a.preset)
     if int(os.environ.get("RANK", "0")) == 0:
         print(json.dumps(o), flush=True)

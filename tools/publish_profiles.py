@@ -1,13 +1,16 @@
 #!/usr/bin/env python
-"""Copy the summaries tools/collect_profiles.sh left under gpurun_out/r02/ into profiles/r02_* (tracked), keeping the
-explanatory header of each tracked file (everything before its first table) and stamping the commit.
+"""Copy the summaries tools/collect_profiles.sh left under gpurun_out/<src>/ into profiles/<round>_* (tracked), keeping the
+explanatory header of each tracked file (everything before its first table; a new round starts from the previous round's
+header) and stamping the commit.
 
-    python tools/publish_profiles.py <commit>
+    python tools/publish_profiles.py <commit> [round = r03] [src dir under gpurun_out = r03p]
 """
 import json, os, re, shutil, sys
 
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC, DST = os.path.join(R, "gpurun_out", "r02"), os.path.join(R, "profiles")
+RND = sys.argv[2] if len(sys.argv) > 2 else "r03"
+PREV = "r%02d" % (int(RND[1:]) - 1)
+SRC, DST = os.path.join(R, "gpurun_out", sys.argv[3] if len(sys.argv) > 3 else "r03p"), os.path.join(R, "profiles")
 
 
 def header_of(path):
@@ -27,21 +30,23 @@ def body_of(path, drop_prefixes=("+ ", "fatal:")):
 
 def main(commit):
     for name in ("kernel_trace_bench", "kernel_trace_bench_seq", "kernel_trace_extract", "pmc_traffic", "pmc_sq"):
-        src, dst = os.path.join(SRC, name + ".md"), os.path.join(DST, "r02_" + name + ".md")
+        src, dst = os.path.join(SRC, name + ".md"), os.path.join(DST, RND + "_" + name + ".md")
         if not os.path.exists(src):
             print("missing", src)
             continue
-        head = re.sub(r"commit [0-9a-f]{7}", "commit " + commit, header_of(dst))
+        head = header_of(dst) or header_of(os.path.join(DST, PREV + "_" + name + ".md")).replace("Round %d" % int(PREV[1:]), "Round %d" % int(RND[1:]))
+        head = head.replace("--no-cpu-baseline --steps 10", "--no-cpu-baseline --no-dataset --repeats 1 --steps 10")
+        head = re.sub(r"commit [0-9a-f]{7}", "commit " + commit, head)
         body = body_of(src)
         if name == "pmc_traffic":                 # the generated file carries its own header
             body = body[body.index("|"):] if head else body
         open(dst, "w").write(head + body)
         print("wrote", dst)
-    shutil.copy(os.path.join(SRC, "pmc_traffic.json"), os.path.join(DST, "r02_pmc_traffic.json"))
+    shutil.copy(os.path.join(SRC, "pmc_traffic.json"), os.path.join(DST, RND + "_pmc_traffic.json"))
     line = open(os.path.join(SRC, "bench.json")).read().strip().splitlines()[-1]
     json.loads(line)
-    open(os.path.join(DST, "r02_bench_profiled.json"), "w").write(line + "\n")
-    print("wrote r02_pmc_traffic.json, r02_bench_profiled.json (the bench line of the profiled run; the unprofiled line is r02_bench.json)")
+    open(os.path.join(DST, RND + "_bench_profiled.json"), "w").write(line + "\n")
+    print(f"wrote {RND}_pmc_traffic.json, {RND}_bench_profiled.json (the bench line of the profiled run; the unprofiled line is {RND}_bench.json)")
 
 
 if __name__ == "__main__":
