@@ -440,9 +440,11 @@ def main():
         streamer = None
         torch.cuda.empty_cache()
         try:
+            import contextlib
             sys.path.insert(0, os.path.join(REPO, "tools"))
             import bench_dataset
-            dataset = bench_dataset.run(nfrag=60, kp=KP, span=9, estimator="yohoo", workdir=os.environ.get("YOHO_DS_WORKDIR", "/tmp/yoho_ds"), runs=2)
+            with contextlib.redirect_stdout(sys.stderr):      # the evaluation code prints file names: stdout carries the one JSON line only
+                dataset = bench_dataset.run(nfrag=60, kp=KP, span=9, estimator="yohoo", workdir=os.environ.get("YOHO_DS_WORKDIR", "/tmp/yoho_ds"), runs=2)
         except Exception as e:           # the headline must survive a failure of this leg
             dataset = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0:

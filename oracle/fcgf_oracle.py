@@ -20,9 +20,12 @@ against MinkowskiEngine 0.5.x, which is vendored in the reference tree as *sourc
 Pinning (tests/test_fcgf_oracle.py): the coordinate-map and kernel-map semantics above are checked against the
 known-answer vectors of MinkowskiEngine's own tests (region order and map direction: tests/cpp/kernel_region_cpu_test.py:22-42,
 100-116; strided maps incl. negative coordinates and batches: tests/cpp/coordinate_map_cpu_test.py:95-125,
-tests/python/coordinate_manager.py:183-200; quantisation collisions: tests/python/quantization.py:104-113; not used:
+tests/python/coordinate_manager.py:183-200; quantisation collisions: tests/python/quantization.py:104-113; round 3:
+first-occurrence rows and duplicate lookups tests/cpp/coordinate_map_cpu_test.py:12-15,47-65, strides :80-86 and
+tests/python/coordinate_manager.py:33-58,255-258, SparseTensor row count tests/python/sparse_tensor.py:91-98; not reproducible:
 the pair count asserted in tests/python/kernel_map.py:78,109 (16), which the sources and the C++ known answers above
-contradict - the map definition yields 26 pairs on that fixture); the sparse
+contradict - the map definition yields 13 pairs per batch item = 26 on that fixture, recorded in the test; DESIGN.md 3.5 has
+the per-layer table of what is pinned by what); the sparse
 convolution arithmetic is checked against torch.nn.functional.conv3d / conv_transpose3d on densified inputs.
 The END-TO-END network output remains PARITY UNPINNED against MinkowskiEngine itself (it cannot run here and the
 pretrained backbone checkpoint is absent from the tree).
