@@ -26,6 +26,7 @@
  *   yoho_gconv_layer             Comb_Conv / Residual_Comb_Conv  utils/network.py:35-62 (forward) and its autograd (training)
  *   yoho_load_fcgf / _voxelize / _forward / _forward_batch        fcgf_model/resunet.py:10-190, simple_yoho/fcgf_feat.py:33-54
  *   yoho_fcgf_voxelize_rotated / yoho_rotate_select               YOHO_testset.py:143-147,92, simple_yoho/yoho_extract.py:46-53
+ *   yoho_group_transfer_batch                                     the feature-transfer body of those loops for the copies of a pass
  *
  * Conventions
  *   - return 0 on success, a negative YOHO_E* code on error; yoho_last_error() gives a
@@ -238,6 +239,18 @@ int yoho_fcgf_voxelize_rotated_batch(yoho_ctx* ctx, const double* pts, int n, co
 /* out (m,3) f32 = (float)(R pts[sel[i]]) with the arithmetic of yoho_fcgf_voxelize_rotated (R may be NULL: plain gather + cast):
  * the rotated keypoints of the feature transfer. */
 int yoho_rotate_select(yoho_ctx* ctx, const double* pts, const double* R, const int64_t* sel, int m, float* out, void* stream);
+
+/* The NN feature transfer of nb (1..64) rotated copies of one cloud in one call - the body of the 60-rotation loop of
+ * simple_yoho/yoho_extract.py:46-53 / YOHO_testset.py:143-166 for the copies of one backbone pass.  For copy b:
+ *   q = (float)(R_b pts[kidx])                          (yoho_rotate_select; R_host = nb row-major 3x3 f64 matrices, host)
+ *   idx = argmin_j |q - ds[b][j]|^2, fp32 'SquareL2'    (yoho_nn_search with D = 3: through the hash grid when yoho_set_nn_grid is set)
+ *   out[:, :, g0 + b] = feat[b][idx]                    (yoho_group_scatter; out (K,32,60) f32)
+ * ds / feat: HOST arrays of nb device pointers ((m[b],3) and (m[b],32) f32), m: host array of row counts; q_scratch (K,3) f32 and
+ * idx_scratch (K) int64 are caller-owned device scratch.  Same results as the three calls per copy, without their 3 nb
+ * host round trips through the binding. */
+int yoho_group_transfer_batch(yoho_ctx* ctx, const double* pts, const int64_t* kidx, int K, const double* R_host, int nb,
+                              const float* const* ds, const float* const* feat, const int* m, int g0, float* out,
+                              float* q_scratch, int64_t* idx_scratch, void* stream);
 /* resunet.py:141-190 + the final normalisation of fcgf_feat.py:48.  coords (n,3) i32 distinct voxels, out (n,out_channels). */
 int yoho_fcgf_forward(yoho_ctx* ctx, const int32_t* coords, int n, float* out, void* stream);
 /* several clouds in one pass (the 60 rotated copies of a fragment, or the reference's DataLoader batch, YOHO_testset.py:172-180):

@@ -522,6 +522,33 @@ def test_group_gather(ctx, tables):
     assert np.array_equal(out.cpu().numpy(), orc.group_gather(keys, pts, feats, tables.R64))
 
 
+def test_group_transfer_batch_equals_per_copy_calls(hip, tables):
+    """yoho_group_transfer_batch (the feature-transfer body of the 60-rotation loop for the copies of one backbone pass) = the three
+    calls per copy it replaces, bit for bit, with and without the hash grid; ragged copy sizes"""
+    c = hip.Context()
+    rs = np.random.RandomState(3)
+    pts = cu(rs.rand(4000, 3) * 1.5)
+    kidx = cu(rs.permutation(4000)[:300].astype(np.int64))
+    Rs = [tables.R64[g] for g in (0, 7, 33, 59)]
+    ds = [cu((rs.rand(m, 3) * 1.5).astype(np.float32)) for m in (3500, 1200, 900, 2048)]
+    ft = [cu(rs.randn(d.shape[0], 32).astype(np.float32)) for d in ds]
+    for cell in (0.0, 0.05):
+        c.set_nn_grid(cell)
+        ref = torch.zeros((300, 32, 60), dtype=torch.float32, device="cuda")
+        for j in range(4):
+            q = c.rotate_select(pts, Rs[j], kidx)
+            _, idx = c.nn_search(q, ds[j], want_dist=False, squared=True)
+            c.group_scatter(ft[j], idx, 10 + j, ref)
+        out = torch.zeros_like(ref)
+        c.group_transfer_batch(pts, kidx, Rs, ds, ft, 10, out)
+        assert torch.equal(out, ref), cell
+    c.set_nn_grid(0)
+    with pytest.raises(ValueError):
+        c.group_transfer_batch(pts, kidx, Rs, ds[:3], ft, 10, out)
+    with pytest.raises(RuntimeError):
+        c.group_transfer_batch(pts, kidx, Rs, ds, ft, 58, out)          # 58 + 4 copies > 60 group elements
+
+
 def test_grid_nn_equals_brute_force(hip, tables):
     """yoho_set_nn_grid changes the search, never the answer: both fp32 distance types and the f64 group gather, for a
     well-chosen cell, one that is far too small (most queries fall back to brute force) and a coarse one (long cell lists);

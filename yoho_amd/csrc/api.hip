@@ -963,6 +963,23 @@ int yoho_rotate_select(yoho_ctx* c, const double* pts, const double* R_host, con
     return fcgf_rotate_select(pts, R_host, sel, m, out, (hipStream_t)stream);
 }
 
+int yoho_group_transfer_batch(yoho_ctx* c, const double* pts, const int64_t* kidx, int K, const double* R_host, int nb,
+                              const float* const* ds, const float* const* feat, const int* m, int g0, float* out,
+                              float* q_scratch, int64_t* idx_scratch, void* stream) {
+    if (!c || K < 0 || nb < 1 || nb > 64 || g0 < 0 || g0 + nb > G) { set_error("yoho_group_transfer_batch: bad argument (1..64 copies, g0 + nb <= 60)"); return YOHO_EINVAL; }
+    if (K == 0) return 0;
+    if (!pts || !kidx || !R_host || !ds || !feat || !m || !out || !q_scratch || !idx_scratch) { set_error("yoho_group_transfer_batch: null argument"); return YOHO_EINVAL; }
+    for (int b = 0; b < nb; ++b)
+        if (!ds[b] || !feat[b] || m[b] < 1) { set_error("yoho_group_transfer_batch: copy %d has no down-sampled points", b); return YOHO_EINVAL; }
+    int rc;
+    for (int b = 0; b < nb; ++b) {
+        if ((rc = yoho_rotate_select(c, pts, R_host + 9 * (size_t)b, kidx, K, q_scratch, stream))) return rc;
+        if ((rc = yoho_nn_search(c, q_scratch, K, ds[b], m[b], 3, YOHO_DIST_SQUARE_L2, idx_scratch, nullptr, stream))) return rc;
+        if ((rc = yoho_group_scatter(c, feat[b], m[b], idx_scratch, K, g0 + b, out, stream))) return rc;
+    }
+    return 0;
+}
+
 int yoho_fcgf_forward(yoho_ctx* c, const int32_t* coords, int n, float* out, void* stream) {
     if (!c || n < 0) { set_error("yoho_fcgf_forward: bad argument"); return YOHO_EINVAL; }
     if (!c->fcgf) { set_error("yoho_fcgf_forward: backbone weights not loaded"); return YOHO_ENOWEIGHTS; }

@@ -22,7 +22,7 @@ SYMBOLS = [
     "yoho_gconv_layer", "yoho_load_fcgf", "yoho_fcgf_voxelize", "yoho_fcgf_forward", "yoho_fcgf_forward_batch", "yoho_fcgf_voxelize_rotated", "yoho_rotate_select",
     "yoho_des2r", "yoho_des2r_indexed", "yoho_partII_forward", "yoho_partII_forward_indexed", "yoho_hyp_from_quat", "yoho_o_score", "yoho_c_ransac",
     "yoho_group_gather", "yoho_set_profiling", "yoho_get_kernel_ms", "yoho_set_gconv_mode", "yoho_set_partII_mode", "yoho_set_nn_grid",
-    "yoho_range_status", "yoho_c_ransac_device", "yoho_group_scatter", "yoho_set_nn_prefilter", "yoho_set_fcgf_sort", "yoho_fcgf_voxelize_rotated_batch", "yoho_gconv_wgrad", "yoho_bn_stats", "yoho_bn_relu_apply", "yoho_bn_relu_backward", "yoho_set_partI_schedule", "yoho_clock_probe",
+    "yoho_range_status", "yoho_c_ransac_device", "yoho_group_scatter", "yoho_set_nn_prefilter", "yoho_set_fcgf_sort", "yoho_fcgf_voxelize_rotated_batch", "yoho_gconv_wgrad", "yoho_bn_stats", "yoho_bn_relu_apply", "yoho_bn_relu_backward", "yoho_set_partI_schedule", "yoho_clock_probe", "yoho_group_transfer_batch",
 ]
 
 
@@ -97,6 +97,7 @@ def load_library():
     lib.yoho_set_partII_mode.argtypes = [vp, ci]
     lib.yoho_set_partI_schedule.argtypes = [vp, ci, ci]
     lib.yoho_clock_probe.argtypes = [vp, ci, vp, vp]
+    lib.yoho_group_transfer_batch.argtypes = [vp, vp, vp, ci, vp, ci, vp, vp, vp, ci, vp, vp, vp, vp]
     lib.yoho_set_nn_grid.argtypes = [vp, C.c_double]
     lib.yoho_set_nn_prefilter.argtypes = [vp, ci]
     lib.yoho_set_fcgf_sort.argtypes = [vp, ci, ci]
@@ -599,6 +600,25 @@ class Context:
             raise ValueError(f"group_scatter: idx (K,), out (K, 32, 60), 0 <= g < 60; got idx {tuple(idx.shape)}, out {tuple(out.shape)}, g {g}")
         _check(self._lib.yoho_group_scatter(self._h, _dev(feat, torch.float32, "feat"), feat.shape[0], _dev(idx, torch.int64, "idx"), idx.shape[0],
                                             int(g), _dev(out, torch.float32, "out"), _stream()))
+
+    def group_transfer_batch(self, pts, kidx, Rs, ds_list, feat_list, g0, out):
+        """The NN feature transfer of a backbone pass in one library call: for copy b, out[:, :, g0 + b] = feat_list[b][nn(R_b
+        pts[kidx], ds_list[b])] (fp32 'SquareL2' search, through the hash grid when set_nn_grid is on).  pts (n,3) f64, kidx (K,)
+        int64, Rs list of (3,3), ds_list[b] (m_b,3) f32, feat_list[b] (m_b,32) f32, out (K,32,60) f32; all on the device."""
+        nb, K = len(Rs), kidx.shape[0]
+        if not (1 <= nb <= 64 and len(ds_list) == nb and len(feat_list) == nb):
+            raise ValueError("group_transfer_batch: 1..64 copies, one ds / feat tensor per rotation")
+        if tuple(out.shape) != (K, 32, 60) or any(f.dim() != 2 or f.shape[1] != 32 or f.shape[0] != d.shape[0] for f, d in zip(feat_list, ds_list)):
+            raise ValueError("group_transfer_batch: out (K,32,60), feat (m,32) and ds (m,3) per copy")
+        Rh = np.ascontiguousarray(np.stack([np.asarray(R, dtype=np.float64).reshape(3, 3) for R in Rs]))
+        dsp = (C.c_void_p * nb)(*[_dev(d, torch.float32, "ds").value for d in ds_list])
+        fp = (C.c_void_p * nb)(*[_dev(f, torch.float32, "feat").value for f in feat_list])
+        m = (C.c_int * nb)(*[int(d.shape[0]) for d in ds_list])
+        q = torch.empty((K, 3), dtype=torch.float32, device=out.device)
+        idx = torch.empty((K,), dtype=torch.int64, device=out.device)
+        _check(self._lib.yoho_group_transfer_batch(self._h, _dev(pts, torch.float64, "pts"), _dev(kidx, torch.int64, "kidx"), K, _np_ptr(Rh), nb,
+                                                   dsp, fp, m, int(g0), _dev(out, torch.float32, "out"), C.c_void_p(q.data_ptr()),
+                                                   C.c_void_p(idx.data_ptr()), _stream()))
 
     def set_gconv_mode(self, mode):
         """'f32' (direct conv, fp32 MFMA), 'bf16x3' (direct conv, fp32-accurate 3-way bf16 split MFMA),

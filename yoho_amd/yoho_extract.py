@@ -61,6 +61,10 @@ class yoho_extractor():
 
     def _transfer(self, res, pc_d, Rs, kidx_d, g0, kpts_f):
         """NN feature transfer of one backbone pass: kpts_f[:, :, g0 + j] = F_j[nn(R_j keypoints, down-sampled points of copy j)]"""
+        if hasattr(self.ctx, "group_transfer_batch") and all(f.shape[1] == 32 for _, f, _ in res):
+            # one library call for the pass (the same three kernels per copy, queued from C: no binding round trips in between)
+            self.ctx.group_transfer_batch(pc_d, kidx_d, list(Rs), [ds for _, _, ds in res], [f.contiguous() for _, f, _ in res], g0, kpts_f)
+            return
         for j, (sel, pci_f, ds) in enumerate(res):
             q = self.ctx.rotate_select(pc_d, Rs[j], kidx_d)
             _, idx = self.ctx.nn_search(q, ds, want_dist=False, squared=True)
