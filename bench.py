@@ -211,6 +211,8 @@ def main():
         return r
 
     mon = PowerMonitor(dev)
+    if os.environ.get("YOHO_BENCH_SMU", "1") == "0":
+        mon.source = None                                  # no SMU sampling thread (diagnostics)
     PROBE_US = int(os.environ.get("YOHO_BENCH_PROBE_US", "20"))       # 0 switches the device-side clock probes off
     PROBES_PER_STEP = float(os.environ.get("YOHO_BENCH_PROBES_PER_STEP", "4"))
 
@@ -226,12 +228,14 @@ def main():
         """warmup steps, then `repeats` timed regions of exactly `steps` steps each (barrier + synchronize on both sides, max over
         ranks) -> (median region time, all region times, per-rank times of the median region, last result, clock / power during
         the regions)"""
-        mon.start()                                        # the sampler's first SMU calls and the probe stream's creation are slow:
-        probe.queue(1)                                     # both happen during the warm-up, not inside a timed region
+        # SMU readings are taken right BEHIND every timed region, not by a poller beside it: a side thread polling amdsmi stalls one
+        # region in three by 35-45 ms (measured: regions of 5.39 / 7.19 / 5.43 ms per step with the poller, 5.44 / 5.37 / 5.36
+        # without), and the socket-power figure is a ~1 s moving average anyway, i.e. still the region's; the clock DURING the
+        # region comes from the device-side probe
+        probe.queue(1)                                     # the probe stream's creation happens during the warm-up
         r = run_steps(warmup, estimator, 1)
         probe.summary()
-        del mon.samples[:]
-        times, per_rank = [], []
+        times, per_rank, smu_after = [], [], []
         for rep in range(max(1, repeats)):
             ydist.barrier()
             torch.cuda.synchronize()
@@ -243,8 +247,11 @@ def main():
             ydist.barrier()
             times.append(ydist.max_over_ranks(time.perf_counter() - t0))
             per_rank.append(ydist.all_ranks(mine_dt))
-        power = mon.stop()
-        power["clock_probe"] = probe.summary()
+            smu_after.append(mon.read_once())
+        pw = [v["power_w"] for v in smu_after if v["power_w"] is not None]
+        power = {"power_w_after_each_region": [v["power_w"] for v in smu_after], "power_w_mean": round(float(np.mean(pw)), 1) if pw else None,
+                 "power_cap_w": None if mon.cap_w is None else round(float(mon.cap_w), 1), "source": mon.source,
+                 "clock_probe": probe.summary()}
         order = sorted(range(len(times)), key=lambda i: times[i])
         med = order[len(order) // 2]
         return times[med], times, per_rank[med], r, power
@@ -424,9 +431,11 @@ def main():
                                "pass_ms_one_stream": round(float(conv_ms[12]), 3),
                                "pass_ms_timed_schedule": round(pass_ms_timed_schedule, 3) if pass_ms_timed_schedule else round(float(conv_ms[12]), 3),
                                "power": {"timed_steps": power_steps, "profiled_partI_passes": power_prof,
-                                         "note": "SMU samples (amdsmi, side thread) and the library's one-wave clock probe (shader cycles per "
-                                                 "constant-rate wall tick, own high-priority stream) taken while the timed steps / the profiled "
-                                                 "PartI passes ran; nominal maximum 2400 MHz"},
+                                         "note": "timed_steps: socket power read from the SMU (amdsmi; a ~1 s moving average) right behind every timed "
+                                                 "region, shader clock from the library's one-wave clock probe (shader cycles per constant-rate wall "
+                                                 "tick, 20 us each, own high-priority stream) DURING the regions; profiled_partI_passes: SMU samples "
+                                                 "by a side thread (sclk per XCD, power) and the probe while the profiled passes ran; nominal "
+                                                 "maximum 2400 MHz"},
                                "range_repeats": int(ctx.range_fallbacks + (sum(c.range_fallbacks for c in streamer.desc + [streamer.est]) if streamer else 0))},
         }
         if yohoc is not None:

@@ -567,7 +567,10 @@ int launch_gft16(const float* in, float* out32, char* planes, int kppad, const v
     } else {
         for (int q = 0; q < G; ++q) { a.qbase[q] = 0; a.qstride[q] = 0; }
     }
-    const int grid = a.nChunks < nCU ? a.nChunks : nCU;
+    // experiment (YOHO_PARTI_DEBUG=xfgridN): N workgroups per CU's worth of chunks instead of one persistent workgroup per CU
+    static const int gmult = [] { const char* e = std::getenv("YOHO_PARTI_DEBUG"); const char* q = e ? std::strstr(e, "xfgrid") : nullptr; return q ? std::atoi(q + 6) : 1; }();
+    const int want = nCU * (gmult > 0 ? gmult : 1);
+    const int grid = a.nChunks < want ? a.nChunks : want;
     if (grid == 0) return 0;
     if (planes && variant != 1 && a.C8 * 8 <= G16X_MAXC) hipLaunchKernelGGL(gft16x_kernel, dim3(grid), dim3(512), G16X_LDS, s, a);       // two waves per SIMD
     else if (planes) hipLaunchKernelGGL(gft16_kernel<G16_ACTP>, dim3(grid), dim3(256), G16_LDS, s, a);

@@ -108,6 +108,11 @@ class PowerMonitor:
             return sclk, pw
         return None, None
 
+    def read_once(self):
+        """one SMU reading -> {"sclk_mhz", "power_w"} (None fields without SMU access)"""
+        sclk, pw = self._read() if self.available else (None, None)
+        return {"sclk_mhz": None if sclk is None else round(float(sclk), 1), "power_w": None if pw is None else round(float(pw), 1)}
+
     def _loop(self):
         while not self._stop.is_set():
             sclk, pw = self._read()
