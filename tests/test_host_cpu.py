@@ -67,3 +67,34 @@ def test_gather_sets_and_clears_the_grid_hint():
     finally:
         torch.Tensor.to = orig
     assert calls[0] == ("grid", 0.025) and calls[-1] == ("grid", 0) and [c for c in calls if c[0] == "g"] == [("g", g) for g in range(60)]
+
+
+def test_power_monitor_degrades_without_smu_access():
+    """bench.py's clock / power section must never break the bench line: without a GPU / SMU the sampler reports None fields"""
+    from yoho_amd.power import PowerMonitor
+    m = PowerMonitor(0)
+    one = m.read_once()
+    assert set(one) == {"sclk_mhz", "power_w"}
+    m.start()
+    out = m.stop()
+    assert set(out) >= {"sclk_mhz_mean", "power_w_mean", "power_cap_w", "samples", "source"}
+    if not m.available:
+        assert one == {"sclk_mhz": None, "power_w": None} and out["samples"] == 0
+
+
+def test_bench_dataset_scene_builder_and_presets(tmp_path):
+    """tools/bench_dataset.py: the synthetic scene lands in the reference's on-disk layout (gt.log / gt.info / keypoints / group
+    feature files) with exactly the requested pair count, and the 3DMatch preset has that test set's fragment and pair counts"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import bench_dataset as bd
+    from yoho_amd.dataset import ThrDMatchPartDataset
+    root, cache = str(tmp_path / "origin" / "s"), str(tmp_path / "cache" / "s")
+    pairs = bd.build_scene(root, cache, 7, 40, 3, device="cpu", npairs=11)
+    ds = ThrDMatchPartDataset(root, 7)
+    assert len(pairs) == 11 and [tuple(int(v) for v in p) for p in ds.pair_ids] == pairs
+    x = np.load(f"{cache}/FCGF_Input_Group_feature/3.npy")
+    assert x.shape == (40, 32, 60) and x.dtype == np.float32 and np.allclose(np.linalg.norm(x, axis=1), 1, atol=1e-5)
+    assert ds.get_kps("3").shape == (40, 3)
+    assert sum(n for _, n, _ in bd.PRESET_3DMATCH) == 433 and sum(p for _, _, p in bd.PRESET_3DMATCH) == 1623
