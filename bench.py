@@ -228,10 +228,10 @@ def main():
         """warmup steps, then `repeats` timed regions of exactly `steps` steps each (barrier + synchronize on both sides, max over
         ranks) -> (median region time, all region times, per-rank times of the median region, last result, clock / power during
         the regions)"""
-        # SMU readings are taken right BEHIND every timed region, not by a poller beside it: a side thread polling amdsmi stalls one
-        # region in three by 35-45 ms (measured: regions of 5.39 / 7.19 / 5.43 ms per step with the poller, 5.44 / 5.37 / 5.36
-        # without), and the socket-power figure is a ~1 s moving average anyway, i.e. still the region's; the clock DURING the
-        # region comes from the device-side probe
+        # The SMU is read ONCE, right behind the last timed region: any amdsmi access while the regions run - a side-thread poller, or
+        # a single read between two regions - costs one of the following regions 35-45 ms (measured: 5.39 / 7.19 / 5.43 ms per step
+        # with a poller, 5.42 / 5.48 / 7.09 with a read between regions, 5.41 / 5.40 / 5.39 with none), and the socket-power figure
+        # is a ~1 s moving average anyway, i.e. still the regions'; the clock DURING the regions comes from the device-side probe
         probe.queue(1)                                     # the probe stream's creation happens during the warm-up
         r = run_steps(warmup, estimator, 1)
         probe.summary()
@@ -247,11 +247,9 @@ def main():
             ydist.barrier()
             times.append(ydist.max_over_ranks(time.perf_counter() - t0))
             per_rank.append(ydist.all_ranks(mine_dt))
-            smu_after.append(mon.read_once())
-        pw = [v["power_w"] for v in smu_after if v["power_w"] is not None]
-        power = {"power_w_after_each_region": [v["power_w"] for v in smu_after], "power_w_mean": round(float(np.mean(pw)), 1) if pw else None,
-                 "power_cap_w": None if mon.cap_w is None else round(float(mon.cap_w), 1), "source": mon.source,
-                 "clock_probe": probe.summary()}
+        smu_after.append(mon.read_once())
+        power = {"power_w_after_last_region": smu_after[0]["power_w"], "power_cap_w": None if mon.cap_w is None else round(float(mon.cap_w), 1),
+                 "source": mon.source, "clock_probe": probe.summary()}
         order = sorted(range(len(times)), key=lambda i: times[i])
         med = order[len(order) // 2]
         return times[med], times, per_rank[med], r, power
@@ -282,7 +280,6 @@ def main():
     ctx.set_partI_schedule(sched_chunk, 1)
     ctx.set_profiling(True)
     conv_ms = []
-    mon.start()
     for _ in range(3):
         # eight passes back to back, then the ninth - queued behind them with no idle gap - is the one whose events are read: the
         # launches are timed at the clock the part holds under sustained PartI load, as in the timed steps, not after a pause
@@ -291,8 +288,7 @@ def main():
         probe.queue(4)
         torch.cuda.synchronize()
         conv_ms.append([ctx.kernel_ms(i) for i in range(13)])
-    power_prof = mon.stop()
-    power_prof["clock_probe"] = probe.summary()
+    power_prof = {"power_w_after": mon.read_once()["power_w"], "clock_probe": probe.summary()}
     pass_ms_timed_schedule = None
     if sched_streams == 2:
         ctx.set_partI_schedule(sched_chunk, 2)
@@ -431,11 +427,10 @@ def main():
                                "pass_ms_one_stream": round(float(conv_ms[12]), 3),
                                "pass_ms_timed_schedule": round(pass_ms_timed_schedule, 3) if pass_ms_timed_schedule else round(float(conv_ms[12]), 3),
                                "power": {"timed_steps": power_steps, "profiled_partI_passes": power_prof,
-                                         "note": "timed_steps: socket power read from the SMU (amdsmi; a ~1 s moving average) right behind every timed "
+                                         "note": "timed_steps: socket power read from the SMU (amdsmi; a ~1 s moving average) once, right behind the last timed "
                                                  "region, shader clock from the library's one-wave clock probe (shader cycles per constant-rate wall "
-                                                 "tick, 20 us each, own high-priority stream) DURING the regions; profiled_partI_passes: SMU samples "
-                                                 "by a side thread (sclk per XCD, power) and the probe while the profiled passes ran; nominal "
-                                                 "maximum 2400 MHz"},
+                                                 "tick, 20 us each, own high-priority stream) DURING the regions; profiled_partI_passes: the same two readings for the "
+                                                 "profiled passes; nominal maximum 2400 MHz"},
                                "range_repeats": int(ctx.range_fallbacks + (sum(c.range_fallbacks for c in streamer.desc + [streamer.est]) if streamer else 0))},
         }
         if yohoc is not None:
