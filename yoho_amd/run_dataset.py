@@ -195,13 +195,24 @@ def run_sharded(datasets, pair_fn, rank=0, world=1, scene_fn=None, gather=None):
     return out
 
 
-def write_scene_results(cfg, dataset, results, yoho_sign, max_iter):
-    """the files tests/estimator.py leaves for one scene: {id0}-{id1}.npz per pair + pre.log in pair order (:12-24)"""
-    save_dir = f'{cfg.output_cache_fn}/Testset/{dataset.name}/Match/{yoho_sign}/{max_iter}iters'
+def result_dir(cfg, dataset, yoho_sign, max_iter):
+    return f'{cfg.output_cache_fn}/Testset/{dataset.name}/Match/{yoho_sign}/{max_iter}iters'
+
+
+def save_pair_npz(save_dir, id0, id1, res):
+    """{id0}-{id1}.npz as tests/estimator.py:131-137,337-339 leaves it"""
+    np.savez(f'{save_dir}/{id0}-{id1}.npz', trans=res["trans"], recalltime=res["recalltime"])
+
+
+def write_scene_results(cfg, dataset, results, yoho_sign, max_iter, npz=True):
+    """the files tests/estimator.py leaves for one scene: {id0}-{id1}.npz per pair + pre.log in pair order (:12-24).
+    npz=False: the per-pair archives were already written by the ranks that ran the pairs (ScenePairRunner.finish_writes)."""
+    save_dir = result_dir(cfg, dataset, yoho_sign, max_iter)
     os.makedirs(save_dir, exist_ok=True)
     text = []
     for (id0, id1), res in zip(dataset.pair_ids, results):
-        np.savez(f'{save_dir}/{id0}-{id1}.npz', trans=res["trans"], recalltime=res["recalltime"])
+        if npz:
+            save_pair_npz(save_dir, id0, id1, res)
         text.append(format_log_entry(id0, id1, len(dataset.pc_ids), res["trans"]))
     with open(f'{save_dir}/pre.log', 'w') as f:
         f.write("".join(text))
@@ -219,7 +230,7 @@ class ScenePairRunner:
     pair, so a rank's footprint is bounded by one scene part whatever the number of parts it walks.
     `stats` accumulates where the time goes (seconds; device work is timed with a synchronise only when timing=True)."""
 
-    def __init__(self, cfg, ctx, estimator="yohoo", max_iter=1000, base_seed=0, timing=False):
+    def __init__(self, cfg, ctx, estimator="yohoo", max_iter=1000, base_seed=0, timing=False, write_npz=False):
         import torch
         from . import pipeline
         self.torch, self.pipeline = torch, pipeline
@@ -229,9 +240,16 @@ class ScenePairRunner:
         self.scene = None
         self.frag = {}
         self.uses = {}
+        self._made_dirs = set()
         self._pin_pool = {}
         import threading
         self._pin_lock = threading.Lock()
+        # write_npz: this rank writes the {id0}-{id1}.npz of the pairs it ran (finish_writes, behind its last pair: 0.15 ms of
+        # Python per archive, spread over the ranks instead of serial on rank 0; a worker thread writing them WHILE the pairs run
+        # was measured and dropped - it saved 0.07 s per 495 pairs and cost every pair 0.1 ms of GIL contention)
+        self.yoho_sign = 'YOHO_O' if estimator == "yohoo" else 'YOHO_C'
+        self._write_npz = bool(write_npz)
+        self._write_jobs = []
         self.timing = bool(timing)
         self.stats = {"fragments": 0, "pairs": 0, "load_s": 0.0, "load_wait_s": 0.0, "h2d_describe_s": 0.0, "setup_s": 0.0, "pairs_s": 0.0,
                       "bytes_read": 0, "peak_resident_fragments": 0}
@@ -363,6 +381,15 @@ class ScenePairRunner:
         self.stats["peak_resident_fragments"] = max(self.stats["peak_resident_fragments"], len(self.frag))
         self.stats["setup_s"] += time.perf_counter() - t_setup
 
+    def finish_writes(self):
+        """write the archives of the pairs this rank ran"""
+        for save_dir, id0, id1, res in self._write_jobs:
+            if save_dir not in self._made_dirs:
+                os.makedirs(save_dir, exist_ok=True)
+                self._made_dirs.add(save_dir)
+            save_pair_npz(save_dir, id0, id1, res)
+        self._write_jobs = []
+
     def _release(self, fid):
         n = self.uses.get(fid, 0) - 1
         if n <= 0:
@@ -385,6 +412,8 @@ class ScenePairRunner:
         out = {"trans": trans, "recalltime": int(r.best_h), "matches": int(r.match.shape[0]), "inliers": int(r.best_count)}
         self._release(id0)
         self._release(id1)
+        if self._write_npz:
+            self._write_jobs.append((result_dir(self.cfg, dataset, self.yoho_sign, self.max_iter), id0, id1, out))
         self.stats["pairs"] += 1
         self.stats["pairs_s"] += time.perf_counter() - t0
         return out
@@ -412,7 +441,8 @@ def eval_sharded(cfg, max_iter=1000, estimator="yohoo", datasets=None, base_seed
     """The sharded counterpart of Evaluator_PartI/II.eval (tests/evaluator.py:75-101,146-173): run every pair of the
     test set over the initialised process group (one rank per GPU), write npz / pre.log on rank 0 and return the
     Registration Recall there (None on the other ranks).  FCGF group features and keypoints are read from the
-    reference's cache layout; descriptors, matches and hypotheses never touch the disk.  stats_out: a dict that receives the
+    reference's cache layout; descriptors, matches and hypotheses never touch the disk.  state_dicts: None = read and broadcast the
+    checkpoints of cfg.model_fn, (PartI, PartII) = load these, "loaded" = ctx already holds the weights.  stats_out: a dict that receives the
     rank's ScenePairRunner.stats and the gathered per-pair results (tools/bench_dataset.py, tests)."""
     import torch
     from . import hip, RR_cal
@@ -424,12 +454,25 @@ def eval_sharded(cfg, max_iter=1000, estimator="yohoo", datasets=None, base_seed
         ctx = hip.get_context(so3_dir=getattr(cfg, "SO3_related_files", None))
     if state_dicts is None:
         load_and_broadcast_weights(cfg, ctx, need_partII=(estimator == "yohoo"))
-    else:                                        # already loaded by the caller (bench / tests): (PartI, PartII or None)
+    elif state_dicts != "loaded":                # given by the caller (bench / tests): (PartI, PartII or None); "loaded": ctx has them
         ctx.load_partI(state_dicts[0])
         if estimator == "yohoo":
             ctx.load_partII(state_dicts[1])
-    runner = ScenePairRunner(cfg, ctx, estimator=estimator, max_iter=max_iter, base_seed=base_seed, timing=stats_out is not None)
-    results = run_sharded(datasets, runner.run_pair, rank=rank, world=world, scene_fn=runner.setup_scene)
+    # every rank writes the archives of the pairs it ran (one node: the cache directory is shared), rank 0 the pre.log files
+    runner = ScenePairRunner(cfg, ctx, estimator=estimator, max_iter=max_iter, base_seed=base_seed, timing=stats_out is not None, write_npz=True)
+
+    def pair_fn(ds, pair):
+        return runner.run_pair(ds, pair)
+    try:
+        results = run_sharded(datasets, pair_fn, rank=rank, world=world, scene_fn=runner.setup_scene)
+    finally:
+        write_error = None
+        try:
+            runner.finish_writes()
+        except Exception as e:               # reported below, symmetrically
+            write_error = f"{type(e).__name__}: {e}"
+    if ydist.max_over_ranks(0.0 if write_error is None else 1.0) > 0.0:
+        raise RuntimeError("writing the per-pair archives failed on at least one rank" + (f": {write_error}" if write_error else ""))
     torch.cuda.synchronize()
     if stats_out is not None:
         stats_out.update(runner.stats)
@@ -440,7 +483,7 @@ def eval_sharded(cfg, max_iter=1000, estimator="yohoo", datasets=None, base_seed
     try:
         sign = 'YOHO_O' if estimator == "yohoo" else 'YOHO_C'
         for key, ds in scene_items(datasets):
-            write_scene_results(cfg, ds, results[key], sign, max_iter)
+            write_scene_results(cfg, ds, results[key], sign, max_iter, npz=False)
         rr, flags, errors = RR_cal.benchmark(cfg, datasets, max_iter, yoho_sign=sign)
         if results_log:
             if os.path.dirname(results_log):
