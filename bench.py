@@ -198,16 +198,17 @@ def main():
         for c_ in streamer.desc:
             c_.set_partI_schedule(sched_chunk, sched_streams)
 
-    def run_steps(n, estimator="yohoo", seed0=0):
+    def run_steps(n, estimator="yohoo", seed0=0, hypotheses="all"):
         """n steps = n sweeps over this rank's pair list, all inside one call so that consecutive steps can overlap"""
         todo = [p for _ in range(n) for p in mine]
         dist = 0.09 if estimator == "yohoo" else 0.07
         if streamer is not None:
             return streamer.run(todo, inlier_dist=dist, max_iter=1000, order_rng=rng, estimator=estimator,
-                                seeds=[seed0 + i for i in range(len(todo))])[-1]
+                                seeds=[seed0 + i for i in range(len(todo))], hypotheses=hypotheses)[-1]
         r = None
         for i, (a0, a1, b0, b1) in enumerate(todo):
-            r = pipeline.run_pair(ctx, a0, a1, b0, b1, inlier_dist=dist, max_iter=1000, order_rng=rng, estimator=estimator, seed=seed0 + i)
+            r = pipeline.run_pair(ctx, a0, a1, b0, b1, inlier_dist=dist, max_iter=1000, order_rng=rng, estimator=estimator, seed=seed0 + i,
+                                  hypotheses=hypotheses)
         return r
 
     mon = PowerMonitor(dev)
@@ -224,7 +225,7 @@ def main():
             return None
     probe = ClockProbe(ctx, us=PROBE_US) if PROBE_US > 0 else _NoProbe()
 
-    def timed(estimator, steps, warmup, repeats=1):
+    def timed(estimator, steps, warmup, repeats=1, hypotheses="all"):
         """warmup steps, then `repeats` timed regions of exactly `steps` steps each (barrier + synchronize on both sides, max over
         ranks) -> (median region time, all region times, per-rank times of the median region, last result, clock / power during
         the regions)"""
@@ -233,7 +234,7 @@ def main():
         # with a poller, 5.42 / 5.48 / 7.09 with a read between regions, 5.41 / 5.40 / 5.39 with none), and the socket-power figure
         # is a ~1 s moving average anyway, i.e. still the regions'; the clock DURING the regions comes from the device-side probe
         probe.queue(1)                                     # the probe stream's creation happens during the warm-up
-        r = run_steps(warmup, estimator, 1)
+        r = run_steps(warmup, estimator, 1, hypotheses)
         probe.summary()
         times, per_rank, smu_after = [], [], []
         for rep in range(max(1, repeats)):
@@ -241,7 +242,7 @@ def main():
             torch.cuda.synchronize()
             probe.queue(max(1, int(steps * PROBES_PER_STEP)))            # short probes on their own high-priority stream
             t0 = time.perf_counter()
-            r = run_steps(steps, estimator, 1000 + 100000 * rep)
+            r = run_steps(steps, estimator, 1000 + 100000 * rep, hypotheses)
             torch.cuda.synchronize()
             mine_dt = time.perf_counter() - t0
             ydist.barrier()
@@ -255,6 +256,20 @@ def main():
         return times[med], times, per_rank[med], r, power
 
     dt, dts, rank_dts, res, power_steps = timed("yohoo", args.steps, max(args.warmup, 1), args.repeats)
+    # the same step with PartII evaluated only for the 1000 matches the YOHO-O vote reads (pipeline.run_pair hypotheses="selected":
+    # identical winner / transform, tests/test_gpu_fullsize.py); reported beside the headline, which keeps the reference's
+    # workload (PartII and [R|t] for every match, as its Trans_pre stage leaves them)
+    sel_leg = None
+    if not args.no_yohoc:
+        dts_, _, _, ress, _ = timed("yohoo", args.steps, max(min(args.warmup, 2), 1), 1, "selected")
+        sel_leg = {"metric": "keypoints/sec (5000 kp x60 rot desc + YOHO-O, PartII only for the 1000 voted hypotheses)",
+                   "value": round(pairs_per_step * 2 * KP * args.steps / dts_, 1), "ms_per_step": round(dts_ / args.steps * 1e3, 3),
+                   "winner_inliers": int(ress.best_count)}
+        # one pair both ways with the same shuffle: the winner and the transform must be the same
+        ra_ = pipeline.run_pair(ctx, f0, f1, k0, k1, max_iter=1000, order_rng=np.random.RandomState(7))
+        rs_ = pipeline.run_pair(ctx, f0, f1, k0, k1, max_iter=1000, order_rng=np.random.RandomState(7), eqv=ra_.eqv, hypotheses="selected")
+        sel_leg["same_winner_and_transform_as_all"] = bool((ra_.best_h, ra_.best_count) == (rs_.best_h, rs_.best_count) and
+                                                           np.array_equal(np.asarray(ra_.trans), np.asarray(rs_.trans)))
     yohoc = None
     if not args.no_yohoc:
         dtc, _, _, resc, _ = timed("yohoc", args.steps, max(min(args.warmup, 2), 1))
@@ -435,6 +450,8 @@ def main():
         }
         if yohoc is not None:
             out["yohoc"] = yohoc
+        if sel_leg is not None:
+            out["yohoo_selected_hypotheses"] = sel_leg
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
     # dataset-scale leg (BASELINE configs 3 / 5): 60 fragments x 5000 keypoints from .npy files on disk, ~500 pairs, through the

@@ -261,3 +261,25 @@ def test_partI_many_short_launches_equal_one_long_launch(hip, sd1):
     for rep in range(6):
         o = c.partI_forward(x, want_inv=False, want_inv_np=True, check_range=False)
         assert torch.equal(o["eqv"], ref["eqv"]), rep
+
+
+def test_run_pair_selected_hypotheses_equal_all(dctx, sd1, sd2):
+    """pipeline.run_pair(hypotheses="selected"): PartII and [R|t] only for the min(max_iter, M) matches the YOHO-O vote reads
+    (tests/estimator.py:321-326) - the winner, its inlier count and the transform are those of the full computation, and the
+    selected rows of quat / trans_pre are bit-identical to the full ones; full size (M = 3233 > 1000) and a small pair with 20 votes"""
+    for K, it in ((5000, 1000), (300, 20)):
+        pr = synth.make_pair(K, seed=10)
+        f0, f1, k0, k1 = cu(pr["feat0"]), cu(pr["feat1"]), cu(pr["keys0"]), cu(pr["keys1"])
+        ra = pipeline.run_pair(dctx, f0, f1, k0, k1, max_iter=it, order_rng=np.random.RandomState(5))
+        rs = pipeline.run_pair(dctx, f0, f1, k0, k1, max_iter=it, order_rng=np.random.RandomState(5), eqv=ra.eqv, hypotheses="selected")
+        M = ra.match.shape[0]
+        assert M > it and rs.quat.shape[0] == it and ra.quat.shape[0] == M
+        assert (rs.best_h, rs.best_count) == (ra.best_h, ra.best_count) and np.array_equal(rs.trans, ra.trans)
+        rows = torch.from_numpy(ra.order[:it]).cuda()
+        assert torch.equal(rs.hyp_rows, rows)
+        assert torch.equal(rs.quat, ra.quat[rows]) and torch.equal(rs.trans_pre, ra.trans_pre[rows])
+    # nothing to select when every match is voted on
+    pr = synth.make_pair(96, seed=3)
+    r = pipeline.run_pair(dctx, cu(pr["feat0"]), cu(pr["feat1"]), cu(pr["keys0"]), cu(pr["keys1"]), order_rng=np.random.RandomState(0),
+                          hypotheses="selected")
+    assert r.hyp_rows is None and r.quat.shape[0] == r.match.shape[0]

@@ -94,7 +94,7 @@ PRESET_3DMATCH = [("kitchen", 60, 506), ("home1", 60, 156), ("home2", 60, 208), 
                   ("study", 66, 292), ("lab", 38, 77)]
 
 
-def run(nfrag=60, kp=5000, span=9, estimator="yohoo", workdir="/tmp/yoho_ds", runs=2, max_iter=1000, keep=False, preset=None):
+def run(nfrag=60, kp=5000, span=9, estimator="yohoo", workdir="/tmp/yoho_ds", runs=2, max_iter=1000, keep=False, preset=None, hypotheses="selected"):
     """-> dict for the bench line.  Every rank of an initialised process group calls this; rank 0 builds the files.
     preset="3dmatch": eight scenes with the fragment and pair counts of the 3DMatch test set instead of one scene."""
     import torch
@@ -140,6 +140,7 @@ def run(nfrag=60, kp=5000, span=9, estimator="yohoo", workdir="/tmp/yoho_ds", ru
                         f"synthetic test set in the shape of 3DMatch's: 8 scenes, {nfrag_all} fragments x {kp} keypoints") +
                        f" ({nfrag_all * kp * 7680 / 1e9:.2f} GB of FCGF group features as .npy on disk), {npairs_all} pairs, estimator {estimator}, {world} rank(s)",
            "fragments": nfrag_all, "keypoints_per_fragment": kp, "pairs": npairs_all, "ranks": world, "estimator": estimator,
+           "hypotheses": ("PartII only for the <= %d matches the YOHO-O vote reads" % max_iter) if hypotheses == "selected" else "PartII for every match (the reference's Trans_pre stage)",
            "scenes": {sn: {"fragments": nf, "pairs": len(datasets[sn].pair_ids)} for sn, nf, _ in scenes},
            "scene_build_s": round(t_build, 2), "load_weights_once_s": round(t_weights, 3), "runs": []}
     for r in range(runs):
@@ -150,7 +151,7 @@ def run(nfrag=60, kp=5000, span=9, estimator="yohoo", workdir="/tmp/yoho_ds", ru
         t0 = time.perf_counter()
         ok, rr = True, None
         try:
-            rr = run_dataset.eval_sharded(cfg, max_iter=max_iter, estimator=estimator, datasets=datasets, base_seed=r, ctx=ctx, state_dicts="loaded",
+            rr = run_dataset.eval_sharded(cfg, max_iter=max_iter, estimator=estimator, datasets=datasets, base_seed=r, ctx=ctx, state_dicts="loaded", hypotheses=hypotheses,
                                           stats_out=stats)
             torch.cuda.synchronize()
         except Exception as e:
@@ -188,7 +189,8 @@ if __name__ == "__main__":
     ap.add_argument("--workdir", default="/tmp/yoho_ds")
     ap.add_argument("--runs", type=int, default=2)
     ap.add_argument("--preset", default=None, choices=[None, "3dmatch"])
+    ap.add_argument("--hypotheses", default="selected", choices=["selected", "all"])
     a = ap.parse_args()
-    o = run(a.nfrag, a.kp, a.span, a.estimator, a.workdir, a.runs, preset=a.preset)
+    o = run(a.nfrag, a.kp, a.span, a.estimator, a.workdir, a.runs, preset=a.preset, hypotheses=a.hypotheses)
     if int(os.environ.get("RANK", "0")) == 0:
         print(json.dumps(o), flush=True)

@@ -15,7 +15,7 @@ import torch
 
 
 class PairResult:
-    __slots__ = ("match", "dr_index", "quat", "trans_pre", "best_h", "best_count", "trans", "order", "eqv", "range_repeats")
+    __slots__ = ("match", "dr_index", "quat", "trans_pre", "best_h", "best_count", "trans", "order", "eqv", "range_repeats", "hyp_rows")
 
 
 def describe_pair(ctx, feat0, feat1, check_range=True):
@@ -29,15 +29,23 @@ def describe_pair(ctx, feat0, feat1, check_range=True):
     return {k: v[:n0] for k, v in o.items()}, {k: v[n0:] for k, v in o.items()}
 
 
-def run_pair(ctx, feat0, feat1, keys0, keys1, inlier_dist=0.09, max_iter=1000, order_rng=None, eqv=None, estimator="yohoo", seed=0):
+def run_pair(ctx, feat0, feat1, keys0, keys1, inlier_dist=0.09, max_iter=1000, order_rng=None, eqv=None, estimator="yohoo", seed=0,
+             hypotheses="all"):
     """feat0/feat1 (K,32,60) f32 cuda (FCGF group features), keys0/keys1 (K,3) f64 cuda.
     estimator 'yohoo' (tests/evaluator.py:112-117: PartII + one-shot vote over <= max_iter per-match hypotheses, order
     shuffled by order_rng) or 'yohoc' (tests/evaluator.py:41-47: max_iter Kabsch RANSAC iterations sampled on the device
     from the Philox stream `seed`; no PartII).  Returns PairResult with device tensors (trans is a (3,4) f64 host array,
-    eye(4) rows if no hypothesis has an inlier, as tests/estimator.py:327-336; best_h is the reference's recalltime)."""
+    eye(4) rows if no hypothesis has an inlier, as tests/estimator.py:327-336; best_h is the reference's recalltime).
+    hypotheses (YOHO-O): "all" = PartII and [R|t] for every match, as the reference's stage PartII_R_pre leaves them in
+    Match/Trans_pre (tests/extractor.py:142-201) - quat / trans_pre have M rows; "selected" = only for the min(max_iter, M) matches
+    the vote will actually read (tests/estimator.py:321-326: T = Trans[index[:max_iter]]) - quat / trans_pre then have H rows in
+    vote order, hyp_rows holds their match rows; winner, count and trans are identical (a match's PartII output does not depend on
+    which other matches share its pass), the other M - H hypotheses - which nothing downstream of the vote reads - are not computed."""
     r = PairResult()
     r.range_repeats = 0
-    r.quat = r.trans_pre = r.order = None
+    r.quat = r.trans_pre = r.order = r.hyp_rows = None
+    if hypotheses not in ("all", "selected"):
+        raise ValueError(f"hypotheses must be 'all' or 'selected', got {hypotheses!r}")
     if eqv is None:
         o0, o1 = describe_pair(ctx, feat0, feat1, check_range=False)
     else:
@@ -75,8 +83,25 @@ def run_pair(ctx, feat0, feat1, keys0, keys1, inlier_dist=0.09, max_iter=1000, o
     order_d = torch.from_numpy(order).to(feat0.device)
     H = min(max_iter, M)
 
+    selected = hypotheses == "selected" and H < M
+    if selected:
+        sel_d = order_d[:H].contiguous()
+        match_s, dr_s = match[sel_d].contiguous(), r.dr_index[sel_d].contiguous()
+        k0s, k1s = k0m[sel_d].contiguous(), k1m[sel_d].contiguous()
+        vote_order = torch.arange(H, dtype=torch.int64, device=feat0.device)
+        r.hyp_rows = sel_d
+
     def head_and_vote():
         # tests/extractor.py:125-138 batch_create (0<->1 exchange) + utils/network.py:259-278
+        if selected:
+            if ctx.supports_matched():
+                r.quat = ctx.partII_forward_matched(feat0, feat1, o0["eqv"], o1["eqv"], match_s, dr_s, check_range=False)
+            else:                                          # the bf16x3 repeat of the range guard takes gathered rows
+                s0, s1 = match_s[:, 0], match_s[:, 1]
+                r.quat = ctx.partII_forward(feat1[s1], feat0[s0], o1["eqv"][s1], o0["eqv"][s0], dr_s, check_range=False)
+            r.trans_pre = ctx.hyp_from_quat(r.quat, dr_s, k0s, k1s)
+            res, _ = ctx.o_score(k0m, k1m, r.trans_pre, vote_order, H, inlier_dist)
+            return res.cpu().numpy()
         if ctx.supports_matched():
             r.quat = ctx.partII_forward_matched(feat0, feat1, o0["eqv"], o1["eqv"], match, r.dr_index, check_range=False)
         else:                                              # other PartII arithmetic modes take gathered rows
@@ -90,7 +115,7 @@ def run_pair(ctx, feat0, feat1, keys0, keys1, inlier_dist=0.09, max_iter=1000, o
         r.range_repeats += 1
         bh, bc = (int(v) for v in ctx._repeat_wider("partII", head_and_vote))
     r.best_h, r.best_count = bh, bc
-    r.trans = r.trans_pre[int(order[bh])].cpu().numpy() if bc > 0 else np.eye(4)
+    r.trans = r.trans_pre[bh if selected else int(order[bh])].cpu().numpy() if bc > 0 else np.eye(4)
     return r
 
 
@@ -138,7 +163,7 @@ class PairStreamer:
                 t.record_stream(self.sb)
         return o0, o1, ev
 
-    def run(self, pairs, inlier_dist=0.09, max_iter=1000, order_rng=None, estimator="yohoo", seeds=None):
+    def run(self, pairs, inlier_dist=0.09, max_iter=1000, order_rng=None, estimator="yohoo", seeds=None, hypotheses="all"):
         """pairs: sequence of (feat0, feat1, keys0, keys1) device tensors.  Returns the list of PairResult."""
         pairs = list(pairs)
         out = []
@@ -164,7 +189,7 @@ class PairStreamer:
                     torch.cuda.current_stream().synchronize()        # d's next pass is queued on the other stream
                     repeats = 1
                 r = run_pair(self.est, pair[0], pair[1], pair[2], pair[3], inlier_dist=inlier_dist, max_iter=max_iter, order_rng=order_rng,
-                             eqv=(o0, o1), estimator=estimator, seed=(seeds[i] if seeds is not None else 0))
+                             eqv=(o0, o1), estimator=estimator, seed=(seeds[i] if seeds is not None else 0), hypotheses=hypotheses)
                 r.range_repeats += repeats
             out.append(r)
         cur.wait_stream(self.sa)

@@ -230,17 +230,22 @@ class ScenePairRunner:
     pair, so a rank's footprint is bounded by one scene part whatever the number of parts it walks.
     `stats` accumulates where the time goes (seconds; device work is timed with a synchronise only when timing=True)."""
 
-    def __init__(self, cfg, ctx, estimator="yohoo", max_iter=1000, base_seed=0, timing=False, write_npz=False):
+    def __init__(self, cfg, ctx, estimator="yohoo", max_iter=1000, base_seed=0, timing=False, write_npz=False, hypotheses="selected"):
         import torch
         from . import pipeline
         self.torch, self.pipeline = torch, pipeline
         self.cfg, self.ctx = cfg, ctx
         self.estimator, self.max_iter, self.base_seed = estimator, int(max_iter), int(base_seed)
         self.inlier_dist = cfg.ransac_o_inlinerdist if estimator == "yohoo" else cfg.ransac_c_inlinerdist
+        # YOHO-O: PartII only for the <= max_iter matches the vote reads (pipeline.run_pair, hypotheses="selected"): the driver's
+        # products are trans / recalltime per pair, identical either way; "all" computes Trans_pre for every match as the
+        # reference's stage does
+        self.hypotheses = hypotheses
         self.scene = None
         self.frag = {}
         self.uses = {}
         self._made_dirs = set()
+        self._copy_stream = None
         self._pin_pool = {}
         import threading
         self._pin_lock = threading.Lock()
@@ -294,7 +299,7 @@ class ScenePairRunner:
                     if not n:
                         raise IOError(f'{fdir}/{fid}.npy: file shorter than its header says')
                     got += n
-        keys = torch.from_numpy(np.ascontiguousarray(dataset.get_kps(fid), dtype=np.float64))
+        keys = torch.from_numpy(np.ascontiguousarray(dataset.get_kps(fid), dtype=np.float64)).pin_memory()
         return fid, x, keys, time.perf_counter() - t0
 
     def setup_scene(self, dataset, pairs):
@@ -334,14 +339,27 @@ class ScenePairRunner:
         th = threading.Thread(target=loader, daemon=True)
         th.start()
 
-        def describe(group):
-            t0 = time.perf_counter()
-            dev = [(fid, x.cuda(non_blocking=True), keys.cuda()) for fid, x, keys in group]
-            up = torch.cuda.Event()
-            up.record()
+        # two-stage device side: the H2D copies of group N + 1 run on a copy stream while PartI describes group N
+        if self._copy_stream is None:
+            self._copy_stream = torch.cuda.Stream()
+        copy, main = self._copy_stream, torch.cuda.current_stream()
+
+        def upload(group):
+            with torch.cuda.stream(copy):
+                dev = [(fid, x.cuda(non_blocking=True), keys.cuda(non_blocking=True)) for fid, x, keys in group]
+                up = torch.cuda.Event()
+                up.record(copy)
             for _, x, _ in group:
                 if x.is_pinned():
                     self._recycle(x, up)
+            return dev, up
+
+        def describe(dev, up):
+            t0 = time.perf_counter()
+            main.wait_event(up)
+            for _, x, keys in dev:                  # allocated on the copy stream, used (and later freed) on this one
+                x.record_stream(main)
+                keys.record_stream(main)
             xs = torch.cat([g[1] for g in dev]) if len(dev) > 1 else dev[0][1]
             out = self.ctx.partI_forward(xs.contiguous(), want_inv=False, want_inv_np=True)
             o = 0
@@ -350,10 +368,16 @@ class ScenePairRunner:
                 # own storage per fragment, so that releasing one fragment frees its memory (slices would pin the whole pass)
                 self.frag[fid] = dict(feat=x, keys=keys, eqv=out["eqv"][o:o + n].clone(), inv_np=out["inv_np"][o:o + n].clone())
                 o += n
-            if self.timing:
-                torch.cuda.synchronize()
             self.stats["h2d_describe_s"] += time.perf_counter() - t0
-            self.stats["fragments"] += len(group)
+            self.stats["fragments"] += len(dev)
+
+        pending = [None]
+
+        def flush(group):
+            u = upload(group)
+            if pending[0] is not None:
+                describe(*pending[0])
+            pending[0] = u
 
         group, rows = [], 0
         while True:
@@ -368,15 +392,21 @@ class ScenePairRunner:
                 item = item[:3]
             # a pass is flushed when full, when the input ends, or when the loader has nothing ready (do not idle the device)
             if group and (item is None or rows + item[1].shape[0] > 16384):
-                describe(group)
+                flush(group)
                 group, rows = [], 0
             if item is None:
                 break
             group.append(item)
             rows += item[1].shape[0]
             if q.empty() and group and rows >= 4096:
-                describe(group)
+                flush(group)
                 group, rows = [], 0
+        if pending[0] is not None:
+            describe(*pending[0])
+        if self.timing:
+            t0 = time.perf_counter()
+            torch.cuda.synchronize()                # once per scene part: the device side of the setup is inside setup_s
+            self.stats["h2d_describe_s"] += time.perf_counter() - t0
         th.join()
         self.stats["peak_resident_fragments"] = max(self.stats["peak_resident_fragments"], len(self.frag))
         self.stats["setup_s"] += time.perf_counter() - t_setup
@@ -407,7 +437,7 @@ class ScenePairRunner:
         r = self.pipeline.run_pair(self.ctx, a["feat"], b["feat"], a["keys"], b["keys"], inlier_dist=self.inlier_dist,
                                    max_iter=self.max_iter, order_rng=np.random.RandomState(seed & 0xFFFFFFFF),
                                    eqv=({"eqv": a["eqv"], "inv_np": a["inv_np"]}, {"eqv": b["eqv"], "inv_np": b["inv_np"]}),
-                                   estimator=self.estimator, seed=seed)
+                                   estimator=self.estimator, seed=seed, hypotheses=self.hypotheses)
         trans = np.asarray(r.trans, dtype=np.float64)
         out = {"trans": trans, "recalltime": int(r.best_h), "matches": int(r.match.shape[0]), "inliers": int(r.best_count)}
         self._release(id0)
@@ -437,7 +467,7 @@ def load_and_broadcast_weights(cfg, ctx, need_partII):
 
 
 def eval_sharded(cfg, max_iter=1000, estimator="yohoo", datasets=None, base_seed=0, results_log=None, ctx=None, state_dicts=None,
-                 stats_out=None):
+                 stats_out=None, hypotheses="selected"):
     """The sharded counterpart of Evaluator_PartI/II.eval (tests/evaluator.py:75-101,146-173): run every pair of the
     test set over the initialised process group (one rank per GPU), write npz / pre.log on rank 0 and return the
     Registration Recall there (None on the other ranks).  FCGF group features and keypoints are read from the
@@ -459,7 +489,8 @@ def eval_sharded(cfg, max_iter=1000, estimator="yohoo", datasets=None, base_seed
         if estimator == "yohoo":
             ctx.load_partII(state_dicts[1])
     # every rank writes the archives of the pairs it ran (one node: the cache directory is shared), rank 0 the pre.log files
-    runner = ScenePairRunner(cfg, ctx, estimator=estimator, max_iter=max_iter, base_seed=base_seed, timing=stats_out is not None, write_npz=True)
+    runner = ScenePairRunner(cfg, ctx, estimator=estimator, max_iter=max_iter, base_seed=base_seed, timing=stats_out is not None, write_npz=True,
+                             hypotheses=hypotheses)
 
     def pair_fn(ds, pair):
         return runner.run_pair(ds, pair)
