@@ -22,6 +22,7 @@ seed = pair_seed(base_seed, dataset.name, id0, id1).  The result of a pair there
 ranks or on which rank ran it (tests/test_dist_cpu.py checks world 2 == world 1).
 """
 import os
+import threading
 import zlib
 import numpy as np
 
@@ -155,9 +156,11 @@ def scene_items(datasets):
     return [(k, d) for k, d in datasets.items() if k != 'wholesetname']
 
 
-def run_sharded(datasets, pair_fn, rank=0, world=1, scene_fn=None, gather=None):
+def run_sharded(datasets, pair_fn, rank=0, world=1, scene_fn=None, gather=None, pairs_fn=None):
     """Run pair_fn(dataset, (id0, id1)) -> picklable result for every pair of every scene, sharded by plan_shards.
     scene_fn(dataset, pairs) is called once per (rank, scene part) before its pairs (descriptor extraction).
+    pairs_fn(dataset, pairs) -> list of results (same order), when given, takes a whole scene part instead of pair_fn being
+    called pair by pair (the GPU worker runs several pairs concurrently).
     Returns on EVERY rank {scene key: [result per pair, in dataset.pair_ids order]} (gathered on the host)."""
     items = scene_items(datasets)
     plan = plan_shards({k: len(d.pair_ids) for k, d in items}, world, {k: len(d.pc_ids) for k, d in items})
@@ -169,8 +172,12 @@ def run_sharded(datasets, pair_fn, rank=0, world=1, scene_fn=None, gather=None):
             pairs = [tuple(ds.pair_ids[p]) for p in positions]
             if scene_fn is not None:
                 scene_fn(ds, pairs)
-            for p, pair in zip(positions, pairs):
-                mine[(key, p)] = pair_fn(ds, pair)
+            if pairs_fn is not None:
+                for p, res in zip(positions, pairs_fn(ds, pairs)):
+                    mine[(key, p)] = res
+            else:
+                for p, pair in zip(positions, pairs):
+                    mine[(key, p)] = pair_fn(ds, pair)
     except Exception as e:
         # a rank that fails must still reach the gather, or the other ranks would wait for it forever: the error travels with
         # the results and is raised on EVERY rank
@@ -230,7 +237,8 @@ class ScenePairRunner:
     pair, so a rank's footprint is bounded by one scene part whatever the number of parts it walks.
     `stats` accumulates where the time goes (seconds; device work is timed with a synchronise only when timing=True)."""
 
-    def __init__(self, cfg, ctx, estimator="yohoo", max_iter=1000, base_seed=0, timing=False, write_npz=False, hypotheses="selected"):
+    def __init__(self, cfg, ctx, estimator="yohoo", max_iter=1000, base_seed=0, timing=False, write_npz=False, hypotheses="selected",
+                 pair_workers=2, partII_sd=None):
         import torch
         from . import pipeline
         self.torch, self.pipeline = torch, pipeline
@@ -241,13 +249,21 @@ class ScenePairRunner:
         # products are trans / recalltime per pair, identical either way; "all" computes Trans_pre for every match as the
         # reference's stage does
         self.hypotheses = hypotheses
+        # pair_workers > 1: run_pairs runs that many pairs at a time, each on its own HIP stream with its own library context
+        # (a context is single-stream by contract; PartI is not needed there, PartII's weights come from partII_sd).  A pair's
+        # kernels at <= 1000 voted matches are a chain of ~25 short launches that fill a fraction of the chip and end in two
+        # host read-backs: two chains side by side hide both.  Results do not depend on the interleaving (per-pair seeds, no
+        # shared state between pairs).
+        self.pair_workers = max(1, int(pair_workers)) if (estimator == "yohoc" or partII_sd is not None) else 1
+        self._partII_sd = partII_sd
+        self._workers = None            # [(context, torch stream)]
+        self._lock = threading.Lock()
         self.scene = None
         self.frag = {}
         self.uses = {}
         self._made_dirs = set()
         self._copy_stream = None
         self._pin_pool = {}
-        import threading
         self._pin_lock = threading.Lock()
         # write_npz: this rank writes the {id0}-{id1}.npz of the pairs it ran (finish_writes, behind its last pair: 0.15 ms of
         # Python per archive, spread over the ranks instead of serial on rank 0; a worker thread writing them WHILE the pairs run
@@ -428,24 +444,79 @@ class ScenePairRunner:
         else:
             self.uses[fid] = n
 
-    def run_pair(self, dataset, pair):
+    def run_pair(self, dataset, pair, ctx=None):
         import time
         t0 = time.perf_counter()
         id0, id1 = pair
         a, b = self.frag[id0], self.frag[id1]
         seed = pair_seed(self.base_seed, dataset.name, id0, id1)
-        r = self.pipeline.run_pair(self.ctx, a["feat"], b["feat"], a["keys"], b["keys"], inlier_dist=self.inlier_dist,
+        r = self.pipeline.run_pair(ctx if ctx is not None else self.ctx, a["feat"], b["feat"], a["keys"], b["keys"], inlier_dist=self.inlier_dist,
                                    max_iter=self.max_iter, order_rng=np.random.RandomState(seed & 0xFFFFFFFF),
                                    eqv=({"eqv": a["eqv"], "inv_np": a["inv_np"]}, {"eqv": b["eqv"], "inv_np": b["inv_np"]}),
                                    estimator=self.estimator, seed=seed, hypotheses=self.hypotheses)
         trans = np.asarray(r.trans, dtype=np.float64)
         out = {"trans": trans, "recalltime": int(r.best_h), "matches": int(r.match.shape[0]), "inliers": int(r.best_count)}
-        self._release(id0)
-        self._release(id1)
-        if self._write_npz:
-            self._write_jobs.append((result_dir(self.cfg, dataset, self.yoho_sign, self.max_iter), id0, id1, out))
-        self.stats["pairs"] += 1
-        self.stats["pairs_s"] += time.perf_counter() - t0
+        with self._lock:
+            self._release(id0)
+            self._release(id1)
+            if self._write_npz:
+                self._write_jobs.append((result_dir(self.cfg, dataset, self.yoho_sign, self.max_iter), id0, id1, out))
+            self.stats["pairs"] += 1
+            self.stats["pairs_s"] += time.perf_counter() - t0
+        return out
+
+    def _make_workers(self):
+        from . import hip
+        torch = self.torch
+        ws = []
+        for _ in range(self.pair_workers):
+            c = hip.Context(self.ctx.device, getattr(self.ctx.tables, "dir", None))
+            c.set_partII_mode(self.ctx.partII_mode)
+            if self.estimator == "yohoo":
+                c.load_partII(self._partII_sd)
+            ws.append((c, torch.cuda.Stream()))
+        return ws
+
+    def run_pairs(self, dataset, pairs):
+        """the pairs of a scene part, pair_workers at a time -> results in the order of `pairs`"""
+        import time
+        pairs = list(pairs)
+        if self.pair_workers <= 1 or len(pairs) < 2:
+            return [self.run_pair(dataset, p) for p in pairs]
+        torch = self.torch
+        if self._workers is None:
+            self._workers = self._make_workers()
+        ready = torch.cuda.Event()
+        ready.record()                                   # the fragments were described on this (the caller's) stream
+        out = [None] * len(pairs)
+        nxt = [0]
+        errors = []
+        t_wall = time.perf_counter()
+
+        def work(wi):
+            c, st = self._workers[wi]
+            try:
+                torch.cuda.set_device(self.ctx.device)
+                with torch.cuda.stream(st):
+                    st.wait_event(ready)
+                    while not errors:
+                        with self._lock:
+                            i = nxt[0]
+                            nxt[0] += 1
+                        if i >= len(pairs):
+                            break
+                        out[i] = self.run_pair(dataset, pairs[i], ctx=c)
+                    st.synchronize()
+            except BaseException as e:
+                errors.append(e)
+        ths = [threading.Thread(target=work, args=(wi,), daemon=True) for wi in range(len(self._workers))]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        if errors:
+            raise errors[0]
+        self.stats["pairs_wall_s"] = self.stats.get("pairs_wall_s", 0.0) + time.perf_counter() - t_wall
         return out
 
 
@@ -461,18 +532,22 @@ def load_and_broadcast_weights(cfg, ctx, need_partII):
         if need_partII:
             sd2 = W.to_numpy_state_dict(W.load_checkpoint(f'{cfg.model_fn}/PartII_train/model_best.pth')[0])
             sd2 = {k: v for k, v in sd2.items() if k in {n for n, _ in W.PARTII_SPEC}}
-    ctx.load_partI(ydist.broadcast_state_dict(sd1, W.PARTI_SPEC))
+    sd1 = ydist.broadcast_state_dict(sd1, W.PARTI_SPEC)
+    ctx.load_partI(sd1)
     if need_partII:
-        ctx.load_partII(ydist.broadcast_state_dict(sd2, W.PARTII_SPEC))
+        sd2 = ydist.broadcast_state_dict(sd2, W.PARTII_SPEC)
+        ctx.load_partII(sd2)
+    return sd1, sd2
 
 
 def eval_sharded(cfg, max_iter=1000, estimator="yohoo", datasets=None, base_seed=0, results_log=None, ctx=None, state_dicts=None,
-                 stats_out=None, hypotheses="selected"):
+                 stats_out=None, hypotheses="selected", weights_loaded=False, pair_workers=2):
     """The sharded counterpart of Evaluator_PartI/II.eval (tests/evaluator.py:75-101,146-173): run every pair of the
     test set over the initialised process group (one rank per GPU), write npz / pre.log on rank 0 and return the
     Registration Recall there (None on the other ranks).  FCGF group features and keypoints are read from the
     reference's cache layout; descriptors, matches and hypotheses never touch the disk.  state_dicts: None = read and broadcast the
-    checkpoints of cfg.model_fn, (PartI, PartII) = load these, "loaded" = ctx already holds the weights.  stats_out: a dict that receives the
+    checkpoints of cfg.model_fn, (PartI, PartII) = use these (weights_loaded=True: ctx already holds them).  pair_workers: pairs run
+    concurrently per rank (ScenePairRunner.run_pairs).  stats_out: a dict that receives the
     rank's ScenePairRunner.stats and the gathered per-pair results (tools/bench_dataset.py, tests)."""
     import torch
     from . import hip, RR_cal
@@ -483,19 +558,21 @@ def eval_sharded(cfg, max_iter=1000, estimator="yohoo", datasets=None, base_seed
     if ctx is None:
         ctx = hip.get_context(so3_dir=getattr(cfg, "SO3_related_files", None))
     if state_dicts is None:
-        load_and_broadcast_weights(cfg, ctx, need_partII=(estimator == "yohoo"))
-    elif state_dicts != "loaded":                # given by the caller (bench / tests): (PartI, PartII or None); "loaded": ctx has them
+        state_dicts = load_and_broadcast_weights(cfg, ctx, need_partII=(estimator == "yohoo"))
+    elif not weights_loaded:                     # given by the caller (bench / tests): (PartI, PartII or None)
         ctx.load_partI(state_dicts[0])
         if estimator == "yohoo":
             ctx.load_partII(state_dicts[1])
     # every rank writes the archives of the pairs it ran (one node: the cache directory is shared), rank 0 the pre.log files
     runner = ScenePairRunner(cfg, ctx, estimator=estimator, max_iter=max_iter, base_seed=base_seed, timing=stats_out is not None, write_npz=True,
-                             hypotheses=hypotheses)
-
-    def pair_fn(ds, pair):
-        return runner.run_pair(ds, pair)
+                             hypotheses=hypotheses, pair_workers=pair_workers, partII_sd=(state_dicts[1] if estimator == "yohoo" else None))
+    cached = getattr(ctx, "_pair_workers_cache", None)           # worker contexts (PartII weight packing: 0.25 s each) live with ctx
+    if cached is not None and cached[0] is state_dicts[1] and len(cached[1]) == runner.pair_workers:
+        runner._workers = cached[1]
     try:
-        results = run_sharded(datasets, pair_fn, rank=rank, world=world, scene_fn=runner.setup_scene)
+        results = run_sharded(datasets, runner.run_pair, rank=rank, world=world, scene_fn=runner.setup_scene, pairs_fn=runner.run_pairs)
+        if runner._workers is not None:
+            ctx._pair_workers_cache = (state_dicts[1], runner._workers)
     finally:
         write_error = None
         try:
