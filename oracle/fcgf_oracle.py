@@ -17,18 +17,24 @@ against MinkowskiEngine 0.5.x, which is vendored in the reference tree as *sourc
     swapped (:756-800), i.e. out[f] += in[c] @ W[k] whenever coord(c) = coord(f) + offset(k) on the finer stride;
   * MinkowskiBatchNorm = BatchNorm1d over the feature rows (eval: running statistics, eps 1e-5); ME.cat = channel concat.
 
-Pinning (tests/test_fcgf_oracle.py): the coordinate-map and kernel-map semantics above are checked against the
-known-answer vectors of MinkowskiEngine's own tests (region order and map direction: tests/cpp/kernel_region_cpu_test.py:22-42,
-100-116; strided maps incl. negative coordinates and batches: tests/cpp/coordinate_map_cpu_test.py:95-125,
-tests/python/coordinate_manager.py:183-200; quantisation collisions: tests/python/quantization.py:104-113; round 3:
-first-occurrence rows and duplicate lookups tests/cpp/coordinate_map_cpu_test.py:12-15,47-65, strides :80-86 and
-tests/python/coordinate_manager.py:33-58,255-258, SparseTensor row count tests/python/sparse_tensor.py:91-98; not reproducible:
-the pair count asserted in tests/python/kernel_map.py:78,109 (16), which the sources and the C++ known answers above
-contradict - the map definition yields 13 pairs per batch item = 26 on that fixture, recorded in the test; DESIGN.md 3.5 has
-the per-layer table of what is pinned by what); the sparse
-convolution arithmetic is checked against torch.nn.functional.conv3d / conv_transpose3d on densified inputs.
-The END-TO-END network output remains PARITY UNPINNED against MinkowskiEngine itself (it cannot run here and the
-pretrained backbone checkpoint is absent from the tree).
+Pinning (tests/test_fcgf_oracle.py):
+  * coordinate maps and kernel maps - which duplicate survives quantisation and in which order, the strided maps, and the kernel
+    map of EVERY convolution of ResUNetBN2C including the strided and the TRANSPOSED ones - against the REFERENCE ITSELF:
+    oracle/build_me_ref.py compiles MinkowskiEngine's own src/coordinate_map_manager.cpp (CPU_ONLY, no BLAS needed) where it lies,
+    oracle/me_ref/me_maps_driver.cpp drives it exactly as src/convolution_cpu.cpp / convolution_transpose_cpu.cpp do, and
+    oracle/gen_golden_me.py stores the maps in tests/golden/me_maps.npz (round 3).  Equal as sets of (kernel index, input
+    coordinate, output coordinate) triples on every map; the reference numbers the rows of a strided map in hash-table order, the
+    oracle in first-occurrence order - internal, no result depends on it (level 0 is equal row by row);
+  * the same semantics on the known-answer vectors of MinkowskiEngine's own tests (region order and map direction:
+    tests/cpp/kernel_region_cpu_test.py:22-42, 100-116; strided maps incl. negative coordinates and batches:
+    tests/cpp/coordinate_map_cpu_test.py:12-15,47-65,80-86,95-125, tests/python/coordinate_manager.py:33-58,183-200,255-258;
+    quantisation collisions: tests/python/quantization.py:104-113, tests/python/sparse_tensor.py:91-98).  The pair count asserted in
+    tests/python/kernel_map.py:78,109 (16) is stale: the reference's own manager yields 26 on that figure, as this oracle does;
+  * the convolution ARITHMETIC given the maps (out[o] += in[i] W[k], kernel indices in order) against torch.nn.functional.conv3d /
+    conv_transpose3d on densified inputs - MinkowskiEngine's own CPU convolution needs a BLAS with cblas.h
+    (src/math_functions_cpu.cpp), which this image lacks, so that translation unit is not built (no stand-in is written for it).
+What remains unpinned is the END-TO-END network output against a running MinkowskiEngine (summation order inside its sgemm calls,
+its BatchNorm wrapper) and against the pretrained backbone checkpoint, which is absent from the tree.
 """
 import numpy as np
 

@@ -175,3 +175,96 @@ def test_minkowski_engine_known_answers_round3():
     for o, c in enumerate(out.tolist()):
         hit = [i for i, p in enumerate(pts.tolist()) if p == c]
         assert (m[13, o] == hit[0]) if hit else (m[13, o] == -1)
+
+
+def _oracle_triples(rows, cin, cout):
+    """kernel map (K, Nout) of input rows -> sorted int32 (P, 7) array of (kernel index, input xyz, output xyz)"""
+    out = []
+    for k in range(rows.shape[0]):
+        o = np.flatnonzero(rows[k] >= 0)
+        if len(o):
+            out.append(np.concatenate([np.full((len(o), 1), k, np.int32), cin[rows[k, o]], cout[o]], 1))
+    t = np.concatenate(out).astype(np.int32) if out else np.zeros((0, 7), np.int32)
+    return t[np.lexsort(t.T[::-1])]
+
+
+def _oracle_levels(q):
+    sel = fo.sparse_quantize(q)
+    c = [np.asarray(q, dtype=np.int32)[sel]]
+    for ts in (2, 4, 8):
+        c.append(fo.stride_coords(c[-1], ts))
+    return sel, c
+
+
+def _oracle_maps(c):
+    maps = {"conv1": (fo.kernel_map(c[0], c[0], 7, 1), c[0], c[0])}
+    for l, ts in enumerate((1, 2, 4, 8)):
+        maps[f"s1_{l}"] = (fo.kernel_map(c[l], c[l], 3, ts), c[l], c[l])
+    for l, ts in enumerate((1, 2, 4)):
+        maps[f"s2_{l}"] = (fo.kernel_map(c[l], c[l + 1], 3, ts), c[l], c[l + 1])
+    for l, ts in ((3, 4), (2, 2), (1, 1)):
+        maps[f"tr_{l}"] = (fo.kernel_map(c[l], c[l - 1], 3, ts, transpose=True), c[l], c[l - 1])
+    return maps
+
+
+def test_oracle_maps_equal_minkowski_engine_cpu_manager():
+    """The coordinate maps and the kernel map of EVERY convolution of ResUNetBN2C - conv1 (k = 7), the 3^3 stride-1 maps of the four
+    levels, the three stride-2 convolutions and the three TRANSPOSED convolutions - as the reference's own CPU coordinate manager
+    builds them (tests/golden/me_maps.npz from oracle/gen_golden_me.py: MinkowskiEngine's src/coordinate_map_manager.cpp compiled
+    where it lies, driven exactly as src/convolution_cpu.cpp / convolution_transpose_cpu.cpp drive it).  Compared as sets of (kernel
+    index, input coordinate, output coordinate) triples: the reference numbers the rows of a strided map in hash-table order, which
+    no result depends on; level 0 is compared row by row (first occurrence, input order)."""
+    import hashlib
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "me_maps.npz"))
+    for name in ("surface", "random", "line"):
+        q = g[f"{name}_input"]
+        sel, c = _oracle_levels(q)
+        assert np.array_equal(sel, g[f"{name}_unique_map"])                         # which duplicate survives, in which order
+        assert np.array_equal(c[0], g[f"{name}_coords_0"])                          # level-0 rows = input order of the survivors
+        for l in (1, 2, 3):
+            ref = g[f"{name}_coords_{l}"]
+            assert len(ref) == len(c[l]) and set(map(tuple, ref.tolist())) == set(map(tuple, c[l].tolist())), (name, l)
+        for mn, (rows, cin, cout) in _oracle_maps(c).items():
+            t = _oracle_triples(rows, cin, cout)
+            assert len(t) == int(g[f"{name}_{mn}_count"]), (name, mn, len(t), int(g[f"{name}_{mn}_count"]))
+            assert hashlib.sha256(np.ascontiguousarray(t).tobytes()).hexdigest() == str(g[f"{name}_{mn}_sha256"]), (name, mn)
+            if f"{name}_{mn}_triples" in g.files:
+                assert np.array_equal(t, g[f"{name}_{mn}_triples"]), (name, mn)
+    # the figure of MinkowskiEngine/tests/python/kernel_map.py: the reference's manager yields 26 pairs (13 per batch item) and the five
+    # output coordinates the oracle derives; the 16 that python test asserts is not what the reference's code computes
+    pts = np.concatenate([g["figure_points"], np.zeros((8, 1), np.int32)], 1)
+    out = fo.stride_coords(pts, 2)
+    assert int(g["figure_pairs_total"]) == 26 == 2 * int((fo.kernel_map(pts, out, 3, 1) >= 0).sum())
+    assert sorted(map(tuple, out[:, :2].tolist())) == sorted(map(tuple, g["figure_out_coords_item0"].tolist()))
+
+
+def test_oracle_maps_against_live_minkowski_engine_manager_if_built():
+    """the same comparison on a fresh random cloud when oracle/_ref/me_maps.so exists (build container, or shipped to the GPU box)"""
+    import pytest
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle"))
+    import build_me_ref
+    me = build_me_ref.load()
+    if me is None:
+        pytest.skip("oracle/_ref/me_maps.so not built here (python oracle/build_me_ref.py needs /root/reference)")
+    rs = np.random.RandomState(123)
+    q = np.concatenate([rs.randint(-12, 12, size=(700, 3)), rs.randint(-3, 3, size=(200, 3))]).astype(np.int32)
+    o = me.fcgf_maps(torch.from_numpy(np.ascontiguousarray(np.concatenate([np.zeros((len(q), 1), np.int32), q], 1))), 7)
+    sel, c = _oracle_levels(q)
+    assert np.array_equal(sel, o["unique_map"].numpy())
+    mc = [o[f"coords_{l}"].numpy()[:, 1:].astype(np.int32) for l in range(4)]
+    assert np.array_equal(mc[0], c[0])
+
+    def me_triples(km, cin, cout):
+        rows = [np.concatenate([np.full((len(a), 1), k, np.int32), cin[a.numpy()], cout[b.numpy()]], 1) for k, (a, b) in enumerate(km) if len(a)]
+        t = np.concatenate(rows).astype(np.int32)
+        return t[np.lexsort(t.T[::-1])]
+    ref = {"conv1": (o["conv1"], mc[0], mc[0])}
+    for l in range(4):
+        ref[f"s1_{l}"] = (o[f"conv_s1_{l}"], mc[l], mc[l])
+    for l in range(3):
+        ref[f"s2_{l}"] = (o[f"conv_s2_{l}"], mc[l], mc[l + 1])
+    for l in (3, 2, 1):
+        assert bool(o[f"tr_out_is_level_{l}"])
+        ref[f"tr_{l}"] = (o[f"conv_tr_{l}"], mc[l], mc[l - 1])
+    for mn, (rows, cin, cout) in _oracle_maps(c).items():
+        assert np.array_equal(_oracle_triples(rows, cin, cout), me_triples(*ref[mn])), mn
