@@ -440,3 +440,39 @@ def test_eval_sharded_world1_on_scene6(gold, tmp_path, sd1, sd2, tables, estimat
     for p in pairs[1:5]:
         runner.run_pair(ds, p)
     assert runner.frag == {} and runner.uses == {}
+
+
+def _world2_dataset_worker(rank, port, workdir, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank),
+                      YOHO_DIST_BACKEND="gloo", YOHO_FORCE_DEVICE="0")
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import bench_dataset
+    out = bench_dataset.run(nfrag=10, kp=600, span=4, estimator="yohoo", workdir=workdir, runs=1, max_iter=100)
+    q.put((rank, out.get("trans_sha256"), [r["registration_recall"] for r in out["runs"]], out["pairs"]))
+    torch.distributed.destroy_process_group()
+
+
+def test_dataset_driver_world2_on_one_gpu_equals_world1(tmp_path):
+    """BASELINE config 5's code path with real kernels: the sharded dataset driver at world = 2 (two processes, gloo for the host-side
+    collectives, both on cuda:0 - a single-GPU box has no second device for RCCL) against world = 1 on the same synthetic scene: every
+    pair's transform and recalltime identical (digest over all pairs), the same Registration Recall, every pair processed once.
+    Exercises the shard plan (the scene is cut over both ranks), per-rank fragment loading, the result gather, the per-rank npz
+    writes and rank 0's pre.log / RR evaluation."""
+    import socket
+    import torch.multiprocessing as mp
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import bench_dataset
+    one = bench_dataset.run(nfrag=10, kp=600, span=4, estimator="yohoo", workdir=str(tmp_path / "w1"), runs=1, max_iter=100)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_world2_dataset_worker, args=(r, port, str(tmp_path / "w2"), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=600) for _ in range(2))
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert one["pairs"] == got[0][3] == 30 and one["trans_sha256"] is not None
+    assert got[0][1] == one["trans_sha256"], "world-2 transforms differ from world-1"
+    assert got[0][2] == [r["registration_recall"] for r in one["runs"]]

@@ -160,6 +160,9 @@ def run(nfrag=60, kp=5000, span=9, estimator="yohoo", workdir="/tmp/yoho_ds", ru
         dt = ydist.max_over_ranks(time.perf_counter() - t0)
         res = stats.pop("results")
         if rank == 0:
+            import hashlib
+            out["trans_sha256"] = hashlib.sha256(b"".join(np.ascontiguousarray(p["trans"], dtype=np.float64).tobytes() + int(p["recalltime"]).to_bytes(8, "little", signed=True)
+                                                          for sn, _, _ in scenes for p in res[sn])).hexdigest()      # of the last run: every pair's transform + recalltime
             inl = [p["inliers"] for sn, _, _ in scenes for p in res[sn]]
             mt = [p["matches"] for sn, _, _ in scenes for p in res[sn]]
             pw = stats.get("pairs_wall_s", stats["pairs_s"])            # wall time of the pair stage (workers run side by side)

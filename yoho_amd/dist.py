@@ -19,12 +19,17 @@ def init_from_env(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    # test hooks: YOHO_DIST_BACKEND=gloo runs the multi-rank host logic without RCCL, YOHO_FORCE_DEVICE=<n> puts every rank on one
+    # device (a world-2 run of the dataset driver on a single-GPU box: tests/test_gpu_dropin.py)
+    backend = os.environ.get("YOHO_DIST_BACKEND", backend)
+    if os.environ.get("YOHO_FORCE_DEVICE") is not None:
+        local = int(os.environ["YOHO_FORCE_DEVICE"])
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
-        if backend == "nccl":
+        if torch.cuda.is_available():
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     elif torch.cuda.is_available():
