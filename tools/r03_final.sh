@@ -13,3 +13,9 @@ print(d["dataset"]["runs"][1]["total_s"], d["yohoc"]["ms_per_step"], d["cpu_base
 print({k:(v["ms"],v["TBps"]) for k,v in d["roofline_extra"]["hbm"].items() if "gft" in k})
 PY
 wc -l $O/bench_final.json
+python - <<PY
+import json
+d=json.loads(open("$O/bench_final.json").read().strip().splitlines()[-1])
+print("selected leg", d.get("yohoo_selected_hypotheses"))
+PY
+bash tools/collect_profiles.sh ${YOHO_COMMIT:-unknown} > $O/collect.log 2>&1; echo "collect rc=$?"
