@@ -185,7 +185,7 @@ int yoho_group_scatter(yoho_ctx* ctx, const float* feat, int n, const int64_t* i
  * device-resident parameters, training layout.  weight (cout,cin,1,13), bias (cout) or NULL: device pointers.
  *   transpose = 0:  y (B,cout,60) = bias + conv(x (B,cin,60))            (utils/network.py:46-52 + Conv2d(cin,cout,(1,13)))
  *   transpose = 1:  y (B,cin,60)  = data gradient of that layer for the output gradient x (B,cout,60); bias ignored.
- * The weight gradient is a plain contraction (dW[o,c,k] = sum_{b,g} dy[b,o,g] x[b,c,N[g,k]]) left to the caller's BLAS. */
+ * The weight / bias gradient of the layer is yoho_gconv_wgrad below. */
 int yoho_gconv_layer(yoho_ctx* ctx, const float* x, int B, int cin, int cout, const float* weight, const float* bias, int transpose,
                      float* y, void* stream);
 
