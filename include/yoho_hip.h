@@ -36,7 +36,8 @@
  *   - calls are asynchronous on the given hipStream_t (pass NULL for the default stream);
  *     the library allocates only its own workspace inside the ctx (which may synchronise
  *     the stream the first time a larger problem is seen).
- *   - one ctx per device; a ctx is not thread-safe, different ctxs are independent.
+ *   - a ctx belongs to one device and is used from one stream / thread at a time (it owns one workspace); different ctxs - also
+ *     several on one device, also on different group tables - are independent: the library has no global mutable state.
  *   - tensors use the reference's layouts: group features (K,32,60) f32 with the group axis
  *     innermost, keypoints (K,3) f64, transforms (.,3,4) f64, indices int64.
  */
