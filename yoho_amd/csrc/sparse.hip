@@ -1352,11 +1352,19 @@ size_t fcgf_workspace_bytes(const FcgfNet* net, int n0) {
 int fcgf_forward(yoho_ctx* ctx, const FcgfNet* net, const int* coords0, int n0, const int* off_host, int nb, float* out, hipStream_t s) {
     if (nb < 1 || nb > 64) { set_error("fcgf_forward: 1..64 clouds per call"); return YOHO_EINVAL; }
     if (n0 == 0) return 0;
-    {   // the gathers address a feature matrix through a 2 GiB buffer window
-        const int* Cc = net->C; const int* Tt = net->T;
-        const int maxld = std::max(std::max(Tt[2] + Cc[1], Tt[3] + Cc[2]), std::max(Tt[4] + Cc[3], Cc[4]));
-        if ((long long)n0 * maxld * 4 >= (1ll << 31)) { set_error("fcgf_forward: %d voxels in one pass exceed the 2 GiB gather window; split the batch", n0); return YOHO_EINVAL; }
-    }
+    // The gathers address a feature matrix through a 2 GiB buffer window.  Level l's widest gathered matrix has ld[l] columns; level 0
+    // is known now, the coarser levels are checked as their sizes come back (they hold a fraction of the rows, so in practice the
+    // level-0 matrices - 96 columns: 5.5 M voxels - are what limits a pass).
+    const int gather_ld[4] = {std::max(net->T[2] + net->C[1], net->C[1]), std::max(net->T[3] + net->C[2], net->C[2]),
+                              std::max(net->T[4] + net->C[3], net->C[3]), net->C[4]};
+    auto window_ok = [&](int level, long long rows) {
+        if (rows * gather_ld[level] * 4 >= (1ll << 31)) {
+            set_error("fcgf_forward: %lld voxels at level %d exceed the 2 GiB gather window (%d columns); split the batch", rows, level, gather_ld[level]);
+            return false;
+        }
+        return true;
+    };
+    if (!window_ok(0, n0)) return YOHO_EINVAL;
     int rc;
     if ((rc = ensure_ws(ctx, fcgf_workspace_bytes(net, n0), s))) return rc;
     Arena ar{(char*)ctx->ws.p, 0, ctx->ws.bytes};
@@ -1418,6 +1426,7 @@ int fcgf_forward(yoho_ctx* ctx, const FcgfNet* net, const int* coords0, int n0, 
             if ((rc = launch_first_compact(src, nprev, L[l].keys, L[l].vals, L[l].mask, bsum, L[l].coords, 4, nullptr, dcount + l, s))) return rc;
             HIPCHK(hipMemcpyAsync(&L[l].n, dcount + l, sizeof(int), hipMemcpyDeviceToHost, s));
             HIPCHK(hipStreamSynchronize(s));
+            if (!window_ok(l, L[l].n)) return YOHO_EINVAL;
             hipLaunchKernelGGL(hash_set_rows_kernel, dim3((L[l].n + 255) / 256), dim3(256), 0, s, L[l].coords, L[l].n, L[l].keys, L[l].vals,
                                L[l].mask);
             HIPCHK(hipGetLastError());

@@ -9,6 +9,8 @@ The checkpoint is the FCGF format the reference reads (:18-29): ``{'config': <na
 normalize_feature, conv1_kernel_size>, 'state_dict': ...}``; a dict with the same keys (or ``state_dict`` + explicit
 arguments) is accepted as well, so that no MinkowskiEngine / easydict is needed to unpickle anything.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -67,7 +69,7 @@ class fcgf_extractor():
         sel, coords = self.ctx.fcgf_voxelize(pts, voxel_size)
         return sel, self.ctx.fcgf_forward(coords)
 
-    MAX_VOXELS_PER_PASS = 1600000
+    MAX_VOXELS_PER_PASS = int(os.environ.get("YOHO_FCGF_MAX_VOXELS", "1600000"))      # level-0 matrices are 96 columns wide: the 2 GiB gather window holds 5.5 M voxels
 
     def extract_features_dev_batch(self, pts_list, voxel_size):
         """several clouds (f64 cuda) in one backbone pass -> list of (sel, F)."""

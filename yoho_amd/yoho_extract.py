@@ -37,7 +37,7 @@ class yoho_extractor():
         self.yoho_ckpt = yoho_ckpt
         self._load_model()
         self.bs = 500
-        self.rot_batch = 15            # rotated copies of the cloud per backbone pass (HBM-resident path; split further by voxel count)
+        self.rot_batch = int(os.environ.get("YOHO_ROT_BATCH", "15"))     # rotated copies of the cloud per backbone pass (HBM-resident path; split further by voxel count)
         self.overlap_keypoint_draw = os.environ.get("YOHO_OVERLAP_DRAW", "1") != "0"   # keypoint permutation drawn while the first backbone pass runs
 
     def _load_model(self):
