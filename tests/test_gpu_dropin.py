@@ -476,3 +476,46 @@ def test_dataset_driver_world2_on_one_gpu_equals_world1(tmp_path):
     assert one["pairs"] == got[0][3] == 30 and one["trans_sha256"] is not None
     assert got[0][1] == one["trans_sha256"], "world-2 transforms differ from world-1"
     assert got[0][2] == [r["registration_recall"] for r in one["runs"]]
+
+
+def test_dataset_driver_missing_or_truncated_cache_file_fails_cleanly(tmp_path, sd1):
+    """ScenePairRunner.setup_scene on a cache with a truncated and a missing fragment file: the loader's error reaches the caller
+    (no silent zeros, no hang) and the loader thread ends - with more fragments queued than the hand-over queue holds, so that a
+    loader blocked on a full queue would stay behind."""
+    import threading
+    import time
+    from yoho_amd import run_dataset, hip, store
+    from yoho_amd.dataset import ThrDMatchPartDataset
+    store.clear()
+    nfrag = 12
+    sc = synth.make_scene(nfrag, 64, seed=5)
+    sroot = tmp_path / "origin" / "synth4" / "room"
+    cache = tmp_path / "cache"
+    synth.write_scene_files(sc, str(sroot), str(cache / "Testset" / "synth4/room"))
+    ds = ThrDMatchPartDataset(str(sroot), nfrag)
+    ds.name = "synth4/room"
+    cfg = types.SimpleNamespace(SO3_related_files=None, model_fn=str(tmp_path / "model"), output_cache_fn=str(cache), origin_data_dir=str(tmp_path / "origin"),
+                                ransac_c_inlinerdist=0.07, ransac_o_inlinerdist=0.09, RR_dist_threshold=0.2, testset_name="synth4")
+    ctx = hip.get_context()
+    ctx.load_partI(sd1)
+    pairs = [tuple(p) for p in ds.pair_ids]
+    fdir = cache / "Testset" / "synth4/room" / "FCGF_Input_Group_feature"
+    whole = (fdir / "1.npy").read_bytes()
+    for damage, exc in (("truncate", IOError), ("remove", FileNotFoundError)):
+        if damage == "truncate":
+            (fdir / "1.npy").write_bytes(whole[:len(whole) // 2])
+        else:
+            (fdir / "1.npy").unlink()
+        before = threading.active_count()
+        runner = run_dataset.ScenePairRunner(cfg, ctx, estimator="yohoc", max_iter=50, base_seed=1)
+        with pytest.raises(exc):
+            runner.setup_scene(ds, pairs)
+        t0 = time.time()
+        while threading.active_count() > before and time.time() - t0 < 5.0:
+            time.sleep(0.05)
+        assert threading.active_count() <= before, "the loader thread is still alive"
+    # intact again: the same runner class describes the scene
+    (fdir / "1.npy").write_bytes(whole)
+    runner = run_dataset.ScenePairRunner(cfg, ctx, estimator="yohoc", max_iter=50, base_seed=1)
+    runner.setup_scene(ds, pairs)
+    assert len(runner.frag) == nfrag

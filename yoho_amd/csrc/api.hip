@@ -260,6 +260,15 @@ int yoho_ctx_create(int device, const float* R, const uint8_t* N, const uint8_t*
         (rc = upload(n32.data(), sizeof(int) * G * NTAP, (void**)&c->dN)) || (rc = upload(p32.data(), sizeof(int) * G * G, (void**)&c->dP))) {
         delete c; return rc;
     }
+    {
+        std::vector<unsigned> pq(15 * 64);
+        for (int q = 0; q < 15; ++q)
+            for (int a = 0; a < 64; ++a) {
+                const int* pr = p32.data() + (a < G ? a : G - 1) * G + 4 * q;
+                pq[q * 64 + a] = (unsigned)pr[0] | ((unsigned)pr[1] << 8) | ((unsigned)pr[2] << 16) | ((unsigned)pr[3] << 24);
+            }
+        if ((rc = upload(pq.data(), sizeof(unsigned) * pq.size(), (void**)&c->dPq))) { delete c; return rc; }
+    }
     // tap inversion table for the data gradient of the group conv (train.hip): n_k = N[e][k] with e the identity,
     // inv[k] = k2 with n_k2 * n_k = e, i.e. N[n_k][k2] == e.  The tap set must be closed under inversion.
     {
@@ -375,6 +384,7 @@ int yoho_ctx_destroy(yoho_ctx* c) {
     if (c->dR64) (void)hipFree(c->dR64);
     if (c->dN) (void)hipFree(c->dN);
     if (c->dP) (void)hipFree(c->dP);
+    if (c->dPq) (void)hipFree(c->dPq);
     if (c->dFpad) (void)hipFree(c->dFpad);
     if (c->dF16) (void)hipFree(c->dF16);
     if (c->fcgf) fcgf_free(c->fcgf);

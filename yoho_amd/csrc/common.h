@@ -184,6 +184,7 @@ struct yoho_ctx {
     double* dR64 = nullptr;      // (60,9) widened from f32 exactly as the reference's f64 @ f32 promotes
     int* dN = nullptr;           // (60,13) int32
     int* dP = nullptr;           // (60,60) int32
+    unsigned* dPq = nullptr;     // P packed for des2r_kernel: word [q][a] (q < 15, a < 64) = P[a][4q .. 4q+3] as bytes (a >= 60: row 59)
     uint8_t hN[60 * 13];
     uint8_t hP[60 * 60];
     float hR[60 * 9];

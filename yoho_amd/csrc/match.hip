@@ -249,78 +249,95 @@ int launch_mutual_compact(const int64_t* fwd, const int64_t* back, int Na, int64
 }
 
 // cor[m, a] = sum_g sum_f d1[m, f, P[a, g]] * d2[m, f, g];  idx[m] = argmax_a (first maximum).
-// One wave per match.  The double sum is a gather of the 60 x 60 Gram matrix C = D1^T D2 (contraction over the 32
-// channels): cor[a] = sum_g C[P[a,g]][g].  C is computed on the fp32 MFMA (64 x v_mfma_f32_32x32x2_f32, exact fp32
-// products, fp32 accumulation) from the two descriptors staged in LDS with rows padded to 64 zeros, written back to LDS
-// (row stride 65: the gather's rows are a permutation, so stride 64 would put all lanes on one bank) and every lane
-// a < 60 adds its 60 entries in the order g = 0..59.  Optional row indices address the descriptors in place.
+// One wave per match, two waves per workgroup, grid-stride over the matches.  The double sum is a gather of the 60 x 60 Gram
+// matrix C = D1^T D2 (contraction over the 32 channels): cor[a] = sum_g C[P[a,g]][g].  C is computed on the fp32 MFMA
+// (64 x v_mfma_f32_32x32x2_f32, exact fp32 products, fp32 accumulation).  The operands go from global memory straight into
+// registers: lane (g' = lane & 31, half = lane >> 5) of step kk holds channel f = 2 kk + half of group elements g' and g' + 32
+// (zero beyond 59), i.e. every load is two 128-byte runs per wave and all 64 of them are in flight at once.  C goes to a
+// wave-private LDS tile (row stride 65: the gather's rows are a permutation, so stride 64 would put all lanes on one bank) and
+// lane a < 60 adds its 60 entries in the order g = 0..59, the rows P[a][g] read as packed bytes (ctx->dPq, in LDS).
+// Optional row indices address the descriptors in place.  (Round 3: the first version staged both descriptors in LDS - 33 KB per
+// one-wave workgroup, i.e. one wave per SIMD - and read P with 60 dependent global loads per lane: 170-300 us per 3233 matches.)
 typedef float floatx16m __attribute__((ext_vector_type(16)));
-constexpr int D2R_S = 64;        // padded group axis of the staged descriptors
 constexpr int D2R_C = 65;        // row stride of the Gram matrix
+constexpr int D2R_W = 2;         // waves (matches in flight) per workgroup
 
-__global__ __launch_bounds__(64) void des2r_kernel(const float* __restrict__ e1, const int64_t* __restrict__ i1, const float* __restrict__ e2,
-                                                   const int64_t* __restrict__ i2, int istride, const int* __restrict__ P, int M,
-                                                   int64_t* __restrict__ idx, float* __restrict__ cor) {
-    __shared__ __attribute__((aligned(16))) float s1[F * D2R_S];
-    __shared__ __attribute__((aligned(16))) float s2[F * D2R_S];
-    __shared__ float Cl[64 * D2R_C];
-    const int m = blockIdx.x, lane = threadIdx.x;
-    const size_t r1 = i1 ? (size_t)i1[(size_t)m * istride] : (size_t)m, r2 = i2 ? (size_t)i2[(size_t)m * istride] : (size_t)m;
-    const float4* p1 = reinterpret_cast<const float4*>(e1 + r1 * F * G);
-    const float4* p2 = reinterpret_cast<const float4*>(e2 + r2 * F * G);
-    for (int i = lane; i < F * (D2R_S / 4); i += 64) {
-        const int f = i >> 4, g4 = i & 15;                   // 15 float4 of data + 1 of zeros per row
-        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-        reinterpret_cast<float4*>(s1)[i] = g4 < 15 ? p1[f * 15 + g4] : z;
-        reinterpret_cast<float4*>(s2)[i] = g4 < 15 ? p2[f * 15 + g4] : z;
-    }
+__global__ __launch_bounds__(64 * D2R_W) void des2r_kernel(const float* __restrict__ e1, const int64_t* __restrict__ i1, const float* __restrict__ e2,
+                                                          const int64_t* __restrict__ i2, int istride, const unsigned* __restrict__ Pq, int M,
+                                                          int64_t* __restrict__ idx, float* __restrict__ cor) {
+    __shared__ float Cls[D2R_W][G * D2R_C];
+    __shared__ unsigned Pl[15 * 64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < 15 * 64; i += 64 * D2R_W) Pl[i] = Pq[i];
     __syncthreads();
-    floatx16m acc[2][2];
-#pragma unroll
-    for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[rb][cb][r] = 0.f;
+    float* Cl = Cls[w];
     const int li = lane & 31, lk = lane >> 5;
+    const bool hi_ok = li + 32 < G;
+    for (int m = blockIdx.x * D2R_W + w; m < M; m += gridDim.x * D2R_W) {
+        const size_t r1 = i1 ? (size_t)i1[(size_t)m * istride] : (size_t)m, r2 = i2 ? (size_t)i2[(size_t)m * istride] : (size_t)m;
+        const float* p1 = e1 + r1 * F * G + lk * G + li;
+        const float* p2 = e2 + r2 * F * G + lk * G + li;
+        float a0[16], a1[16], b0[16], b1[16];
 #pragma unroll
-    for (int kk = 0; kk < 16; ++kk) {
-        const int f = 2 * kk + lk;
-        const float a0 = s1[f * D2R_S + li], a1 = s1[f * D2R_S + 32 + li];
-        const float b0 = s2[f * D2R_S + li], b1 = s2[f * D2R_S + 32 + li];
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        for (int kk = 0; kk < 16; ++kk) {
+            a0[kk] = p1[2 * kk * G];
+            b0[kk] = p2[2 * kk * G];
+            a1[kk] = hi_ok ? p1[2 * kk * G + 32] : 0.f;
+            b1[kk] = hi_ok ? p2[2 * kk * G + 32] : 0.f;
+        }
+        floatx16m acc[2][2];
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[rb][cb][r] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[kk], b0[kk], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[kk], b1[kk], acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[kk], b0[kk], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[kk], b1[kk], acc[1][1], 0, 0, 0);
+        }
+        // D[row g'][col g]: lane (col = lane & 31, half = lane >> 5), reg r -> row = (r & 3) + 8 (r >> 2) + 4 half
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = 32 * rb + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                    if (row < G && (cb == 0 || hi_ok)) Cl[row * D2R_C + 32 * cb + li] = acc[rb][cb][r];
+                }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        float sum = 0.f;
+#pragma unroll
+        for (int q = 0; q < 15; ++q) {
+            const unsigned pw = Pl[q * 64 + lane];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sum += Cl[((pw >> (8 * j)) & 255u) * D2R_C + 4 * q + j];
+        }
+        if (cor && lane < G) cor[(size_t)m * G + lane] = sum;
+        float bv = lane < G ? sum : -__builtin_inff();
+        int bi = lane;
+        for (int o = 32; o >= 1; o >>= 1) {
+            const float ov = __shfl_xor(bv, o);
+            const int oi = __shfl_xor(bi, o);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        if (lane == 0) idx[m] = bi;
+        __builtin_amdgcn_wave_barrier();             // the next match's tile overwrites Cl
     }
-    // D[row g'][col g]: lane (col = lane & 31, half = lane >> 5), reg r -> row = (r & 3) + 8 (r >> 2) + 4 half
-#pragma unroll
-    for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = 32 * rb + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                Cl[row * D2R_C + 32 * cb + li] = acc[rb][cb][r];
-            }
-    __syncthreads();
-    const int a = lane < G ? lane : G - 1;
-    float sum = 0.f;
-    for (int g = 0; g < G; ++g) sum += Cl[P[a * G + g] * D2R_C + g];
-    if (cor && lane < G) cor[(size_t)m * G + lane] = sum;
-    float bv = lane < G ? sum : -__builtin_inff();
-    int bi = lane;
-    for (int o = 32; o >= 1; o >>= 1) {
-        const float ov = __shfl_xor(bv, o);
-        const int oi = __shfl_xor(bi, o);
-        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-    }
-    if (lane == 0) idx[m] = bi;
 }
 
-int launch_des2r(const float* e1, const int64_t* i1, const float* e2, const int64_t* i2, int istride, const int* P, int M, int64_t* idx,
+int launch_des2r(const float* e1, const int64_t* i1, const float* e2, const int64_t* i2, int istride, const unsigned* Pq, int M, int64_t* idx,
                  float* cor, hipStream_t s) {
-    hipLaunchKernelGGL(des2r_kernel, dim3(M), dim3(64), 0, s, e1, i1, e2, i2, istride, P, M, idx, cor);
+    if (M <= 0) return 0;
+    static const int ncu = [] { int d = 0, n = 256; (void)hipGetDevice(&d); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d); return n; }();
+    const int nwg = std::min((M + D2R_W - 1) / D2R_W, 4 * ncu);          // 35 KB of LDS per workgroup: four per CU
+    hipLaunchKernelGGL(des2r_kernel, dim3(nwg), dim3(64 * D2R_W), 0, s, e1, i1, e2, i2, istride, Pq, M, idx, cor);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -384,7 +401,7 @@ int yoho_des2r(yoho_ctx* c, const float* d1, const float* d2, int M, int64_t* id
     if (!c || !d1 || !d2 || !idx || M < 0) { set_error("yoho_des2r: bad argument"); return YOHO_EINVAL; }
     if (M == 0) return 0;
     HIPCHK(hipSetDevice(c->device));
-    return launch_des2r(d1, nullptr, d2, nullptr, 1, c->dP, M, idx, cor, (hipStream_t)stream);
+    return launch_des2r(d1, nullptr, d2, nullptr, 1, c->dPq, M, idx, cor, (hipStream_t)stream);
 }
 
 int yoho_des2r_indexed(yoho_ctx* c, const float* e1, const int64_t* i1, const float* e2, const int64_t* i2, int istride, int M,
@@ -392,7 +409,7 @@ int yoho_des2r_indexed(yoho_ctx* c, const float* e1, const int64_t* i1, const fl
     if (!c || !e1 || !e2 || !i1 || !i2 || !idx || M < 0 || istride < 1) { set_error("yoho_des2r_indexed: bad argument"); return YOHO_EINVAL; }
     if (M == 0) return 0;
     HIPCHK(hipSetDevice(c->device));
-    return launch_des2r(e1, i1, e2, i2, istride, c->dP, M, idx, cor, (hipStream_t)stream);
+    return launch_des2r(e1, i1, e2, i2, istride, c->dPq, M, idx, cor, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -337,21 +337,34 @@ class ScenePairRunner:
         q = queue.Queue(maxsize=6)
         NLOAD = 3                                       # loader threads (file reads release the GIL); results are consumed in order
 
+        stop = threading.Event()                        # set when the consumer gives up (its exception must not leave the loader blocked)
+
+        def put(item):
+            while not stop.is_set():
+                try:
+                    q.put(item, timeout=0.2)
+                    return True
+                except queue.Full:
+                    pass
+            return False
+
         def loader():
             from concurrent.futures import ThreadPoolExecutor
             try:
                 with ThreadPoolExecutor(NLOAD) as ex:
                     pending = []
-                    it = iter(need)
-                    for fid in it:
+                    for fid in need:
+                        if stop.is_set():
+                            break
                         pending.append(ex.submit(self._load_fragment, dataset, fdir, fid))
-                        if len(pending) >= NLOAD + 1:
-                            q.put(pending.pop(0).result())
+                        if len(pending) >= NLOAD + 1 and not put(pending.pop(0).result()):
+                            break
                     for fut in pending:
-                        q.put(fut.result())
+                        if not put(fut.result()):
+                            break
             except BaseException as e:          # surfaced in the consumer
-                q.put(e)
-            q.put(None)
+                put(e)
+            put(None)
         th = threading.Thread(target=loader, daemon=True)
         th.start()
 
@@ -396,29 +409,34 @@ class ScenePairRunner:
             pending[0] = u
 
         group, rows = [], 0
-        while True:
-            t0 = time.perf_counter()
-            item = q.get()
-            self.stats["load_wait_s"] += time.perf_counter() - t0
-            if isinstance(item, BaseException):
-                raise item
-            if item is not None:
-                self.stats["load_s"] += item[3]
-                self.stats["bytes_read"] += item[1].numel() * 4 + item[2].numel() * 8
-                item = item[:3]
-            # a pass is flushed when full, when the input ends, or when the loader has nothing ready (do not idle the device)
-            if group and (item is None or rows + item[1].shape[0] > 16384):
-                flush(group)
-                group, rows = [], 0
-            if item is None:
-                break
-            group.append(item)
-            rows += item[1].shape[0]
-            if q.empty() and group and rows >= 4096:
-                flush(group)
-                group, rows = [], 0
-        if pending[0] is not None:
-            describe(*pending[0])
+        try:
+            while True:
+                t0 = time.perf_counter()
+                item = q.get()
+                self.stats["load_wait_s"] += time.perf_counter() - t0
+                if isinstance(item, BaseException):
+                    raise item
+                if item is not None:
+                    self.stats["load_s"] += item[3]
+                    self.stats["bytes_read"] += item[1].numel() * 4 + item[2].numel() * 8
+                    item = item[:3]
+                # a pass is flushed when full, when the input ends, or when the loader has nothing ready (do not idle the device)
+                if group and (item is None or rows + item[1].shape[0] > 16384):
+                    flush(group)
+                    group, rows = [], 0
+                if item is None:
+                    break
+                group.append(item)
+                rows += item[1].shape[0]
+                if q.empty() and group and rows >= 4096:
+                    flush(group)
+                    group, rows = [], 0
+            if pending[0] is not None:
+                describe(*pending[0])
+        except BaseException:
+            stop.set()                              # unblock the loader, then let the error travel
+            th.join(timeout=5.0)
+            raise
         if self.timing:
             t0 = time.perf_counter()
             torch.cuda.synchronize()                # once per scene part: the device side of the setup is inside setup_s
