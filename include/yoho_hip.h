@@ -172,6 +172,33 @@ int yoho_c_ransac_device(yoho_ctx* ctx, const double* keys0, const int64_t* i0, 
                          int istride, const int64_t* dr_index, int M, int max_iter, uint64_t seed, double d,
                          double* best_T, int* best_iter, int* best_count, int64_t* triples_out, void* stream);
 
+/* ---- one scene pair in one call (the pair loop of tests/evaluator.py:112-117 / :41-47; yoho_amd/pipeline.py:run_pair composes the
+ * same entries from Python).  Both fragments are already described: feat (n,32,60) FCGF group features (YOHO-O only, may be NULL
+ * for YOHO-C), eqv (n,32,60) / inv (n,32) = yoho_partI_forward's eqv / inv_np, keys (n,3) f64; all device pointers.
+ *   mutual NN of inv0 / inv1 -> Des2R -> YOHO_ESTIMATOR_O: vote order = numpy's RandomState(seed & 0xFFFFFFFF).shuffle(arange(M))
+ *   (tests/estimator.py:321-323; yoho_vote_order), PartII + [R|t] for the min(max_iter, M) matches the vote reads (selected != 0)
+ *   or for every match (selected = 0: the reference's Trans_pre stage), inlier vote with threshold inlier_dist;
+ *   YOHO_ESTIMATOR_C: yoho_c_ransac_device with max_iter iterations from the Philox stream `seed`.
+ * Waits for `stream` twice (match count, winner) and fills *out on the host.  YOHO-O needs the default PartII arithmetic mode
+ * (YOHO_EINVAL otherwise); out->range_flag != 0 reports (and clears) the PartII fp16 range flag: the result is then not to be
+ * trusted and the caller repeats the pair through the staged entries after yoho_set_partII_mode(ctx, 1). */
+#define YOHO_ESTIMATOR_O 0
+#define YOHO_ESTIMATOR_C 1
+typedef struct yoho_pair_result {
+    double trans[12];      /* (3,4) row-major [R|t] of the winner; not meaningful when best_count == 0 (the reference returns eye(4)) */
+    int32_t matches;       /* M */
+    int32_t best_h;        /* YOHO-O: position of the winner in the vote order; YOHO-C: its 1-based iteration (both: 'recalltime') */
+    int32_t best_count;    /* inliers of the winner; 0 = no estimate */
+    int32_t hypotheses;    /* hypotheses scored */
+    int32_t range_flag;
+    int32_t reserved;
+} yoho_pair_result;
+int yoho_register_pair(yoho_ctx* ctx, const float* feat0, const float* feat1, const float* eqv0, const float* eqv1, const float* inv0,
+                       const float* inv1, const double* keys0, const double* keys1, int n0, int n1, int estimator, int max_iter,
+                       double inlier_dist, uint64_t seed, int selected, yoho_pair_result* out, void* stream);
+/* order[0..M) = numpy.random.RandomState(seed).shuffle applied to arange(M) (host memory; no device work, no context) */
+int yoho_vote_order(uint32_t seed, int M, int64_t* order);
+
 /* one group element of the 60-fold gather: rotate keys (K,3) f64 by Rg (3x3 f64, host ptr),
  * 1-NN among pts (n,3) f32 in f64, copy feat (n,32) rows into out[:, :, g] of (K,32,60);
  * nn_idx (K) int64 may be NULL. */

@@ -283,3 +283,41 @@ def test_run_pair_selected_hypotheses_equal_all(dctx, sd1, sd2):
     r = pipeline.run_pair(dctx, cu(pr["feat0"]), cu(pr["feat1"]), cu(pr["keys0"]), cu(pr["keys1"]), order_rng=np.random.RandomState(0),
                           hypotheses="selected")
     assert r.hyp_rows is None and r.quat.shape[0] == r.match.shape[0]
+
+
+def test_register_pair_one_call_equals_python_composition(dctx, sd1, sd2):
+    """yoho_register_pair (one library call per pair: mutual NN -> Des2R -> PartII + vote / device-sampled YOHO-C) against
+    pipeline.run_pair composing the staged entries from Python with the same vote order (RandomState(seed & 0xFFFFFFFF)) and
+    sampling stream: winner, inlier count, match count and the transform are identical bits - full size (M = 3233, 1000 votes,
+    selected and all hypotheses), a small pair with 20 votes, a pair where every match is voted on, ragged fragment sizes, and
+    fragments with no mutual match at all (eye(4), as tests/estimator.py:327-336)."""
+    cases = [(5000, 5000, 1000, 10), (300, 300, 20, 11), (96, 96, 1000, 3), (700, 450, 100, 12)]
+    for K0, K1, it, sd in cases:
+        pr = synth.make_pair(max(K0, K1), seed=sd)
+        f0, f1, k0, k1 = cu(pr["feat0"][:K0]), cu(pr["feat1"][:K1]), cu(pr["keys0"][:K0]), cu(pr["keys1"][:K1])
+        o0, o1 = pipeline.describe_pair(dctx, f0, f1)
+        o0 = {k: v.contiguous() for k, v in o0.items()}
+        o1 = {k: v.contiguous() for k, v in o1.items()}
+        for seed in (7, 2 ** 40 + 12345):
+            for est, dist in (("yohoo", 0.09), ("yohoc", 0.07)):
+                for hyp in (("selected", "all") if est == "yohoo" else ("selected",)):
+                    r = pipeline.run_pair(dctx, f0, f1, k0, k1, inlier_dist=dist, max_iter=it, order_rng=np.random.RandomState(seed & 0xFFFFFFFF),
+                                          eqv=(o0, o1), estimator=est, seed=seed, hypotheses=hyp)
+                    f = dctx.register_pair(f0, f1, o0["eqv"], o1["eqv"], o0["inv_np"], o1["inv_np"], k0, k1, estimator=est, max_iter=it,
+                                           inlier_dist=dist, seed=seed, selected=(hyp == "selected"))
+                    tag = (K0, K1, it, seed, est, hyp)
+                    assert f["matches"] == r.match.shape[0] and f["matches"] > 0, tag
+                    assert (f["best_h"], f["best_count"]) == (int(r.best_h), int(r.best_count)), tag
+                    assert np.array_equal(f["trans"], np.asarray(r.trans, np.float64)), tag
+                    assert not f["range_flag"]
+    # no mutual match: descriptors of fragment 1 all equal, so at most one row of fragment 0 can be mutual; with the invariant
+    # parts made unreachable nothing matches
+    z0 = torch.zeros((64, 32), dtype=torch.float32, device="cuda")
+    z1 = torch.full((64, 32), float("nan"), dtype=torch.float32, device="cuda")
+    e = torch.zeros((64, 32, 60), dtype=torch.float32, device="cuda")
+    k = torch.zeros((64, 3), dtype=torch.float64, device="cuda")
+    M = dctx.mutual_nn(z0, z1).shape[0]
+    f = dctx.register_pair(e, e, e, e, z0, z1, k, k, estimator="yohoc", max_iter=10, inlier_dist=0.07, seed=1)
+    assert f["matches"] == M
+    if M == 0:
+        assert f["best_count"] == 0 and np.array_equal(f["trans"], np.eye(4))

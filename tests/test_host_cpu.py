@@ -98,3 +98,17 @@ def test_bench_dataset_scene_builder_and_presets(tmp_path):
     assert x.shape == (40, 32, 60) and x.dtype == np.float32 and np.allclose(np.linalg.norm(x, axis=1), 1, atol=1e-5)
     assert ds.get_kps("3").shape == (40, 3)
     assert sum(n for _, n, _ in bd.PRESET_3DMATCH) == 433 and sum(p for _, _, p in bd.PRESET_3DMATCH) == 1623
+
+
+def test_library_vote_order_is_numpys_shuffle():
+    """yoho_vote_order (host code of the library, no device): numpy's RandomState(seed).shuffle(arange(M)) - MT19937 seeded by
+    init_genrand, Fisher-Yates from the top with masked rejection sampling - for seeds at both ends of the 32-bit range and sizes
+    around the power-of-two mask boundaries; this is what makes yoho_register_pair's YOHO-O vote the reference's
+    (tests/estimator.py:321-323) for a seeded generator."""
+    from yoho_amd import hip
+    for seed in (0, 1, 5, 123456789, 2 ** 32 - 1, 3141592653):
+        for M in (0, 1, 2, 3, 4, 5, 7, 8, 9, 63, 64, 65, 625, 1000, 1023, 1024, 1025, 3233, 5000, 16385):
+            a = np.arange(M)
+            np.random.RandomState(seed).shuffle(a)
+            assert np.array_equal(a, hip.vote_order(seed, M)), (seed, M)
+    assert np.array_equal(hip.vote_order(2 ** 32 + 5, 100), hip.vote_order(5, 100))       # the seed is taken modulo 2^32

@@ -15,11 +15,11 @@ REPO = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "libyoho_hip.so")
-SOURCES = ["api.hip", "gconv.hip", "gconv16.hip", "fourier.hip", "gemmf.hip", "gemmf2.hip", "gft16.hip", "cone1.hip", "sparse.hip", "train.hip", "layout.hip", "match.hip", "matchf.hip", "gridnn.hip", "estim.hip"]
+SOURCES = ["api.hip", "gconv.hip", "gconv16.hip", "fourier.hip", "gemmf.hip", "gemmf2.hip", "gft16.hip", "cone1.hip", "sparse.hip", "train.hip", "layout.hip", "match.hip", "matchf.hip", "gridnn.hip", "estim.hip", "pair.hip"]
 # Kernels whose results must be bit-exact against numpy / torch-CPU arithmetic are compiled without
 # FMA contraction (hipcc defaults to -ffp-contract=fast and __fmul_rn/__fadd_rn are plain operators
 # in this ROCm, so they would fuse); explicit fma()/fmaf() calls are unaffected.
-EXTRA = {"layout.hip": ["-ffp-contract=off"], "match.hip": ["-ffp-contract=off"], "matchf.hip": ["-ffp-contract=off"], "gridnn.hip": ["-ffp-contract=off"], "estim.hip": ["-ffp-contract=off"]}
+EXTRA = {"layout.hip": ["-ffp-contract=off"], "match.hip": ["-ffp-contract=off"], "matchf.hip": ["-ffp-contract=off"], "gridnn.hip": ["-ffp-contract=off"], "estim.hip": ["-ffp-contract=off"], "pair.hip": ["-ffp-contract=off"]}
 if os.environ.get("YOHO_SPCONV_ABLATE"):          # timing experiments: compile-time ablations of the fine-level sparse conv (YOHO_SPCONV_DEBUG)
     EXTRA["sparse.hip"] = ["-DYOHO_SPCONV_ABLATE"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",

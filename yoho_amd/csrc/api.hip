@@ -385,6 +385,8 @@ int yoho_ctx_destroy(yoho_ctx* c) {
     if (c->dN) (void)hipFree(c->dN);
     if (c->dP) (void)hipFree(c->dP);
     if (c->dPq) (void)hipFree(c->dPq);
+    if (c->pair_ws) (void)hipFree(c->pair_ws);
+    if (c->pair_host) (void)hipHostFree(c->pair_host);
     if (c->dFpad) (void)hipFree(c->dFpad);
     if (c->dF16) (void)hipFree(c->dF16);
     if (c->fcgf) fcgf_free(c->fcgf);

@@ -211,6 +211,8 @@ struct yoho_ctx {
     double nn_cell = 0.0;        // > 0: 3-D nearest-neighbour searches go through a hash grid of this cell size (gridnn.hip)
     // workspace (grown on demand)
     yoho::Workspace ws;
+    void* pair_ws = nullptr; size_t pair_ws_bytes = 0;        // yoho_register_pair: device scratch that outlives the staged calls' use of ws
+    void* pair_host = nullptr; size_t pair_host_bytes = 0;    // ... and its page-locked host side (match count, vote order, result)
     // depth-first PartI schedule (default mode): the pass is cut into chunks of partI_chunk keypoints (a multiple of 256; 0 = one
     // breadth-first pass), each chunk running head -> 4 GEMMs + 3 transforms -> tail on its own slice of the workspace so that
     // the intermediates of a chunk stay in the 256 MB Infinity Cache; with partI_streams == 2 the chunks alternate between the

@@ -23,6 +23,7 @@ SYMBOLS = [
     "yoho_des2r", "yoho_des2r_indexed", "yoho_partII_forward", "yoho_partII_forward_indexed", "yoho_hyp_from_quat", "yoho_o_score", "yoho_c_ransac",
     "yoho_group_gather", "yoho_set_profiling", "yoho_get_kernel_ms", "yoho_set_gconv_mode", "yoho_set_partII_mode", "yoho_set_nn_grid",
     "yoho_range_status", "yoho_c_ransac_device", "yoho_group_scatter", "yoho_set_nn_prefilter", "yoho_set_fcgf_sort", "yoho_fcgf_voxelize_rotated_batch", "yoho_gconv_wgrad", "yoho_bn_stats", "yoho_bn_relu_apply", "yoho_bn_relu_backward", "yoho_set_partI_schedule", "yoho_clock_probe", "yoho_group_transfer_batch",
+    "yoho_register_pair", "yoho_vote_order",
 ]
 
 
@@ -52,6 +53,11 @@ def lib_path():
 class FcgfConfig(C.Structure):
     _fields_ = [("channels", C.c_int * 5), ("tr_channels", C.c_int * 5), ("out_channels", C.c_int),
                 ("conv1_kernel_size", C.c_int), ("in_channels", C.c_int), ("normalize_feature", C.c_int)]
+
+
+class PairResultC(C.Structure):
+    _fields_ = [("trans", C.c_double * 12), ("matches", C.c_int32), ("best_h", C.c_int32), ("best_count", C.c_int32),
+                ("hypotheses", C.c_int32), ("range_flag", C.c_int32), ("reserved", C.c_int32)]
 
 
 def load_library():
@@ -112,10 +118,22 @@ def load_library():
     lib.yoho_group_scatter.argtypes = [vp, vp, ci, vp, ci, ci, vp, vp]
     lib.yoho_range_status.argtypes = [vp, C.POINTER(ci), C.POINTER(ci), vp]
     lib.yoho_c_ransac_device.argtypes = [vp, vp, vp, vp, vp, ci, vp, ci, ci, C.c_uint64, C.c_double, vp, vp, vp, vp, vp]
+    lib.yoho_register_pair.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, C.c_double, C.c_uint64, ci, C.POINTER(PairResultC), vp]
+    lib.yoho_vote_order.argtypes = [C.c_uint32, ci, vp]
     for s in SYMBOLS[2:]:
         getattr(lib, s).restype = ci
     _lib = lib
     return lib
+
+
+def vote_order(seed, M):
+    """np.random.RandomState(seed).shuffle(np.arange(M)) as the library computes it on the host (yoho_vote_order)"""
+    lib = load_library()
+    out = np.empty((M,), dtype=np.int64)
+    rc = lib.yoho_vote_order(int(seed) & 0xFFFFFFFF, int(M), out.ctypes.data_as(C.c_void_p))
+    if rc != 0:
+        raise YohoError(f"libyoho_hip error {rc}: {lib.yoho_last_error().decode()}", rc)
+    return out
 
 
 class YohoError(RuntimeError):
@@ -581,6 +599,28 @@ class Context:
                                               float(d), C.c_void_p(best_T.data_ptr()), C.c_void_p(res.data_ptr()),
                                               C.c_void_p(res.data_ptr() + 4), C.c_void_p(tri.data_ptr()) if want_triples else None, _stream()))
         return best_T, res, tri
+
+    def register_pair(self, feat0, feat1, eqv0, eqv1, inv0, inv1, keys0, keys1, estimator="yohoo", max_iter=1000, inlier_dist=0.09,
+                      seed=0, selected=True):
+        """One pair of described fragments in one library call (yoho_register_pair: mutual NN -> Des2R -> PartII + vote, or the
+        device-sampled YOHO-C); the GIL is released for its whole duration.  feat / eqv (n,32,60) f32, inv (n,32) f32 = inv_np,
+        keys (n,3) f64, all cuda.  The YOHO-O vote order is np.random.RandomState(seed & 0xFFFFFFFF)'s shuffle, the YOHO-C sampling
+        stream is `seed`: the result equals pipeline.run_pair(..., order_rng=RandomState(seed & 0xFFFFFFFF), seed=seed).
+        -> dict(trans (3,4) f64 or eye(4), best_h, best_count, matches, hypotheses, range_flag)"""
+        if estimator not in ("yohoo", "yohoc"):
+            raise ValueError(f"estimator must be 'yohoo' or 'yohoc', got {estimator!r}")
+        res = PairResultC()
+        est = 0 if estimator == "yohoo" else 1
+        _check(self._lib.yoho_register_pair(
+            self._h, _dev(feat0, torch.float32, "feat0") if est == 0 else None, _dev(feat1, torch.float32, "feat1") if est == 0 else None,
+            _dev(eqv0, torch.float32, "eqv0"), _dev(eqv1, torch.float32, "eqv1"), _dev(inv0, torch.float32, "inv0"),
+            _dev(inv1, torch.float32, "inv1"), _dev(keys0, torch.float64, "keys0"), _dev(keys1, torch.float64, "keys1"),
+            eqv0.shape[0], eqv1.shape[0], est, int(max_iter), float(inlier_dist), int(seed) & (2 ** 64 - 1), 1 if selected else 0,
+            C.byref(res), _stream()))
+        ok = res.matches > 0 and res.best_count > 0
+        trans = np.array(res.trans, dtype=np.float64).reshape(3, 4) if ok else np.eye(4)
+        return {"trans": trans, "best_h": int(res.best_h), "best_count": int(res.best_count), "matches": int(res.matches),
+                "hypotheses": int(res.hypotheses), "range_flag": bool(res.range_flag)}
 
     def group_gather(self, keys, pts, feat, g, out, want_idx=False):
         K, n = keys.shape[0], pts.shape[0]

@@ -238,7 +238,7 @@ class ScenePairRunner:
     `stats` accumulates where the time goes (seconds; device work is timed with a synchronise only when timing=True)."""
 
     def __init__(self, cfg, ctx, estimator="yohoo", max_iter=1000, base_seed=0, timing=False, write_npz=False, hypotheses="selected",
-                 pair_workers=2, partII_sd=None):
+                 pair_workers=2, partII_sd=None, fused=True):
         import torch
         from . import pipeline
         self.torch, self.pipeline = torch, pipeline
@@ -249,6 +249,10 @@ class ScenePairRunner:
         # products are trans / recalltime per pair, identical either way; "all" computes Trans_pre for every match as the
         # reference's stage does
         self.hypotheses = hypotheses
+        # fused: a pair is ONE library call (yoho_register_pair; the GIL is released for its whole duration, so the pair workers
+        # really overlap) instead of pipeline.run_pair's ~25 calls from Python - the same entries in the same order with the same
+        # vote order / sampling stream, hence the same bits (tests/test_gpu_dropin.py); False keeps the Python composition
+        self.fused = bool(fused)
         # pair_workers > 1: run_pairs runs that many pairs at a time, each on its own HIP stream with its own library context
         # (a context is single-stream by contract; PartI is not needed there, PartII's weights come from partII_sd).  A pair's
         # kernels at <= 1000 voted matches are a chain of ~25 short launches that fill a fraction of the chip and end in two
@@ -468,12 +472,20 @@ class ScenePairRunner:
         id0, id1 = pair
         a, b = self.frag[id0], self.frag[id1]
         seed = pair_seed(self.base_seed, dataset.name, id0, id1)
-        r = self.pipeline.run_pair(ctx if ctx is not None else self.ctx, a["feat"], b["feat"], a["keys"], b["keys"], inlier_dist=self.inlier_dist,
-                                   max_iter=self.max_iter, order_rng=np.random.RandomState(seed & 0xFFFFFFFF),
-                                   eqv=({"eqv": a["eqv"], "inv_np": a["inv_np"]}, {"eqv": b["eqv"], "inv_np": b["inv_np"]}),
-                                   estimator=self.estimator, seed=seed, hypotheses=self.hypotheses)
-        trans = np.asarray(r.trans, dtype=np.float64)
-        out = {"trans": trans, "recalltime": int(r.best_h), "matches": int(r.match.shape[0]), "inliers": int(r.best_count)}
+        c = ctx if ctx is not None else self.ctx
+        out = None
+        if self.fused and (self.estimator == "yohoc" or c.supports_matched()):
+            f = c.register_pair(a["feat"], b["feat"], a["eqv"], b["eqv"], a["inv_np"], b["inv_np"], a["keys"], b["keys"], estimator=self.estimator,
+                                max_iter=self.max_iter, inlier_dist=self.inlier_dist, seed=seed, selected=(self.hypotheses == "selected"))
+            if not f["range_flag"]:                 # a value left the fp16 range: the Python composition below repeats PartII in bf16x3
+                out = {"trans": f["trans"], "recalltime": f["best_h"], "matches": f["matches"], "inliers": f["best_count"]}
+        if out is None:
+            r = self.pipeline.run_pair(c, a["feat"], b["feat"], a["keys"], b["keys"], inlier_dist=self.inlier_dist,
+                                       max_iter=self.max_iter, order_rng=np.random.RandomState(seed & 0xFFFFFFFF),
+                                       eqv=({"eqv": a["eqv"], "inv_np": a["inv_np"]}, {"eqv": b["eqv"], "inv_np": b["inv_np"]}),
+                                       estimator=self.estimator, seed=seed, hypotheses=self.hypotheses)
+            out = {"trans": np.asarray(r.trans, dtype=np.float64), "recalltime": int(r.best_h), "matches": int(r.match.shape[0]),
+                   "inliers": int(r.best_count)}
         with self._lock:
             self._release(id0)
             self._release(id1)
@@ -559,7 +571,7 @@ def load_and_broadcast_weights(cfg, ctx, need_partII):
 
 
 def eval_sharded(cfg, max_iter=1000, estimator="yohoo", datasets=None, base_seed=0, results_log=None, ctx=None, state_dicts=None,
-                 stats_out=None, hypotheses="selected", weights_loaded=False, pair_workers=2):
+                 stats_out=None, hypotheses="selected", weights_loaded=False, pair_workers=2, fused=True):
     """The sharded counterpart of Evaluator_PartI/II.eval (tests/evaluator.py:75-101,146-173): run every pair of the
     test set over the initialised process group (one rank per GPU), write npz / pre.log on rank 0 and return the
     Registration Recall there (None on the other ranks).  FCGF group features and keypoints are read from the
@@ -583,7 +595,8 @@ def eval_sharded(cfg, max_iter=1000, estimator="yohoo", datasets=None, base_seed
             ctx.load_partII(state_dicts[1])
     # every rank writes the archives of the pairs it ran (one node: the cache directory is shared), rank 0 the pre.log files
     runner = ScenePairRunner(cfg, ctx, estimator=estimator, max_iter=max_iter, base_seed=base_seed, timing=stats_out is not None, write_npz=True,
-                             hypotheses=hypotheses, pair_workers=pair_workers, partII_sd=(state_dicts[1] if estimator == "yohoo" else None))
+                             hypotheses=hypotheses, pair_workers=pair_workers, partII_sd=(state_dicts[1] if estimator == "yohoo" else None),
+                             fused=fused)
     cached = getattr(ctx, "_pair_workers_cache", None)           # worker contexts (PartII weight packing: 0.25 s each) live with ctx
     if cached is not None and cached[0] is state_dicts[1] and len(cached[1]) == runner.pair_workers:
         runner._workers = cached[1]
