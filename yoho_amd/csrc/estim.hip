@@ -101,18 +101,23 @@ __global__ __launch_bounds__(256) void score_kernel(const double* __restrict__ k
 // first strict maximum over counts[0..H): reproduces `if overlap > best_overlap` with best = 0 initially
 __global__ __launch_bounds__(256) void argbest_kernel(const int32_t* __restrict__ counts, int H, int* __restrict__ best_h,
                                                       int* __restrict__ best_count) {
-    __shared__ int sv[256];
-    __shared__ int si[256];
+    __shared__ int sv[4];
+    __shared__ int si[4];
     int bv = 0, bi = -1;
     for (int h = threadIdx.x; h < H; h += 256) {
         const int c = counts[h];
         if (c > bv) { bv = c; bi = h; }
     }
-    sv[threadIdx.x] = bv; si[threadIdx.x] = bi;
+    // larger count wins, equal (positive) counts go to the lower index: butterfly inside the wave, then the four waves
+    for (int o = 32; o >= 1; o >>= 1) {
+        const int ov = __shfl_xor(bv, o), oi = __shfl_xor(bi, o);
+        if (ov > bv || (ov == bv && ov > 0 && oi < bi)) { bv = ov; bi = oi; }
+    }
+    if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = bv; si[threadIdx.x >> 6] = bi; }
     __syncthreads();
     if (threadIdx.x == 0) {
         int v = 0, i = -1;
-        for (int k = 0; k < 256; ++k) {
+        for (int k = 0; k < 4; ++k) {
             if (sv[k] > v) { v = sv[k]; i = si[k]; }
             else if (sv[k] == v && v > 0 && si[k] < i) i = si[k];
         }

@@ -19,6 +19,7 @@
 // descriptors the band is 5e-3 of squared distance: a handful of candidates per row.  Non-finite inputs or magnitudes beyond the
 // fp16 range raise a flag and the brute-force kernels run instead (they are launched behind the flag either way).
 // Compiled with -ffp-contract=off like match.hip (the exact distances must not fuse).
+#include <cstdlib>
 #include "common.h"
 #include "nnmath.h"
 
@@ -31,12 +32,12 @@ struct MfArgs {
     const float* a; const float* b;
     int Na, Nb;
     float* na2; float* nb2;              // squared norms
-    float* bandA; float* bandB;          // candidate bands
+    _Float16* a16; _Float16* b16;        // the rows rounded to fp16 (RNE), 32 halfs each: the MFMA operands of both Gram passes
     unsigned* rowmin; unsigned* colmin;  // ordered-integer images of the minima of s (per a row) and t (per b row)
     unsigned long long* keysA; unsigned long long* keysB;   // packed (distance bits << 32 | index) winners
     unsigned* maxn2;                     // [0] max |a_i|^2 bits, [1] max |b_j|^2 bits
     int* bad;                            // non-finite / out-of-range input: brute force instead
-    int segRows;                         // a rows per workgroup of the Gram passes
+    int tilesPer;                        // 32-row tiles of the OTHER set per workgroup of the Gram passes
     unsigned long long* cand;            // pass 2: candidate pairs (i << 34 | j << 4 | for_row << 1 | for_col), evaluated exactly by mf_exact_kernel
     unsigned* ncand; unsigned cap;       // their number (may exceed cap: then `bad` is raised and brute force answers)
 };
@@ -47,7 +48,7 @@ __device__ __forceinline__ unsigned ord_of(float f) {          // monotone map f
 }
 __device__ __forceinline__ float ord_to(unsigned o) { return __uint_as_float((o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o); }
 
-// squared norms, their maxima, the range check, and the initial values of minima and keys
+// squared norms, their maxima, the range check, the fp16 image of every row, and the initial values of minima and keys
 __global__ __launch_bounds__(256) void mf_norms_kernel(MfArgs p) {
     __shared__ unsigned red[2][4];
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -57,11 +58,18 @@ __global__ __launch_bounds__(256) void mf_norms_kernel(MfArgs p) {
     float s = 0.f, m = 0.f;
     if (live) {
         const float4* x = reinterpret_cast<const float4*>((isa ? p.a : p.b) + (size_t)r * 32);
+        halfx8* h16 = reinterpret_cast<halfx8*>((isa ? p.a16 : p.b16) + (size_t)r * 32);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const float4 v = x[k];
+        for (int k = 0; k < 4; ++k) {
+            const float4 v = x[2 * k], u = x[2 * k + 1];
             s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+            s += u.x * u.x + u.y * u.y + u.z * u.z + u.w * u.w;
             m = fmaxf(fmaxf(fmaxf(m, fabsf(v.x)), fmaxf(fabsf(v.y), fabsf(v.z))), fabsf(v.w));
+            m = fmaxf(fmaxf(fmaxf(m, fabsf(u.x)), fmaxf(fabsf(u.y), fabsf(u.z))), fabsf(u.w));
+            halfx8 h;
+            h[0] = (_Float16)v.x; h[1] = (_Float16)v.y; h[2] = (_Float16)v.z; h[3] = (_Float16)v.w;
+            h[4] = (_Float16)u.x; h[5] = (_Float16)u.y; h[6] = (_Float16)u.z; h[7] = (_Float16)u.w;
+            h16[k] = h;
         }
         (isa ? p.na2 : p.nb2)[r] = s;
         (isa ? p.rowmin : p.colmin)[r] = 0xFFFFFFFFu;
@@ -80,24 +88,11 @@ __global__ __launch_bounds__(256) void mf_norms_kernel(MfArgs p) {
     }
 }
 
-__global__ __launch_bounds__(256) void mf_band_kernel(MfArgs p) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    const int n = p.Na + p.Nb;
-    if (i >= n) return;
-    const bool isa = i < p.Na;
-    const int r = isa ? i : i - p.Na;
-    const float mine = sqrtf((isa ? p.na2 : p.nb2)[r]) * 1.000001f;
-    const float other = sqrtf(__uint_as_float(p.maxn2[isa ? 1 : 0])) * 1.000001f;
+// the candidate band of a row with squared norm n2 against a set whose largest squared norm is m2 (header comment)
+__device__ __forceinline__ float band_of(float n2, float m2) {
+    const float mine = sqrtf(n2) * 1.000001f, other = sqrtf(m2) * 1.000001f;
     const float sum = mine + other;
-    (isa ? p.bandA : p.bandB)[r] = 4.5e-3f * mine * other + 2e-5f * sum * sum + 4e-6f * sum + 1e-30f;
-}
-
-__device__ __forceinline__ halfx8 frag_of(const float* row) {      // 8 consecutive floats -> 8 halfs (round to nearest even)
-    const float4 lo = *reinterpret_cast<const float4*>(row), hi = *reinterpret_cast<const float4*>(row + 4);
-    halfx8 h;
-    h[0] = (_Float16)lo.x; h[1] = (_Float16)lo.y; h[2] = (_Float16)lo.z; h[3] = (_Float16)lo.w;
-    h[4] = (_Float16)hi.x; h[5] = (_Float16)hi.y; h[6] = (_Float16)hi.z; h[7] = (_Float16)hi.w;
-    return h;
+    return 4.5e-3f * mine * other + 2e-5f * sum * sum + 4e-6f * sum + 1e-30f;
 }
 
 // exact distances of the candidates of pass 2, one thread per pair, merged as packed keys (distance bits << 32 | index) like the
@@ -123,16 +118,35 @@ __global__ __launch_bounds__(256) void mf_exact_kernel(MfArgs p) {
     }
 }
 
-// One workgroup: 128 b rows (columns of G, fragments kept in registers) x segRows a rows, 32 a rows per wave and step.
-// MFMA 32x32x16 f16: A = a rows (lane & 31, k group lane >> 5), B = b rows; D[row][col]: lane -> col = lane & 31, half = lane >> 5,
-// register e -> row (e & 3) + 8 (e >> 2) + 4 half.
-template <int PASS>
+// The Gram passes, one search direction per workgroup (blockIdx.z = 0: every a row against b, minima of s = |b_j|^2 - 2 G; 1: every
+// b row against a, minima of t = |a_i|^2 - 2 G).  A workgroup OWNS 128 rows of its set - 32 per wave, their fragments in registers
+// for the whole kernel - and streams tilesPer 32-row tiles of the other set past them (fp16 rows written by mf_norms_kernel, two
+// 16-byte loads per lane and tile, three tiles in flight).  MFMA 32x32x16 f16: A = own rows (lane & 31, k group lane >> 5), B =
+// other rows; D[own][other]: lane -> other = lane & 31, half = lane >> 5, register e -> own row (e & 3) + 8 (e >> 2) + 4 half.
+// The running minimum of an own row stays in a register across all tiles: one shuffle reduction and ONE atomicMin per row and
+// workgroup at the end (blockIdx.y splits the other set, so a row meets gridDim.y of them).  Until round 3 one Gram tile served both
+// directions: 128 columns in registers x 384 streamed rows per workgroup, which cost Na Nb / 128 + Na Nb / 384 = 260 k atomics per
+// pass on 40 KB of minima - the passes were bound by those, not by their arithmetic (computing G twice is 3 GFLOP).
+template <int PASS, int D>
 __global__ __launch_bounds__(256) void mf_gram_kernel(MfArgs p) {
-    if (*p.bad) return;
+    // one reading of the flag per workgroup (another workgroup may raise it at any moment, and pass 2 ends in workgroup barriers)
+    __shared__ int wg_bad;
+    if (threadIdx.x == 0) wg_bad = *p.bad;
+    __syncthreads();
+    if (wg_bad) return;
     constexpr int WL = PASS == 2 ? 1024 : 1;                 // pass 2: per-wave list of the candidates found since the last flush
     __shared__ unsigned long long wl[4][WL];
+    __shared__ unsigned wtot[4], wbase;
     int wcnt = 0;                                            // wave-uniform
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    // A wave's list goes to the global list when it is full (rare: a handful of candidates per row) and, for all four waves
+    // together, once at the end of the workgroup: ONE atomicAdd on the shared counter per workgroup.  (A flush per wave and row
+    // step was 6000 returning atomics on one address per launch - they serialise in the L2 and were most of the pass.)
+    auto copy_out = [&](unsigned base) {
+        if (base + (unsigned)wcnt > p.cap) { if (lane == 0) *p.bad = 1; }       // list full: brute force answers instead
+        else for (int k = lane; k < wcnt; k += 64) p.cand[base + k] = wl[w][k];
+        wcnt = 0;
+    };
     auto flush = [&]() {
         if (wcnt == 0) return;
         // the list was written by other lanes of this wave: all their LDS stores are issued and complete before the cross-lane
@@ -142,95 +156,108 @@ __global__ __launch_bounds__(256) void mf_gram_kernel(MfArgs p) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         unsigned base = 0;
         if (lane == 0) base = atomicAdd(p.ncand, (unsigned)wcnt);
-        base = __builtin_amdgcn_readfirstlane(base);
-        if (base + (unsigned)wcnt > p.cap) { if (lane == 0) *p.bad = 1; }       // list full: brute force answers instead
-        else for (int k = lane; k < wcnt; k += 64) p.cand[base + k] = wl[w][k];
-        wcnt = 0;
+        copy_out(__builtin_amdgcn_readfirstlane(base));
     };
     const int l31 = lane & 31, half = lane >> 5;
-    const int col0 = blockIdx.x * 128;
-    halfx8 Bf[4][2];
-    float nbj[4], cbest[4], cband[4];
-    int jcol[4];
+    const int dir = blockIdx.z;
+    const int No = dir ? p.Nb : p.Na, Nt = dir ? p.Na : p.Nb;              // own rows, rows of the other set
+    const _Float16* own16 = dir ? p.b16 : p.a16;
+    const _Float16* oth16 = dir ? p.a16 : p.b16;
+    const float* n2oth = dir ? p.na2 : p.nb2;                               // the score carries the OTHER row's squared norm
+    const float* n2own = dir ? p.nb2 : p.na2;
+    unsigned* omin = dir ? p.colmin : p.rowmin;
+    const int r0 = blockIdx.x * 128 + w * 32;
+    const int t0 = blockIdx.y * p.tilesPer;
+    const int ntile_all = (Nt + 31) >> 5;
+    const int t1 = t0 + p.tilesPer < ntile_all ? t0 + p.tilesPer : ntile_all;
+    if (r0 < No && t0 < t1) {
+        const int io = r0 + l31 < No ? r0 + l31 : No - 1;
+        const halfx8 A0 = *reinterpret_cast<const halfx8*>(own16 + (size_t)io * 32 + 8 * half);
+        const halfx8 A1 = *reinterpret_cast<const halfx8*>(own16 + (size_t)io * 32 + 16 + 8 * half);
+        // per-register own-row data: rows r0 + (e & 3) + 8 (e >> 2) + 4 half
+        float rth[16];
+        bool rok[16];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const int j = col0 + t * 32 + l31;
-        jcol[t] = j;
-        const int jc = j < p.Nb ? j : p.Nb - 1;
-        const float* row = p.b + (size_t)jc * 32 + 8 * half;
-        Bf[t][0] = frag_of(row);
-        Bf[t][1] = frag_of(row + 16);
-        nbj[t] = p.nb2[jc];
-        if (PASS == 1) cbest[t] = __builtin_inff();
-        else { cbest[t] = ord_to(p.colmin[jc]); cband[t] = p.bandB[jc]; }
-    }
-    const int rlo = blockIdx.y * p.segRows;
-    const int rhi = rlo + p.segRows < p.Na ? rlo + p.segRows : p.Na;
-    for (int r0 = rlo + w * 32; r0 < rhi; r0 += 128) {
-        const int ia = r0 + l31 < p.Na ? r0 + l31 : p.Na - 1;
-        const float* arow = p.a + (size_t)ia * 32 + 8 * half;
-        const halfx8 A0 = frag_of(arow), A1 = frag_of(arow + 16);
-        // per-register row data: rows r0 + (e & 3) + 8 (e >> 2) + 4 half
-        float na[16], rth[16];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int rb = r0 + 8 * q + 4 * half;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int rr = rb + e < p.Na ? rb + e : p.Na - 1;
-                na[4 * q + e] = p.na2[rr];
-                if (PASS == 2) rth[4 * q + e] = ord_to(p.rowmin[rr]) + p.bandA[rr];
-                else rth[4 * q + e] = __builtin_inff();             // running row minimum
+        for (int e = 0; e < 16; ++e) {
+            const int row = r0 + (e & 3) + 8 * (e >> 2) + 4 * half;
+            rok[e] = row < No;
+            if (PASS == 1) rth[e] = __builtin_inff();                       // running minimum
+            else {
+                const int rr = rok[e] ? row : No - 1;
+                rth[e] = ord_to(omin[rr]) + band_of(n2own[rr], __uint_as_float(p.maxn2[dir ? 0 : 1]));
             }
         }
+        halfx8 B0[D], B1[D];
+        float nj[D];
+        auto load = [&](int t, int slot) {
+            const int j = (t << 5) + l31;
+            const int jc = j < Nt ? j : Nt - 1;
+            B0[slot] = *reinterpret_cast<const halfx8*>(oth16 + (size_t)jc * 32 + 8 * half);
+            B1[slot] = *reinterpret_cast<const halfx8*>(oth16 + (size_t)jc * 32 + 16 + 8 * half);
+            nj[slot] = n2oth[jc];
+        };
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            floatx16 g;
+        for (int d = 0; d < D; ++d) load(t0 + d < t1 ? t0 + d : t1 - 1, d);
+        for (int tb = t0; tb < t1; tb += D) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) g[e] = 0.f;
-            g = __builtin_amdgcn_mfma_f32_32x32x16_f16(A0, Bf[t][0], g, 0, 0, 0);
-            g = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1, Bf[t][1], g, 0, 0, 0);
-            const bool jok = jcol[t] < p.Nb;
+            for (int d = 0; d < D; ++d) {
+                const int t = tb + d;
+                if (t < t1) {                                               // uniform
+                    floatx16 g;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int i = r0 + (e & 3) + 8 * (e >> 2) + 4 * half;
-                const bool ok = jok && i < rhi;
-                const float s = nbj[t] - 2.f * g[e], tt = na[e] - 2.f * g[e];
-                if (PASS == 1) {
-                    if (ok) { rth[e] = fminf(rth[e], s); cbest[t] = fminf(cbest[t], tt); }
-                } else {
-                    const bool cr = ok && s <= rth[e], cc = ok && tt <= cbest[t] + cband[t];
-                    const unsigned long long m = __ballot(cr || cc);
-                    if (m) {                                              // uniform
-                        const int add = __popcll(m);
-                        if (wcnt + add > WL) flush();
-                        if (cr || cc)
-                            wl[w][wcnt + __popcll(m & ((1ull << lane) - 1ull))] =
-                                ((unsigned long long)i << 34) | ((unsigned long long)jcol[t] << 4) | (cr ? 2ull : 0ull) | (cc ? 1ull : 0ull);
-                        wcnt += add;
+                    for (int e = 0; e < 16; ++e) g[e] = 0.f;
+                    g = __builtin_amdgcn_mfma_f32_32x32x16_f16(A0, B0[d], g, 0, 0, 0);
+                    g = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1, B1[d], g, 0, 0, 0);
+                    const float njd = nj[d];
+                    const int j = (t << 5) + l31;
+                    const bool jok = j < Nt;
+                    load(t + D < t1 ? t + D : t1 - 1, d);                   // this slot's next tile (its operands are consumed above)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const float sc = njd - 2.f * g[e];
+                        if (PASS == 1) {
+                            if (jok) rth[e] = fminf(rth[e], sc);
+                        } else {
+                            const bool c = jok && rok[e] && sc <= rth[e];
+                            const unsigned long long m = __ballot(c);
+                            if (m) {                                        // uniform
+                                const int add = __popcll(m);
+                                if (wcnt + add > WL) flush();
+                                if (c) {
+                                    const unsigned long long own = (unsigned long long)(r0 + (e & 3) + 8 * (e >> 2) + 4 * half), oth = (unsigned long long)j;
+                                    wl[w][wcnt + __popcll(m & ((1ull << lane) - 1ull))] =
+                                        dir ? ((oth << 34) | (own << 4) | 1ull) : ((own << 34) | (oth << 4) | 2ull);
+                                }
+                                wcnt += add;
+                            }
+                        }
                     }
                 }
             }
         }
         if (PASS == 1) {
-            // row minima over this workgroup's 128 columns: across the 32 lanes of a half, then one atomic per row
+            // minimum of every own row over this workgroup's part of the other set: across the 32 lanes of a half, one atomic per row
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 float v = rth[e];
 #pragma unroll
                 for (int o = 16; o >= 1; o >>= 1) v = fminf(v, __shfl_xor(v, o));
-                const int i = r0 + (e & 3) + 8 * (e >> 2) + 4 * half;
-                if (l31 == 0 && i < rhi && v < __builtin_inff()) atomicMin(p.rowmin + i, ord_of(v));
+                const int row = r0 + (e & 3) + 8 * (e >> 2) + 4 * half;
+                if (l31 == 0 && rok[e] && v < __builtin_inff()) atomicMin(omin + row, ord_of(v));
             }
         }
-        if (PASS == 2) flush();
     }
-    if (PASS == 1) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            float v = fminf(cbest[t], __shfl_xor(cbest[t], 32));      // the two halves hold different rows of the same column
-            if (half == 0 && jcol[t] < p.Nb && v < __builtin_inff()) atomicMin(p.colmin + jcol[t], ord_of(v));
+    if (PASS == 2) {
+        if (lane == 0) wtot[w] = (unsigned)wcnt;
+        __syncthreads();                                     // also orders every wave's list stores before the copies below
+        if (threadIdx.x == 0) {
+            const unsigned tot = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+            wbase = tot ? atomicAdd(p.ncand, tot) : 0u;
         }
+        __syncthreads();
+        unsigned base = wbase;
+        for (int k = 0; k < w; ++k) base += wtot[k];
+        if (wcnt) copy_out(base);
     }
 }
 
@@ -238,7 +265,7 @@ int launch_nn32seg_if(const float* src, int Ns, const float* tgt, int Nt, unsign
 
 size_t mutual_prefilter_ws_bytes(int Na, int Nb) {
     const size_t n = (size_t)Na + Nb;
-    return n * (sizeof(unsigned long long) + 3 * sizeof(float) + sizeof(unsigned)) + 256 + (16 * n + 4096) * sizeof(unsigned long long);
+    return n * (sizeof(unsigned long long) + sizeof(float) + sizeof(unsigned) + 64) + 512 + (16 * n + 4096) * sizeof(unsigned long long);
 }
 
 // keysA (Na) / keysB (Nb) receive the packed winners (the layout launch_mutual_compact<PACKED> reads); ws as sized above
@@ -251,28 +278,31 @@ int launch_mutual_prefilter(const float* a, int Na, const float* b, int Nb, void
     p.keysB = (unsigned long long*)w; w += sizeof(unsigned long long) * (size_t)Nb;
     p.na2 = (float*)w; w += sizeof(float) * (size_t)Na;
     p.nb2 = (float*)w; w += sizeof(float) * (size_t)Nb;
-    p.bandA = (float*)w; w += sizeof(float) * (size_t)Na;
-    p.bandB = (float*)w; w += sizeof(float) * (size_t)Nb;
     p.rowmin = (unsigned*)w; w += sizeof(unsigned) * (size_t)Na;
     p.colmin = (unsigned*)w; w += sizeof(unsigned) * (size_t)Nb;
     p.maxn2 = (unsigned*)w; w += 2 * sizeof(unsigned);
     p.bad = (int*)w; w += sizeof(int);
     p.ncand = (unsigned*)w; w += sizeof(unsigned);
+    w = (char*)(((size_t)w + 63) & ~(size_t)63);
+    p.a16 = (_Float16*)w; w += 64 * (size_t)Na;
+    p.b16 = (_Float16*)w; w += 64 * (size_t)Nb;
     p.cand = (unsigned long long*)(((size_t)w + 15) & ~(size_t)15);
     p.cap = 16u * (unsigned)(Na + Nb) + 4000u;
     *keysA = p.keysA; *keysB = p.keysB;
     HIPCHK(hipMemsetAsync(p.maxn2, 0, 16, s));                  // maxima, `bad`, candidate count
     const int n = Na + Nb;
     hipLaunchKernelGGL(mf_norms_kernel, dim3((n + 255) / 256), dim3(256), 0, s, p);
-    hipLaunchKernelGGL(mf_band_kernel, dim3((n + 255) / 256), dim3(256), 0, s, p);
-    const int cb = (Nb + 127) / 128;
-    int segs = (2 * nCU + cb - 1) / cb;                         // about two workgroups per CU: the column fragments are loaded once per workgroup
-    const int maxsegs = (Na + 127) / 128;
-    segs = segs < 1 ? 1 : (segs > maxsegs ? maxsegs : segs);
-    p.segRows = ((Na + segs - 1) / segs + 127) / 128 * 128;
-    segs = (Na + p.segRows - 1) / p.segRows;
-    hipLaunchKernelGGL(mf_gram_kernel<1>, dim3(cb, segs), dim3(256), 0, s, p);
-    hipLaunchKernelGGL(mf_gram_kernel<2>, dim3(cb, segs), dim3(256), 0, s, p);
+    // grid: (128-row blocks of the larger set, splits of the other set, 2 directions), about two workgroups per CU
+    const int nmax = Na > Nb ? Na : Nb, nmin = Na < Nb ? Na : Nb;
+    const int rb = (nmax + 127) / 128, tiles = (nmax + 31) / 32;
+    static const int segmult = [] { const char* e = std::getenv("YOHO_NN_SPLITS"); return e ? std::atoi(e) : 0; }();
+    int splits = segmult > 0 ? segmult : (2 * nCU + 2 * rb - 1) / (2 * rb);
+    splits = splits < 1 ? 1 : (splits > tiles ? tiles : splits);
+    p.tilesPer = (tiles + splits - 1) / splits;
+    splits = (tiles + p.tilesPer - 1) / p.tilesPer;
+    (void)nmin;
+    hipLaunchKernelGGL((mf_gram_kernel<1, 3>), dim3(rb, splits, 2), dim3(256), 0, s, p);
+    hipLaunchKernelGGL((mf_gram_kernel<2, 3>), dim3(rb, splits, 2), dim3(256), 0, s, p);
     hipLaunchKernelGGL(mf_exact_kernel, dim3(nCU > 0 ? 2 * nCU : 512), dim3(256), 0, s, p);
     HIPCHK(hipGetLastError());
     // inputs the pre-filter cannot take: the brute-force kernels run (they return at once otherwise)
