@@ -852,6 +852,8 @@ static int partII_pass16(yoho_ctx* c, const float* s0, const float* s1, const fl
         if ((rc = launch_gconv16(c->p2[1], bA0, nT16, nullptr, nullptr, nullptr, EPI_ACT32, s, 2, nullptr, bA1, npl))) return rc;
         if ((rc = launch_gconv(conv_args(c->p2[2], bA1, nT, bH0, bF, nullptr, true), -1, EPI_RES | EPI_RAW, s))) return rc;
     }
+    static const bool staged_tail = [] { const char* e = std::getenv("YOHO_PARTII_TAIL"); return e && std::strcmp(e, "staged") == 0; }();
+    if (!staged_tail && mlp_head_supported(c->p2[3], c->p2[4], c->p2[5])) return launch_mlp_head(c->p2[3], c->p2[4], c->p2[5], bF, nT, M, quat, s);
     if ((rc = launch_gconv(conv_args(c->p2[3], bF, nT, nullptr, nullptr, bF0, true), -1, EPI_ACT, s))) return rc;
     if ((rc = launch_gconv(conv_args(c->p2[4], bF0, nT, nullptr, nullptr, bF1, true), -1, EPI_ACT, s))) return rc;
     if ((rc = launch_gconv(conv_args(c->p2[5], bF1, nT, nullptr, bQ, nullptr, false), 1, EPI_RAW, s))) return rc;
@@ -880,6 +882,8 @@ static int partII_pass(yoho_ctx* c, const float* s0, const float* s1, const floa
     if ((rc = launch_gconv(conv_args(c->p2[0], bX, nT, nullptr, bH0, bA0, false), 12, EPI_RAW | EPI_ACT, s))) return rc;
     if ((rc = launch_gconv(conv_args(c->p2[1], bA0, nT, nullptr, nullptr, bA1, false), 4, EPI_ACT, s))) return rc;
     if ((rc = launch_gconv(conv_args(c->p2[2], bA1, nT, bH0, bF, nullptr, true), -1, EPI_RES | EPI_RAW, s))) return rc;
+    static const bool staged_tail = [] { const char* e = std::getenv("YOHO_PARTII_TAIL"); return e && std::strcmp(e, "staged") == 0; }();
+    if (!staged_tail && mlp_head_supported(c->p2[3], c->p2[4], c->p2[5])) return launch_mlp_head(c->p2[3], c->p2[4], c->p2[5], bF, nT, M, quat, s);
     if ((rc = launch_gconv(conv_args(c->p2[3], bF, nT, nullptr, nullptr, bF0, true), -1, EPI_ACT, s))) return rc;
     if ((rc = launch_gconv(conv_args(c->p2[4], bF0, nT, nullptr, nullptr, bF1, true), -1, EPI_ACT, s))) return rc;
     if ((rc = launch_gconv(conv_args(c->p2[5], bF1, nT, nullptr, bQ, nullptr, false), 1, EPI_RAW, s))) return rc;

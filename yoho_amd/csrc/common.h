@@ -89,6 +89,8 @@ struct ConvArgs {
 // slot-table configurations (constant memory, see gconv.hip)
 enum { CFG_FULL = 0, CFG_C45 = 1, CFG_C13 = 2, CFG_C1 = 3, NCFG = 4 };
 int upload_slot_tables(const int* slab_h /*[NCFG][13*60]*/, const int* outg_h /*[NCFG][60]*/, SlotTables& t);
+bool mlp_head_supported(const Layer& A, const Layer& B, const Layer& C);      // PartII's 1x1 tail in one launch (gconv.hip)
+int launch_mlp_head(const Layer& A, const Layer& B, const Layer& C, const float* X, int nTiles, int M, float* quat, hipStream_t s);
 int launch_gconv(const ConvArgs& a, int gpw, int flags, hipStream_t s);
 int gconv_init();   // sets the dynamic-LDS attribute of every instantiation
 

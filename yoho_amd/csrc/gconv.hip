@@ -154,8 +154,186 @@ static int init_t() {
     return 0;
 }
 
+// PartII's tail in one launch (utils/network.py:273-277: the three 1x1 convolutions on the feature at the identity, 256 -> 512 ->
+// 128 -> 4, each followed by BN + ReLU except the last, then q / |q|): one workgroup per 32-match tile keeps the activations in
+// LDS between the layers.  As three gconv_kernel<1, .> launches + quat_norm the tail was a chain of 80 workgroup barriers with a
+// weight load behind each (32 + 64 + 16 eight-channel chunks): 80 us per 1000 matches for 0.4 GFLOP.  Same fp32 MFMAs in the same
+// order per output (chunks ascending, x y z w inside a chunk) and the same epilogue expressions: the bits of the staged path.
+struct MlpArgs {
+    const float* X;                                        // [tile][cinA/8][60 slabs][256]: slab 0 = the group identity
+    const float *WA, *biasA, *sA, *tA;                     // 256 -> 512, BN + ReLU
+    const float *WB, *biasB, *sB, *tB;                     // 512 -> 128, BN + ReLU
+    const float *WC, *biasC;                               // 128 -> 32 (4 used), raw
+    int cinA8, obA, obB, M;
+    float* quat;
+};
+
+__device__ __forceinline__ floatx4 quat_unit(floatx4 q) {
+#pragma clang fp contract(off)                             // layout.hip:quat_norm_kernel's arithmetic (compiled without contraction)
+    const float n = sqrtf(((q.x * q.x + q.y * q.y) + q.z * q.z) + q.w * q.w);
+    floatx4 o;
+    o.x = q.x / n; o.y = q.y / n; o.z = q.z / n; o.w = q.w / n;
+    return o;
+}
+
+__global__ __launch_bounds__(256, 1) void mlp_head_kernel(MlpArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tile = blockIdx.x;
+    char* sX = smem;
+    char* sA = sX + a.cinA8 * 1024;
+    char* sB = sA + a.obA * 4 * 1024;
+    const float* Xt = a.X + (size_t)tile * a.cinA8 * CHUNK_FLOATS;
+    for (int p = w; p < a.cinA8; p += 4)
+        __builtin_amdgcn_global_load_lds((gptr_t)(Xt + (size_t)p * CHUNK_FLOATS + lane * 4), (lptr_t)(sX + p * 1024), 16, 0, 0);
+    const int half = lane >> 5;
+    // ---- layer A: wave w owns the output blocks w, w + 4, w + 8, w + 12 (one fragment of the input serves four accumulators)
+    {
+        floatx16 acc[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
+        const floatx4* W0 = reinterpret_cast<const floatx4*>(a.WA) + (size_t)w * a.cinA8 * 64 + lane;
+        const size_t wstride = (size_t)4 * a.cinA8 * 64;
+        floatx4 wn[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wn[j] = W0[j * wstride];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int c8 = 0; c8 < a.cinA8; ++c8) {
+            floatx4 wc[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wc[j] = wn[j];
+            if (c8 + 1 < a.cinA8) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) wn[j] = W0[j * wstride + (size_t)(c8 + 1) * 64];
+            }
+            const floatx4 xf = *reinterpret_cast<const floatx4*>(sX + c8 * 1024 + lane * 16);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[j].x, xf.x, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[j].y, xf.y, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[j].z, xf.z, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[j].w, xf.w, acc[j], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int ob = w + 4 * j;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int ch = ob * 32 + q * 8 + half * 4;
+                floatx4 val;
+                val.x = acc[j][4 * q + 0]; val.y = acc[j][4 * q + 1];
+                val.z = acc[j][4 * q + 2]; val.w = acc[j][4 * q + 3];
+                val += *reinterpret_cast<const floatx4*>(a.biasA + ch);
+                const floatx4 sc = *reinterpret_cast<const floatx4*>(a.sA + ch);
+                const floatx4 sh = *reinterpret_cast<const floatx4*>(a.tA + ch);
+                floatx4 y = val * sc + sh;
+                y.x = fmaxf(y.x, 0.f); y.y = fmaxf(y.y, 0.f); y.z = fmaxf(y.z, 0.f); y.w = fmaxf(y.w, 0.f);
+                *reinterpret_cast<floatx4*>(sA + (ob * 4 + q) * 1024 + lane * 16) = y;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- layer B: wave w owns output block w
+    {
+        floatx16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        const int cin8 = a.obA * 4;
+        const floatx4* W0 = reinterpret_cast<const floatx4*>(a.WB) + (size_t)w * cin8 * 64 + lane;
+        floatx4 wr[4];                                      // weights run four chunks ahead
+#pragma unroll
+        for (int d = 0; d < 4; ++d) wr[d] = W0[(size_t)(d < cin8 ? d : cin8 - 1) * 64];
+        for (int c0 = 0; c0 < cin8; c0 += 4) {
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const int c8 = c0 + d;
+                const floatx4 wc = wr[d];
+                const int nx = c8 + 4 < cin8 ? c8 + 4 : cin8 - 1;
+                wr[d] = W0[(size_t)nx * 64];
+                const floatx4 xf = *reinterpret_cast<const floatx4*>(sA + c8 * 1024 + lane * 16);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wc.x, xf.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wc.y, xf.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wc.z, xf.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wc.w, xf.w, acc, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int ch = w * 32 + q * 8 + half * 4;
+            floatx4 val;
+            val.x = acc[4 * q + 0]; val.y = acc[4 * q + 1];
+            val.z = acc[4 * q + 2]; val.w = acc[4 * q + 3];
+            val += *reinterpret_cast<const floatx4*>(a.biasB + ch);
+            const floatx4 sc = *reinterpret_cast<const floatx4*>(a.sB + ch);
+            const floatx4 sh = *reinterpret_cast<const floatx4*>(a.tB + ch);
+            floatx4 y = val * sc + sh;
+            y.x = fmaxf(y.x, 0.f); y.y = fmaxf(y.y, 0.f); y.z = fmaxf(y.z, 0.f); y.w = fmaxf(y.w, 0.f);
+            *reinterpret_cast<floatx4*>(sB + (w * 4 + q) * 1024 + lane * 16) = y;
+        }
+    }
+    __syncthreads();
+    // ---- layer C (one output block, of which the first four channels are the quaternion) + normalisation: wave 0
+    if (w == 0) {
+        floatx16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        const int cin8 = a.obB * 4;
+        const floatx4* W0 = reinterpret_cast<const floatx4*>(a.WC) + lane;
+        floatx4 wr[4];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) wr[d] = W0[(size_t)(d < cin8 ? d : cin8 - 1) * 64];
+        for (int c0 = 0; c0 < cin8; c0 += 4) {
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const int c8 = c0 + d;
+                const floatx4 wc = wr[d];
+                const int nx = c8 + 4 < cin8 ? c8 + 4 : cin8 - 1;
+                wr[d] = W0[(size_t)nx * 64];
+                const floatx4 xf = *reinterpret_cast<const floatx4*>(sB + c8 * 1024 + lane * 16);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wc.x, xf.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wc.y, xf.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wc.z, xf.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wc.w, xf.w, acc, 0, 0, 0);
+            }
+        }
+        // channels 0..3 of match kp: registers 0..3 of the lanes of half 0
+        floatx4 val;
+        val.x = acc[0]; val.y = acc[1]; val.z = acc[2]; val.w = acc[3];
+        val += *reinterpret_cast<const floatx4*>(a.biasC + half * 4);
+        const int m = tile * TILE + (lane & 31);
+        if (half == 0 && m < a.M) *reinterpret_cast<floatx4*>(a.quat + (size_t)m * 4) = quat_unit(val);
+    }
+}
+
+// A: 256 -> 512, B: 512 -> 128, C: 128 -> 4 (padded to 32); X = A's input [tile][32][60 slabs][256].  false: shapes this kernel
+// does not take (the caller runs the staged launches).
+bool mlp_head_supported(const Layer& A, const Layer& B, const Layer& C) {
+    return A.ntaps == 1 && B.ntaps == 1 && C.ntaps == 1 && A.cin == 256 && A.cout_pad == 512 && B.cin == 512 && B.cout_pad == 128 &&
+           C.cin == 128 && C.cout_pad == 32;
+}
+
+int launch_mlp_head(const Layer& A, const Layer& B, const Layer& C, const float* X, int nTiles, int M, float* quat, hipStream_t s) {
+    MlpArgs a;
+    a.X = X;
+    a.WA = A.wp; a.biasA = A.bias; a.sA = A.bn_s; a.tA = A.bn_t;
+    a.WB = B.wp; a.biasB = B.bias; a.sB = B.bn_s; a.tB = B.bn_t;
+    a.WC = C.wp; a.biasC = C.bias;
+    a.cinA8 = A.cin / 8; a.obA = A.cout_pad / 32; a.obB = B.cout_pad / 32; a.M = M;
+    a.quat = quat;
+    const int lds = (a.cinA8 + a.obA * 4 + a.obB * 4) * 1024;
+    hipLaunchKernelGGL(mlp_head_kernel, dim3(nTiles), dim3(256), lds, s, a);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 int gconv_init() {
     int rc;
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_head_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024));
     if ((rc = init_t<15, false>())) return rc;
     if ((rc = init_t<12, false>())) return rc;
     if ((rc = init_t<4, false>())) return rc;
