@@ -519,3 +519,21 @@ def test_dataset_driver_missing_or_truncated_cache_file_fails_cleanly(tmp_path, 
     runner = run_dataset.ScenePairRunner(cfg, ctx, estimator="yohoc", max_iter=50, base_seed=1)
     runner.setup_scene(ds, pairs)
     assert len(runner.frag) == nfrag
+
+
+@pytest.mark.parametrize("estimator", ["yohoo", "yohoc"])
+def test_dataset_driver_overlapped_one_call_pairs_equal_sequential_staged(tmp_path, monkeypatch, estimator):
+    """The dataset driver's fast configuration - pairs as single library calls (yoho_register_pair) on three worker contexts,
+    running WHILE further fragments and the next scene part are loaded and described - against its plainest one: part by part,
+    one worker, every pair composed from the staged entries in Python.  Several scenes of different sizes (a three-fragment scene included): every pair's transform and recalltime identical (digest over all
+    pairs of all scenes), the same Registration Recall."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import bench_dataset
+    monkeypatch.setattr(bench_dataset, "PRESET_3DMATCH", [("a", 9, 20), ("b", 3, 3), ("c", 12, 40), ("d", 5, 10), ("e", 7, 9)])
+    outs = []
+    for kw in (dict(pair_workers=3, fused=True, overlap=True), dict(pair_workers=1, fused=False, overlap=False),
+               dict(pair_workers=2, fused=True, overlap=True)):
+        o = bench_dataset.run(kp=700, estimator=estimator, workdir=str(tmp_path / "ds"), runs=1, max_iter=200, preset="3dmatch", **kw)
+        outs.append((o["trans_sha256"], o["runs"][0]["registration_recall"], o["pairs"]))
+    assert outs[0][2] == 82
+    assert outs[0] == outs[1] == outs[2], outs

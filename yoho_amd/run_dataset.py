@@ -156,18 +156,25 @@ def scene_items(datasets):
     return [(k, d) for k, d in datasets.items() if k != 'wholesetname']
 
 
-def run_sharded(datasets, pair_fn, rank=0, world=1, scene_fn=None, gather=None, pairs_fn=None):
+def run_sharded(datasets, pair_fn, rank=0, world=1, scene_fn=None, gather=None, pairs_fn=None, parts_fn=None):
     """Run pair_fn(dataset, (id0, id1)) -> picklable result for every pair of every scene, sharded by plan_shards.
     scene_fn(dataset, pairs) is called once per (rank, scene part) before its pairs (descriptor extraction).
     pairs_fn(dataset, pairs) -> list of results (same order), when given, takes a whole scene part instead of pair_fn being
     called pair by pair (the GPU worker runs several pairs concurrently).
+    parts_fn([(dataset, pairs), ...]) -> [list of results per part], when given, takes ALL of the rank's scene parts at once (the GPU
+    worker overlaps one part's pairs with the next part's descriptor extraction).
     Returns on EVERY rank {scene key: [result per pair, in dataset.pair_ids order]} (gathered on the host)."""
     items = scene_items(datasets)
     plan = plan_shards({k: len(d.pair_ids) for k, d in items}, world, {k: len(d.pc_ids) for k, d in items})
     by_key = dict(items)
     mine = {}
     try:
-        for key, positions in plan[rank]:
+        if parts_fn is not None:
+            todo = [(key, positions, by_key[key], [tuple(by_key[key].pair_ids[p]) for p in positions]) for key, positions in plan[rank]]
+            for (key, positions, _, _), results in zip(todo, parts_fn([(ds, pairs) for _, _, ds, pairs in todo])):
+                for p, res in zip(positions, results):
+                    mine[(key, p)] = res
+        for key, positions in (plan[rank] if parts_fn is None else []):
             ds = by_key[key]
             pairs = [tuple(ds.pair_ids[p]) for p in positions]
             if scene_fn is not None:
@@ -229,6 +236,39 @@ def write_scene_results(cfg, dataset, results, yoho_sign, max_iter, npz=True):
 # ---------------------------------------------------------------------------------------------------------------
 # the GPU worker of one rank
 # ---------------------------------------------------------------------------------------------------------------
+class _Part:
+    """the resident fragments of one scene part: fid -> dict(feat, keys, eqv, inv_np), how many pairs still need each, the
+    event behind which each is described (frag_ev: set, under `cond`, when its PartI pass has been queued) and the order in which
+    the fragments are described (rank_of), from which the pair workers take the pairs in the order they become runnable"""
+
+    def __init__(self, scene, pairs=()):
+        self.scene = scene
+        self.frag = {}
+        self.frag_ev = {}
+        self.uses = {}
+        self.cond = threading.Condition()
+        self.failed = False
+        for p in pairs:
+            for i in p:
+                self.uses[i] = self.uses.get(i, 0) + 1
+        self.need = sorted(self.uses, key=lambda v: int(v))
+        self.rank_of = {fid: k for k, fid in enumerate(self.need)}
+
+    def wait_for(self, pair):
+        """block until both fragments of the pair are described (their passes queued) -> the events to wait for on the device"""
+        with self.cond:
+            while not self.failed and not all(f in self.frag_ev for f in pair):
+                self.cond.wait(0.5)
+            if self.failed:
+                raise RuntimeError(f"scene part {self.scene}: loading / describing its fragments failed")
+            return [self.frag_ev[f] for f in pair]
+
+    def fail(self):
+        with self.cond:
+            self.failed = True
+            self.cond.notify_all()
+
+
 class ScenePairRunner:
     """HBM-resident execution of the pairs one rank owns.  estimator 'yohoo' (needs the PartII weights) or 'yohoc'.
 
@@ -238,7 +278,7 @@ class ScenePairRunner:
     `stats` accumulates where the time goes (seconds; device work is timed with a synchronise only when timing=True)."""
 
     def __init__(self, cfg, ctx, estimator="yohoo", max_iter=1000, base_seed=0, timing=False, write_npz=False, hypotheses="selected",
-                 pair_workers=2, partII_sd=None, fused=True):
+                 pair_workers=2, partII_sd=None, fused=True, overlap=True):
         import torch
         from . import pipeline
         self.torch, self.pipeline = torch, pipeline
@@ -253,18 +293,21 @@ class ScenePairRunner:
         # really overlap) instead of pipeline.run_pair's ~25 calls from Python - the same entries in the same order with the same
         # vote order / sampling stream, hence the same bits (tests/test_gpu_dropin.py); False keeps the Python composition
         self.fused = bool(fused)
+        # overlap: run_parts lets pairs run while further fragments are loaded and described; False = part by part, setup then pairs
+        self.overlap = bool(overlap)
         # pair_workers > 1: run_pairs runs that many pairs at a time, each on its own HIP stream with its own library context
         # (a context is single-stream by contract; PartI is not needed there, PartII's weights come from partII_sd).  A pair's
         # kernels at <= 1000 voted matches are a chain of ~25 short launches that fill a fraction of the chip and end in two
         # host read-backs: two chains side by side hide both.  Results do not depend on the interleaving (per-pair seeds, no
         # shared state between pairs).
-        self.pair_workers = max(1, int(pair_workers)) if (estimator == "yohoc" or partII_sd is not None) else 1
+        # own_contexts: the pairs can run in library contexts of their own (YOHO-C needs no weights there, YOHO-O the PartII state
+        # dict); only then may pairs run while the caller's context describes further fragments (run_parts)
+        self.own_contexts = estimator == "yohoc" or partII_sd is not None
+        self.pair_workers = max(1, int(pair_workers)) if self.own_contexts else 1
         self._partII_sd = partII_sd
         self._workers = None            # [(context, torch stream)]
         self._lock = threading.Lock()
-        self.scene = None
-        self.frag = {}
-        self.uses = {}
+        self.part = _Part(None)         # the scene part set up last (run_parts keeps two alive: one being set up, one being run)
         self._made_dirs = set()
         self._copy_stream = None
         self._pin_pool = {}
@@ -322,7 +365,7 @@ class ScenePairRunner:
         keys = torch.from_numpy(np.ascontiguousarray(dataset.get_kps(fid), dtype=np.float64)).pin_memory()
         return fid, x, keys, time.perf_counter() - t0
 
-    def setup_scene(self, dataset, pairs):
+    def setup_scene(self, dataset, pairs, part=None):
         """load + describe every fragment the pairs touch (tests/extractor.py:37-62 without the .npy round trip): a loader
         thread reads the cache files into pinned memory while the device describes the fragments already there; up to 16384
         keypoints (3 fragments of 5000) go through one PartI pass"""
@@ -331,12 +374,9 @@ class ScenePairRunner:
         import time
         torch = self.torch
         t_setup = time.perf_counter()
-        if self.scene != dataset.name:
-            self.scene, self.frag, self.uses = dataset.name, {}, {}
-        for p in pairs:
-            for i in p:
-                self.uses[i] = self.uses.get(i, 0) + 1
-        need = sorted({i for p in pairs for i in p if i not in self.frag}, key=lambda v: int(v))
+        if part is None:
+            part = _Part(dataset.name, pairs)
+        need = part.need
         fdir = self._feature_dir(dataset)
         q = queue.Queue(maxsize=6)
         NLOAD = 3                                       # loader threads (file reads release the GIL); results are consumed in order
@@ -399,8 +439,15 @@ class ScenePairRunner:
             for fid, x, keys in dev:
                 n = x.shape[0]
                 # own storage per fragment, so that releasing one fragment frees its memory (slices would pin the whole pass)
-                self.frag[fid] = dict(feat=x, keys=keys, eqv=out["eqv"][o:o + n].clone(), inv_np=out["inv_np"][o:o + n].clone())
+                part.frag[fid] = dict(feat=x, keys=keys, eqv=out["eqv"][o:o + n].clone(), inv_np=out["inv_np"][o:o + n].clone())
                 o += n
+            self.stats["peak_resident_fragments"] = max(self.stats["peak_resident_fragments"], len(part.frag))
+            ev = torch.cuda.Event()
+            ev.record(main)
+            with part.cond:                         # pairs of these fragments may start (run_parts: the workers are already waiting)
+                for fid, _, _ in dev:
+                    part.frag_ev[fid] = ev
+                part.cond.notify_all()
             self.stats["h2d_describe_s"] += time.perf_counter() - t0
             self.stats["fragments"] += len(dev)
 
@@ -440,14 +487,17 @@ class ScenePairRunner:
         except BaseException:
             stop.set()                              # unblock the loader, then let the error travel
             th.join(timeout=5.0)
+            part.fail()
             raise
         if self.timing:
             t0 = time.perf_counter()
-            torch.cuda.synchronize()                # once per scene part: the device side of the setup is inside setup_s
-            self.stats["h2d_describe_s"] += time.perf_counter() - t0
+            main.synchronize()                      # once per scene part: the device side of the setup is inside setup_s (this
+            self.stats["h2d_describe_s"] += time.perf_counter() - t0        # stream only: the pairs of the part before may be running)
         th.join()
-        self.stats["peak_resident_fragments"] = max(self.stats["peak_resident_fragments"], len(self.frag))
+        self.stats["peak_resident_fragments"] = max(self.stats["peak_resident_fragments"], len(part.frag))
         self.stats["setup_s"] += time.perf_counter() - t_setup
+        self.part = part
+        return part
 
     def finish_writes(self):
         """write the archives of the pairs this rank ran"""
@@ -458,19 +508,30 @@ class ScenePairRunner:
             save_pair_npz(save_dir, id0, id1, res)
         self._write_jobs = []
 
-    def _release(self, fid):
-        n = self.uses.get(fid, 0) - 1
-        if n <= 0:
-            self.uses.pop(fid, None)
-            self.frag.pop(fid, None)
-        else:
-            self.uses[fid] = n
+    # the part set up last, under the names the single-part interface (setup_scene -> run_pair / run_pairs) has always used
+    @property
+    def frag(self):
+        return self.part.frag
 
-    def run_pair(self, dataset, pair, ctx=None):
+    @property
+    def uses(self):
+        return self.part.uses
+
+    @staticmethod
+    def _release(part, fid):
+        n = part.uses.get(fid, 0) - 1
+        if n <= 0:
+            part.uses.pop(fid, None)
+            part.frag.pop(fid, None)
+        else:
+            part.uses[fid] = n
+
+    def run_pair(self, dataset, pair, ctx=None, part=None):
         import time
         t0 = time.perf_counter()
         id0, id1 = pair
-        a, b = self.frag[id0], self.frag[id1]
+        part = part if part is not None else self.part
+        a, b = part.frag[id0], part.frag[id1]
         seed = pair_seed(self.base_seed, dataset.name, id0, id1)
         c = ctx if ctx is not None else self.ctx
         out = None
@@ -487,8 +548,8 @@ class ScenePairRunner:
             out = {"trans": np.asarray(r.trans, dtype=np.float64), "recalltime": int(r.best_h), "matches": int(r.match.shape[0]),
                    "inliers": int(r.best_count)}
         with self._lock:
-            self._release(id0)
-            self._release(id1)
+            self._release(part, id0)
+            self._release(part, id1)
             if self._write_npz:
                 self._write_jobs.append((result_dir(self.cfg, dataset, self.yoho_sign, self.max_iter), id0, id1, out))
             self.stats["pairs"] += 1
@@ -507,17 +568,23 @@ class ScenePairRunner:
             ws.append((c, torch.cuda.Stream()))
         return ws
 
-    def run_pairs(self, dataset, pairs):
+    def run_pairs(self, dataset, pairs, part=None):
         """the pairs of a scene part, pair_workers at a time -> results in the order of `pairs`"""
         import time
         pairs = list(pairs)
-        if self.pair_workers <= 1 or len(pairs) < 2:
-            return [self.run_pair(dataset, p) for p in pairs]
+        part = part if part is not None else self.part
         torch = self.torch
+        # in the order the pairs become runnable: by the later of their two fragments in the order of description
+        order = sorted(range(len(pairs)), key=lambda i: max(part.rank_of.get(pairs[i][0], 0), part.rank_of.get(pairs[i][1], 0)))
+        if not self.own_contexts:                        # on the caller's context and stream: nothing else may use them meanwhile
+            res = [None] * len(pairs)
+            for i in order:
+                for ev in part.wait_for(pairs[i]):
+                    torch.cuda.current_stream().wait_event(ev)
+                res[i] = self.run_pair(dataset, pairs[i], part=part)
+            return res
         if self._workers is None:
             self._workers = self._make_workers()
-        ready = torch.cuda.Event()
-        ready.record()                                   # the fragments were described on this (the caller's) stream
         out = [None] * len(pairs)
         nxt = [0]
         errors = []
@@ -528,18 +595,20 @@ class ScenePairRunner:
             try:
                 torch.cuda.set_device(self.ctx.device)
                 with torch.cuda.stream(st):
-                    st.wait_event(ready)
                     while not errors:
                         with self._lock:
-                            i = nxt[0]
+                            k = nxt[0]
                             nxt[0] += 1
-                        if i >= len(pairs):
+                        if k >= len(order):
                             break
-                        out[i] = self.run_pair(dataset, pairs[i], ctx=c)
+                        i = order[k]
+                        for ev in part.wait_for(pairs[i]):      # blocks while the fragments are still being loaded / described
+                            st.wait_event(ev)
+                        out[i] = self.run_pair(dataset, pairs[i], ctx=c, part=part)
                     st.synchronize()
             except BaseException as e:
                 errors.append(e)
-        ths = [threading.Thread(target=work, args=(wi,), daemon=True) for wi in range(len(self._workers))]
+        ths = [threading.Thread(target=work, args=(wi,), daemon=True) for wi in range(min(len(self._workers), max(1, len(pairs))))]
         for t in ths:
             t.start()
         for t in ths:
@@ -547,6 +616,66 @@ class ScenePairRunner:
         if errors:
             raise errors[0]
         self.stats["pairs_wall_s"] = self.stats.get("pairs_wall_s", 0.0) + time.perf_counter() - t_wall
+        return out
+
+
+    def run_parts(self, parts):
+        """[(dataset, pairs), ...] -> [results per part].  The pair workers of a part start BEFORE its fragments are loaded: a pair
+        runs (on a worker's stream) as soon as both its fragments are described, while the caller's thread keeps loading and
+        describing the rest of the part and then the next part - the descriptor pass fills the matrix pipes, the pair chains are
+        short latency-bound launches that slot in between its workgroups (the overlap bench.py's pair streamer lives on).  At most
+        two parts are in flight, so two parts' fragments bound the footprint."""
+        import time
+        out = [None] * len(parts)
+        t_all = time.perf_counter()
+        if not self.own_contexts or not self.overlap:   # the pairs need the caller's context (or the caller asked): one thing at a time
+            for i, (ds, pairs) in enumerate(parts):
+                self.setup_scene(ds, pairs)
+                out[i] = self.run_pairs(ds, pairs)
+            self.stats["parts_wall_s"] = self.stats.get("parts_wall_s", 0.0) + time.perf_counter() - t_all
+            return out
+
+        def start(i, part, ds, pairs, after):
+            box = {}
+
+            def body():
+                try:
+                    if after is not None:           # the pair workers (contexts, streams) serve one part at a time: the part
+                        after.join()                # before must have run all its pairs; this part's SETUP overlaps them meanwhile
+                    self.torch.cuda.set_device(self.ctx.device)
+                    box["res"] = self.run_pairs(ds, pairs, part=part)
+                except BaseException as e:
+                    box["err"] = e
+            th = threading.Thread(target=body, daemon=True)
+            th.start()
+            return i, th, box, part
+
+        def finish(p):
+            i, th, box, _ = p
+            th.join()
+            if "err" in box:
+                raise box["err"]
+            out[i] = box["res"]
+
+        inflight = []
+        t_last_setup = t_all
+        try:
+            for i, (ds, pairs) in enumerate(parts):
+                while len(inflight) >= 2:
+                    finish(inflight.pop(0))
+                part = _Part(ds.name, pairs)
+                inflight.append(start(i, part, ds, pairs, inflight[-1][1] if inflight else None))
+                self.setup_scene(ds, pairs, part=part)
+                t_last_setup = time.perf_counter()
+            while inflight:
+                finish(inflight.pop(0))
+        finally:
+            for p in inflight:                      # an error above: stop and collect the workers before the exception travels
+                p[3].fail()
+                p[1].join()
+        t_end = time.perf_counter()
+        self.stats["parts_wall_s"] = self.stats.get("parts_wall_s", 0.0) + t_end - t_all
+        self.stats["pairs_tail_s"] = self.stats.get("pairs_tail_s", 0.0) + t_end - t_last_setup      # pairs not hidden behind a setup
         return out
 
 
@@ -571,7 +700,7 @@ def load_and_broadcast_weights(cfg, ctx, need_partII):
 
 
 def eval_sharded(cfg, max_iter=1000, estimator="yohoo", datasets=None, base_seed=0, results_log=None, ctx=None, state_dicts=None,
-                 stats_out=None, hypotheses="selected", weights_loaded=False, pair_workers=2, fused=True):
+                 stats_out=None, hypotheses="selected", weights_loaded=False, pair_workers=2, fused=True, overlap=True):
     """The sharded counterpart of Evaluator_PartI/II.eval (tests/evaluator.py:75-101,146-173): run every pair of the
     test set over the initialised process group (one rank per GPU), write npz / pre.log on rank 0 and return the
     Registration Recall there (None on the other ranks).  FCGF group features and keypoints are read from the
@@ -596,12 +725,12 @@ def eval_sharded(cfg, max_iter=1000, estimator="yohoo", datasets=None, base_seed
     # every rank writes the archives of the pairs it ran (one node: the cache directory is shared), rank 0 the pre.log files
     runner = ScenePairRunner(cfg, ctx, estimator=estimator, max_iter=max_iter, base_seed=base_seed, timing=stats_out is not None, write_npz=True,
                              hypotheses=hypotheses, pair_workers=pair_workers, partII_sd=(state_dicts[1] if estimator == "yohoo" else None),
-                             fused=fused)
+                             fused=fused, overlap=overlap)
     cached = getattr(ctx, "_pair_workers_cache", None)           # worker contexts (PartII weight packing: 0.25 s each) live with ctx
     if cached is not None and cached[0] is state_dicts[1] and len(cached[1]) == runner.pair_workers:
         runner._workers = cached[1]
     try:
-        results = run_sharded(datasets, runner.run_pair, rank=rank, world=world, scene_fn=runner.setup_scene, pairs_fn=runner.run_pairs)
+        results = run_sharded(datasets, runner.run_pair, rank=rank, world=world, parts_fn=runner.run_parts)
         if runner._workers is not None:
             ctx._pair_workers_cache = (state_dicts[1], runner._workers)
     finally:
