@@ -27,13 +27,16 @@
  *   yoho_load_fcgf / _voxelize / _forward / _forward_batch        fcgf_model/resunet.py:10-190, simple_yoho/fcgf_feat.py:33-54
  *   yoho_fcgf_voxelize_rotated / yoho_rotate_select               YOHO_testset.py:143-147,92, simple_yoho/yoho_extract.py:46-53
  *   yoho_group_transfer_batch                                     the feature-transfer body of those loops for the copies of a pass
+ *   yoho_register_pair           one iteration of the pair loop  tests/evaluator.py:112-117 / :41-47 (matcher -> Des2R -> PartII + vote | YOHO-C)
+ *   yoho_vote_order              np.random.shuffle(index)        tests/estimator.py:321-323 (seeded RandomState, host code)
  *
  * Conventions
  *   - return 0 on success, a negative YOHO_E* code on error; yoho_last_error() gives a
  *     thread-local message.  No C++ exception crosses the ABI.
  *   - every data pointer is a DEVICE pointer owned by the caller (contiguous, 16-byte
  *     aligned), except the yoho_load_* / yoho_ctx_create inputs which are HOST pointers.
- *   - calls are asynchronous on the given hipStream_t (pass NULL for the default stream);
+ *   - calls are asynchronous on the given hipStream_t (pass NULL for the default stream; yoho_register_pair and
+ *     yoho_range_status, which return results to the host, wait for it);
  *     the library allocates only its own workspace inside the ctx (which may synchronise
  *     the stream the first time a larger problem is seen).
  *   - a ctx belongs to one device and is used from one stream / thread at a time (it owns one workspace); different ctxs - also

@@ -30,6 +30,8 @@ done
 rocprofv3 --kernel-trace --stats -d $O/prof_extract -- python $R/tools/bench_extract.py 300000 5000 > $O/extract.log 2>&1
 python $R/tools/rocpd_stats.py $O/prof_extract > $O/kernel_trace_extract.md 2>&1
 cd $R
+# 6. the dataset-scale rows (profiles/rNN_dataset.md)
+python tools/dataset_profile.py $O/dataset.md > $O/dataset.log 2>&1
 # keep only the summaries (the raw databases / csv stay on the box)
 rm -rf $O/prof_bench_seq $O/prof_bench $O/prof_extract $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_sq_plain $O/pmc_sq_nostore
 ls -la $O

@@ -6,7 +6,8 @@
 // those cost 0.2 ms of vector fp32 per pair, and almost all of them are nowhere near the minimum.  Here the Gram matrix G = a b^T is
 // computed on the fp16 MFMA (one rounding of the inputs, fp32 accumulation: a few microseconds), twice:
 //   pass 1   row minima of s_ij = |b_j|^2 - 2 G_ij and column minima of t_ij = |a_i|^2 - 2 G_ij (the squared distance up to the
-//            term that is constant along the search), by ordered-integer atomicMin;
+//            term that is constant along the search): a workgroup serves ONE direction, owns 128 rows of its set and streams the
+//            other set past them, so a minimum is a register until the end (one ordered-integer atomicMin per row and workgroup);
 //   pass 2   every (i, j) whose score is within a PROVEN error band of its row (column) minimum is a candidate: its exact distance
 //            is evaluated with dist2_f32 / dist_of_f32 and merged as the packed key (distance bits << 32 | index) the brute-force
 //            path uses, so ties go to the lowest index as there.
