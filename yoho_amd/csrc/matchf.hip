@@ -266,7 +266,7 @@ int launch_nn32seg_if(const float* src, int Ns, const float* tgt, int Nt, unsign
 
 size_t mutual_prefilter_ws_bytes(int Na, int Nb) {
     const size_t n = (size_t)Na + Nb;
-    return n * (sizeof(unsigned long long) + sizeof(float) + sizeof(unsigned) + 64) + 512 + (16 * n + 4096) * sizeof(unsigned long long);
+    return n * (sizeof(unsigned long long) + sizeof(float) + sizeof(unsigned) + 64) + 512 + (32 * n + 4096) * sizeof(unsigned long long);
 }
 
 // keysA (Na) / keysB (Nb) receive the packed winners (the layout launch_mutual_compact<PACKED> reads); ws as sized above
@@ -288,7 +288,7 @@ int launch_mutual_prefilter(const float* a, int Na, const float* b, int Nb, void
     p.a16 = (_Float16*)w; w += 64 * (size_t)Na;
     p.b16 = (_Float16*)w; w += 64 * (size_t)Nb;
     p.cand = (unsigned long long*)(((size_t)w + 15) & ~(size_t)15);
-    p.cap = 16u * (unsigned)(Na + Nb) + 4000u;
+    p.cap = 32u * (unsigned)(Na + Nb) + 4000u;                 // a pair in the band of both its row and its column is listed once per direction
     *keysA = p.keysA; *keysB = p.keysB;
     HIPCHK(hipMemsetAsync(p.maxn2, 0, 16, s));                  // maxima, `bad`, candidate count
     const int n = Na + Nb;
