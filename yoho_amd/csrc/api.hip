@@ -847,6 +847,13 @@ static int partII_pass16(yoho_ctx* c, const float* s0, const float* s1, const fl
         int n0[NTAP];
         for (int k = 0; k < NTAP; ++k) n0[k] = c->hN[k];
         if ((rc = launch_gconv16(c->p2[1], bA0, nT16, nullptr, nullptr, bA1p, EPI_ACT, s, 2, nullptr, nullptr, npl, rf))) return rc;
+        // with the one-launch tail behind it the layer runs its K over two workgroups per tile and the tail adds the halves (bF0,
+        // the staged tail's 512-channel buffer, holds them)
+        static const bool staged_tail16 = [] { const char* e = std::getenv("YOHO_PARTII_TAIL"); return e && std::strcmp(e, "staged") == 0; }();
+        if (!staged_tail16 && mlp_head_supported(c->p2[3], c->p2[4], c->p2[5])) {
+            if ((rc = launch_cone1(c->p2[2], bA1p, nT, nT16, nullptr, nullptr, n0, s, bF0))) return rc;
+            return launch_mlp_head(c->p2[3], c->p2[4], c->p2[5], nullptr, nT, M, quat, s, bF0, &c->p2[2], bH0);
+        }
         if ((rc = launch_cone1(c->p2[2], bA1p, nT, nT16, bH0, bF, n0, s))) return rc;
     } else {
         if ((rc = launch_gconv16(c->p2[1], bA0, nT16, nullptr, nullptr, nullptr, EPI_ACT32, s, 2, nullptr, bA1, npl))) return rc;

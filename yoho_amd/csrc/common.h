@@ -90,7 +90,8 @@ struct ConvArgs {
 enum { CFG_FULL = 0, CFG_C45 = 1, CFG_C13 = 2, CFG_C1 = 3, NCFG = 4 };
 int upload_slot_tables(const int* slab_h /*[NCFG][13*60]*/, const int* outg_h /*[NCFG][60]*/, SlotTables& t);
 bool mlp_head_supported(const Layer& A, const Layer& B, const Layer& C);      // PartII's 1x1 tail in one launch (gconv.hip)
-int launch_mlp_head(const Layer& A, const Layer& B, const Layer& C, const float* X, int nTiles, int M, float* quat, hipStream_t s);
+int launch_mlp_head(const Layer& A, const Layer& B, const Layer& C, const float* X, int nTiles, int M, float* quat, hipStream_t s,
+                    const float* part = nullptr, const Layer* P = nullptr, const float* res = nullptr);
 int launch_gconv(const ConvArgs& a, int gpw, int flags, hipStream_t s);
 int gconv_init();   // sets the dynamic-LDS attribute of every instantiation
 
@@ -133,7 +134,7 @@ int fcgf_voxelize(yoho_ctx* ctx, const double* pts, int n, const double* R_host,
 int fcgf_rotate_select(const double* pts, const double* R_host, const int64_t* sel, int m, float* out, hipStream_t s);
 int fcgf_voxelize_batch(yoho_ctx* ctx, const double* pts, int n, const double* R_host, int nb, double voxel, int64_t* sel, int* coords,
                         float* pts_sel, int* counts_host, hipStream_t s);
-int launch_cone1(const Layer& L, const char* X, int nTiles32, int nTiles16, const float* res, float* out, const int* n0, hipStream_t s);
+int launch_cone1(const Layer& L, const char* X, int nTiles32, int nTiles16, const float* res, float* out, const int* n0, hipStream_t s, float* part = nullptr);
 int gft16_init();
 int launch_gft16(const float* in, float* out32, char* planes, int kppad, const void* Ffrag, const float* bn_s, const float* bn_t, int nTiles,
                  int C8, int nCU, hipStream_t s, int B = 0, int* rflag = nullptr, int variant = 2);

@@ -4,7 +4,10 @@
 // on the fp16x2 split MFMA.  Input = the activated 13-cone planes the previous layer left behind
 // ([tile16][c8][plane][60][16 kp][8 ch] fp16, only the slabs N[0][k] are valid).  A workgroup owns 32 matches (two
 // 16-match tiles = the two column halves of the MFMA) and 128 output channels (one 32-row block per wave); per
-// 8-channel chunk only the 13 needed slabs of both tiles and planes are gathered into LDS (14 KiB, double buffered).
+// 8-channel chunk only the 13 needed slabs of both tiles and planes are gathered into LDS (14 KiB, ring of three).  In front of the
+// one-launch tail (gconv.hip: mlp_head_kernel) the 64 channel chunks are walked by TWO workgroups per tile (a fixed split) that
+// leave raw partial sums; the tail adds them: a 1000-match pass then has 128 chains of 32 dependent chunks instead of 64 of 64
+// (71 -> ~40 us); at 3233 matches (408 workgroups) it makes no difference.
 #include <hip/hip_runtime.h>
 #include <type_traits>
 
@@ -31,6 +34,7 @@ struct Cone1Args {
     const float* res;      // fp32 [tile32][cout8][60][h][kp32][4], slab 0 used
     float* out;            // same layout, slab 0 written
     int nTiles32, nTiles16, cin8, cout8;
+    float* part;           // K split (gridDim.y = 2): raw partial sums [half of K][tile32][cout8][h][kp32][4], no descale / bias / residual
     float descale;
     int n0[14];            // N[0][k]; n0[13] = n0[0] (tap 13 has zero weights, its slab only has to be finite)
 };
@@ -53,6 +57,9 @@ __global__ __launch_bounds__(256, 1) void cone1_kernel(Cone1Args a) {       // <
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nog = a.cout8 / 16;                         // groups of 128 output channels
+    // K split: workgroup (x, y) walks the channel chunks [y cn, (y + 1) cn).  The split is FIXED (never a function of the number of
+    // matches), so a match's result does not depend on which other matches share its pass.
+    const int cn = a.cin8 / (int)gridDim.y, c0 = (int)blockIdx.y * cn;
     const int tile32 = blockIdx.x / nog, og = blockIdx.x - tile32 * nog;
     const int ob = og * 4 + w;
     if (tid < 14) n0s[tid] = a.n0[tid];
@@ -75,7 +82,7 @@ __global__ __launch_bounds__(256, 1) void cone1_kernel(Cone1Args a) {       // <
             // (same bytes to the same place for the repeated piece: every wave issues four, so the wait counts are uniform and the
             // loop body has no branch)
             const int u = w + 4 * i < C1_UNITS ? w + 4 * i : w + 4 * (i - 1);
-            __builtin_amdgcn_global_load_lds((gptr_t)(a.X + soff[i] + (long long)c8 * C1_CHUNK), (lptr_t)(dst + u * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(a.X + soff[i] + (long long)(c0 + c8) * C1_CHUNK), (lptr_t)(dst + u * 1024), 16, 0, 0);
         }
     };
 
@@ -99,7 +106,7 @@ __global__ __launch_bounds__(256, 1) void cone1_kernel(Cone1Args a) {       // <
     constexpr int RING = 3;
     uintx4 wreg[RING][7][2];
     auto loadW = [&](int c8, uintx4 (&wr)[7][2]) {
-        const uintx4* Wn = Wl + (size_t)c8 * (7 * 2 * 64);
+        const uintx4* Wn = Wl + (size_t)(c0 + c8) * (7 * 2 * 64);
 #pragma unroll
         for (int tp = 0; tp < 7; ++tp) { wr[tp][0] = Wn[(tp * 2) * 64]; wr[tp][1] = Wn[(tp * 2 + 1) * 64]; }
     };
@@ -130,12 +137,12 @@ __global__ __launch_bounds__(256, 1) void cone1_kernel(Cone1Args a) {       // <
         __builtin_amdgcn_sched_barrier(0);
     };
     auto stage_of = [&](int c8) { return smem + (c8 % RING) * C1_STAGE; };
-    const int last = a.cin8 - 1;
+    const int last = cn - 1;
     auto clamp = [&](int c8) { return c8 <= last ? c8 : last; };
     // prologue: chunks 0, 1, 2 (in the order the loop keeps: W then DMA)
     loadW(clamp(0), wreg[0]); stage(clamp(0), stage_of(0));
     loadW(clamp(1), wreg[1]); stage(clamp(1), stage_of(1));
-    const int nmain = (a.cin8 / RING) * RING;
+    const int nmain = (cn / RING) * RING;
     for (int c8 = 0; c8 < nmain; c8 += RING) {
         sfor_c1<0, RING>([&](auto jc) {
             constexpr int jj = decltype(jc)::value;
@@ -168,6 +175,10 @@ __global__ __launch_bounds__(256, 1) void cone1_kernel(Cone1Args a) {       // <
         val.y = (acc[0][4 * q + 1] + acc[1][4 * q + 1]) + acc[2][4 * q + 1];
         val.z = (acc[0][4 * q + 2] + acc[1][4 * q + 2]) + acc[2][4 * q + 2];
         val.w = (acc[0][4 * q + 3] + acc[1][4 * q + 3]) + acc[2][4 * q + 3];
+        if (gridDim.y > 1) {                                 // the consumer (mlp_head_kernel) adds the halves, then descale, bias, residual
+            *reinterpret_cast<floatx4*>(a.part + ((((size_t)blockIdx.y * a.nTiles32 + tile32) * a.cout8 + ob * 4 + q) * 64 + lane) * 4) = val;
+            continue;
+        }
         val *= a.descale;
         val += *reinterpret_cast<const floatx4*>(a.bias + ch);
         const size_t off = (((((size_t)tile32 * a.cout8 + ob * 4 + q) * G + 0) * 2 + half) * TILE + kp32) * 4;
@@ -176,15 +187,17 @@ __global__ __launch_bounds__(256, 1) void cone1_kernel(Cone1Args a) {       // <
     }
 }
 
-int launch_cone1(const Layer& L, const char* X, int nTiles32, int nTiles16, const float* res, float* out, const int* n0, hipStream_t s) {
+// part != null: K over two workgroups, partial sums to `part` (2 * nTiles32 * cout8 * 256 floats) instead of the finished `out`
+int launch_cone1(const Layer& L, const char* X, int nTiles32, int nTiles16, const float* res, float* out, const int* n0, hipStream_t s, float* part) {
     if (L.cout_pad % 128 || !L.wph || L.cin % 32) { set_error("cone1: needs cout %% 128 == 0, cin %% 32 == 0 and fp16x2 weights"); return YOHO_EINVAL; }
     Cone1Args a;
-    a.X = X; a.Wp = reinterpret_cast<const char*>(L.wph); a.bias = L.bias; a.res = res; a.out = out;
+    a.X = X; a.Wp = reinterpret_cast<const char*>(L.wph); a.bias = L.bias; a.res = res; a.out = out; a.part = part;
+    if (part && (L.cin / 8) % 2) { set_error("cone1: K split needs an even number of channel chunks"); return YOHO_EINVAL; }
     a.nTiles32 = nTiles32; a.nTiles16 = nTiles16; a.cin8 = L.cin / 8; a.cout8 = L.cout_pad / 8; a.descale = L.wph_descale;
     for (int k = 0; k < 13; ++k) a.n0[k] = n0[k];
     a.n0[13] = n0[0];
     if (nTiles32 == 0) return 0;
-    hipLaunchKernelGGL(cone1_kernel, dim3(nTiles32 * (a.cout8 / 16)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(cone1_kernel, dim3(nTiles32 * (a.cout8 / 16), part ? 2 : 1), dim3(256), 0, s, a);
     HIPCHK(hipGetLastError());
     return 0;
 }

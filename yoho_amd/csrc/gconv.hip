@@ -158,7 +158,9 @@ static int init_t() {
 // 128 -> 4, each followed by BN + ReLU except the last, then q / |q|): one workgroup per 32-match tile keeps the activations in
 // LDS between the layers.  As three gconv_kernel<1, .> launches + quat_norm the tail was a chain of 80 workgroup barriers with a
 // weight load behind each (32 + 64 + 16 eight-channel chunks): 80 us per 1000 matches for 0.4 GFLOP.  Same fp32 MFMAs in the same
-// order per output (chunks ascending, x y z w inside a chunk) and the same epilogue expressions: the bits of the staged path.
+// order per output (chunks ascending, x y z w inside a chunk) and the same epilogue expressions: given the same input, the bits of
+// the staged path.  In the default PartII mode the input arrives as the two K halves of cone1_kernel and is finished while it is
+// staged (the staged path's cone1 sums its K in one chain: the last bits of its quaternions differ).
 struct MlpArgs {
     const float* X;                                        // [tile][cinA/8][60 slabs][256]: slab 0 = the group identity
     const float *WA, *biasA, *sA, *tA;                     // 256 -> 512, BN + ReLU
@@ -166,6 +168,9 @@ struct MlpArgs {
     const float *WC, *biasC;                               // 128 -> 32 (4 used), raw
     int cinA8, obA, obB, M;
     float* quat;
+    // X not finished yet: the producing layer (cone1_kernel with its K over two workgroups) left two partial sums
+    // [2][tile][cinA/8][256]; X = (p0 + p1) * descale + bias + res (res in X's layout), formed while staging
+    const float* part; const float* biasP; const float* resP; float descaleP; int nTiles;
 };
 
 __device__ __forceinline__ floatx4 quat_unit(floatx4 q) {
@@ -184,10 +189,21 @@ __global__ __launch_bounds__(256, 1) void mlp_head_kernel(MlpArgs a) {
     char* sX = smem;
     char* sA = sX + a.cinA8 * 1024;
     char* sB = sA + a.obA * 4 * 1024;
-    const float* Xt = a.X + (size_t)tile * a.cinA8 * CHUNK_FLOATS;
-    for (int p = w; p < a.cinA8; p += 4)
-        __builtin_amdgcn_global_load_lds((gptr_t)(Xt + (size_t)p * CHUNK_FLOATS + lane * 4), (lptr_t)(sX + p * 1024), 16, 0, 0);
     const int half = lane >> 5;
+    if (a.part) {
+        for (int p = w; p < a.cinA8; p += 4) {
+            const size_t o0 = (((size_t)tile * a.cinA8 + p) * 64 + lane) * 4, o1 = o0 + (size_t)a.nTiles * a.cinA8 * 256;
+            floatx4 val = *reinterpret_cast<const floatx4*>(a.part + o0) + *reinterpret_cast<const floatx4*>(a.part + o1);
+            val *= a.descaleP;
+            val += *reinterpret_cast<const floatx4*>(a.biasP + p * 8 + half * 4);
+            if (a.resP) val += *reinterpret_cast<const floatx4*>(a.resP + ((size_t)tile * a.cinA8 + p) * CHUNK_FLOATS + lane * 4);
+            *reinterpret_cast<floatx4*>(sX + p * 1024 + lane * 16) = val;
+        }
+    } else {
+        const float* Xt = a.X + (size_t)tile * a.cinA8 * CHUNK_FLOATS;
+        for (int p = w; p < a.cinA8; p += 4)
+            __builtin_amdgcn_global_load_lds((gptr_t)(Xt + (size_t)p * CHUNK_FLOATS + lane * 4), (lptr_t)(sX + p * 1024), 16, 0, 0);
+    }
     // ---- layer A: wave w owns the output blocks w, w + 4, w + 8, w + 12 (one fragment of the input serves four accumulators)
     {
         floatx16 acc[4];
@@ -317,9 +333,12 @@ bool mlp_head_supported(const Layer& A, const Layer& B, const Layer& C) {
            C.cin == 128 && C.cout_pad == 32;
 }
 
-int launch_mlp_head(const Layer& A, const Layer& B, const Layer& C, const float* X, int nTiles, int M, float* quat, hipStream_t s) {
+int launch_mlp_head(const Layer& A, const Layer& B, const Layer& C, const float* X, int nTiles, int M, float* quat, hipStream_t s,
+                    const float* part, const Layer* P, const float* res) {
     MlpArgs a;
     a.X = X;
+    a.part = part; a.biasP = P ? P->bias : nullptr; a.resP = res; a.descaleP = P ? P->wph_descale : 1.f; a.nTiles = nTiles;
+    if (part && !P) { set_error("mlp head: partial sums without their layer"); return YOHO_EINVAL; }
     a.WA = A.wp; a.biasA = A.bias; a.sA = A.bn_s; a.tA = A.bn_t;
     a.WB = B.wp; a.biasB = B.bias; a.sB = B.bn_s; a.tB = B.bn_t;
     a.WC = C.wp; a.biasC = C.bias;
