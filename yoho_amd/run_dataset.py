@@ -273,8 +273,9 @@ class ScenePairRunner:
     """HBM-resident execution of the pairs one rank owns.  estimator 'yohoo' (needs the PartII weights) or 'yohoc'.
 
     A fragment stays resident (FCGF group feature, PartI descriptor, keypoints: 77 MB at 5000 keypoints) exactly as long as a
-    pair of the current scene part still needs it: setup_scene counts the uses, run_pair releases a fragment after its last
-    pair, so a rank's footprint is bounded by one scene part whatever the number of parts it walks.
+    pair of its scene part still needs it: the part counts the uses, run_pair releases a fragment after its last pair, and
+    run_parts keeps at most two parts in flight (one whose pairs run, one being loaded and described), so a rank's footprint is
+    bounded by two scene parts whatever the number of parts it walks.
     `stats` accumulates where the time goes (seconds; device work is timed with a synchronise only when timing=True)."""
 
     def __init__(self, cfg, ctx, estimator="yohoo", max_iter=1000, base_seed=0, timing=False, write_npz=False, hypotheses="selected",
