@@ -349,6 +349,18 @@ int yoho_set_partI_schedule(yoho_ctx* ctx, int chunk_kp, int streams);
 int yoho_set_profiling(yoho_ctx* ctx, int enable);
 int yoho_get_kernel_ms(yoho_ctx* ctx, int which, float* ms);
 
+/* measurement hook for bench.py's `fcgf` leg: phase profile of the entries that are many launches long (the raw-cloud path
+ * yoho_fcgf_voxelize* -> yoho_fcgf_forward* -> yoho_group_transfer_batch; the reference has no counterpart, its extractor is timed
+ * from outside, simple_yoho/yoho_extract.py:57-77).  With the profile enabled those entries record events on their launch stream at
+ * phase boundaries; yoho_phase_read waits for `stream`, returns the accumulated milliseconds per category (ms[16]), the fp16 MFMA
+ * flops the category's launches issued (flops[16], counted at launch; null to skip), the number of such launches (launches[16]), and
+ * starts the accumulation again.  Categories: 0 voxelisation, 1 coordinate maps (hash tables, strided maps, cell sort, bounding
+ * boxes), 2 kernel maps (3^3 / strided / transposed maps, occupancy bitmaps, parity orders), 3 first convolution, 4..7 the 3^3
+ * stride-1 convolutions of level 0..3, 8..10 the strided convolution into level 1..3, 11..13 the transposed convolution out to level
+ * 0..2, 14 the 1x1 heads + normalisation, 15 nearest-neighbour feature transfer. */
+int yoho_phase_profile(yoho_ctx* ctx, int enable);
+int yoho_phase_read(yoho_ctx* ctx, double* ms, double* flops, double* launches, void* stream);
+
 /* measurement hook for bench.py: the shader clock the part actually sustains while other streams are loaded.  One wave spins for
  * `microseconds` of the constant-rate wall counter and writes out[0] = shader cycles elapsed (s_memtime), out[1] = wall-counter
  * ticks elapsed, out[2] = the wall counter's rate in kHz (device int64[3]); shader MHz = out[0] / out[1] * out[2] / 1000.  Launch

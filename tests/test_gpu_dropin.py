@@ -346,6 +346,100 @@ def test_evaluator_fmr_and_registration_recall(gold, tmp_path, sd1, sd2, part, i
     assert "Mean_Registration_Recall" in (tmp_path / "results.log").read_text()
 
 
+def _lay_out_lo(tmp_path, g, sd1, sd2):
+    """sceneLo.npz's scene as the reference saw it: origin/3dmatch/room (keypoints, gt.log, gtLo.log / gtLo.info), the FCGF group
+    features under Testset/3dmatch/room, PartII weights with the near-identity quaternion head."""
+    from yoho_amd import store
+    from yoho_amd.dataset import ThrDMatchPartDataset
+    store.clear()
+    nfrag = int(g["nfrag"])
+    lo_pairs = [tuple(int(v) for v in p) for p in g["lo_pairs"]]
+    sc = synth.make_scene(nfrag, int(g["K"]), seed=int(g["seed"]), res_deg=[float(v) for v in g["res_deg"]])
+    sroot = tmp_path / "origin" / "3dmatch" / "room"
+    cache = tmp_path / "cache"
+    synth.write_scene_files(sc, str(sroot), str(cache / "Testset" / "3dmatch/room"), lo_pairs=lo_pairs)
+    model_fn = tmp_path / "model"
+    for sub, sd in (("PartI_train", sd1), ("PartII_train", W.identity_head(sd2))):
+        os.makedirs(model_fn / sub)
+        W.save_checkpoint(str(model_fn / sub / "model_best.pth"), sd, 0.5)
+    ds3 = ThrDMatchPartDataset(str(sroot), nfrag)
+    ds3.name = "3dmatch/room"
+    dsLo = ThrDMatchPartDataset(str(sroot), nfrag, f"{sroot}/PointCloud/gtLo.log")        # utils/dataset.py:176-182
+    dsLo.name = "3dLomatch/room"
+    assert [tuple(int(v) for v in p) for p in dsLo.pair_ids] == lo_pairs and len(ds3.pair_ids) == nfrag * (nfrag - 1) // 2
+
+    def cfg(p):
+        return types.SimpleNamespace(
+            SO3_related_files=None, model_fn=str(model_fn), output_cache_fn=str(cache), origin_data_dir=str(tmp_path / "origin"),
+            test_network_type=f"{p}_test", train_network_type=f"{p}_train", test_batch_size=40 if p == "PartI" else 50,
+            ransac_c_inlinerdist=0.07, ransac_o_inlinerdist=0.09, extractor=p, matcher="Match",
+            estimator="yohoc" if p == "PartI" else "yohoo", descriptor="YOHO", fmr_ratio=0.05,
+            ok_match_dist_threshold=0.1, RR_dist_threshold=0.2, testset_name="3dLomatch")
+    return types.SimpleNamespace(sc=sc, ds3=ds3, dsLo=dsLo, cfg=cfg, cache=cache, lo_pairs=lo_pairs,
+                                 datasets={"wholesetname": "3dLomatch", "room": dsLo})
+
+
+@pytest.mark.parametrize("part,it,seedv,sign", [("PartI", 100, 15, "YOHO_C"), ("PartII", 1000, 16, "YOHO_O")])
+def test_3dLomatch_evaluators_match_reference(gold, tmp_path, sd1, sd2, part, it, seedv, sign):
+    """BASELINE config 4's 3DLoMatch half - the name-mapping path (tests/extractor.py:84-87,:152-158, tests/matcher.py:24-27,
+    tests/evaluator.py:41-47,:50-54, tests/estimator.py:84-87,:310-313, utils/dataset.py:176-182): a dataset named '3dLomatch/room'
+    reads features, descriptors and keypoints of '3dmatch/room', writes its own Match / DR_index / Trans_pre / YOHO_* / pre.log under
+    Testset/3dLomatch/room, and Evaluator_PartI skips Extract for it.  Golden: the reference's own classes on the same files
+    (oracle/gen_golden_r4.py): match lists, coarse rotations, FMR, per-pair flags, RR, pre.log, result.txt."""
+    from yoho_amd import evaluator, extractor, RR_cal
+    g = gold("sceneLo.npz")
+    w = _lay_out_lo(tmp_path, g, sd1, sd2)
+    cache3, cacheLo = w.cache / "Testset" / "3dmatch/room", w.cache / "Testset" / "3dLomatch/room"
+    ev = evaluator.name2evaluator[part](w.cfg(part), it)
+    if part == "PartI":
+        # without 3dmatch's descriptors the 3dLomatch evaluation has nothing to read: Extract is NOT run for '3dLo' names
+        with pytest.raises(FileNotFoundError):
+            ev.run_onescene(w.dsLo)
+        import shutil
+        shutil.rmtree(cacheLo)
+    extractor.extractor_PartI(w.cfg("PartI")).Extract(w.ds3)          # what a 3dmatch evaluation leaves behind
+    np.random.seed(seedv)
+    RR, FMRS, pair_fmrs = ev.eval(w.datasets, results_log=str(tmp_path / "results.log"))
+    assert sorted(os.listdir(cache3)) == ["FCGF_Input_Group_feature", "YOHO_Output_Group_feature"]
+    assert sorted(os.listdir(cacheLo)) == ["Match"]
+    for (a, b) in w.lo_pairs:
+        assert np.array_equal(np.load(cacheLo / "Match" / f"{a}-{b}.npy"), g[f"match_{a}_{b}"])
+        assert np.array_equal(np.load(cacheLo / "Match" / "DR_index" / f"{a}-{b}.npy"), g[f"dr_{a}_{b}"])
+        if part == "PartII":
+            z = np.load(cacheLo / "Match" / "YOHO_O" / "1000iters" / f"{a}-{b}.npz")
+            assert int(z["recalltime"]) == int(g[f"yohoo_recall_{a}_{b}"]) and rel(z["trans"], g[f"yohoo_trans_{a}_{b}"]) < 1e-4
+    assert np.array_equal(pair_fmrs, g[f"{part}_pair_fmrs"]) and FMRS[0] == float(g[f"{part}_FMR"])
+    assert RR == float(g[f"{part}_RR"])
+    _, flags, errors = RR_cal.benchmark(w.cfg(part), w.datasets, it, yoho_sign=sign)
+    assert flags["3dLomatch/room"] == list(g[f"{part}_flags"])
+    txt = (w.cache / "Testset" / "3dLomatch" / "Eval_results" / f"{sign}_RR" / f"{it}iters" / "result.txt").read_text()
+    assert txt.splitlines()[0] == str(g[f"{part}_result_txt"]).splitlines()[0] and "3dLomatch/room" in txt
+    _, mine = RR_cal.read_pre_trajectory(str(cacheLo / "Match" / sign / f"{it}iters" / "pre.log"))
+    ref_log = tmp_path / "ref_pre.log"
+    ref_log.write_text(str(g[f"{part}_prelog"]))
+    ref_pairs, ref = RR_cal.read_pre_trajectory(str(ref_log))
+    assert rel(mine, ref) < 1e-4
+    print("sceneLo %s: RR %.3f (reference %.3f), FMR %.3f" % (part, RR, float(g[f"{part}_RR"]), FMRS[0]))
+
+
+def test_3dLomatch_through_the_dataset_driver(gold, tmp_path, sd1, sd2):
+    """The sharded driver on the same 3DLoMatch files: run_dataset.eval_sharded reads 3dmatch's FCGF features / keypoints for a
+    '3dLomatch/..' scene, writes npz + pre.log under Testset/3dLomatch/.., and gets the reference's YOHO-O flags and RR."""
+    from yoho_amd import run_dataset, RR_cal
+    g = gold("sceneLo.npz")
+    w = _lay_out_lo(tmp_path, g, sd1, sd2)
+    stats = {}
+    rr = run_dataset.eval_sharded(w.cfg("PartII"), max_iter=1000, estimator="yohoo", datasets=w.datasets, base_seed=3,
+                                  results_log=str(tmp_path / "results.log"), stats_out=stats)
+    _, flags, _ = RR_cal.benchmark(w.cfg("PartII"), w.datasets, 1000, yoho_sign="YOHO_O")
+    assert flags["3dLomatch/room"] == list(g["PartII_flags"]) and rr == float(g["PartII_RR"])
+    assert stats["pairs"] == len(w.lo_pairs) and stats["fragments"] == int(g["nfrag"])
+    sdir = w.cache / "Testset" / "3dLomatch/room" / "Match" / "YOHO_O" / "1000iters"
+    est_pairs, _ = RR_cal.read_pre_trajectory(str(sdir / "pre.log"))
+    assert [tuple(int(v) for v in p[:2]) for p in est_pairs] == w.lo_pairs
+    assert not (w.cache / "Testset" / "3dmatch/room" / "Match").exists()
+
+
 def test_testset_create_from_point_clouds(tmp_path, tables):
     """YOHO_testset.py drop-in: fragment point clouds + keypoints -> FCGF_Input_Group_feature/{id}.npy; three of the
     sixty group elements are checked against the oracle chain (voxelise, backbone, f64 NN gather)."""
@@ -409,6 +503,7 @@ def test_eval_sharded_world1_on_scene6(gold, tmp_path, sd1, sd2, tables, estimat
     assert np.array_equal(np.asarray(flags[ds.name]), g[f"{part}_flags"]), (flags[ds.name], g[f"{part}_flags"])
     assert rr == float(g[f"{part}_RR"])
     assert stats["fragments"] == nfrag and stats["pairs"] == len(ds.pair_ids) and stats["peak_resident_fragments"] == nfrag
+    assert stats["range_guard"]["repeats_this_run"] == 0 and not stats["range_guard"]["partI_stays_bf16x3"]
     # the files the reference's estimator leaves: one npz per pair + pre.log in pair order
     sdir = cache / "Testset" / "synth4/room" / "Match" / sign / f"{it}iters"
     est_pairs, est = RR_cal.read_pre_trajectory(str(sdir / "pre.log"))
@@ -440,6 +535,56 @@ def test_eval_sharded_world1_on_scene6(gold, tmp_path, sd1, sd2, tables, estimat
     for p in pairs[1:5]:
         runner.run_pair(ds, p)
     assert runner.frag == {} and runner.uses == {}
+
+
+def test_eval_sharded_counts_range_repeats_and_workers_go_sticky(gold, tmp_path, sd1, sd2):
+    """A PartII checkpoint whose activations leave the fp16 planes (BN gamma x 20000) through the dataset driver: the one-call pair
+    reports the flag, the pair is composed once more in bf16x3 (not a second fp16x2 attempt), after three such pairs a worker's
+    PartII stays in bf16x3, and the run's stats say so; every transform equals run_pair with PartII in bf16x3 from the start."""
+    import warnings
+    from yoho_amd import run_dataset, store, pipeline, hip
+    from yoho_amd.dataset import ThrDMatchPartDataset
+    store.clear()
+    g = gold("scene6.npz")
+    sdx = {k: v.copy() for k, v in W.identity_head(sd2).items()}
+    key = "PartII_SO3_Conv_layers.0.comb_layer_in.0.weight"
+    sdx[key] = (sdx[key] * np.float32(20000.0)).astype(np.float32)
+    nfrag = int(g["nfrag"])
+    sc = synth.make_scene(nfrag, int(g["K"]), seed=int(g["seed"]), res_deg=[float(v) for v in g["res_deg"]])
+    sroot, cache = tmp_path / "origin" / "synth4" / "room", tmp_path / "cache"
+    synth.write_scene_files(sc, str(sroot), str(cache / "Testset" / "synth4/room"))
+    ds = ThrDMatchPartDataset(str(sroot), nfrag)
+    ds.name = "synth4/room"
+    cfg = types.SimpleNamespace(SO3_related_files=None, model_fn=None, output_cache_fn=str(cache), origin_data_dir=str(tmp_path / "origin"),
+                                ransac_c_inlinerdist=0.07, ransac_o_inlinerdist=0.09, RR_dist_threshold=0.2, testset_name="synth4")
+    ctx = hip.Context()
+    stats = {}
+    with warnings.catch_warnings(record=True) as wrn:
+        warnings.simplefilter("always")
+        run_dataset.eval_sharded(cfg, max_iter=1000, estimator="yohoo", datasets={"wholesetname": "synth4", "room": ds}, base_seed=3,
+                                 ctx=ctx, state_dicts=(sd1, sdx), stats_out=stats, hypotheses="all")
+    rg = stats["range_guard"]
+    npairs = len(ds.pair_ids)
+    print("range guard through the dataset driver:", rg)
+    assert 3 <= rg["repeats_this_run"] <= npairs and rg["partII_repeats_since_checkpoint"] == rg["repeats_this_run"]
+    assert rg["partII_workers_staying_bf16x3"] >= 1 and not rg["partI_stays_bf16x3"]
+    assert any("STAYS in bf16x3" in str(w.message) for w in wrn)
+    wide = hip.Context()
+    wide.load_partI(sd1)
+    wide.load_partII(sdx)
+    wide.set_partII_mode("bf16x3")
+    cu = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    desc = {}
+    for k in range(nfrag):
+        o = wide.partI_forward(cu(sc["feats"][k]), want_inv=False, want_inv_np=True)
+        desc[str(k)] = (cu(sc["feats"][k]), cu(sc["keys"][k]), {"eqv": o["eqv"], "inv_np": o["inv_np"]})
+    for (a, b), res in zip(ds.pair_ids, stats["results"]["room"]):
+        seed = run_dataset.pair_seed(3, ds.name, a, b)
+        fa, ka, oa = desc[str(a)]
+        fb, kb, ob = desc[str(b)]
+        r = pipeline.run_pair(wide, fa, fb, ka, kb, inlier_dist=0.09, max_iter=1000, order_rng=np.random.RandomState(seed & 0xFFFFFFFF),
+                              eqv=(oa, ob), seed=seed)
+        assert np.array_equal(np.asarray(r.trans, np.float64), res["trans"]) and int(r.best_h) == res["recalltime"], (a, b)
 
 
 def _world2_dataset_worker(rank, port, workdir, q):

@@ -396,6 +396,7 @@ int yoho_ctx_destroy(yoho_ctx* c) {
     delete c->fb;
     for (auto& e : c->ev) (void)hipEventDestroy(e);
     for (auto& e : c->ev_pass) if (e) (void)hipEventDestroy(e);
+    for (auto& e : c->phase.pool) (void)hipEventDestroy(e);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
@@ -520,6 +521,38 @@ int yoho_set_profiling(yoho_ctx* c, int enable) {
     c->profiling = enable != 0;
     c->ev_chunks = 0;
     for (auto& m : c->kernel_ms) m = -1.f;
+    return 0;
+}
+
+// Phase profile of the multi-launch entries (PhaseProf in common.h; categories in include/yoho_hip.h).
+int yoho_phase_profile(yoho_ctx* c, int enable) {
+    if (!c) { set_error("null ctx"); return YOHO_EINVAL; }
+    PhaseProf& p = c->phase;
+    p.on = enable != 0;
+    p.used = 0; p.spans.clear(); p.open_cat = -1;
+    for (int i = 0; i < PhaseProf::NCAT; ++i) { p.flops[i] = 0; p.launches[i] = 0; }
+    return 0;
+}
+
+int yoho_phase_read(yoho_ctx* c, double* ms, double* flops, double* launches, void* stream) {
+    if (!c || !ms) { set_error("yoho_phase_read: bad argument"); return YOHO_EINVAL; }
+    HIPCHK(hipSetDevice(c->device));
+    PhaseProf& p = c->phase;
+    phase_mark(c, -1, (hipStream_t)stream);                   // ends a span left open
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    for (int i = 0; i < PhaseProf::NCAT; ++i) ms[i] = 0.0;
+    for (const auto& sp : p.spans) {
+        float d = 0.f;
+        HIPCHK(hipEventSynchronize(sp.b));
+        HIPCHK(hipEventElapsedTime(&d, sp.a, sp.b));
+        ms[sp.cat] += d;
+    }
+    for (int i = 0; i < PhaseProf::NCAT; ++i) {
+        if (flops) flops[i] = p.flops[i];
+        if (launches) launches[i] = p.launches[i];
+        p.flops[i] = 0; p.launches[i] = 0;
+    }
+    p.used = 0; p.spans.clear(); p.open_cat = -1;
     return 0;
 }
 
@@ -995,11 +1028,13 @@ int yoho_group_transfer_batch(yoho_ctx* c, const double* pts, const int64_t* kid
     for (int b = 0; b < nb; ++b)
         if (!ds[b] || !feat[b] || m[b] < 1) { set_error("yoho_group_transfer_batch: copy %d has no down-sampled points", b); return YOHO_EINVAL; }
     int rc;
+    phase_mark(c, 15, (hipStream_t)stream);
     for (int b = 0; b < nb; ++b) {
         if ((rc = yoho_rotate_select(c, pts, R_host + 9 * (size_t)b, kidx, K, q_scratch, stream))) return rc;
         if ((rc = yoho_nn_search(c, q_scratch, K, ds[b], m[b], 3, YOHO_DIST_SQUARE_L2, idx_scratch, nullptr, stream))) return rc;
         if ((rc = yoho_group_scatter(c, feat[b], m[b], idx_scratch, K, g0 + b, out, stream))) return rc;
     }
+    phase_mark(c, -1, (hipStream_t)stream);
     return 0;
 }
 

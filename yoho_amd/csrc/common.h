@@ -178,6 +178,24 @@ struct Workspace {
     size_t bytes = 0;
 };
 
+// Accumulating phase timer for the entries that are many launches long (the FCGF path: voxelisation, coordinate / kernel maps, the
+// convolutions of each level, the feature transfer).  phase_mark(ctx, cat, s) records ONE event on the launch stream: it ends the
+// span that is open and starts one in category `cat` (cat < 0: only ends); yoho_phase_read sums the spans per category.  Beside
+// the time a category collects the fp16 MFMA flops its launches issue (counted on the host at launch).  Off by default
+// (yoho_phase_profile): then a mark is one load and a branch.
+struct PhaseProf {
+    static constexpr int NCAT = 16;
+    bool on = false;
+    std::vector<hipEvent_t> pool;
+    size_t used = 0;
+    struct Span { int cat; hipEvent_t a, b; };
+    std::vector<Span> spans;
+    int open_cat = -1;
+    hipEvent_t open_ev = nullptr;
+    double flops[NCAT] = {0};
+    double launches[NCAT] = {0};
+};
+
 }  // namespace yoho
 
 struct yoho_ctx {
@@ -231,5 +249,26 @@ struct yoho_ctx {
     hipEvent_t ev_pass[2] = {nullptr, nullptr};   // around the whole pass on the caller's stream
     bool ev_created = false;
     float kernel_ms[8];
+    yoho::PhaseProf phase;
 };
+namespace yoho {
+inline void phase_mark(yoho_ctx* c, int cat, hipStream_t s) {
+    PhaseProf& p = c->phase;
+    if (!p.on) return;
+    if (p.open_cat < 0 && cat < 0) return;
+    if (p.used == p.pool.size()) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return;
+        p.pool.push_back(e);
+    }
+    hipEvent_t e = p.pool[p.used++];
+    (void)hipEventRecord(e, s);
+    if (p.open_cat >= 0) p.spans.push_back({p.open_cat, p.open_ev, e});
+    p.open_cat = cat < PhaseProf::NCAT ? cat : -1;
+    p.open_ev = e;
+}
+inline void phase_work(yoho_ctx* c, int cat, double flops) {
+    if (c->phase.on && cat >= 0 && cat < PhaseProf::NCAT) { c->phase.flops[cat] += flops; c->phase.launches[cat] += 1.0; }
+}
+}  // namespace yoho
 namespace yoho { constexpr int EV_PER_PASS = 11; }

@@ -186,6 +186,111 @@ static int launch_first_compact(const CoordSrc& src, int n, const u64* keys, con
     return 0;
 }
 
+// ---- batched voxelisation: the rotated copies of ONE cloud, copy = blockIdx.y --------------------------------------------------
+// Per copy the same stages as fcgf_voxelize (insert-min, count, scan, scatter), but one launch per stage for up to VOX_BATCH
+// copies: 300 k points are ~1200 workgroups, far too few to cover the latency of the table atomics, and 7 launches per copy were
+// 105 per backbone pass.  The rotations travel in the kernel arguments.  A copy's table / block sums / counters are slices of one
+// allocation; the scatter also writes the rotated fp32 points of the selected rows (the reference's pcd[sel].float(): the very f64
+// values the voxel index was taken from), so no second pass over `sel` is needed.
+constexpr int VOX_BATCH = 16;
+struct VoxBatch {
+    const double* pts; int n; double voxel;
+    double R[VOX_BATCH][9];
+    u64* keys; int* vals; unsigned cap;          // copy b: keys + b * cap
+    int* bsum; int nblk;                         // copy b: bsum + b * (nblk + 1)
+    int* dcount;                                 // copy b: [2b] voxels, [2b + 1] out-of-range flag
+    int* coords; int64_t* sel; float* pts_sel;   // copy b: + b * n rows (pts_sel may be null)
+};
+__device__ __forceinline__ void vox_point(const VoxBatch& a, int b, int i, double& p0, double& p1, double& p2) {
+    const double q0 = a.pts[3 * (size_t)i], q1 = a.pts[3 * (size_t)i + 1], q2 = a.pts[3 * (size_t)i + 2];
+    const double* R = a.R[b];
+    p0 = rot_coord(R, q0, q1, q2); p1 = rot_coord(R + 3, q0, q1, q2); p2 = rot_coord(R + 6, q0, q1, q2);
+}
+__global__ void vox_clear_kernel(u64* keys, int* vals, size_t total) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < total) { keys[i] = HEMPTY; vals[i] = 0x7FFFFFFF; }
+}
+__global__ void vox_insert_kernel(VoxBatch a) {
+    const int i = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    if (i >= a.n) return;
+    double p0, p1, p2;
+    vox_point(a, b, i, p0, p1, p2);
+    const int x = voxel_index(p0, a.voxel), y = voxel_index(p1, a.voxel), z = voxel_index(p2, a.voxel);
+    if (x < -VOX_LIM || x > VOX_LIM || y < -VOX_LIM || y > VOX_LIM || z < -VOX_LIM || z > VOX_LIM) atomicOr(a.dcount + 2 * b + 1, 1);
+    const u64 key = pack_key(x, y, z, 0);
+    u64* keys = a.keys + (size_t)b * a.cap;
+    int* vals = a.vals + (size_t)b * a.cap;
+    const unsigned mask = a.cap - 1;
+    unsigned s = hslot(key, mask);
+    for (;;) {
+        const u64 old = atomicCAS(&keys[s], HEMPTY, key);
+        if (old == HEMPTY || old == key) { atomicMin(&vals[s], i); return; }
+        s = (s + 1) & mask;
+    }
+}
+__device__ __forceinline__ bool vox_is_first(const VoxBatch& a, int b, int i, int& x, int& y, int& z, double& p0, double& p1, double& p2) {
+    if (i >= a.n) return false;
+    vox_point(a, b, i, p0, p1, p2);
+    x = voxel_index(p0, a.voxel); y = voxel_index(p1, a.voxel); z = voxel_index(p2, a.voxel);
+    const int slot = hash_find_slot(a.keys + (size_t)b * a.cap, a.cap - 1, pack_key(x, y, z, 0));
+    return a.vals[(size_t)b * a.cap + slot] == i;
+}
+__global__ __launch_bounds__(1024) void vox_count_kernel(VoxBatch a) {
+    __shared__ int wsum[16];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, b = blockIdx.y;
+    int x, y, z; double p0, p1, p2;
+    const bool keep = vox_is_first(a, b, blockIdx.x * 1024 + tid, x, y, z, p0, p1, p2);
+    const unsigned long long m = __ballot(keep);
+    if (lane == 0) wsum[wv] = __popcll(m);
+    __syncthreads();
+    if (tid == 0) { int t = 0; for (int k = 0; k < 16; ++k) t += wsum[k]; a.bsum[(size_t)b * (a.nblk + 1) + blockIdx.x] = t; }
+}
+// one workgroup per copy: exclusive scan of its block counts in place, total -> dcount[2b]
+__global__ __launch_bounds__(1024) void vox_scan_kernel(VoxBatch a) {
+    __shared__ int sh[1024];
+    __shared__ int carry;
+    const int tid = threadIdx.x, b = blockIdx.x;
+    int* bsum = a.bsum + (size_t)b * (a.nblk + 1);
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (int b0 = 0; b0 < a.nblk; b0 += 1024) {
+        const int i = b0 + tid;
+        const int v = i < a.nblk ? bsum[i] : 0;
+        sh[tid] = v;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {
+            const int t = tid >= o ? sh[tid - o] : 0;
+            __syncthreads();
+            sh[tid] += t;
+            __syncthreads();
+        }
+        if (i < a.nblk) bsum[i] = carry + sh[tid] - v;
+        __syncthreads();
+        if (tid == 0) carry += sh[1023];
+        __syncthreads();
+    }
+    if (tid == 0) a.dcount[2 * b] = carry;
+}
+__global__ __launch_bounds__(1024) void vox_scatter_kernel(VoxBatch a) {
+    __shared__ int wsum[16];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, b = blockIdx.y;
+    const int i = blockIdx.x * 1024 + tid;
+    int x = 0, y = 0, z = 0; double p0 = 0, p1 = 0, p2 = 0;
+    const bool keep = vox_is_first(a, b, i, x, y, z, p0, p1, p2);
+    const unsigned long long m = __ballot(keep);
+    const int before = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) wsum[wv] = __popcll(m);
+    __syncthreads();
+    int off = a.bsum[(size_t)b * (a.nblk + 1) + blockIdx.x];
+    for (int k = 0; k < wv; ++k) off += wsum[k];
+    if (keep) {
+        const size_t r = (size_t)b * a.n + off + before;
+        a.coords[3 * r] = x; a.coords[3 * r + 1] = y; a.coords[3 * r + 2] = z;
+        a.sel[r] = i;
+        if (a.pts_sel) { a.pts_sel[3 * r] = (float)p0; a.pts_sel[3 * r + 1] = (float)p1; a.pts_sel[3 * r + 2] = (float)p2; }
+    }
+}
+
 // table value := row of the compacted map
 __global__ void hash_set_rows_kernel(const int* coords, int n, const u64* keys, int* vals, unsigned mask) {
     const int r = blockIdx.x * 256 + threadIdx.x;
@@ -230,6 +335,46 @@ __global__ void build_map_kernel(const int* out_coords, int nout, const u64* key
         row = slot < 0 ? -1 : vals[slot];
     }
     map[(size_t)k * nout + n] = row;
+}
+
+// The 3^3 stride-1 map of a level onto itself is symmetric under the point reflection of the kernel: (k, in = i, out = o) is a
+// pair iff (26 - k, in = o, out = i) is.  So only the offsets k < 13 are looked up; a hit also fills map[26 - k][i] = o (each
+// (k', row) entry has one possible writer: the row at coord(row) + offset(k'), so the stores do not race), k = 13 is the identity,
+// and the upper half is preset to -1 by the caller.  Halves the hash probes of the largest maps.
+__global__ void build_map_sym_kernel(const int* out_coords, int nout, const u64* keys, const int* vals, unsigned mask, int ts,
+                                     const BmDesc* __restrict__ desc, const unsigned* __restrict__ bm, int* map) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    const int k = blockIdx.y;                                  // 0..13
+    if (n >= nout) return;
+    if (k == 13) { map[(size_t)13 * nout + n] = n; return; }
+    const int ox = (k % 3 - 1) * ts, oy = ((k / 3) % 3 - 1) * ts, oz = (k / 9 - 1) * ts;
+    const int4 c = reinterpret_cast<const int4*>(out_coords)[n];
+    const int qx = c.x + ox, qy = c.y + oy, qz = c.z + oz;
+    int row = -1;
+    bool probe = true;
+    if (bm) {
+        const BmDesc d = desc[c.w];
+        const int bx = qx - d.x0, by = qy - d.y0, bz = qz - d.z0;
+        if (bx >= 0 && bx < d.wx * 32 && by >= 0 && by < d.ny && bz >= 0 && bz < d.nz)
+            probe = (bm[d.base + ((long long)bz * d.ny + by) * d.wx + (bx >> 5)] >> (bx & 31)) & 1u;
+    }
+    if (probe) {
+        const int slot = hash_find_slot(keys, mask, pack_key(qx, qy, qz, c.w));
+        row = slot < 0 ? -1 : vals[slot];
+    }
+    map[(size_t)k * nout + n] = row;
+    if (row >= 0) map[(size_t)(26 - k) * nout + row] = n;
+}
+
+// A transposed convolution's kernel map is the strided convolution's with input and output exchanged (MinkowskiEngine asks its
+// manager for the same map with is_transpose, src/convolution_transpose_cpu.cpp:75-107): up[k][f] = c  iff  down[k][c] = f.
+// `up` is preset to -1; every (k, f) has at most one coarse row c, so the stores do not race.
+__global__ void invert_map_kernel(const int* __restrict__ down, int ncoarse, int nfine, int* __restrict__ up) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int k = blockIdx.y;
+    if (c >= ncoarse) return;
+    const int f = down[(size_t)k * ncoarse + c];
+    if (f >= 0) up[(size_t)k * nfine + f] = c;
 }
 
 // (n,3) voxel rows of `nb` concatenated clouds (row ranges off[0..nb]) -> (n,4) rows with the cloud index
@@ -1371,6 +1516,7 @@ int fcgf_forward(yoho_ctx* ctx, const FcgfNet* net, const int* coords0, int n0, 
     const int* C = net->C; const int* T = net->T;
     Level L[4];
     int* dcount = ar.take<int>(4);
+    phase_mark(ctx, 1, s);
     // ---- coordinate maps
     L[0].n = n0; L[0].ts = 1; L[0].coords = ar.take<int>((size_t)n0 * 4);
     {
@@ -1446,6 +1592,7 @@ int fcgf_forward(yoho_ctx* ctx, const FcgfNet* net, const int* coords0, int n0, 
             }
     }
     // ---- kernel maps
+    phase_mark(ctx, 2, s);
     const BmDesc* map_desc = nullptr;          // set once the level-0 occupancy bitmaps exist
     const unsigned* map_bm = nullptr;
     auto make_map = [&](const Level& outL, const Level& inL, int ksize, int ts, int sign) -> int* {
@@ -1489,10 +1636,28 @@ int fcgf_forward(yoho_ctx* ctx, const FcgfNet* net, const int* coords0, int n0, 
     }
     if (dbm) { map_desc = ddesc; map_bm = dbm; }
     int* Msame[4]; int* Mdown[3]; int* Mup[3];
-    for (int l = 0; l < 4; ++l) Msame[l] = make_map(L[l], L[l], 3, L[l].ts, +1);
+    static const bool full_maps = [] { const char* e = std::getenv("YOHO_FCGF_MAPS"); return e && std::strcmp(e, "full") == 0; }();   // A/B: every map by hash probes
+    for (int l = 0; l < 4; ++l) {
+        if (full_maps) { Msame[l] = make_map(L[l], L[l], 3, L[l].ts, +1); continue; }
+        // symmetric 3^3 map: offsets 0..12 looked up, 14..26 mirrored, 13 = identity (build_map_sym_kernel)
+        Msame[l] = ar.take<int>((size_t)27 * L[l].n);
+        if (ar.off > ar.cap) { set_error("fcgf_forward: workspace estimate too small"); return YOHO_ENOMEM; }
+        if (L[l].n == 0) continue;
+        HIPCHK(hipMemsetAsync(Msame[l] + (size_t)14 * L[l].n, 0xFF, sizeof(int) * (size_t)13 * L[l].n, s));
+        const bool filter = map_bm && L[l].ts == 1;
+        hipLaunchKernelGGL(build_map_sym_kernel, dim3((L[l].n + 255) / 256, 14), dim3(256), 0, s, L[l].coords, L[l].n, L[l].keys, L[l].vals, L[l].mask,
+                           L[l].ts, filter ? map_desc : nullptr, filter ? map_bm : nullptr, Msame[l]);
+    }
     for (int l = 0; l < 3; ++l) {
         Mdown[l] = make_map(L[l + 1], L[l], 3, L[l].ts, +1);           // strided conv: offsets on the input (finer) stride
-        Mup[l] = make_map(L[l], L[l + 1], 3, L[l].ts, -1);             // transposed: coarse row at coord(fine) - offset
+        if (full_maps) { Mup[l] = make_map(L[l], L[l + 1], 3, L[l].ts, -1); continue; }     // transposed: coarse row at coord(fine) - offset
+        // ... which is the strided map with input and output exchanged (invert_map_kernel): no second probe pass
+        Mup[l] = ar.take<int>((size_t)27 * L[l].n);
+        if (ar.off > ar.cap) { set_error("fcgf_forward: workspace estimate too small"); return YOHO_ENOMEM; }
+        if (L[l].n == 0) continue;
+        HIPCHK(hipMemsetAsync(Mup[l], 0xFF, sizeof(int) * (size_t)27 * L[l].n, s));
+        if (L[l + 1].n > 0)
+            hipLaunchKernelGGL(invert_map_kernel, dim3((L[l + 1].n + 255) / 256, 27), dim3(256), 0, s, Mdown[l], L[l + 1].n, L[l].n, Mup[l]);
     }
     // parity-sorted row orders of levels 0..2 for the transposed convolutions
     int* perm[3]; int nperm[3];
@@ -1521,9 +1686,14 @@ int fcgf_forward(yoho_ctx* ctx, const FcgfNet* net, const int* coords0, int n0, 
     enc3 = ar.take<float>((size_t)L[3].n * C[4]);
     if (ar.off > ar.cap) { set_error("fcgf_forward: workspace estimate too small (%zu > %zu)", ar.off, ar.cap); return YOHO_ENOMEM; }
 
+    int conv_cat = -1;                          // phase category of the next conv() calls (yoho_phase_read)
     auto conv = [&](const float* in, int ldin, int cin, const int* map, int K, int nout, const ConvW& W, int cout, float* o, int ldout,
                     int ocoff, const BnAff* bn, const float* bias, const float* res, int ldres, int rcoff, int relu,
                     const int* rowperm = nullptr, int nslots = 0) -> int {
+        phase_mark(ctx, conv_cat, s);
+        // fp16 MFMA flops the launch issues: every 32-row tile walks all K offsets x cin x cout, 3 split products (the
+        // parity-sorted transposed convolutions skip offsets by data: not counted)
+        if (W.wh && !rowperm && cin % 32 == 0 && cout % 32 == 0) phase_work(ctx, conv_cat, 2.0 * 3.0 * (double)((nout + 31) / 32 * 32) * K * cin * cout);
         SpConvArgs a;
         a.rowperm = rowperm; a.nslots = rowperm ? nslots : nout;
         a.in = in; a.ldin = ldin; a.cin = cin; a.map = map; a.K = K; a.nout = nout; a.W = W.w; a.Wh = W.wh; a.descale = W.descale; a.cout = cout;
@@ -1540,6 +1710,8 @@ int fcgf_forward(yoho_ctx* ctx, const FcgfNet* net, const int* coords0, int n0, 
 
     // encoder (resunet.py:142-160).  The block outputs land in the decoder's concatenation buffers (right-hand columns).
     const int k1v = net->k1 * net->k1 * net->k1;
+    phase_mark(ctx, 3, s);
+    conv_cat = 3;
     if (conv1_fused) {
         if (dbm && net->c1planes)
             hipLaunchKernelGGL(conv1_mfma_kernel, dim3(std::min((n0 + 127) / 128, 3 * (ctx->nCU > 0 ? ctx->nCU : 256))), dim3(256), 0, s, L[0].coords, n0, ddesc, dbm,
@@ -1553,12 +1725,15 @@ int fcgf_forward(yoho_ctx* ctx, const FcgfNet* net, const int* coords0, int n0, 
         HIPCHK(hipGetLastError());
     } else if ((rc = conv(ones, net->in_ch, net->in_ch, M1, k1v, n0, net->conv[0], C[1], x[0], C[1], 0, &net->norm[0], nullptr, nullptr, 0, 0, 0)))
         return rc;
+    conv_cat = 4;
     if ((rc = block(0, x[0], C[1], net->bconv[0], net->bnorm[0], tmp[0], cat[0], catw[0], catoff[0]))) return rc;
     for (int l = 1; l < 4; ++l) {
         const float* in = cat[l - 1] + catoff[l - 1];
+        conv_cat = 7 + l;
         if ((rc = conv(in, catw[l - 1], C[l], Mdown[l - 1], 27, L[l].n, net->conv[l], C[l + 1], x[l], C[l + 1], 0, &net->norm[l], nullptr, nullptr,
                        0, 0, 0))) return rc;
         float* o = l < 3 ? cat[l] : enc3;
+        conv_cat = 4 + l;
         if ((rc = block(l, x[l], C[l + 1], net->bconv[l], net->bnorm[l], tmp[l], o, l < 3 ? catw[l] : C[4], l < 3 ? catoff[l] : 0))) return rc;
     }
     // decoder (resunet.py:162-181): conv_tr -> norm -> block -> left-hand columns of the concatenation buffer
@@ -1569,19 +1744,23 @@ int fcgf_forward(yoho_ctx* ctx, const FcgfNet* net, const int* coords0, int n0, 
         float* u = ar.take<float>((size_t)L[l].n * co);
         float* sc = ar.take<float>((size_t)L[l].n * co);
         if (ar.off > ar.cap) { set_error("fcgf_forward: workspace estimate too small"); return YOHO_ENOMEM; }
+        conv_cat = 11 + l;
         if ((rc = conv(din, dld, dcin, Mup[l], 27, L[l].n, net->conv_tr[j], co, u, co, 0, &net->norm_tr[j], nullptr, nullptr, 0, 0, 0,
                        ctx->fcgf_parity_sort ? perm[l] : nullptr, nperm[l]))) return rc;
+        conv_cat = 4 + l;
         if ((rc = block(l, u, co, net->bconv_tr[j], net->bnorm_tr[j], sc, cat[l], catw[l], 0))) return rc;
         din = cat[l]; dld = catw[l]; dcin = catw[l];
     }
     float* f1 = ar.take<float>((size_t)n0 * T[1]);
     float* f2 = ar.take<float>((size_t)n0 * net->out_ch);
     if (ar.off > ar.cap) { set_error("fcgf_forward: workspace estimate too small"); return YOHO_ENOMEM; }
+    conv_cat = 14;
     if ((rc = conv(cat[0], catw[0], catw[0], nullptr, 1, n0, net->conv1_tr, T[1], f1, T[1], 0, nullptr, nullptr, nullptr, 0, 0, 1))) return rc;
     if ((rc = conv(f1, T[1], T[1], nullptr, 1, n0, net->final_k, net->out_ch, f2, net->out_ch, 0, nullptr, net->final_b, nullptr, 0, 0, 0))) return rc;
     hipLaunchKernelGGL(row_normalize_kernel, dim3(net->out_ch <= 32 ? (n0 + 31) / 32 : (n0 + 3) / 4), dim3(256), 0, s, f2, n0, net->out_ch, out,
                        net->normalize ? 1 : 0, operm);
     HIPCHK(hipGetLastError());
+    phase_mark(ctx, -1, s);
     return 0;
 }
 
@@ -1647,28 +1826,38 @@ int fcgf_voxelize_batch(yoho_ctx* ctx, const double* pts, int n, const double* R
     if (n == 0) return 0;
     int rc;
     const unsigned cap = table_cap(n);
-    const size_t per = (size_t)cap * 12 + ((size_t)(n + 1023) / 1024 + 1) * 4 + 1024;
+    const int nblk = (n + 1023) / 1024;
+    const size_t per = (size_t)cap * 12 + ((size_t)nblk + 1) * 4 + 1024;
     if ((rc = ensure_ws(ctx, per * nb + 8192, s))) return rc;
     Arena ar{(char*)ctx->ws.p, 0, ctx->ws.bytes};
     int* dcount = ar.take<int>(2 * (size_t)nb);          // per copy: [0] number of voxels, [1] out-of-range flag
+    u64* keys = ar.take<u64>((size_t)cap * nb);
+    int* vals = ar.take<int>((size_t)cap * nb);
+    int* bsum = ar.take<int>(((size_t)nblk + 1) * nb);
+    if (ar.off > ar.cap) { set_error("fcgf_voxelize_batch: workspace estimate too small"); return YOHO_ENOMEM; }
+    phase_mark(ctx, 0, s);
     HIPCHK(hipMemsetAsync(dcount, 0, 2 * sizeof(int) * nb, s));
-    for (int b = 0; b < nb; ++b) {
-        Level L;
-        L.mask = cap - 1; L.keys = ar.take<u64>(cap); L.vals = ar.take<int>(cap);
-        int* bsum = ar.take<int>((size_t)(n + 1023) / 1024 + 1);
-        if (ar.off > ar.cap) { set_error("fcgf_voxelize_batch: workspace estimate too small"); return YOHO_ENOMEM; }
-        CoordSrc src{nullptr, pts, voxel, 1, 1, {0}, dcount + 2 * b + 1};
-        for (int i = 0; i < 9; ++i) src.R[i] = R_host[9 * b + i];
-        if ((rc = build_table(src, n, L, s))) return rc;
-        if ((rc = launch_first_compact(src, n, L.keys, L.vals, L.mask, bsum, coords + (size_t)b * n * 3, 3, sel + (size_t)b * n, dcount + 2 * b, s))) return rc;
-        if (pts_sel) {
-            CoordSrc rs{nullptr, pts, 1.0, 1, 1, {0}};
-            for (int i = 0; i < 9; ++i) rs.R[i] = R_host[9 * b + i];
-            hipLaunchKernelGGL(rotate_sel_kernel, dim3((n + 255) / 256), dim3(256), 0, s, rs, sel + (size_t)b * n, n, pts_sel + (size_t)b * n * 3,
-                               (const int*)(dcount + 2 * b));
-        }
+    {
+        const size_t total = (size_t)cap * nb;
+        hipLaunchKernelGGL(vox_clear_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, keys, vals, total);
+    }
+    // the stages of up to VOX_BATCH copies per launch (copy = blockIdx.y; the rotations travel in the kernel arguments)
+    for (int b0 = 0; b0 < nb; b0 += VOX_BATCH) {
+        const int nbc = nb - b0 < VOX_BATCH ? nb - b0 : VOX_BATCH;
+        VoxBatch a;
+        a.pts = pts; a.n = n; a.voxel = voxel;
+        for (int b = 0; b < nbc; ++b) for (int i = 0; i < 9; ++i) a.R[b][i] = R_host[9 * (size_t)(b0 + b) + i];
+        a.keys = keys + (size_t)b0 * cap; a.vals = vals + (size_t)b0 * cap; a.cap = cap;
+        a.bsum = bsum + (size_t)b0 * (nblk + 1); a.nblk = nblk;
+        a.dcount = dcount + 2 * (size_t)b0;
+        a.coords = coords + (size_t)b0 * n * 3; a.sel = sel + (size_t)b0 * n; a.pts_sel = pts_sel ? pts_sel + (size_t)b0 * n * 3 : nullptr;
+        hipLaunchKernelGGL(vox_insert_kernel, dim3((n + 255) / 256, nbc), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(vox_count_kernel, dim3(nblk, nbc), dim3(1024), 0, s, a);
+        hipLaunchKernelGGL(vox_scan_kernel, dim3(nbc), dim3(1024), 0, s, a);
+        hipLaunchKernelGGL(vox_scatter_kernel, dim3(nblk, nbc), dim3(1024), 0, s, a);
     }
     HIPCHK(hipGetLastError());
+    phase_mark(ctx, -1, s);
     int hc[128];
     HIPCHK(hipMemcpyAsync(hc, dcount, 2 * sizeof(int) * nb, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));

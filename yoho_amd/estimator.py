@@ -78,6 +78,22 @@ class _Base:
 
 
 class yohoc(_Base):
+    """tests/estimator.py:28-141.  TWO modes, one contract each (timed side by side in bench.py's `yohoc` leg):
+
+    * host-parity (default; cfg.yohoc_lapack_parity=True, cfg.yohoc_device_sampling=False): REFERENCE-EXACT.  The host consumes
+      the global np.random stream exactly as the reference's loop does (:119-128: one weighted draw of a coarse rotation, three
+      matches of its bucket with replacement, per accepted iteration) and decides, with one batched np.linalg.svd over the sampled
+      triples, where LAPACK's sign of the null direction makes the reference's R = Vt.T @ U.T a reflection (:55-63 has no
+      determinant fix; 3 centred points give a rank-2 covariance).  The device does everything else: Kabsch for all iterations,
+      the optional reflection, the inlier vote, the first strict maximum.  Per-iteration counts, winner and transform are the
+      reference's (atol 1e-9, goldens chain*.npz / scene*.npz).  Cost: the numpy draws and the SVDs, tens of ms per pair on the host.
+    * device sampling (cfg.yohoc_device_sampling=True; pipeline.run_pair(estimator="yohoc"), the dataset driver, bench.py):
+      STATISTICAL parity.  Statistic, sampling (Philox4x32-10 keyed by a seed), Kabsch and vote run on the device, no host work but
+      the launches; proper rotations only.  The random stream is not numpy's MT19937, so results equal the reference's in
+      distribution (same success flags / RR on the goldens), and bit-exactly equal oracle/yoho_oracle.yohoc_device_triples +
+      yohoc_select for the same seed.
+    """
+
     def __init__(self, cfg):
         self.cfg = cfg
         self.inliner_dist = cfg.ransac_c_inlinerdist
@@ -131,6 +147,33 @@ class yohoc(_Base):
                 triples.append(np.random.choice(np.array(buckets[rot]), 3))
         return np.array(triples, dtype=np.int64).reshape(-1, 3)
 
+    def estimate_host_sampled(self, km0, km1, dr, max_iter, timings=None):
+        """The host-parity mode for one pair's matched keypoints (M,3) f64 and coarse rotations (M,): np.random draws (+ the LAPACK
+        sign mask) on the host, Kabsch + vote for all iterations in one device call.  -> None if no rotation bucket has two matches
+        (the reference's recalltime 50001), else (trans (3,4) or eye(4), recalltime, winning triple or None).
+        timings: optional dict receiving the seconds spent in the host draws, the host SVDs and the device call."""
+        import time
+        t0 = time.perf_counter()
+        buckets, prob = self.DR_statictic(dr)
+        if prob is None:
+            return None
+        triples = self._draw(buckets, prob, max_iter)
+        t1 = time.perf_counter()
+        trans, recall, tri = np.eye(4), 0, None
+        t2 = t1
+        if triples.shape[0] > 0:
+            refl = _cu(self._reflect_mask(km0[triples], km1[triples]), np.uint8) if self.lapack_parity else None
+            t2 = time.perf_counter()
+            T, res, _, _ = self.ctx.c_ransac(_cu(km0, np.float64), _cu(km1, np.float64), _cu(triples, np.int64), refl, self.inliner_dist)
+            it, cnt = (int(v) for v in res.cpu().numpy())
+            if cnt > 0:
+                trans, recall, tri = T.cpu().numpy(), it, triples[it - 1]
+        if timings is not None:
+            t3 = time.perf_counter()
+            for k, v in (("draw_s", t1 - t0), ("svd_mask_s", t2 - t1), ("device_call_s", t3 - t2)):
+                timings[k] = timings.get(k, 0.0) + v
+        return trans, recall, tri
+
     def _ransac_pair(self, dataset, max_iter, pair, Save_dir, match_dir, Index_dir, Keys_dir):
         id0, id1 = pair
         keys0 = np.load(f'{Keys_dir}/cloud_bin_{id0}Keypoints.npy')
@@ -155,17 +198,11 @@ class yohoc(_Base):
             km0, km1 = keys0[pps[:, 0]], keys1[pps[:, 1]]
         else:
             km0, km1 = keys0[pps[:, 0]], keys1[pps[:, 1]]
-            buckets, prob = self.DR_statictic(dr)
-            if prob is None:
+            est = self.estimate_host_sampled(km0, km1, dr, max_iter)
+            if est is None:
                 np.savez(out, trans=np.eye(4), center=0, axis=0, recalltime=NO_ESTIMATE)
                 return
-            triples = self._draw(buckets, prob, max_iter)
-            if triples.shape[0] > 0:
-                refl = _cu(self._reflect_mask(km0[triples], km1[triples]), np.uint8) if self.lapack_parity else None
-                T, res, _, _ = self.ctx.c_ransac(_cu(km0, np.float64), _cu(km1, np.float64), _cu(triples, np.int64), refl, self.inliner_dist)
-                it, cnt = (int(v) for v in res.cpu().numpy())
-                if cnt > 0:
-                    trans, recall, tri = T.cpu().numpy(), it, triples[it - 1]
+            trans, recall, tri = est
         center = np.concatenate([km0[tri], km1[tri]], axis=0) if tri is not None else np.ones([6, 3])
         np.savez(out, trans=trans, center=center, recalltime=recall)
 

@@ -23,7 +23,7 @@ SYMBOLS = [
     "yoho_des2r", "yoho_des2r_indexed", "yoho_partII_forward", "yoho_partII_forward_indexed", "yoho_hyp_from_quat", "yoho_o_score", "yoho_c_ransac",
     "yoho_group_gather", "yoho_set_profiling", "yoho_get_kernel_ms", "yoho_set_gconv_mode", "yoho_set_partII_mode", "yoho_set_nn_grid",
     "yoho_range_status", "yoho_c_ransac_device", "yoho_group_scatter", "yoho_set_nn_prefilter", "yoho_set_fcgf_sort", "yoho_fcgf_voxelize_rotated_batch", "yoho_gconv_wgrad", "yoho_bn_stats", "yoho_bn_relu_apply", "yoho_bn_relu_backward", "yoho_set_partI_schedule", "yoho_clock_probe", "yoho_group_transfer_batch",
-    "yoho_register_pair", "yoho_vote_order",
+    "yoho_register_pair", "yoho_vote_order", "yoho_phase_profile", "yoho_phase_read",
 ]
 
 
@@ -120,6 +120,8 @@ def load_library():
     lib.yoho_c_ransac_device.argtypes = [vp, vp, vp, vp, vp, ci, vp, ci, ci, C.c_uint64, C.c_double, vp, vp, vp, vp, vp]
     lib.yoho_register_pair.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, C.c_double, C.c_uint64, ci, C.POINTER(PairResultC), vp]
     lib.yoho_vote_order.argtypes = [C.c_uint32, ci, vp]
+    lib.yoho_phase_profile.argtypes = [vp, ci]
+    lib.yoho_phase_read.argtypes = [vp, vp, vp, vp, vp]
     for s in SYMBOLS[2:]:
         getattr(lib, s).restype = ci
     _lib = lib
@@ -191,7 +193,11 @@ class Context:
         self.partII_mode = pm if pm in PARTII_MODES else "bf16x3"
         self.set_gconv_mode(self.gconv_mode)
         self.set_partII_mode(self.partII_mode)
-        self.range_fallbacks = 0            # passes repeated in bf16x3 because a value left the fp16 range
+        self.range_fallbacks = 0            # passes repeated in bf16x3 because a value left the fp16 range (both networks, ever)
+        # per network, since its checkpoint was loaded: repeats, and whether the network has been switched to bf16x3 for good
+        self.range_repeats = {"gconv": 0, "partII": 0}
+        self.range_sticky = {"gconv": None, "partII": None}       # None, or the mode the network ran in before it was switched
+        self.range_sticky_after = int(os.environ.get("YOHO_RANGE_STICKY", "3"))    # 0: never switch, repeat every time
         self._range_pending = [False, False]  # flags read from the device but not yet consumed by a caller (range_status)
         self.partI_owner = self.partII_owner = self.fcgf_owner = None      # whose weights are resident (network objects)
 
@@ -222,6 +228,7 @@ class Context:
         """owner: the network object these weights belong to; objects sharing the context compare ``ctx.partI_owner``
         with themselves before a forward pass and upload again when another checkpoint has been loaded since."""
         self.partI_owner = owner
+        self._new_checkpoint("gconv")
         sd = _weights.to_numpy_state_dict(sd)
         _weights.check_state_dict(sd, _weights.PARTI_SPEC, strict=False)
         keep = []
@@ -234,6 +241,7 @@ class Context:
 
     def load_partII(self, sd, owner=None):
         self.partII_owner = owner
+        self._new_checkpoint("partII")
         sd = _weights.to_numpy_state_dict(sd)
         _weights.check_state_dict(sd, _weights.PARTII_SPEC, strict=False)
         keep = []
@@ -404,17 +412,47 @@ class Context:
     def partII_overflow(self):
         return self.range_status(consume=(False, True))[1]
 
+    def _new_checkpoint(self, which):
+        """another checkpoint for network `which`: its repeat count starts again, and a network that had been switched to bf16x3
+        for the previous checkpoint goes back to the mode it was configured with"""
+        self.range_repeats[which] = 0
+        prev, self.range_sticky[which] = self.range_sticky[which], None
+        if prev is not None:
+            (self.set_gconv_mode if which == "gconv" else self.set_partII_mode)(prev)
+
     def _repeat_wider(self, which, fn):
-        """repeat fn() with `which` ('gconv' / 'partII') switched to the bf16x3 planes (fp32 exponent range)"""
+        """repeat fn() with `which` ('gconv' / 'partII') switched to the bf16x3 planes (fp32 exponent range).
+
+        A checkpoint whose activations do not fit the fp16 planes would otherwise pay fp16x2 pass + flag + bf16x3 pass on EVERY
+        call, behind nothing but a RuntimeWarning per pass: after `range_sticky_after` repeats since the checkpoint was loaded the
+        network STAYS in bf16x3 (about 3x the fp16x2 time, but once instead of 1 + 3), which is said once, loudly, and is visible
+        in range_report(); loading another checkpoint restores the configured mode."""
         self.range_fallbacks += 1
-        warnings.warn(f"yoho_amd: a value left the fp16 range of the {which} fp16x2 arithmetic; pass repeated in bf16x3", RuntimeWarning)
+        self.range_repeats[which] += 1
         attr, setter = ("gconv_mode", self.set_gconv_mode) if which == "gconv" else ("partII_mode", self.set_partII_mode)
         old = getattr(self, attr)
+        stick = self.range_sticky_after > 0 and self.range_repeats[which] >= self.range_sticky_after and old != "bf16x3"
+        if stick:
+            warnings.warn(f"yoho_amd: {self.range_repeats[which]} passes of this checkpoint left the fp16 range of the {which} fp16x2 arithmetic; "
+                          f"the network now STAYS in bf16x3 (fp32 exponent range, about 3x slower than {old}) until another checkpoint is "
+                          f"loaded (YOHO_RANGE_STICKY=0 keeps repeating pass by pass instead)", RuntimeWarning)
+        else:
+            warnings.warn(f"yoho_amd: a value left the fp16 range of the {which} fp16x2 arithmetic; pass repeated in bf16x3", RuntimeWarning)
         setter("bf16x3")
         try:
             return fn()
         finally:
-            setter(old)
+            if stick:
+                self.range_sticky[which] = old
+            else:
+                setter(old)
+
+    def range_report(self):
+        """what the range guard has done on this context: repeats per network since its checkpoint was loaded, networks switched
+        to bf16x3 for good, total repeats ever - for the stats of the dataset driver and the bench line"""
+        return {"partI_repeats": self.range_repeats["gconv"], "partII_repeats": self.range_repeats["partII"],
+                "partI_stays_bf16x3": self.range_sticky["gconv"] is not None, "partII_stays_bf16x3": self.range_sticky["partII"] is not None,
+                "repeats_total": self.range_fallbacks}
 
     def supports_pair(self, n_rows):
         """yoho_partI_forward_pair (no concatenation copy) exists for the default arithmetic mode and one pass"""
@@ -704,6 +742,20 @@ class Context:
     # ---- profiling hook (bench.py) ------------------------------------------------------------
     def set_profiling(self, on=True):
         _check(self._lib.yoho_set_profiling(self._h, 1 if on else 0))
+
+    PHASES = ("voxelise", "coordinate_maps", "kernel_maps", "conv1", "conv3x3_level0", "conv3x3_level1", "conv3x3_level2", "conv3x3_level3",
+              "strided_into_level1", "strided_into_level2", "strided_into_level3", "transposed_to_level0", "transposed_to_level1",
+              "transposed_to_level2", "heads_1x1_normalise", "nn_feature_transfer")
+
+    def phase_profile(self, on=True):
+        """accumulating phase timer of the raw-cloud path (include/yoho_hip.h: yoho_phase_profile); read with phase_read()"""
+        _check(self._lib.yoho_phase_profile(self._h, 1 if on else 0))
+
+    def phase_read(self):
+        """-> {phase: {"ms", "mfma_flops", "launches"}} accumulated since the last read (waits for the current stream)"""
+        ms, fl, ln = (np.zeros(16, dtype=np.float64) for _ in range(3))
+        _check(self._lib.yoho_phase_read(self._h, _np_ptr(ms), _np_ptr(fl), _np_ptr(ln), _stream()))
+        return {n: {"ms": float(ms[i]), "mfma_flops": float(fl[i]), "launches": int(ln[i])} for i, n in enumerate(self.PHASES)}
 
     def kernel_ms(self, which):
         ms = C.c_float(-1.0)

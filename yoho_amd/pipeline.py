@@ -163,8 +163,9 @@ class PairStreamer:
                 t.record_stream(self.sb)
         return o0, o1, ev
 
-    def run(self, pairs, inlier_dist=0.09, max_iter=1000, order_rng=None, estimator="yohoo", seeds=None, hypotheses="all"):
-        """pairs: sequence of (feat0, feat1, keys0, keys1) device tensors.  Returns the list of PairResult."""
+    def run(self, pairs, inlier_dist=0.09, max_iter=1000, order_rng=None, estimator="yohoo", seeds=None, hypotheses="all", keep="all"):
+        """pairs: sequence of (feat0, feat1, keys0, keys1) device tensors.  Returns the list of PairResult; keep="last": only the
+        last pair's (a PairResult holds its descriptors, 77 MB at 2 x 5000 keypoints: a long throughput run must not keep them all)."""
         pairs = list(pairs)
         out = []
         if not pairs:
@@ -191,7 +192,10 @@ class PairStreamer:
                 r = run_pair(self.est, pair[0], pair[1], pair[2], pair[3], inlier_dist=inlier_dist, max_iter=max_iter, order_rng=order_rng,
                              eqv=(o0, o1), estimator=estimator, seed=(seeds[i] if seeds is not None else 0), hypotheses=hypotheses)
                 r.range_repeats += repeats
-            out.append(r)
+            if keep == "last":
+                out = [r]
+            else:
+                out.append(r)
         cur.wait_stream(self.sa)
         cur.wait_stream(self.sb)
         return out

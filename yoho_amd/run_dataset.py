@@ -348,6 +348,8 @@ class ScenePairRunner:
         reader, then one readinto: no intermediate array, no page-fault-driven mmap copy)"""
         import time
         torch = self.torch
+        # loader threads start on device 0: pin_memory() there would create a primary context on GPU 0 in every rank's process
+        torch.cuda.set_device(self.ctx.device)
         t0 = time.perf_counter()
         with open(f'{fdir}/{fid}.npy', 'rb') as f:
             major, minor = np.lib.format.read_magic(f)
@@ -535,17 +537,24 @@ class ScenePairRunner:
         a, b = part.frag[id0], part.frag[id1]
         seed = pair_seed(self.base_seed, dataset.name, id0, id1)
         c = ctx if ctx is not None else self.ctx
-        out = None
+        out = f = None
         if self.fused and (self.estimator == "yohoc" or c.supports_matched()):
             f = c.register_pair(a["feat"], b["feat"], a["eqv"], b["eqv"], a["inv_np"], b["inv_np"], a["keys"], b["keys"], estimator=self.estimator,
                                 max_iter=self.max_iter, inlier_dist=self.inlier_dist, seed=seed, selected=(self.hypotheses == "selected"))
-            if not f["range_flag"]:                 # a value left the fp16 range: the Python composition below repeats PartII in bf16x3
+            if not f["range_flag"]:
                 out = {"trans": f["trans"], "recalltime": f["best_h"], "matches": f["matches"], "inliers": f["best_count"]}
         if out is None:
-            r = self.pipeline.run_pair(c, a["feat"], b["feat"], a["keys"], b["keys"], inlier_dist=self.inlier_dist,
-                                       max_iter=self.max_iter, order_rng=np.random.RandomState(seed & 0xFFFFFFFF),
-                                       eqv=({"eqv": a["eqv"], "inv_np": a["inv_np"]}, {"eqv": b["eqv"], "inv_np": b["inv_np"]}),
-                                       estimator=self.estimator, seed=seed, hypotheses=self.hypotheses)
+            compose = lambda: self.pipeline.run_pair(
+                c, a["feat"], b["feat"], a["keys"], b["keys"], inlier_dist=self.inlier_dist, max_iter=self.max_iter,
+                order_rng=np.random.RandomState(seed & 0xFFFFFFFF), eqv=({"eqv": a["eqv"], "inv_np": a["inv_np"]}, {"eqv": b["eqv"], "inv_np": b["inv_np"]}),
+                estimator=self.estimator, seed=seed, hypotheses=self.hypotheses)
+            if f is not None:
+                # the one-call pair reported a value outside the fp16 range of PartII (the call consumed the device flag): the pair is
+                # composed ONCE more with this worker's PartII in bf16x3 - not a second fp16x2 attempt that would have to overflow
+                # again to be noticed; after hip.Context.range_sticky_after such pairs the worker stays in bf16x3 (range_report)
+                r = c._repeat_wider("partII", compose)
+            else:
+                r = compose()
             out = {"trans": np.asarray(r.trans, dtype=np.float64), "recalltime": int(r.best_h), "matches": int(r.match.shape[0]),
                    "inliers": int(r.best_count)}
         with self._lock:
@@ -730,10 +739,20 @@ def eval_sharded(cfg, max_iter=1000, estimator="yohoo", datasets=None, base_seed
     cached = getattr(ctx, "_pair_workers_cache", None)           # worker contexts (PartII weight packing: 0.25 s each) live with ctx
     if cached is not None and cached[0] is state_dicts[1] and len(cached[1]) == runner.pair_workers:
         runner._workers = cached[1]
+    guard_ctxs = lambda: [ctx] + [w for w, _ in (runner._workers or [])]
+    repeats_before = sum(c.range_fallbacks for c in guard_ctxs())
     try:
         results = run_sharded(datasets, runner.run_pair, rank=rank, world=world, parts_fn=runner.run_parts)
         if runner._workers is not None:
             ctx._pair_workers_cache = (state_dicts[1], runner._workers)
+        # fp16 range guard: how many passes / pairs of this run were repeated in bf16x3, and whether a network of this checkpoint now
+        # stays there (hip.Context._repeat_wider) - a checkpoint that trips the guard costs ~3x and must not hide behind warnings
+        reports = [c.range_report() for c in guard_ctxs()]
+        runner.stats["range_guard"] = {
+            "repeats_this_run": sum(c.range_fallbacks for c in guard_ctxs()) - repeats_before,
+            "partI_repeats_since_checkpoint": reports[0]["partI_repeats"], "partI_stays_bf16x3": reports[0]["partI_stays_bf16x3"],
+            "partII_repeats_since_checkpoint": sum(r["partII_repeats"] for r in reports),
+            "partII_workers_staying_bf16x3": sum(1 for r in reports if r["partII_stays_bf16x3"])}
     finally:
         write_error = None
         try:

@@ -175,24 +175,29 @@ def make_scene(nfrag=4, K=64, seed=0, tables=None, noise=0.02, outlier_frac=0.3,
     return dict(feats=feats, keys=keys, poses=poses, pairs=pairs, gt=gt)
 
 
-def write_scene_files(scene, root, cache_scene_dir=None):
+def write_scene_files(scene, root, cache_scene_dir=None, lo_pairs=None):
     """Lay a make_scene() result out as the reference expects: {root}/PointCloud/gt.log + gt.info (Redwood format),
-    {root}/Keypoints_PC/cloud_bin_{k}Keypoints.npy and, optionally, the FCGF_Input_Group_feature cache."""
+    {root}/Keypoints_PC/cloud_bin_{k}Keypoints.npy and, optionally, the FCGF_Input_Group_feature cache.
+    lo_pairs: a second ground-truth pair list written as gtLo.log / gtLo.info beside gt.log - the layout of 3DLoMatch, which
+    shares 3DMatch's scene directories and differs only in its pair list (utils/dataset.py:176-182)."""
     import os
     n = len(scene["feats"])
     os.makedirs(f"{root}/PointCloud", exist_ok=True)
     os.makedirs(f"{root}/Keypoints_PC", exist_ok=True)
-    with open(f"{root}/PointCloud/gt.log", "w") as f:
-        for (i, j) in scene["pairs"]:
-            T = scene["gt"][(i, j)]
-            f.write(f"{i}\t{j}\t{n}\n")
-            for r in range(4):
-                f.write("\t".join(repr(float(v)) for v in T[r]) + "\n")
-    with open(f"{root}/PointCloud/gt.info", "w") as f:
-        for (i, j) in scene["pairs"]:
-            f.write(f"{i}\t{j}\t{n}\n")
-            for r in range(6):
-                f.write("\t".join(repr(float(1.0 + 0.25 * r if r == c else 0.0)) for c in range(6)) + "\n")
+    for stem, plist in (("gt", scene["pairs"]), ("gtLo", lo_pairs)):
+        if plist is None:
+            continue
+        with open(f"{root}/PointCloud/{stem}.log", "w") as f:
+            for (i, j) in plist:
+                T = scene["gt"][(i, j)]
+                f.write(f"{i}\t{j}\t{n}\n")
+                for r in range(4):
+                    f.write("\t".join(repr(float(v)) for v in T[r]) + "\n")
+        with open(f"{root}/PointCloud/{stem}.info", "w") as f:
+            for (i, j) in plist:
+                f.write(f"{i}\t{j}\t{n}\n")
+                for r in range(6):
+                    f.write("\t".join(repr(float(1.0 + 0.25 * r if r == c else 0.0)) for c in range(6)) + "\n")
     for k in range(n):
         np.save(f"{root}/Keypoints_PC/cloud_bin_{k}Keypoints.npy", scene["keys"][k])
     if cache_scene_dir is not None:
