@@ -683,22 +683,6 @@ def main():
             out["yohoc"] = yohoc
         if sel_leg is not None:
             out["yohoo_selected_hypotheses"] = sel_leg
-        if not args.no_cpu_baseline and world == 1:
-            rb = pipeline.run_pair(ctx, f0, f1, k0, k1, max_iter=1000, order_rng=np.random.RandomState(7))       # this rank's first pair
-            pr0 = {"feat0": f0.cpu().numpy(), "feat1": f1.cpu().numpy(), "keys0": k0.cpu().numpy(), "keys1": k1.cpu().numpy()}
-            out["cpu_baseline"] = cpu_baseline(pr0, rb.eqv[0]["eqv"].cpu().numpy(), rb.eqv[1]["eqv"].cpu().numpy(), rb.match.cpu().numpy(),
-                                               rb.dr_index.cpu().numpy())
-            del rb, pr0
-    # raw-cloud leg (SURVEY 8f #3): rank 0 only, the other ranks wait at the barrier below
-    fcgf = None
-    if not args.no_fcgf and rank == 0:
-        streamer = None
-        torch.cuda.empty_cache()
-        try:
-            fcgf = fcgf_leg(ctx, dev)
-        except Exception as e:           # the headline must survive a failure of this leg
-            fcgf = {"error": f"{type(e).__name__}: {e}"}
-        out["fcgf"] = fcgf
     # dataset-scale leg (BASELINE configs 3 / 5): 60 fragments x 5000 keypoints from .npy files on disk, ~500 pairs, through the
     # dataset driver; with N ranks the scene's pairs are dealt to them by run_dataset.plan_shards.  Never part of `value`.
     dataset = None
@@ -713,9 +697,26 @@ def main():
                 dataset = bench_dataset.run(nfrag=60, kp=KP, span=9, estimator="yohoo", workdir=os.environ.get("YOHO_DS_WORKDIR", "/tmp/yoho_ds"), runs=2)
         except Exception as e:           # the headline must survive a failure of this leg
             dataset = {"error": f"{type(e).__name__}: {e}"}
+    # raw-cloud leg (SURVEY 8f #3): rank 0 only, the other ranks wait at the barrier below
+    fcgf = None
+    if not args.no_fcgf and rank == 0:
+        streamer = None
+        torch.cuda.empty_cache()
+        try:
+            fcgf = fcgf_leg(ctx, dev)
+        except Exception as e:           # the headline must survive a failure of this leg
+            fcgf = {"error": f"{type(e).__name__}: {e}"}
+        out["fcgf"] = fcgf
     if rank == 0:
         if dataset is not None:
             out["dataset"] = dataset
+        # last: the CPU legs (64+ host threads and a few GB of host arrays) stay out of the way of the device legs above
+        if not args.no_cpu_baseline and world == 1:
+            rb = pipeline.run_pair(ctx, f0, f1, k0, k1, max_iter=1000, order_rng=np.random.RandomState(7))       # this rank's first pair
+            pr0 = {"feat0": f0.cpu().numpy(), "feat1": f1.cpu().numpy(), "keys0": k0.cpu().numpy(), "keys1": k1.cpu().numpy()}
+            out["cpu_baseline"] = cpu_baseline(pr0, rb.eqv[0]["eqv"].cpu().numpy(), rb.eqv[1]["eqv"].cpu().numpy(), rb.match.cpu().numpy(),
+                                               rb.dr_index.cpu().numpy())
+            del rb, pr0
         print(json.dumps(out), flush=True)
     ydist.barrier()
 

@@ -42,3 +42,14 @@ def test_context_requires_gpu():
         pytest.skip("GPU present")
     with pytest.raises(RuntimeError):
         hip.Context()
+
+
+def test_gft16x_hidden_ticket_register_is_untouched():
+    """gft16x_kernel requests its chunk tickets with a returning atomic the compiler does not see (so that it does not drain the
+    pending LDS DMA at a control-flow join); the register the value returns into must not be spilled, copied or referenced anywhere
+    else in the kernel.  Checked on the gfx950 assembly of the file as built (tools/check_isa.py)."""
+    import sys
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import check_isa
+    ok, msg = check_isa.check()
+    assert ok, msg

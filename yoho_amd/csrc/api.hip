@@ -367,6 +367,8 @@ int yoho_ctx_create(int device, const float* R, const uint8_t* N, const uint8_t*
     }
     HIPCHK(hipMalloc((void**)&c->d_rflag, 4 * sizeof(int)));
     HIPCHK(hipMemset(c->d_rflag, 0, 4 * sizeof(int)));
+    HIPCHK(hipMalloc((void**)&c->d_xfctr, 16 * sizeof(int)));
+    HIPCHK(hipMemset(c->d_xfctr, 0, 16 * sizeof(int)));
     *out = c;
     return 0;
 }
@@ -392,6 +394,7 @@ int yoho_ctx_destroy(yoho_ctx* c) {
     if (c->fcgf) fcgf_free(c->fcgf);
     if (c->d_tap_inv) (void)hipFree(c->d_tap_inv);
     if (c->d_rflag) (void)hipFree(c->d_rflag);
+    if (c->d_xfctr) (void)hipFree(c->d_xfctr);
     for (int* t : {c->tabs.slabtab, c->tabs.outg, c->tabs.slab4, c->tabs.unitg}) if (t) (void)hipFree(t);
     delete c->fb;
     for (auto& e : c->ev) (void)hipEventDestroy(e);
@@ -676,7 +679,7 @@ static size_t partI_G_ws_bytes(int B) {
 // one chunk of the pass: B keypoints through head -> 4 GEMMs + 3 transforms -> tail on the workspace slice at `ws`; rows >= B0 of
 // the chunk come from x1 (when set).  evbase: first of this chunk's EV_PER_PASS profiling events.
 static int partI_passG_chunk(yoho_ctx* c, char* ws, int evbase, const float* x, int B, float* eqv, float* inv, float* inv_np, hipStream_t s,
-                             const float* x1, int B0) {
+                             const float* x1, int B0, int slot) {
     // GEMM blocking: mode 4 = 256 x 256 tile, eight waves (two per SIMD) sharing the A stage | mode 5 = 256 x 256, four waves (one per SIMD) |
     // mode 6 = 256 x 128 tiles, two four-wave workgroups per CU.  The transform kernel follows: two waves per SIMD except in mode 5.
     const int gv = c->gconv_mode == 5 ? 1 : (c->gconv_mode == 6 ? 2 : 3);
@@ -698,19 +701,20 @@ static int partI_passG_chunk(yoho_ctx* c, char* ws, int evbase, const float* x, 
     const Layer* L = c->p1;
     mark(0);
     int* rf = c->d_rflag;
+    int* xc = c->d_xfctr + (size_t)slot * 8;     // ticket counters of this stream slot's three transform launches (a launch leaves them at zero)
     if ((rc = launch_head16(x, B, nT, bP32, kppad, c->dF16, s, x1, B0, rf))) return rc;
     mark(1);
     if ((rc = launch_fgemm(L[0], bP32, kppad, nT, nullptr, bH0, 0, s, rf, gv))) return rc;
     mark(2);
-    if ((rc = launch_gft16(bH0, nullptr, bP256, kppad, c->dF16, L[0].bn_s, L[0].bn_t, nT, 32, c->nCU, s, 0, rf, gv))) return rc;
+    if ((rc = launch_gft16(bH0, nullptr, bP256, kppad, c->dF16, L[0].bn_s, L[0].bn_t, nT, 32, c->nCU, s, 0, rf, gv, xc))) return rc;
     mark(3);
     if ((rc = launch_fgemm(L[1], bP256, kppad, nT, nullptr, bM, 0, s, rf, gv))) return rc;
     mark(4);
-    if ((rc = launch_gft16(bM, nullptr, bP512, kppad, c->dF16, L[1].bn_s, L[1].bn_t, nT, 64, c->nCU, s, 0, rf, gv))) return rc;
+    if ((rc = launch_gft16(bM, nullptr, bP512, kppad, c->dF16, L[1].bn_s, L[1].bn_t, nT, 64, c->nCU, s, 0, rf, gv, xc + 2))) return rc;
     mark(5);
     if ((rc = launch_fgemm(L[2], bP512, kppad, nT, bH0, bA, EPI_RES, s, rf, gv))) return rc;
     mark(6);
-    if ((rc = launch_gft16(bA, nullptr, bP256, kppad, c->dF16, L[2].bn_s, L[2].bn_t, nT, 32, c->nCU, s, 0, rf, gv))) return rc;
+    if ((rc = launch_gft16(bA, nullptr, bP256, kppad, c->dF16, L[2].bn_s, L[2].bn_t, nT, 32, c->nCU, s, 0, rf, gv, xc + 4))) return rc;
     mark(7);
     if ((rc = launch_fgemm(L[3], bP256, kppad, nT, nullptr, bY, 0, s, rf, gv))) return rc;
     mark(8);
@@ -765,7 +769,7 @@ static int partI_passG(yoho_ctx* c, const float* x, int B, float* eqv, float* in
         hipStream_t sk = on_side ? c->side_stream : s;
         char* ws = (char*)c->ws.p + (dbg_own ? slice * (size_t)k : (on_side ? slice : 0));
         if ((rc = partI_passG_chunk(c, ws, k * EV_PER_PASS, xc, n, eqv + (size_t)off * F * G, inv ? inv + (size_t)off * F : nullptr,
-                                    inv_np ? inv_np + (size_t)off * F : nullptr, sk, x1c, B0c))) return rc;
+                                    inv_np ? inv_np + (size_t)off * F : nullptr, sk, x1c, B0c, on_side ? 1 : 0))) return rc;
         if (dbg_serial) HIPCHK(hipStreamSynchronize(sk));
     }
     if (nstr == 2) {

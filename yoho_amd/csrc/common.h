@@ -137,7 +137,7 @@ int fcgf_voxelize_batch(yoho_ctx* ctx, const double* pts, int n, const double* R
 int launch_cone1(const Layer& L, const char* X, int nTiles32, int nTiles16, const float* res, float* out, const int* n0, hipStream_t s, float* part = nullptr);
 int gft16_init();
 int launch_gft16(const float* in, float* out32, char* planes, int kppad, const void* Ffrag, const float* bn_s, const float* bn_t, int nTiles,
-                 int C8, int nCU, hipStream_t s, int B = 0, int* rflag = nullptr, int variant = 2);
+                 int C8, int nCU, hipStream_t s, int B = 0, int* rflag = nullptr, int variant = 2, int* ctr = nullptr);
 int launch_gft16_invp(const float* in, float* res0, char* planes16, int nTiles16, const void* Ffrag, const float* bn_s, const float* bn_t,
                       int nTiles, int C8, int nCU, hipStream_t s, int* rflag = nullptr);
 int launch_head2(const float* s0, const float* s1, const float* s2, const float* s3, const int64_t* pre_idx, const int* P, const float* bn_s,
@@ -226,6 +226,7 @@ struct yoho_ctx {
     int nCU = 256;
     yoho::SlotTables tabs;       // direct-conv slot tables (device)
     int* d_rflag = nullptr;      // fp16 range words (note_range): [0] PartI, [1] PartII; read and cleared by yoho_range_status
+    int* d_xfctr = nullptr;      // chunk tickets of the persistent transform kernel (gft16x work stealing): [stream slot 2][launch 4][2], zero between launches
     int fcgf_cell_sort = 1;      // FCGF backbone: level-0 rows grouped by 8^3-voxel cell inside the pass (gather locality): 0 never, 1 passes of >= 2^18 rows, 2 always
     int fcgf_parity_sort = 1;    // transposed convolutions of the FCGF backbone walk parity-sorted rows (sparse.hip); 0: YOHO_FCGF_SORT=0
     int nn_prefilter = 1;        // mutual NN of large sets: MFMA pre-filter + exact candidates (matchf.hip); 0 = brute force (YOHO_NN=brute)

@@ -49,6 +49,7 @@ struct Gft16Args {
     int qstride[G];           // bytes per 256-column tile of q's irrep (= K stages * 32 KiB)
     int* rflag;               // fp16 range flag of the context (note_range)
     int drain;                // experiment (YOHO_PARTI_DEBUG=drain): wait for every outstanding vector-memory operation instead of the counted wait
+    int* ctr;                 // gft16x work stealing: [0] next chunk ticket, [1] finished workgroups (both 0 between launches), or null = static striding
 };
 
 __device__ __forceinline__ floatx16 mfma_hh(uintx4 a, uintx4 b, floatx16 c) {
@@ -380,12 +381,32 @@ __global__ __launch_bounds__(512, 2) void gft16x_kernel(Gft16Args a) {
     };
     const int hsel = w8 >> 2, kp = 8 * (w8 & 3) + (n >> 2), e = n & 3;
     unsigned top = 0u;
-    int chunk = blockIdx.x;
+    // Chunks are TAKEN, not dealt (a.ctr): the grid is one persistent workgroup per CU with 136 KB of LDS, so a CU that holds any other
+    // resident workgroup (the estimator's kernels of the pair pipeline, a clock probe) starts its workgroup late - with static striding
+    // that workgroup's 1/256 of the chunks became a second round (+4 % streamed, +50 % beside a 1 ms probe, DESIGN 8 of round 3); with
+    // tickets a late workgroup simply takes fewer.  Thread 0 draws tickets from a device counter: two in the prologue (the chunk to
+    // compute and the chunk to stage at the top of iteration 0), then one per iteration - requested right behind the iteration's DMA,
+    // read at the top of the next one where the counted wait for that DMA has covered it (vector-memory operations complete in issue
+    // order), handed to the other waves through LDS at the barrier that is there anyway.  A chunk's arithmetic does not depend on who
+    // takes it: same bits.  The last workgroup to finish zeroes the counters for the next launch.
+    int* ids = reinterpret_cast<int*>(smem + 2 * GB + 768);      // [2]: ticket slots, written by thread 0 in front of a barrier
+    const bool steal = a.ctr != nullptr;
+    int chunk = blockIdx.x, nxt = blockIdx.x + gridDim.x;
+    int ticket = 0;
+    if (steal) {
+        if (tid == 0) {
+            const int t0 = __hip_atomic_fetch_add(a.ctr, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ids[0] = t0;
+        }
+        __syncthreads();
+        chunk = ids[0];
+        nxt = chunk + 1;
+    }
     if (chunk < a.nChunks) stage(chunk, smem);
     // first chunk, tables, transform fragments: a wait the compiler's own scoreboard sees (vmcnt(0) expcnt(7) lgkmcnt(15)) - behind
     // an opaque asm wait it would put a vmcnt(0) in front of the first use of the fragments, inside the loop
     __builtin_amdgcn_s_waitcnt(0x0F70);
-    for (int it = 0; chunk < a.nChunks; chunk += gridDim.x, ++it) {
+    for (int it = 0; chunk < a.nChunks; ++it) {
         char* cur = smem + (it & 1) * GB;
         // vector-memory operations complete in issue order: behind this chunk's DMA (issued one iteration ago) are only the
         // plane stores of the previous chunk - 8 per thread in waves 0-3, 7 in waves 4-7 - which may stay in flight
@@ -394,8 +415,34 @@ __global__ __launch_bounds__(512, 2) void gft16x_kernel(Gft16Args a) {
             else if (w8 < 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
         }
+        if (steal) {
+            // Thread 0 (EXEC = lane 0 of wave 0; empty in the other waves, where the two memory instructions are not issued at all):
+            // publish the ticket requested one iteration ago - the counted wait above has covered its return, it was issued before
+            // that iteration's plane stores - and request the next one INTO THE SAME REGISTER.  Hidden from the compiler on purpose:
+            // a returning atomic it knows about makes it drain the vector-memory counter at the next control-flow join, i.e. the
+            // DMA just issued (measured in the ISA: s_waitcnt vmcnt(0) right behind the atomic).  A hidden operation can only make
+            // the compiler's own counted waits stricter.  `ticket` must stay in one physical register and untouched between two
+            // executions of this block: tools/check_isa.py verifies that on the built object (no spill, no copy, no other reference).
+            const unsigned emask = (unsigned)__builtin_amdgcn_readfirstlane(w8 == 0 ? 1 : 0);
+            unsigned long long esave;
+            asm volatile("s_mov_b64 %[sv], exec\n\t"
+                         "s_mov_b32 exec_lo, %[m]\n\t"
+                         "s_mov_b32 exec_hi, 0\n\t"
+                         "ds_write_b32 %[slot], %[t]\n\t"
+                         "global_atomic_add %[t], %[addr], %[one], off sc0\n\t"
+                         "s_mov_b64 exec, %[sv]"
+                         : [t] "+v"(ticket), [sv] "=&s"(esave)
+                         : [m] "s"(emask), [slot] "v"((unsigned)(size_t)(ids + (it & 1))), [addr] "v"(a.ctr), [one] "v"(1)
+                         : "memory");
+        }
         lds_barrier();
-        const int next = chunk + gridDim.x;
+        if (steal && it > 0) {
+            // through asm: in front of a C++ LDS load the compiler waits for every pending vector-memory operation
+            int t;
+            asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(t) : "v"((unsigned)(size_t)(ids + (it & 1))) : "memory");
+            nxt = __builtin_amdgcn_readfirstlane(t);
+        }
+        const int next = nxt;
         if (next < a.nChunks) stage(next, smem + ((it + 1) & 1) * GB);
         const int c8 = chunk % a.C8, tile32 = chunk / a.C8;
 
@@ -486,8 +533,20 @@ __global__ __launch_bounds__(512, 2) void gft16x_kernel(Gft16Args a) {
                 *reinterpret_cast<uintx4*>(dst0 + qb[q] + (long long)nt * qs[q] + kpp * 16 + pl * 16384) = uintx4{c03.x, c03.y, c47.x, c47.y};
             }
         }
+        chunk = next;
+        if (!steal) nxt = next + gridDim.x;
     }
     note_range_bits(a.rflag, top);
+    if (steal && tid == 0) {
+        // every ticket this workgroup requested has been answered before it reports (the adds complete in issue order, the last one
+        // is waited for by using its value); the last workgroup to report leaves the counters at zero for the next launch
+        __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0): the last ticket request has been answered
+        const int done = __hip_atomic_fetch_add(a.ctr + 1, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (done == (int)gridDim.x - 1) {
+            __hip_atomic_store(a.ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(a.ctr + 1, 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
 static inline unsigned short hbits(float x) {
@@ -553,9 +612,11 @@ static void fill_qtables(int kppad, int cin, long long* qbase, int* qstride) {
 // else bn_s != null: BN + ReLU, fp32 chunks to out32 (may alias in);
 // else: inverse transform only, out32 = group-domain values (B,32,60) (C8 must be 4)
 int launch_gft16(const float* in, float* out32, char* planes, int kppad, const void* Ffrag, const float* bn_s, const float* bn_t, int nTiles,
-                 int C8, int nCU, hipStream_t s, int B, int* rflag, int variant) {
+                 int C8, int nCU, hipStream_t s, int B, int* rflag, int variant, int* ctr) {
     Gft16Args a;
     a.B = B; a.res0 = nullptr; a.nTiles16 = 0; a.rflag = rflag;
+    static const bool no_steal = [] { const char* e = std::getenv("YOHO_XF_STEAL"); return e && std::strcmp(e, "0") == 0; }();    // A/B: static striding
+    a.ctr = no_steal ? nullptr : ctr;
     a.in = in; a.out32 = out32; a.planes = planes; a.Ffrag = reinterpret_cast<const uintx4*>(Ffrag); a.bn_s = bn_s; a.bn_t = bn_t;
     a.nChunks = nTiles * C8; a.C8 = C8;
     static const int dbg_drain = [] { const char* e = std::getenv("YOHO_PARTI_DEBUG"); return (e && std::strstr(e, "drain")) ? 1 : 0; }();
@@ -723,9 +784,18 @@ struct Head2Args {
     int* rflag;
 };
 
+// Permuted sources (before_eqv0 / after_eqv0): a lane needs x[m][c][P[idx_m][g']] for its own match m - 4-byte gathers at 64 different
+// rows per load instruction when taken straight from global memory (1.2 TB/s, round 3).  Instead the 240-byte run (one channel, 60
+// group elements) of each of the wave's 32 matches is copied into a wave-private LDS image by LDS DMA - 15 lanes x 16 bytes per
+// match, four matches per instruction, whole lines used - and the permutation is applied by the LDS reads.  Double buffered per
+// wave: the copy of channel f + 1 is issued right after channel f's values are in registers and lands under f's conversions and
+// MFMAs.  Same values into the same arithmetic: bits unchanged.
+constexpr int H2_STG = 8192;                  // one staging image: 8 groups of 4 matches, 1 KiB per group (4 x 240 B + 64 B unused)
+
 __global__ __launch_bounds__(256, 1) void head2_kernel(Head2Args a) {
     __shared__ long long qb[G];
     __shared__ int qs[G];
+    __shared__ __attribute__((aligned(16))) char stg[4][2][H2_STG];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int Lp = lane & 31, kg = lane >> 5;
@@ -763,6 +833,27 @@ __global__ __launch_bounds__(256, 1) void head2_kernel(Head2Args a) {
         const size_t srow = (ok && a.ridx[sidx]) ? (size_t)a.ridx[sidx][(size_t)m * a.istride] : (size_t)m;
         const float* sp = a.src[sidx] + srow * (F * G) + (size_t)(w * 8) * G;
         const bool permute = (sidx == 0) || (sidx == 2);
+        // LDS-DMA staging of the permuted sources: instruction j copies matches 4 j .. 4 j + 3 of the tile (lane -> match 4 j + lane / 15,
+        // 16-byte piece lane % 15; lanes 60-63 repeat pieces of the fourth match into the unused tail of the group)
+        int rowj[8];
+        const int dl = lane < 60 ? lane : lane - 15;
+        const int dmi = dl / 15, dpc = dl - dmi * 15;
+        if (permute) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                int mm = tile32 * TILE + 4 * j + dmi;
+                mm = mm < a.M ? mm : a.M - 1;                  // rows beyond M: any valid row (their values are masked below)
+                rowj[j] = a.ridx[sidx] ? (int)a.ridx[sidx][(size_t)mm * a.istride] : mm;
+            }
+        }
+        auto stage = [&](int f, int buf) {
+            const char* base = reinterpret_cast<const char*>(a.src[sidx]) + (size_t)(w * 8 + f) * (G * 4) + dpc * 16;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                __builtin_amdgcn_global_load_lds((gptr_t)(base + (size_t)rowj[j] * (F * G * 4)), (lptr_t)(&stg[w][buf][j * 1024]), 16, 0, 0);
+        };
+        if (permute) stage(0, 0);
+        const char* myrow = &stg[w][0][(Lp >> 2) * 1024 + (Lp & 3) * 240];
         floatx16 acc[8][2];
 #pragma unroll
         for (int f = 0; f < 8; ++f) {
@@ -774,10 +865,19 @@ __global__ __launch_bounds__(256, 1) void head2_kernel(Head2Args a) {
             const float* xp = sp + f * G;
             float v[4][8];
             if (permute) {
+                const char* rowf = myrow + (f & 1) * H2_STG;   // (the compiler waits for the pending DMA in front of these reads)
 #pragma unroll
                 for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[kb][e] = ok ? xp[gsrc[kb][e]] : 0.f;
+                    for (int e = 0; e < 8; ++e) {
+                        const float t = *reinterpret_cast<const float*>(rowf + gsrc[kb][e] * 4);
+                        v[kb][e] = ok ? t : 0.f;
+                    }
+                if (f + 1 < 8) {
+                    // the values of channel f are in registers before the copy of f + 1 is issued (it targets the other buffer anyway)
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    stage(f + 1, (f + 1) & 1);
+                }
             } else {
 #pragma unroll
                 for (int kb = 0; kb < 4; ++kb) {

@@ -348,8 +348,6 @@ class ScenePairRunner:
         reader, then one readinto: no intermediate array, no page-fault-driven mmap copy)"""
         import time
         torch = self.torch
-        # loader threads start on device 0: pin_memory() there would create a primary context on GPU 0 in every rank's process
-        torch.cuda.set_device(self.ctx.device)
         t0 = time.perf_counter()
         with open(f'{fdir}/{fid}.npy', 'rb') as f:
             major, minor = np.lib.format.read_magic(f)
@@ -398,7 +396,8 @@ class ScenePairRunner:
         def loader():
             from concurrent.futures import ThreadPoolExecutor
             try:
-                with ThreadPoolExecutor(NLOAD) as ex:
+                # loader threads start on device 0: pin_memory() there would create a primary context on GPU 0 in every rank's process
+                with ThreadPoolExecutor(NLOAD, initializer=torch.cuda.set_device, initargs=(self.ctx.device,)) as ex:
                     pending = []
                     for fid in need:
                         if stop.is_set():
