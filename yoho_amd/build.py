@@ -24,6 +24,8 @@ if os.environ.get("YOHO_SPCONV_ABLATE"):          # timing experiments: compile-
     EXTRA["sparse.hip"] = ["-DYOHO_SPCONV_ABLATE"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-I" + os.path.join(REPO, "include"), "-I" + CSRC]
+if os.environ.get("YOHO_EXPERIMENTS") == "1":     # timing-experiment switches (YOHO_PARTI_DEBUG / YOHO_FGEMM_DEBUG) are compiled in only on request
+    FLAGS.append("-DYOHO_EXPERIMENTS")
 
 
 def _stale():

@@ -736,7 +736,9 @@ static int partI_passG(yoho_ctx* c, const float* x, int B, float* eqv, float* in
     const int nstr = (nch > 1 && c->partI_streams == 2) ? 2 : 1;
     const size_t slice = partI_G_ws_bytes(nch > 1 ? chunk : B);
     int rc;
-    if ((rc = ensure_ws(c, slice * nstr, s))) return rc;
+    static const char* dbg = experiment_env("YOHO_PARTI_DEBUG");   // experiments (-DYOHO_EXPERIMENTS builds only): "serial" = wait after every chunk, "sideonly" = all chunks on the side stream
+    // the workspace is sized BEFORE the side stream is forked (growing it frees the old allocation behind a device synchronisation)
+    if ((rc = ensure_ws(c, slice * (size_t)((dbg && std::strstr(dbg, "ownslice")) ? nch : nstr), s))) return rc;
     const bool prof = c->profiling && c->ev_created;
     if (prof) {
         if ((rc = ensure_events(c, nch))) return rc;
@@ -752,10 +754,8 @@ static int partI_passG(yoho_ctx* c, const float* x, int B, float* eqv, float* in
         HIPCHK(hipEventRecord(c->ev_fork, s));                      // the side stream starts behind everything queued on the caller's
         HIPCHK(hipStreamWaitEvent(c->side_stream, c->ev_fork, 0));
     }
-    static const char* dbg = std::getenv("YOHO_PARTI_DEBUG");      // experiments: "serial" = wait after every chunk, "sideonly" = all chunks on the side stream
     const bool dbg_serial = dbg && std::strstr(dbg, "serial"), dbg_side = dbg && std::strstr(dbg, "sideonly");
     const bool dbg_own = dbg && std::strstr(dbg, "ownslice");      // every chunk on its own workspace slice (no address is reused inside a pass)
-    if (dbg_own && (rc = ensure_ws(c, slice * (size_t)nch, s))) return rc;
     for (int k = 0; k < nch; ++k) {
         const int off = k * chunk, n = B - off < chunk ? B - off : chunk;
         const float *xc, *x1c = nullptr;
@@ -769,13 +769,16 @@ static int partI_passG(yoho_ctx* c, const float* x, int B, float* eqv, float* in
         hipStream_t sk = on_side ? c->side_stream : s;
         char* ws = (char*)c->ws.p + (dbg_own ? slice * (size_t)k : (on_side ? slice : 0));
         if ((rc = partI_passG_chunk(c, ws, k * EV_PER_PASS, xc, n, eqv + (size_t)off * F * G, inv ? inv + (size_t)off * F : nullptr,
-                                    inv_np ? inv_np + (size_t)off * F : nullptr, sk, x1c, B0c, on_side ? 1 : 0))) return rc;
-        if (dbg_serial) HIPCHK(hipStreamSynchronize(sk));
+                                    inv_np ? inv_np + (size_t)off * F : nullptr, sk, x1c, B0c, on_side ? 1 : 0))) break;
+        if (dbg_serial && hipStreamSynchronize(sk) != hipSuccess) { set_error("hipStreamSynchronize failed"); rc = YOHO_EHIP; break; }
     }
     if (nstr == 2) {
-        HIPCHK(hipEventRecord(c->ev_join, c->side_stream));          // the caller's stream continues behind the side stream's last chunk
+        // also on an error inside the loop: the caller's stream continues behind whatever the side stream was given, so the fork is
+        // always joined and the call keeps its contract (ordered on the caller's stream) when it reports a failure
+        HIPCHK(hipEventRecord(c->ev_join, c->side_stream));
         HIPCHK(hipStreamWaitEvent(s, c->ev_join, 0));
     }
+    if (rc) return rc;
     if (prof) (void)hipEventRecord(c->ev_pass[1], s);
     return 0;
 }
@@ -1033,6 +1036,18 @@ int yoho_group_transfer_batch(yoho_ctx* c, const double* pts, const int64_t* kid
         if (!ds[b] || !feat[b] || m[b] < 1) { set_error("yoho_group_transfer_batch: copy %d has no down-sampled points", b); return YOHO_EINVAL; }
     int rc;
     phase_mark(c, 15, (hipStream_t)stream);
+    static const bool staged_transfer = [] { const char* e = std::getenv("YOHO_TRANSFER"); return e && std::strcmp(e, "staged") == 0; }();   // A/B
+    if (c->nn_cell > 0.0 && !staged_transfer) {
+        // with a cell-size hint: all copies of the pass through the hash grid in four launches (gridnn.hip), the keypoints rotated and
+        // the feature rows written by the query kernel itself; q_scratch / idx_scratch stay unused
+        HIPCHK(hipSetDevice(c->device));
+        int mmax = 1;
+        for (int b = 0; b < nb; ++b) mmax = m[b] > mmax ? m[b] : mmax;
+        if ((rc = ensure_ws(c, grid_transfer_ws_bytes(K, nb, mmax), (hipStream_t)stream))) return rc;
+        rc = launch_grid_transfer_batch(pts, kidx, K, R_host, nb, ds, feat, m, g0, out, c->nn_cell, c->ws.p, c->nCU, (hipStream_t)stream);
+        phase_mark(c, -1, (hipStream_t)stream);
+        return rc;
+    }
     for (int b = 0; b < nb; ++b) {
         if ((rc = yoho_rotate_select(c, pts, R_host + 9 * (size_t)b, kidx, K, q_scratch, stream))) return rc;
         if ((rc = yoho_nn_search(c, q_scratch, K, ds[b], m[b], 3, YOHO_DIST_SQUARE_L2, idx_scratch, nullptr, stream))) return rc;

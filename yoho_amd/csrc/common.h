@@ -55,7 +55,7 @@ struct SlotTables {
 };
 
 struct Layer {
-    const SlotTables* tabs = nullptr;   // the owning context's slot tables (set by build_layer)
+    const SlotTables* tabs = nullptr;   // the owning context's slot tables (set by yoho_load_partI / yoho_load_partII for every layer they build)
     int cin = 0, cout = 0, cout_pad = 0, ntaps = 0;
     float* wp = nullptr;      // packed MFMA A-fragments [ob][c8][tap][lane64][4]
     void* wp16 = nullptr;     // bf16x3 planes [ob][c8][tap-pair 7][plane 3][lane64][8] (13-tap layers only)
@@ -107,6 +107,7 @@ struct FourierBasis {
 int build_fourier(const uint8_t* N, const uint8_t* P, FourierBasis& fb);
 }  // namespace yoho
 #include <vector>
+#include <cstdlib>
 namespace yoho {
 void pack_fourier_weights(const FourierBasis& fb, const float* W, int cin, int cout, int cout_pad, std::vector<float>& out);
 int gft_init();
@@ -163,6 +164,9 @@ int launch_quat_norm(const float* y, int M, float* quat, hipStream_t s);
 size_t mutual_prefilter_ws_bytes(int Na, int Nb);
 int launch_mutual_prefilter(const float* a, int Na, const float* b, int Nb, void* ws, unsigned long long** keysA, unsigned long long** keysB,
                             int nCU, hipStream_t s);
+size_t grid_transfer_ws_bytes(int K, int nb, int mmax);
+int launch_grid_transfer_batch(const double* pts, const int64_t* kidx, int K, const double* R_host, int nb, const float* const* ds,
+                               const float* const* feat, const int* m, int g0, float* out, double cell, void* ws, int nCU, hipStream_t s);
 struct Workspace;
 }  // namespace yoho
 struct yoho_ctx;
@@ -177,6 +181,18 @@ struct Workspace {
     void* p = nullptr;
     size_t bytes = 0;
 };
+
+// Timing-experiment switches (YOHO_PARTI_DEBUG, YOHO_FGEMM_DEBUG: serialised chunks, GEMMs without their stores, drained waits ...)
+// exist only in a build made with -DYOHO_EXPERIMENTS (YOHO_EXPERIMENTS=1 python -m yoho_amd.build --force): the shipped library
+// does not read them, so no environment variable can change what a production pass computes or how it is ordered.
+inline const char* experiment_env(const char* name) {
+#ifdef YOHO_EXPERIMENTS
+    return std::getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
 
 // Accumulating phase timer for the entries that are many launches long (the FCGF path: voxelisation, coordinate / kernel maps, the
 // convolutions of each level, the feature transfer).  phase_mark(ctx, cat, s) records ONE event on the launch stream: it ends the

@@ -351,7 +351,7 @@ int launch_fgemm(const Layer& L, const char* Bplanes, int kppad, int nT32, const
                  int variant) {
     FGemmArgs a;
     fgemm_fill_args(a, L, Bplanes, kppad, nT32, res, out, rflag);
-    static const int dbg_gemm1 = [] { const char* e = std::getenv("YOHO_PARTI_DEBUG"); return (e && std::strstr(e, "gemm1")) ? 1 : 0; }();
+    static const int dbg_gemm1 = [] { const char* e = experiment_env("YOHO_PARTI_DEBUG"); return (e && std::strstr(e, "gemm1")) ? 1 : 0; }();
     if (dbg_gemm1) variant = 1;
     if (variant == 3) return launch_fgemm3(a, flags, s);
     if (variant != 1) return launch_fgemm2(a, flags, s);

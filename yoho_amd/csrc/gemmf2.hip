@@ -689,7 +689,7 @@ int fgemm3_init() {
 }
 
 int launch_fgemm3(const FGemmArgs& a, int flags, hipStream_t s) {
-    if (const char* dbg = std::getenv("YOHO_FGEMM_DEBUG")) {
+    if (const char* dbg = experiment_env("YOHO_FGEMM_DEBUG")) {
         if (std::strstr(dbg, "nostore")) flags |= F2_NOSTORE;
     }
     int tot = 0;
@@ -703,7 +703,7 @@ int launch_fgemm3(const FGemmArgs& a, int flags, hipStream_t s) {
     }
     tot *= 8;
     // 32 output channels, no residual: all 32 d live rows in every wave (fgemm3s); YOHO_FGEMM_DEBUG=nosmall keeps fgemm3
-    static const bool small_ok = [] { const char* e = std::getenv("YOHO_FGEMM_DEBUG"); return !(e && std::strstr(e, "nosmall")); }();
+    static const bool small_ok = [] { const char* e = experiment_env("YOHO_FGEMM_DEBUG"); return !(e && std::strstr(e, "nosmall")); }();
     if (small_ok && a.cout == 32 && !(flags & EPI_RES)) hipLaunchKernelGGL(fgemm3s_kernel, dim3(tot), dim3(512), F3_LDS, s, a, flags);
     else hipLaunchKernelGGL(fgemm3_kernel, dim3(tot), dim3(512), F3_LDS, s, a, flags);
     HIPCHK(hipGetLastError());
@@ -716,7 +716,7 @@ int fgemm2_init() {
 }
 
 int launch_fgemm2(const FGemmArgs& a, int flags, hipStream_t s) {
-    if (const char* dbg = std::getenv("YOHO_FGEMM_DEBUG")) {          // kernel-timing experiments only (results are not valid with nostore)
+    if (const char* dbg = experiment_env("YOHO_FGEMM_DEBUG")) {          // kernel-timing experiments only (results are not valid with nostore)
         if (std::strstr(dbg, "nostore")) flags |= F2_NOSTORE;       // no coefficient stores at all (K loops alone)
         if (std::strstr(dbg, "mix")) flags |= F2_MIX;               // slots alternate between the d = 5 irrep and the others
         if (std::strstr(dbg, "sc1")) flags |= F2_ST_SC1;            // write-through stores that do not stay in the L2

@@ -619,8 +619,8 @@ int launch_gft16(const float* in, float* out32, char* planes, int kppad, const v
     a.ctr = no_steal ? nullptr : ctr;
     a.in = in; a.out32 = out32; a.planes = planes; a.Ffrag = reinterpret_cast<const uintx4*>(Ffrag); a.bn_s = bn_s; a.bn_t = bn_t;
     a.nChunks = nTiles * C8; a.C8 = C8;
-    static const int dbg_drain = [] { const char* e = std::getenv("YOHO_PARTI_DEBUG"); return (e && std::strstr(e, "drain")) ? 1 : 0; }();
-    static const int dbg_xf1 = [] { const char* e = std::getenv("YOHO_PARTI_DEBUG"); return (e && std::strstr(e, "xf1")) ? 1 : 0; }();
+    static const int dbg_drain = [] { const char* e = experiment_env("YOHO_PARTI_DEBUG"); return (e && std::strstr(e, "drain")) ? 1 : 0; }();
+    static const int dbg_xf1 = [] { const char* e = experiment_env("YOHO_PARTI_DEBUG"); return (e && std::strstr(e, "xf1")) ? 1 : 0; }();
     a.drain = dbg_drain;
     if (dbg_xf1) variant = 1;
     if (planes) {
@@ -629,7 +629,7 @@ int launch_gft16(const float* in, float* out32, char* planes, int kppad, const v
         for (int q = 0; q < G; ++q) { a.qbase[q] = 0; a.qstride[q] = 0; }
     }
     // experiment (YOHO_PARTI_DEBUG=xfgridN): N workgroups per CU's worth of chunks instead of one persistent workgroup per CU
-    static const int gmult = [] { const char* e = std::getenv("YOHO_PARTI_DEBUG"); const char* q = e ? std::strstr(e, "xfgrid") : nullptr; return q ? std::atoi(q + 6) : 1; }();
+    static const int gmult = [] { const char* e = experiment_env("YOHO_PARTI_DEBUG"); const char* q = e ? std::strstr(e, "xfgrid") : nullptr; return q ? std::atoi(q + 6) : 1; }();
     const int want = nCU * (gmult > 0 ? gmult : 1);
     const int grid = a.nChunks < want ? a.nChunks : want;
     if (grid == 0) return 0;

@@ -211,4 +211,176 @@ int launch_grid_nn(int mode, const void* src, int Ns, const GnMat3* R, const flo
     return 0;
 }
 
+// ---- the feature transfer of one backbone pass in four launches (copy = blockIdx.y) -------------------------------------------
+// simple_yoho/yoho_extract.py:33-39 per rotated copy b: q = (R_b keypoint).float(), nearest down-sampled point of copy b in fp32
+// 'SquareL2', out[k, :, g0 + b] = feat_b[nn].  Per copy that was rotate -> clear -> build -> query -> fallback -> scatter, six
+// launches of 5-15 us on 5000 queries: 90 launches per 15-copy pass.  Here the copies share the launches; the query kernel rotates
+// its keypoint itself (the rotate kernel's expression: f64 fma chain, then the cast) and writes the feature row as soon as it knows
+// the winner.  Same arithmetic, same (distance, index) minimum: the same rows.
+constexpr int GT_BATCH = 16;
+struct GtBatch {
+    const double* pts; const int64_t* kidx; int K, nb;
+    double R[GT_BATCH][9];
+    const float* ds[GT_BATCH]; const float* feat[GT_BATCH]; int m[GT_BATCH];
+    double inv_cell, lim2;
+    u64* keys; int* head; unsigned cap;          // copy b: + b * cap
+    int* next; int mmax;                         // copy b: + b * mmax
+    int* ulist; int* ucount;                     // copy b: ulist + b * K, ucount[b]
+    int g0; float* out;
+};
+
+__global__ void gt_clear_kernel(u64* keys, int* head, size_t total, int* ucount, int nb) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < total) { keys[i] = GN_EMPTY; head[i] = -1; }
+    if (i < (size_t)nb) ucount[i] = 0;
+}
+
+__global__ void gt_build_kernel(GtBatch a) {
+    const int i = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    if (i >= a.m[b]) return;
+    const float* pts = a.ds[b];
+    u64* keys = a.keys + (size_t)b * a.cap;
+    int* head = a.head + (size_t)b * a.cap;
+    const unsigned mask = a.cap - 1;
+    const u64 key = gn_key(gn_cell((double)pts[3 * (size_t)i], a.inv_cell), gn_cell((double)pts[3 * (size_t)i + 1], a.inv_cell),
+                           gn_cell((double)pts[3 * (size_t)i + 2], a.inv_cell));
+    unsigned s = gn_slot(key, mask);
+    for (;;) {
+        const u64 old = atomicCAS(&keys[s], GN_EMPTY, key);
+        if (old == GN_EMPTY || old == key) break;
+        s = (s + 1) & mask;
+    }
+    a.next[(size_t)b * a.mmax + i] = atomicExch(&head[s], i);
+}
+
+// the rotated keypoint as the rotate kernel (sparse.hip rotate_sel_kernel / point_of) forms it: f64 fma chain per coordinate, then float
+__device__ __forceinline__ void gt_query_point(const GtBatch& a, int b, int k, float (&q)[3]) {
+    const size_t r = (size_t)a.kidx[k];
+    const double p0 = a.pts[3 * r], p1 = a.pts[3 * r + 1], p2 = a.pts[3 * r + 2];
+    const double* R = a.R[b];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) q[c] = (float)fma(p2, R[3 * c + 2], fma(p1, R[3 * c + 1], p0 * R[3 * c]));
+}
+
+// out[k, :, g] = feat[row, :] by the first 32 threads of the caller's wave / workgroup (group_scatter_kernel's clamp)
+__device__ __forceinline__ void gt_scatter(const GtBatch& a, int b, int k, int row, int t) {
+    row = row < 0 ? 0 : (row >= a.m[b] ? a.m[b] - 1 : row);
+    if (t < F) a.out[((size_t)k * F + t) * G + a.g0 + b] = a.feat[b][(size_t)row * F + t];
+}
+
+__global__ __launch_bounds__(256) void gt_query_kernel(GtBatch a) {
+    const int lane = threadIdx.x & 63, b = blockIdx.y;
+    const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (k >= a.K) return;                                            // wave-uniform
+    GnMetric<0> m;
+    gt_query_point(a, b, k, m.q);
+    const u64* keys = a.keys + (size_t)b * a.cap;
+    const int* head = a.head + (size_t)b * a.cap;
+    const int* next = a.next + (size_t)b * a.mmax;
+    const float* tgt = a.ds[b];
+    const unsigned mask = a.cap - 1;
+    const int cx = gn_cell(m.pos(0), a.inv_cell), cy = gn_cell(m.pos(1), a.inv_cell), cz = gn_cell(m.pos(2), a.inv_cell);
+    float bd = gn_inf<float>();
+    int bi = 0x7FFFFFFF;
+    for (int c = lane; c < 125; c += 64) {
+        const u64 key = gn_key(gn_clampi(cx + c % 5 - 2), gn_clampi(cy + (c / 5) % 5 - 2), gn_clampi(cz + c / 25 - 2));
+        unsigned s = gn_slot(key, mask);
+        int i = -1;
+        for (;;) {
+            const u64 kk = keys[s];
+            if (kk == key) { i = head[s]; break; }
+            if (kk == GN_EMPTY) break;
+            s = (s + 1) & mask;
+        }
+        for (; i >= 0; i = next[i]) {
+            const float d = m.eval(tgt + 3 * (size_t)i);
+            if (d < bd || (d == bd && i < bi)) { bd = d; bi = i; }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const float od = __shfl_xor(bd, o);
+        const int oi = __shfl_xor(bi, o);
+        if (od < bd || (od == bd && oi < bi)) { bd = od; bi = oi; }
+    }
+    if (bi != 0x7FFFFFFF && GnMetric<0>::resolved(bd, a.lim2)) gt_scatter(a, b, k, bi, lane);       // every lane holds the winner
+    else if (lane == 0) a.ulist[(size_t)b * a.K + atomicAdd(a.ucount + b, 1)] = k;
+}
+
+__global__ __launch_bounds__(256) void gt_fallback_kernel(GtBatch a) {
+    __shared__ float rd[256];
+    __shared__ int ri[256];
+    const int b = blockIdx.y;
+    const int count = a.ucount[b];
+    const float* tgt = a.ds[b];
+    for (int u = blockIdx.x; u < count; u += gridDim.x) {
+        const int k = a.ulist[(size_t)b * a.K + u];
+        GnMetric<0> m;
+        gt_query_point(a, b, k, m.q);
+        float bd = gn_inf<float>();
+        int bi = 0x7FFFFFFF;
+        for (int i = threadIdx.x; i < a.m[b]; i += 256) {
+            const float d = m.eval(tgt + 3 * (size_t)i);
+            if (d < bd || (d == bd && i < bi)) { bd = d; bi = i; }
+        }
+        __syncthreads();
+        rd[threadIdx.x] = bd; ri[threadIdx.x] = bi;
+        __syncthreads();
+        for (int o = 128; o >= 1; o >>= 1) {
+            if (threadIdx.x < o) {
+                const float od = rd[threadIdx.x + o];
+                const int oi = ri[threadIdx.x + o];
+                if (od < rd[threadIdx.x] || (od == rd[threadIdx.x] && oi < ri[threadIdx.x])) { rd[threadIdx.x] = od; ri[threadIdx.x] = oi; }
+            }
+            __syncthreads();
+        }
+        gt_scatter(a, b, k, ri[0] == 0x7FFFFFFF ? 0 : ri[0], threadIdx.x);       // all distances NaN: the brute-force kernels answer index 0
+    }
+}
+
+size_t grid_transfer_ws_bytes(int K, int nb, int mmax) {
+    unsigned cap = 1024;
+    while (cap < 2u * (unsigned)mmax) cap <<= 1;
+    return ((size_t)cap * 12 + ((size_t)mmax + K) * 4) * nb + 1024;
+}
+
+// nb <= 64 copies (launched GT_BATCH at a time); ws: grid_transfer_ws_bytes(K, nb, max m) bytes
+int launch_grid_transfer_batch(const double* pts, const int64_t* kidx, int K, const double* R_host, int nb, const float* const* ds,
+                               const float* const* feat, const int* m, int g0, float* out, double cell, void* ws, int nCU, hipStream_t s) {
+    int mmax = 1;
+    for (int b = 0; b < nb; ++b) mmax = m[b] > mmax ? m[b] : mmax;
+    unsigned cap = 1024;
+    while (cap < 2u * (unsigned)mmax) cap <<= 1;
+    char* p = (char*)ws;
+    u64* keys = (u64*)p; p += (size_t)cap * 8 * nb;
+    int* head = (int*)p; p += (size_t)cap * 4 * nb;
+    int* next = (int*)p; p += (size_t)mmax * 4 * nb;
+    int* ulist = (int*)p; p += (size_t)K * 4 * nb;
+    int* ucount = (int*)p;
+    {
+        const size_t total = (size_t)cap * nb;
+        hipLaunchKernelGGL(gt_clear_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, keys, head, total, ucount, nb);
+    }
+    for (int b0 = 0; b0 < nb; b0 += GT_BATCH) {
+        const int nbc = nb - b0 < GT_BATCH ? nb - b0 : GT_BATCH;
+        GtBatch a;
+        a.pts = pts; a.kidx = kidx; a.K = K; a.nb = nbc;
+        for (int b = 0; b < GT_BATCH; ++b) {
+            const int sb = b < nbc ? b0 + b : b0;
+            for (int i = 0; i < 9; ++i) a.R[b][i] = R_host[9 * (size_t)sb + i];
+            a.ds[b] = ds[sb]; a.feat[b] = feat[sb]; a.m[b] = m[sb];
+        }
+        a.inv_cell = 1.0 / cell; a.lim2 = 4.0 * cell * cell * (1.0 - 1e-4);
+        a.keys = keys + (size_t)b0 * cap; a.head = head + (size_t)b0 * cap; a.cap = cap;
+        a.next = next + (size_t)b0 * mmax; a.mmax = mmax;
+        a.ulist = ulist + (size_t)b0 * K; a.ucount = ucount + b0;
+        a.g0 = g0 + b0; a.out = out;
+        hipLaunchKernelGGL(gt_build_kernel, dim3((mmax + 255) / 256, nbc), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(gt_query_kernel, dim3((K + 3) / 4, nbc), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(gt_fallback_kernel, dim3(nCU > 64 ? 64 : (nCU > 0 ? nCU : 64), nbc), dim3(256), 0, s, a);
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 }  // namespace yoho

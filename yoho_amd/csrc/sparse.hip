@@ -1549,7 +1549,9 @@ int fcgf_forward(yoho_ctx* ctx, const FcgfNet* net, const int* coords0, int n0, 
     {   // per-cloud bounding boxes of the voxel indices: range check of the 19-bit key fields, and the first convolution's bitmaps
         hipLaunchKernelGGL(bbox_init_kernel, dim3(2), dim3(256), 0, s, dbb, nb);
         {
-            const int rpw = std::max(1024, (n0 + 127) / 128);              // <= 128 workgroups
+            // <= 1024 workgroups: a run is a few iterations of dependent loads per thread (128 long runs were latency-bound: 94 us
+            // for a 1.3 M-voxel pass); ~6 k atomics per pass
+            const int rpw = std::max(1024, (n0 + 1023) / 1024);
             hipLaunchKernelGGL(bbox_kernel, dim3((n0 + rpw - 1) / rpw), dim3(256), 0, s, L[0].coords, n0, rpw, dbb);
         }
         HIPCHK(hipMemcpyAsync(hbb, dbb, sizeof(int) * 6 * nb, hipMemcpyDeviceToHost, s));     // completes with the level-1 sync below
