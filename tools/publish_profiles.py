@@ -8,9 +8,9 @@ header) and stamping the commit.
 import json, os, re, shutil, sys
 
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-RND = sys.argv[2] if len(sys.argv) > 2 else "r03"
+RND = sys.argv[2] if len(sys.argv) > 2 else "r04"
 PREV = "r%02d" % (int(RND[1:]) - 1)
-SRC, DST = os.path.join(R, "gpurun_out", sys.argv[3] if len(sys.argv) > 3 else "r03p"), os.path.join(R, "profiles")
+SRC, DST = os.path.join(R, "gpurun_out", sys.argv[3] if len(sys.argv) > 3 else "r04p"), os.path.join(R, "profiles")
 
 
 def header_of(path):
