@@ -14,7 +14,11 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
-LIB = os.path.join(LIBDIR, "libyoho_hip.so")
+# YOHO_EXPERIMENTS=1: a second library beside the shipped one, with the timing-experiment switches compiled in (YOHO_PARTI_DEBUG /
+# YOHO_FGEMM_DEBUG, csrc/common.h experiment_env); tools select it with YOHO_LIB=exp, nothing else ever loads it
+EXPERIMENTS = os.environ.get("YOHO_EXPERIMENTS") == "1"
+OBJDIR = os.path.join(LIBDIR, "exp") if EXPERIMENTS else LIBDIR
+LIB = os.path.join(LIBDIR, "libyoho_hip_exp.so" if EXPERIMENTS else "libyoho_hip.so")
 SOURCES = ["api.hip", "gconv.hip", "gconv16.hip", "fourier.hip", "gemmf.hip", "gemmf2.hip", "gft16.hip", "cone1.hip", "sparse.hip", "train.hip", "layout.hip", "match.hip", "matchf.hip", "gridnn.hip", "estim.hip", "pair.hip"]
 # Kernels whose results must be bit-exact against numpy / torch-CPU arithmetic are compiled without
 # FMA contraction (hipcc defaults to -ffp-contract=fast and __fmul_rn/__fadd_rn are plain operators
@@ -24,7 +28,7 @@ if os.environ.get("YOHO_SPCONV_ABLATE"):          # timing experiments: compile-
     EXTRA["sparse.hip"] = ["-DYOHO_SPCONV_ABLATE"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-I" + os.path.join(REPO, "include"), "-I" + CSRC]
-if os.environ.get("YOHO_EXPERIMENTS") == "1":     # timing-experiment switches (YOHO_PARTI_DEBUG / YOHO_FGEMM_DEBUG) are compiled in only on request
+if EXPERIMENTS:
     FLAGS.append("-DYOHO_EXPERIMENTS")
 
 
@@ -42,11 +46,11 @@ def build(force=False, verbose=True):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if not os.path.exists(hipcc):
         hipcc = "hipcc"
-    os.makedirs(LIBDIR, exist_ok=True)
+    os.makedirs(OBJDIR, exist_ok=True)
     objs = []
     procs = []
     for src in SOURCES:
-        obj = os.path.join(LIBDIR, src.replace(".hip", ".o"))
+        obj = os.path.join(OBJDIR, src.replace(".hip", ".o"))
         cmd = [hipcc] + FLAGS + EXTRA.get(src, []) + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)

@@ -13,7 +13,9 @@ import torch  # must be imported before the library so that both share one HIP r
 from . import tables as _tables
 from . import weights as _weights
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libyoho_hip.so")
+# YOHO_LIB=exp: the experiments build (YOHO_EXPERIMENTS=1 python -m yoho_amd.build: the timing switches compiled in) - measurement tools only
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib",
+                         "libyoho_hip_exp.so" if os.environ.get("YOHO_LIB") == "exp" else "libyoho_hip.so")
 _lib = None
 
 SYMBOLS = [
