@@ -310,7 +310,11 @@ int yoho_set_nn_grid(yoho_ctx* ctx, double cell);
  * cannot take (non-finite values, magnitudes beyond the fp16 range) go to the brute-force kernels by themselves. */
 int yoho_set_nn_prefilter(yoho_ctx* ctx, int enable);
 
-/* FCGF backbone, internal row orders (outputs are bit-identical either way, rows come back in the caller's order):
+/* FCGF backbone, internal row orders (outputs are bit-identical either way, rows come back in the caller's order).
+ * Coordinate maps: by default every level's map is a rank-ordered occupancy bitmap (row = prefix popcount; rows of every level in
+ * brick order of the bitmap) whenever every cloud of the pass fits one (< 2^24 words) and the rows are distinct voxels; otherwise, or
+ * with bit 2 of cell_sort set (cell_sort | 4, YOHO_FCGF_COORDS=hash), hash tables over packed voxel keys with rows in first-occurrence
+ * order as MinkowskiEngine's CPU manager numbers them - the options below then apply:
  *   cell_sort   - 0 never, 1 (default) for passes of at least 2^18 voxels, 2 always: the level-0 rows of a pass are grouped
  *                 by 8^3-voxel cell (Morton order of the cells), so the rows a workgroup gathers are shared by its output
  *                 rows and stay in the L2 (the sort pays for itself only on large passes);

@@ -117,10 +117,11 @@ def test_internal_row_orders_are_bit_identical(fctx):
     clouds = [torch.from_numpy(fo.voxelize(synth.surface_cloud(n, seed=sd), 0.025)[1]).cuda() for n, sd in ((6000, 5), (37, 6), (2500, 7))]
     clouds.append(torch.from_numpy(fo.voxelize(synth.surface_cloud(20000, seed=8, extent=6.0), 0.025)[1]).cuda())    # wider than the 128-voxel cell wrap
     try:
-        fctx.set_fcgf_sort(False, 0)
+        fctx.set_fcgf_sort(False, 4)                          # hash-table coordinate maps, first-occurrence rows, no sorting at all
         ref = [fctx.fcgf_forward(c) for c in clouds] + list(fctx.fcgf_forward_batch(clouds))
         outs = []
-        for par, cells in ((True, 0), (False, 2), (True, 2)):
+        # hash-table path with its sorts; then the default path (rank-ordered bitmaps: rows of every level in brick order)
+        for par, cells in ((True, 4), (False, 6), (True, 6), (False, 0), (True, 1)):
             fctx.set_fcgf_sort(par, cells)
             outs.append([fctx.fcgf_forward(c) for c in clouds] + list(fctx.fcgf_forward_batch(clouds)))
     finally:
@@ -128,6 +129,26 @@ def test_internal_row_orders_are_bit_identical(fctx):
     for got in outs:
         for a, b in zip(ref, got):
             assert torch.equal(a, b)
+
+
+def test_duplicate_voxel_rows_are_computed_like_their_first_occurrence(fctx):
+    """The C ABI takes 'the distinct voxels' of a cloud; rows that repeat a voxel are still answered - as MinkowskiEngine answers a
+    duplicate's lookup with the first row (tests/cpp/coordinate_map_cpu_test.py:47-65): the rank-ordered bitmaps notice the repeat
+    (fewer set bits than rows) and hand over to the hash tables, and the maps are then built by every row's own probes (the
+    mirrored / inverted maps only ever reach a voxel's first row).  Both coordinate-map paths, same bits."""
+    c = torch.from_numpy(fo.voxelize(synth.surface_cloud(5000, seed=4), 0.025)[1]).cuda()
+    dup = torch.cat([c[:300], c, c[100:150]])
+    try:
+        outs = []
+        for cells in (1, 5):
+            fctx.set_fcgf_sort(True, cells)
+            F = fctx.fcgf_forward(c)
+            Fd = fctx.fcgf_forward(dup)
+            assert torch.equal(Fd[300:300 + c.shape[0]], F) and torch.equal(Fd[:300], F[:300]) and torch.equal(Fd[300 + c.shape[0]:], F[100:150])
+            outs.append(Fd)
+        assert torch.equal(outs[0], outs[1])
+    finally:
+        fctx.set_fcgf_sort(True, 1)
 
 
 def test_other_model_configs_and_tiny_clouds(hip):

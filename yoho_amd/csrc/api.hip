@@ -341,6 +341,7 @@ int yoho_ctx_create(int device, const float* R, const uint8_t* N, const uint8_t*
     c->partII_mode = 2;     // default: fp16x2 cone layers; YOHO_PARTII=f32 | bf16x3 | fp16x2
     if (const char* m = std::getenv("YOHO_FCGF_CELLS")) c->fcgf_cell_sort = std::atoi(m);
     if (const char* m = std::getenv("YOHO_FCGF_SORT")) c->fcgf_parity_sort = std::strcmp(m, "0") == 0 ? 0 : 1;
+    if (const char* m = std::getenv("YOHO_FCGF_COORDS")) c->fcgf_hash_coords = std::strcmp(m, "hash") == 0 ? 1 : 0;
     if (const char* m = std::getenv("YOHO_NN")) c->nn_prefilter = std::strcmp(m, "brute") == 0 ? 0 : 1;
     if (const char* m = std::getenv("YOHO_PARTII")) c->partII_mode = std::strcmp(m, "f32") == 0 ? 0 : (std::strcmp(m, "fp16x2") == 0 ? 2 : 1);
     if (const char* m = std::getenv("YOHO_PARTI_CHUNK")) {       // "1024" or "1024x2" (chunk keypoints x streams), see yoho_set_partI_schedule
@@ -473,7 +474,9 @@ int yoho_set_nn_prefilter(yoho_ctx* c, int enable) {
 int yoho_set_fcgf_sort(yoho_ctx* c, int parity_sort, int cell_sort) {
     if (!c) { set_error("yoho_set_fcgf_sort: null ctx"); return YOHO_EINVAL; }
     c->fcgf_parity_sort = parity_sort ? 1 : 0;
-    c->fcgf_cell_sort = cell_sort < 0 ? 0 : (cell_sort > 2 ? 2 : cell_sort);
+    c->fcgf_hash_coords = (cell_sort >= 0 && (cell_sort & 4)) ? 1 : 0;
+    cell_sort = cell_sort < 0 ? 0 : (cell_sort & 3);
+    c->fcgf_cell_sort = cell_sort > 2 ? 2 : cell_sort;
     return 0;
 }
 

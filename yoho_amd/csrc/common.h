@@ -244,6 +244,7 @@ struct yoho_ctx {
     int* d_rflag = nullptr;      // fp16 range words (note_range): [0] PartI, [1] PartII; read and cleared by yoho_range_status
     int* d_xfctr = nullptr;      // chunk tickets of the persistent transform kernel (gft16x work stealing): [stream slot 2][launch 4][2], zero between launches
     int fcgf_cell_sort = 1;      // FCGF backbone: level-0 rows grouped by 8^3-voxel cell inside the pass (gather locality): 0 never, 1 passes of >= 2^18 rows, 2 always
+    int fcgf_hash_coords = 0;    // 1: coordinate maps through hash tables even when the clouds fit rank-ordered bitmaps (YOHO_FCGF_COORDS=hash, yoho_set_fcgf_sort cell_sort | 4)
     int fcgf_parity_sort = 1;    // transposed convolutions of the FCGF backbone walk parity-sorted rows (sparse.hip); 0: YOHO_FCGF_SORT=0
     int nn_prefilter = 1;        // mutual NN of large sets: MFMA pre-filter + exact candidates (matchf.hip); 0 = brute force (YOHO_NN=brute)
     double nn_cell = 0.0;        // > 0: 3-D nearest-neighbour searches go through a hash grid of this cell size (gridnn.hip)

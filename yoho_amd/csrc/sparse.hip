@@ -53,6 +53,7 @@ struct CoordSrc {
     int rot;                 // pts are rotated on the fly: p' = R p  (the 60 rotated copies of a fragment, YOHO_testset.py:143)
     double R[9];
     int* oor;                // optional device flag: raised when a point's voxel index does not fit the 19-bit key fields
+    int* dup;                // optional device flag: raised by the table insert when a voxel arrives a second time
 };
 constexpr int VOX_LIM = (1 << 18) - 16;      // |voxel index| bound of pack_key, minus the reach of the coarsest kernel offsets
 // floor(p / voxel) as an int with defined behaviour for huge or non-finite values (they land outside VOX_LIM)
@@ -92,7 +93,11 @@ __global__ void hash_insert_min_kernel(CoordSrc src, int n, u64* keys, int* vals
     unsigned s = hslot(key, mask);
     for (;;) {
         const u64 old = atomicCAS(&keys[s], HEMPTY, key);
-        if (old == HEMPTY || old == key) { atomicMin(&vals[s], i); return; }
+        if (old == HEMPTY || old == key) {
+            atomicMin(&vals[s], i);
+            if (old == key && src.dup) atomicOr(src.dup, 1);
+            return;
+        }
         s = (s + 1) & mask;
     }
 }
@@ -309,12 +314,143 @@ struct BmDesc {
     int wx, ny, nz;          // words per x row, rows per z slice, slices
 };
 
+// ---- rank-ordered occupancy bitmaps: the coordinate maps of all four levels without a hash table ------------------------------
+// When every cloud of a pass fits a dense bitmap (it does for anything the backbone is used on: bounding boxes of a few hundred voxels
+// per axis), a level's coordinate map IS its bitmap plus a prefix popcount: row(voxel) = rank[word] + popcount(bits below it).  The
+// bitmap of level l + 1 is the 2 x 2 x 2 OR-reduction of level l's (coordinates are floored to the coarser stride,
+// src/coordinate_map.hpp:58-76, and the bitmap origin is a multiple of 16, so flooring is a shift of the cell index); sizes, rows and
+// coordinates of all levels come out of bit operations and scans over a few MB instead of four hash tables of up to 48 MB built with
+// two atomics per voxel (8 ms per fragment with the lookups that followed).  The INTERNAL row order of every level becomes rank order.
+// Ranks run over 32 (x) x 8 x 8 bricks of words, so rows that are close in space are close in memory - the job the cell sort did
+// for level 0.  The order is free: a row's sum is taken in kernel-offset order whatever its number, level 0 is handed back in the
+// caller's order (operm), so every output bit is what the hash-table path produces (YOHO_FCGF_COORDS=hash, and the automatic fall-back
+// for clouds too large for a bitmap or inputs with duplicate voxels).
+struct RkDesc {
+    long long base;          // first word of this cloud's bitmap at this level (row-major: x words fastest, then y, then z)
+    int x0, y0, z0;          // voxel coordinate of cell (0,0,0): the same multiples of 16 at every level
+    int wx, ny, nz;          // words per x row, rows, slices at this level
+    long long rbase;         // first entry of this cloud's rank array at this level
+    int nyb, nrank;          // y bricks; rank entries of this cloud = nzb * nyb * wx * 64
+    int blk0;                // first 1024-entry scan block of this cloud
+};
+__device__ __forceinline__ long long rk_index(const RkDesc& d, int w, int Y, int Z) {
+    return d.rbase + ((long long)((Z >> 3) * d.nyb + (Y >> 3)) * d.wx + w) * 64 + (Z & 7) * 8 + (Y & 7);
+}
+// row of the voxel at coordinate (qx, qy, qz) - a multiple of the level's stride 2^sh - or -1
+__device__ __forceinline__ int rk_lookup(const RkDesc& d, const unsigned* __restrict__ bm, const int* __restrict__ rank, int qx, int qy, int qz, int sh) {
+    const int X = (qx - d.x0) >> sh, Y = (qy - d.y0) >> sh, Z = (qz - d.z0) >> sh;
+    if (X < 0 || X >= d.wx * 32 || Y < 0 || Y >= d.ny || Z < 0 || Z >= d.nz) return -1;
+    const unsigned word = bm[d.base + ((long long)Z * d.ny + Y) * d.wx + (X >> 5)];
+    const int bit = X & 31;
+    if (!((word >> bit) & 1u)) return -1;
+    return rank[rk_index(d, X >> 5, Y, Z)] + __popc(word & ((1u << bit) - 1u));
+}
+
+// level l -> l + 1: out cell (X, Y, Z) = OR of the in cells (2X .. 2X+1, 2Y .. 2Y+1, 2Z .. 2Z+1); one thread per output word
+__global__ void rk_coarsen_kernel(const RkDesc* __restrict__ din, const RkDesc* __restrict__ dout, const unsigned* __restrict__ bin, unsigned* __restrict__ bout) {
+    const RkDesc di = din[blockIdx.y], d = dout[blockIdx.y];
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)d.wx * d.ny * d.nz) return;
+    const int w = (int)(i % d.wx), Y = (int)((i / d.wx) % d.ny), Z = (int)(i / ((long long)d.wx * d.ny));
+    unsigned a = 0u, b = 0u;
+#pragma unroll
+    for (int dz = 0; dz < 2; ++dz)
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy) {
+            const int y = 2 * Y + dy, z = 2 * Z + dz;
+            if (y < di.ny && z < di.nz) {
+                const unsigned* row = bin + di.base + ((long long)z * di.ny + y) * di.wx;
+                a |= row[2 * w];
+                if (2 * w + 1 < di.wx) b |= row[2 * w + 1];
+            }
+        }
+    auto squeeze = [](unsigned v) {                      // bit i of the result = bits 2i | 2i+1 of v
+        v = (v | (v >> 1)) & 0x55555555u;
+        v = (v | (v >> 1)) & 0x33333333u;
+        v = (v | (v >> 2)) & 0x0F0F0F0Fu;
+        v = (v | (v >> 4)) & 0x00FF00FFu;
+        v = (v | (v >> 8)) & 0x0000FFFFu;
+        return v;
+    };
+    bout[d.base + i] = squeeze(a) | (squeeze(b) << 16);
+}
+
+// the word of rank entry r (brick order) of cloud descriptor d, 0 for the padding of incomplete bricks
+__device__ __forceinline__ unsigned rk_word_of(const RkDesc& d, const unsigned* __restrict__ bm, int r, int& w, int& Y, int& Z) {
+    const int in = r & 63, br = r >> 6;
+    w = br % d.wx;
+    const int byz = br / d.wx;
+    Y = (byz % d.nyb) * 8 + (in & 7);
+    Z = (byz / d.nyb) * 8 + (in >> 3);
+    return (Y < d.ny && Z < d.nz) ? bm[d.base + ((long long)Z * d.ny + Y) * d.wx + w] : 0u;
+}
+
+// popcounts of 1024 rank entries: exclusive prefix inside the block -> rank[], block total -> btot[]   (grid: blocks of the cloud, cloud)
+__global__ __launch_bounds__(1024) void rk_count_kernel(const RkDesc* __restrict__ desc, const unsigned* __restrict__ bm, int* __restrict__ rank,
+                                                         int* __restrict__ btot) {
+    __shared__ int wsum[16];
+    const RkDesc d = desc[blockIdx.y];
+    if ((int)blockIdx.x * 1024 >= d.nrank) return;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int r = blockIdx.x * 1024 + tid;
+    int w, Y, Z;
+    const int v = r < d.nrank ? __popc(rk_word_of(d, bm, r, w, Y, Z)) : 0;
+    int sc = v;
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(sc, o); if (lane >= o) sc += t; }
+    if (lane == 63) wsum[wv] = sc;
+    __syncthreads();
+    int off = 0;
+    for (int k = 0; k < wv; ++k) off += wsum[k];
+    if (r < d.nrank) rank[d.rbase + r] = off + sc - v;
+    if (tid == 1023) btot[d.blk0 + blockIdx.x] = off + sc;
+}
+
+// finishes rank[] (adds the scanned block offsets) and writes the level's rows in rank order: coords[row] = (x, y, z, cloud)
+__global__ __launch_bounds__(256) void rk_rows_kernel(const RkDesc* __restrict__ desc, const unsigned* __restrict__ bm, int* __restrict__ rank,
+                                                      const int* __restrict__ bscan, int ts, int* __restrict__ coords) {
+    const RkDesc d = desc[blockIdx.y];
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= d.nrank) return;
+    int w, Y, Z;
+    unsigned word = rk_word_of(d, bm, r, w, Y, Z);
+    const int row0 = rank[d.rbase + r] + bscan[d.blk0 + (r >> 10)];
+    rank[d.rbase + r] = row0;
+    int k = 0;
+    while (word) {
+        const int bit = __ffs(word) - 1;
+        word &= word - 1u;
+        reinterpret_cast<int4*>(coords)[row0 + k] = make_int4(d.x0 + (w * 32 + bit) * ts, d.y0 + Y * ts, d.z0 + Z * ts, (int)blockIdx.y);
+        ++k;
+    }
+}
+
+// caller's level-0 row i -> internal row: operm[row] = i (the input voxels of a cloud are distinct, so every row has one writer)
+__global__ void rk_operm_kernel(const int* __restrict__ c4, int n, const RkDesc* __restrict__ desc, const unsigned* __restrict__ bm,
+                                const int* __restrict__ rank, int* __restrict__ operm) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int4 c = reinterpret_cast<const int4*>(c4)[i];
+    const int r = rk_lookup(desc[c.w], bm, rank, c.x, c.y, c.z, 0);
+    if (r >= 0) operm[r] = i;
+}
+
+__global__ void rk_fill_kernel(const int* __restrict__ c4, int n, const RkDesc* __restrict__ desc, unsigned* __restrict__ bm) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int4 c = reinterpret_cast<const int4*>(c4)[i];
+    const RkDesc d = desc[c.w];
+    const int bx = c.x - d.x0;
+    atomicOr(bm + d.base + ((long long)(c.z - d.z0) * d.ny + (c.y - d.y0)) * d.wx + (bx >> 5), 1u << (bx & 31));
+}
+
 // map[k][n] = row of (coord(n) + sign * offset(k) * ts) in the table, -1 if absent; kernel index with x fastest.
+// (rk != null: the looked-up level is a rank-ordered bitmap, `sh` = log2 of its stride; else its hash table.)
 // Two cheap rejections before the hash probe: a coordinate that is not a multiple of the table's tensor stride ts_in
 // cannot be in it (7 of 8 candidates of a transposed map, whose offsets live on the finer stride), and for a level-0
 // table the occupancy bitmap (bm != null) answers "absent" for the two thirds of a 3^3 region that are empty.
 __global__ void build_map_kernel(const int* out_coords, int nout, const u64* keys, const int* vals, unsigned mask, int ksize, int ts,
-                                 int sign, int ts_in, const BmDesc* __restrict__ desc, const unsigned* __restrict__ bm, int* map) {
+                                 int sign, int ts_in, const BmDesc* __restrict__ desc, const unsigned* __restrict__ bm, int* map,
+                                 const RkDesc* __restrict__ rk = nullptr, const int* __restrict__ rkrank = nullptr, int sh = 0) {
     const int n = blockIdx.x * 256 + threadIdx.x;
     const int k = blockIdx.y;
     if (n >= nout) return;
@@ -324,6 +460,10 @@ __global__ void build_map_kernel(const int* out_coords, int nout, const u64* key
     const int qx = c.x + ox, qy = c.y + oy, qz = c.z + oz;
     int row = -1;
     bool probe = ((qx | qy | qz) & (ts_in - 1)) == 0;                 // tensor strides are powers of two
+    if (rk) {
+        map[(size_t)k * nout + n] = probe ? rk_lookup(rk[c.w], bm, rkrank, qx, qy, qz, sh) : -1;
+        return;
+    }
     if (probe && bm) {
         const BmDesc d = desc[c.w];
         const int bx = qx - d.x0, by = qy - d.y0, bz = qz - d.z0;
@@ -342,7 +482,8 @@ __global__ void build_map_kernel(const int* out_coords, int nout, const u64* key
 // (k', row) entry has one possible writer: the row at coord(row) + offset(k'), so the stores do not race), k = 13 is the identity,
 // and the upper half is preset to -1 by the caller.  Halves the hash probes of the largest maps.
 __global__ void build_map_sym_kernel(const int* out_coords, int nout, const u64* keys, const int* vals, unsigned mask, int ts,
-                                     const BmDesc* __restrict__ desc, const unsigned* __restrict__ bm, int* map) {
+                                     const BmDesc* __restrict__ desc, const unsigned* __restrict__ bm, int* map,
+                                     const RkDesc* __restrict__ rk = nullptr, const int* __restrict__ rkrank = nullptr, int sh = 0) {
     const int n = blockIdx.x * 256 + threadIdx.x;
     const int k = blockIdx.y;                                  // 0..13
     if (n >= nout) return;
@@ -352,6 +493,12 @@ __global__ void build_map_sym_kernel(const int* out_coords, int nout, const u64*
     const int qx = c.x + ox, qy = c.y + oy, qz = c.z + oz;
     int row = -1;
     bool probe = true;
+    if (rk) {
+        row = rk_lookup(rk[c.w], bm, rkrank, qx, qy, qz, sh);
+        map[(size_t)k * nout + n] = row;
+        if (row >= 0) map[(size_t)(26 - k) * nout + row] = n;
+        return;
+    }
     if (bm) {
         const BmDesc d = desc[c.w];
         const int bx = qx - d.x0, by = qy - d.y0, bz = qz - d.z0;
@@ -378,9 +525,11 @@ __global__ void invert_map_kernel(const int* __restrict__ down, int ncoarse, int
 }
 
 // (n,3) voxel rows of `nb` concatenated clouds (row ranges off[0..nb]) -> (n,4) rows with the cloud index
-__global__ void coords4_kernel(const int* c3, int n, const int* off, int nb, int* c4) {
+struct CloudOff { int off[65]; };             // row offsets of the clouds of a pass, in the kernel arguments
+__global__ void coords4_kernel(const int* c3, int n, CloudOff o, int nb, int* c4) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
+    const int* off = o.off;
     int b = 0;
     while (b + 1 < nb && i >= off[b + 1]) ++b;
     reinterpret_cast<int4*>(c4)[i] = make_int4(c3[3 * (size_t)i], c3[3 * (size_t)i + 1], c3[3 * (size_t)i + 2], b);
@@ -486,6 +635,8 @@ struct SpConvArgs {
     const int* rowperm;      // fp16x2 kernels: tile slot -> output row (-1 = padding), or null (slot = row)
     int nslots;              // tile slots (= nout without a permutation)
     int debug;               // timing experiments only (YOHO_SPCONV_DEBUG): 1 = no (offset, chunk) loop, 2 = no epilogue
+    int norm;                // spconv16w_kernel<1>, cout == 32 only: rows /= |row| this many times in the epilogue (the feature head)
+    const int* operm;        // with norm: output row -> caller's row (level-0 rows are kept in an internal order), or null
 };
 
 // Offsets that no row of a tile reaches are skipped (their rows of the A operand are all zero: the skipped MFMAs would add
@@ -944,7 +1095,21 @@ __global__ __launch_bounds__(256) void spconv16w_kernel(SpConvArgs a) {
                     v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
                 }
                 if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                *reinterpret_cast<float4*>(a.out + (size_t)orow * a.ldout + a.ocoff + co) = v;
+                size_t drow = (size_t)orow;
+                if constexpr (NCB == 1) {
+                    if (a.norm) {
+                        // the feature head: a row's 32 channels sit in the eight lanes of its group (4 each) - unit-normalise here
+                        // (resunet.py:183-187, once more in fcgf_feat.py:48) instead of a pass of its own over the (n, 32) matrix
+                        for (int pass = 0; pass < a.norm; ++pass) {
+                            float ss = fmaf(v.x, v.x, v.y * v.y) + fmaf(v.z, v.z, v.w * v.w);      // explicit: the compiler's contraction must not differ between the two places this is written
+                            ss += __shfl_xor(ss, 1); ss += __shfl_xor(ss, 2); ss += __shfl_xor(ss, 4);
+                            const float nr = sqrtf(ss);
+                            v.x /= nr; v.y /= nr; v.z /= nr; v.w /= nr;
+                        }
+                        if (a.operm) drow = (size_t)a.operm[orow];
+                    }
+                }
+                *reinterpret_cast<float4*>(a.out + drow * a.ldout + a.ocoff + co) = v;
             }
         }
     }
@@ -1204,6 +1369,9 @@ static int launch_spconv(const SpConvArgs& a_in, hipStream_t s) {
     static const int dbg = [] { const char* e = std::getenv("YOHO_SPCONV_DEBUG"); return e ? std::atoi(e) : 0; }();
     a.debug = dbg;
     if (!a.Wh || !a.rowperm) { a.rowperm = nullptr; a.nslots = a.nout; }     // the permutation is an optimisation of the fp16x2 kernels
+    if (a.norm && !(a.Wh && a.cout == 32 && a.cin % 32 == 0 && (a.nslots + 31) / 32 >= 1024)) {
+        set_error("sparse conv: the fused row normalisation exists in the 32-channel fine-level kernel only"); return YOHO_EINVAL;
+    }
     const bool vec_ok = a.ldout % 4 == 0 && a.ocoff % 4 == 0 && (!a.res || (a.ldres % 4 == 0 && a.rcoff % 4 == 0));      // 16-byte epilogue accesses
     if (a.cin % 32 == 0 && a.cout % 32 == 0 && a.cout <= 256 && a.ldin % 4 == 0 && a.K <= SP_MAXK && vec_ok) {
         // Two 32-channel output blocks per wave where possible (halves the gather traffic).  Levels with fewer than ~1024
@@ -1256,6 +1424,25 @@ __global__ void fill_ones_kernel(float* p, int n) {
 // 32 lanes gives the same sum as the 64-lane tree with zeros in the upper half), 8 rows per wave; else one wave per row.
 __global__ __launch_bounds__(256) void row_normalize_kernel(const float* in, int n, int c, float* out, int twice, const int* __restrict__ operm) {
     const int lane = threadIdx.x & 63, wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c == 32) {
+        // eight lanes per row, four channels each, the sum of squares in the order of the fused epilogue of spconv16w_kernel<1>
+        // (a pass large enough for that kernel normalises there): the same bits whichever of the two runs
+        const int ep = lane & 7;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = (wave * 4 + i) * 8 + (lane >> 3);
+            const bool ok = row < n;
+            float4 v = ok ? *reinterpret_cast<const float4*>(in + (size_t)row * 32 + 4 * ep) : make_float4(1.f, 0.f, 0.f, 0.f);
+            for (int pass = 0; pass < (twice ? 2 : 1); ++pass) {
+                float ss = fmaf(v.x, v.x, v.y * v.y) + fmaf(v.z, v.z, v.w * v.w);      // explicit: the compiler's contraction must not differ between the two places this is written
+                ss += __shfl_xor(ss, 1); ss += __shfl_xor(ss, 2); ss += __shfl_xor(ss, 4);
+                const float nr = sqrtf(ss);
+                v.x /= nr; v.y /= nr; v.z /= nr; v.w /= nr;
+            }
+            if (ok) *reinterpret_cast<float4*>(out + (size_t)(operm ? operm[row] : row) * 32 + 4 * ep) = v;
+        }
+        return;
+    }
     if (c <= 32) {
         const int l32 = lane & 31;
 #pragma unroll
@@ -1520,15 +1707,128 @@ int fcgf_forward(yoho_ctx* ctx, const FcgfNet* net, const int* coords0, int n0, 
     // ---- coordinate maps
     L[0].n = n0; L[0].ts = 1; L[0].coords = ar.take<int>((size_t)n0 * 4);
     {
-        int* doff = ar.take<int>(66);
-        int hoff[66] = {0, n0};
-        if (off_host) for (int b = 0; b <= nb; ++b) hoff[b] = off_host[b];
-        HIPCHK(hipMemcpyAsync(doff, hoff, sizeof(int) * (nb + 1), hipMemcpyHostToDevice, s));
-        HIPCHK(hipStreamSynchronize(s));                     // hoff lives on this stack frame
-        hipLaunchKernelGGL(coords4_kernel, dim3((n0 + 255) / 256), dim3(256), 0, s, coords0, n0, doff, nb, L[0].coords);
+        CloudOff ho;
+        ho.off[0] = 0; ho.off[1] = n0;
+        if (off_host) for (int b = 0; b <= nb; ++b) ho.off[b] = off_host[b];
+        hipLaunchKernelGGL(coords4_kernel, dim3((n0 + 255) / 256), dim3(256), 0, s, coords0, n0, ho, nb, L[0].coords);
     }
+    const bool conv1_fused = net->in_ch == 1 && C[1] == 32 && net->k1 * net->k1 * net->k1 <= C1O_MAXK;
+    int* dbb = ar.take<int>(64 * 6);
+    int hbb[64 * 6];
+    auto bounding_boxes = [&](const int* c4) -> int {      // per-cloud boxes of the voxel indices -> hbb (waits for the stream)
+        hipLaunchKernelGGL(bbox_init_kernel, dim3(2), dim3(256), 0, s, dbb, nb);
+        // <= 1024 workgroups: a run is a few iterations of dependent loads per thread
+        const int rpw = std::max(1024, (n0 + 1023) / 1024);
+        hipLaunchKernelGGL(bbox_kernel, dim3((n0 + rpw - 1) / rpw), dim3(256), 0, s, c4, n0, rpw, dbb);
+        HIPCHK(hipMemcpyAsync(hbb, dbb, sizeof(int) * 6 * nb, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        // the packed 64-bit voxel keys hold 19 bits per axis: indices outside +-(2^18 - 16) (16 = reach of the coarsest kernel
+        // offsets) would alias other voxels and give wrong kernel maps without any error - refuse them here
+        for (int b = 0; b < nb; ++b) {
+            const int* bb = hbb + 6 * b;
+            if (bb[0] > bb[3]) continue;                        // empty cloud
+            for (int a = 0; a < 3; ++a)
+                if (bb[a] < -VOX_LIM || bb[3 + a] > VOX_LIM) {
+                    set_error("FCGF backbone: voxel index %d of cloud %d is outside +-%d (cloud extent / voxel size too large, or a non-finite point)",
+                              bb[a] < -VOX_LIM ? bb[a] : bb[3 + a], b, VOX_LIM);
+                    return YOHO_EINVAL;
+                }
+        }
+        return 0;
+    };
     int* operm = nullptr;                          // internal level-0 row -> caller's row (null: same order)
-    if (ctx->fcgf_cell_sort > 1 || (ctx->fcgf_cell_sort == 1 && n0 >= CELL_SORT_MIN_ROWS)) {
+    // ---- rank-ordered bitmaps (see RkDesc): every level's coordinate map without a hash table, when every cloud fits one
+    const bool force_hash = ctx->fcgf_hash_coords != 0;
+    bool rank_mode = false;
+    bool has_dups = false;                         // the caller's rows repeat voxels: every row is then mapped by its own probes (full maps)
+    RkDesc* rkd[4] = {nullptr, nullptr, nullptr, nullptr};      // device descriptors per level [nb]
+    unsigned* rkbm[4] = {nullptr, nullptr, nullptr, nullptr};
+    int* rkrank[4] = {nullptr, nullptr, nullptr, nullptr};
+    BmDesc hdesc[64];
+    BmDesc* ddesc = nullptr;
+    unsigned* dbm = nullptr;
+    long long dbm_words = 0;
+    RkDesc hrk[4][64];
+    if (conv1_fused && !force_hash) {
+        if ((rc = bounding_boxes(L[0].coords))) return rc;
+        const int hk = net->k1 / 2;
+        long long words[4] = {0, 0, 0, 0}, ranks[4] = {0, 0, 0, 0};
+        int blocks[4] = {0, 0, 0, 0};
+        bool ok = true;
+        auto floor16 = [](int v) { return v >= 0 ? v / 16 * 16 : -((-v + 15) / 16 * 16); };
+        for (int b = 0; b < nb && ok; ++b) {
+            const int* bb = hbb + 6 * b;
+            const bool empty = bb[0] > bb[3];
+            const int x0 = empty ? 0 : floor16(bb[0] - hk), y0 = empty ? 0 : floor16(bb[1] - hk), z0 = empty ? 0 : floor16(bb[2] - hk);
+            long long dx = empty ? 1 : (long long)bb[3] + hk + 1 - x0, dy = empty ? 1 : (long long)bb[4] + hk + 1 - y0, dz = empty ? 1 : (long long)bb[5] + hk + 1 - z0;
+            for (int l = 0; l < 4; ++l) {
+                const long long wx = (dx + 31) / 32;
+                if (l == 0 && wx * dy * dz > (1ll << 24)) { ok = false; break; }           // > 64 MiB for one cloud: the hash-table path
+                RkDesc& d = hrk[l][b];
+                d.base = words[l]; d.x0 = x0; d.y0 = y0; d.z0 = z0; d.wx = (int)wx; d.ny = (int)dy; d.nz = (int)dz;
+                d.nyb = (int)((dy + 7) / 8);
+                d.nrank = (int)(((dz + 7) / 8) * d.nyb * wx * 64);
+                d.rbase = ranks[l]; d.blk0 = blocks[l];
+                words[l] += wx * dy * dz; ranks[l] += d.nrank; blocks[l] += (d.nrank + 1023) / 1024;
+                dx = (dx + 1) / 2; dy = (dy + 1) / 2; dz = (dz + 1) / 2;                    // cells of the next level
+            }
+        }
+        const size_t mark = ar.off;
+        int* btot[4]; int* lcoords[4];
+        if (ok) {
+            for (int l = 0; l < 4; ++l) {
+                rkd[l] = reinterpret_cast<RkDesc*>(ar.take<char>(sizeof(RkDesc) * 64));
+                rkbm[l] = ar.take<unsigned>((size_t)words[l] + 2);        // + spare zero words: conv1_mfma_kernel reads word pairs
+                rkrank[l] = ar.take<int>((size_t)ranks[l] + 1);
+                btot[l] = ar.take<int>((size_t)blocks[l] + 2);
+                lcoords[l] = ar.take<int>((size_t)n0 * 4);
+            }
+            ddesc = reinterpret_cast<BmDesc*>(ar.take<char>(sizeof(BmDesc) * 64));
+            operm = ar.take<int>((size_t)n0);
+            if (ar.off > ar.cap) ok = false;
+        }
+        if (ok) {
+            for (int b = 0; b < nb; ++b) hdesc[b] = BmDesc{hrk[0][b].base, hrk[0][b].x0, hrk[0][b].y0, hrk[0][b].z0, hrk[0][b].wx, hrk[0][b].ny, hrk[0][b].nz};
+            // (the host arrays live on this frame; the copies complete with the synchronisation behind the level sizes below)
+            for (int l = 0; l < 4; ++l) {
+                HIPCHK(hipMemcpyAsync(rkd[l], hrk[l], sizeof(RkDesc) * nb, hipMemcpyHostToDevice, s));
+                HIPCHK(hipMemsetAsync(rkbm[l], 0, ((size_t)words[l] + 2) * 4, s));
+            }
+            HIPCHK(hipMemcpyAsync(ddesc, hdesc, sizeof(BmDesc) * nb, hipMemcpyHostToDevice, s));
+            hipLaunchKernelGGL(rk_fill_kernel, dim3((n0 + 255) / 256), dim3(256), 0, s, L[0].coords, n0, rkd[0], rkbm[0]);
+            long long maxw[4] = {1, 1, 1, 1};
+            int maxr[4] = {1, 1, 1, 1};
+            for (int l = 0; l < 4; ++l)
+                for (int b = 0; b < nb; ++b) {
+                    maxw[l] = std::max(maxw[l], (long long)hrk[l][b].wx * hrk[l][b].ny * hrk[l][b].nz);
+                    maxr[l] = std::max(maxr[l], hrk[l][b].nrank);
+                }
+            for (int l = 0; l < 3; ++l)
+                hipLaunchKernelGGL(rk_coarsen_kernel, dim3((unsigned)((maxw[l + 1] + 255) / 256), nb), dim3(256), 0, s, rkd[l], rkd[l + 1], rkbm[l], rkbm[l + 1]);
+            for (int l = 0; l < 4; ++l) {
+                hipLaunchKernelGGL(rk_count_kernel, dim3((maxr[l] + 1023) / 1024, nb), dim3(1024), 0, s, rkd[l], rkbm[l], rkrank[l], btot[l]);
+                hipLaunchKernelGGL(block_scan_kernel, dim3(1), dim3(1024), 0, s, btot[l], blocks[l], dcount + l);
+            }
+            int hn[4] = {0, 0, 0, 0};
+            HIPCHK(hipMemcpyAsync(hn, dcount, sizeof(int) * 4, hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+            has_dups = hn[0] != n0;
+            if (!has_dups) {                                   // else: duplicate voxels in the input - the hash-table path keeps the first of each
+                rank_mode = true;
+                for (int l = 0; l < 4; ++l) {
+                    L[l].ts = 1 << l; L[l].n = hn[l];
+                    if (!window_ok(l, hn[l])) return YOHO_EINVAL;
+                    hipLaunchKernelGGL(rk_rows_kernel, dim3((maxr[l] + 255) / 256, nb), dim3(256), 0, s, rkd[l], rkbm[l], rkrank[l], btot[l], 1 << l, lcoords[l]);
+                }
+                hipLaunchKernelGGL(rk_operm_kernel, dim3((n0 + 255) / 256), dim3(256), 0, s, L[0].coords, n0, rkd[0], rkbm[0], rkrank[0], operm);
+                for (int l = 0; l < 4; ++l) L[l].coords = lcoords[l];
+                dbm = rkbm[0]; dbm_words = words[0];
+                HIPCHK(hipGetLastError());
+            }
+        }
+        if (!rank_mode) { ar.off = mark; operm = nullptr; ddesc = nullptr; }
+    }
+    if (!rank_mode && (ctx->fcgf_cell_sort > 1 || (ctx->fcgf_cell_sort == 1 && n0 >= CELL_SORT_MIN_ROWS))) {
         const int ncell = nb * CELL_PER_CLOUD, nblk = ncell / 1024;
         int* cnt = ar.take<int>((size_t)2 * ncell);            // histogram -> in-block prefix | cursors
         int* btot = ar.take<int>(nblk + 1);
@@ -1543,55 +1843,38 @@ int fcgf_forward(yoho_ctx* ctx, const FcgfNet* net, const int* coords0, int n0, 
         HIPCHK(hipGetLastError());
         L[0].coords = sorted;
     }
-    const bool conv1_fused = net->in_ch == 1 && C[1] == 32 && net->k1 * net->k1 * net->k1 <= C1O_MAXK;
-    int* dbb = ar.take<int>(64 * 6);
-    int hbb[64 * 6];
-    {   // per-cloud bounding boxes of the voxel indices: range check of the 19-bit key fields, and the first convolution's bitmaps
-        hipLaunchKernelGGL(bbox_init_kernel, dim3(2), dim3(256), 0, s, dbb, nb);
-        {
-            // <= 1024 workgroups: a run is a few iterations of dependent loads per thread (128 long runs were latency-bound: 94 us
-            // for a 1.3 M-voxel pass); ~6 k atomics per pass
-            const int rpw = std::max(1024, (n0 + 1023) / 1024);
-            hipLaunchKernelGGL(bbox_kernel, dim3((n0 + rpw - 1) / rpw), dim3(256), 0, s, L[0].coords, n0, rpw, dbb);
-        }
-        HIPCHK(hipMemcpyAsync(hbb, dbb, sizeof(int) * 6 * nb, hipMemcpyDeviceToHost, s));     // completes with the level-1 sync below
-    }
-    for (int l = 0; l < 4; ++l) {
-        L[l].ts = 1 << l;
-        const int nprev = l == 0 ? n0 : L[l - 1].n;
-        L[l].mask = table_cap(nprev) - 1;
-        L[l].keys = ar.take<u64>(L[l].mask + 1);
-        L[l].vals = ar.take<int>(L[l].mask + 1);
-        if (l == 0) {
-            CoordSrc src{L[0].coords, nullptr, 1.0, 1, 0, {0}};
-            if ((rc = build_table(src, n0, L[0], s))) return rc;
-            // distinct input voxels: value = row (atomicMin of the single source row)
-        } else {
-            CoordSrc src{L[l - 1].coords, nullptr, 1.0, L[l].ts, 0, {0}};
-            if ((rc = build_table(src, nprev, L[l], s))) return rc;
-            L[l].coords = ar.take<int>((size_t)nprev * 4);
-            int* bsum = ar.take<int>((size_t)(nprev + 1023) / 1024 + 1);
-            if ((rc = launch_first_compact(src, nprev, L[l].keys, L[l].vals, L[l].mask, bsum, L[l].coords, 4, nullptr, dcount + l, s))) return rc;
-            HIPCHK(hipMemcpyAsync(&L[l].n, dcount + l, sizeof(int), hipMemcpyDeviceToHost, s));
-            HIPCHK(hipStreamSynchronize(s));
-            if (!window_ok(l, L[l].n)) return YOHO_EINVAL;
-            hipLaunchKernelGGL(hash_set_rows_kernel, dim3((L[l].n + 255) / 256), dim3(256), 0, s, L[l].coords, L[l].n, L[l].keys, L[l].vals,
-                               L[l].mask);
-            HIPCHK(hipGetLastError());
-        }
-    }
-    // the packed 64-bit voxel keys hold 19 bits per axis: indices outside +-(2^18 - 16) (16 = reach of the coarsest kernel
-    // offsets) would alias other voxels and give wrong kernel maps without any error - refuse them here
-    for (int b = 0; b < nb; ++b) {
-        const int* bb = hbb + 6 * b;
-        if (bb[0] > bb[3]) continue;                        // empty cloud
-        const int lim = VOX_LIM;
-        for (int a = 0; a < 3; ++a)
-            if (bb[a] < -lim || bb[3 + a] > lim) {
-                set_error("FCGF backbone: voxel index %d of cloud %d is outside +-%d (cloud extent / voxel size too large, or a non-finite point)",
-                          bb[a] < -lim ? bb[a] : bb[3 + a], b, lim);
-                return YOHO_EINVAL;
+    if (!rank_mode) {
+        // (the bounding boxes again when the rank path was tried: the rows may have been cell-sorted since - same boxes, one more
+        // reduction on the rare path)
+        if ((rc = bounding_boxes(L[0].coords))) return rc;
+        HIPCHK(hipMemsetAsync(dcount, 0, sizeof(int) * 4, s));       // [0]: raised when the level-0 insert meets a voxel twice
+        for (int l = 0; l < 4; ++l) {
+            L[l].ts = 1 << l;
+            const int nprev = l == 0 ? n0 : L[l - 1].n;
+            L[l].mask = table_cap(nprev) - 1;
+            L[l].keys = ar.take<u64>(L[l].mask + 1);
+            L[l].vals = ar.take<int>(L[l].mask + 1);
+            if (l == 0) {
+                CoordSrc src{L[0].coords, nullptr, 1.0, 1, 0, {0}, nullptr, dcount};
+                if ((rc = build_table(src, n0, L[0], s))) return rc;
+                // value = first row of the voxel (atomicMin); the input voxels are normally distinct
+            } else {
+                CoordSrc src{L[l - 1].coords, nullptr, 1.0, L[l].ts, 0, {0}};
+                if ((rc = build_table(src, nprev, L[l], s))) return rc;
+                L[l].coords = ar.take<int>((size_t)nprev * 4);
+                int* bsum = ar.take<int>((size_t)(nprev + 1023) / 1024 + 1);
+                if ((rc = launch_first_compact(src, nprev, L[l].keys, L[l].vals, L[l].mask, bsum, L[l].coords, 4, nullptr, dcount + l, s))) return rc;
+                int hd[2] = {0, 0};
+                HIPCHK(hipMemcpyAsync(hd, dcount + l - 1, sizeof(int) * 2, hipMemcpyDeviceToHost, s));      // l = 1: [duplicate flag, n1]
+                HIPCHK(hipStreamSynchronize(s));
+                L[l].n = hd[1];
+                if (l == 1 && hd[0]) has_dups = true;
+                if (!window_ok(l, L[l].n)) return YOHO_EINVAL;
+                hipLaunchKernelGGL(hash_set_rows_kernel, dim3((L[l].n + 255) / 256), dim3(256), 0, s, L[l].coords, L[l].n, L[l].keys, L[l].vals,
+                                   L[l].mask);
+                HIPCHK(hipGetLastError());
             }
+        }
     }
     // ---- kernel maps
     phase_mark(ctx, 2, s);
@@ -1601,18 +1884,20 @@ int fcgf_forward(yoho_ctx* ctx, const FcgfNet* net, const int* coords0, int n0, 
         const int kv = ksize * ksize * ksize;
         int* m = ar.take<int>((size_t)kv * outL.n);
         const bool filter = map_bm && inL.ts == 1;             // the bitmap holds the level-0 voxels
-        if (outL.n > 0)
+        const int li = (int)(&inL - L);                        // level that is looked up
+        if (outL.n > 0 && rank_mode)
+            hipLaunchKernelGGL(build_map_kernel, dim3((outL.n + 255) / 256, kv), dim3(256), 0, s, outL.coords, outL.n, (const u64*)nullptr, (const int*)nullptr,
+                               0u, ksize, ts, sign, inL.ts, (const BmDesc*)nullptr, (const unsigned*)rkbm[li], m, (const RkDesc*)rkd[li], (const int*)rkrank[li], li);
+        else if (outL.n > 0)
             hipLaunchKernelGGL(build_map_kernel, dim3((outL.n + 255) / 256, kv), dim3(256), 0, s, outL.coords, outL.n, inL.keys, inL.vals,
-                               inL.mask, ksize, ts, sign, inL.ts, filter ? map_desc : nullptr, filter ? map_bm : nullptr, m);
+                               inL.mask, ksize, ts, sign, inL.ts, filter ? map_desc : nullptr, filter ? map_bm : nullptr, m,
+                               (const RkDesc*)nullptr, (const int*)nullptr, 0);
         return m;
     };
     int* M1 = conv1_fused ? nullptr : make_map(L[0], L[0], net->k1, 1, +1);
-    // occupancy bitmaps for the first convolution (skipped if a cloud's bounding box is too large: hash probes then)
-    BmDesc hdesc[64];
-    BmDesc* ddesc = nullptr;
-    unsigned* dbm = nullptr;
-    long long dbm_words = 0;
-    if (conv1_fused) {
+    // occupancy bitmaps for the first convolution (skipped if a cloud's bounding box is too large: hash probes then); the rank
+    // path has them already
+    if (conv1_fused && !rank_mode) {
         const int hk = net->k1 / 2;
         long long words = 0;
         bool ok = true;
@@ -1638,7 +1923,10 @@ int fcgf_forward(yoho_ctx* ctx, const FcgfNet* net, const int* coords0, int n0, 
     }
     if (dbm) { map_desc = ddesc; map_bm = dbm; }
     int* Msame[4]; int* Mdown[3]; int* Mup[3];
-    static const bool full_maps = [] { const char* e = std::getenv("YOHO_FCGF_MAPS"); return e && std::strcmp(e, "full") == 0; }();   // A/B: every map by hash probes
+    // every map by its own probes: A/B switch, and whenever the caller's rows repeat voxels - the mirrored entries of the symmetric
+    // build and the inverted maps are only ever written for the FIRST row of a voxel
+    static const bool full_maps_env = [] { const char* e = std::getenv("YOHO_FCGF_MAPS"); return e && std::strcmp(e, "full") == 0; }();
+    const bool full_maps = full_maps_env || has_dups;
     for (int l = 0; l < 4; ++l) {
         if (full_maps) { Msame[l] = make_map(L[l], L[l], 3, L[l].ts, +1); continue; }
         // symmetric 3^3 map: offsets 0..12 looked up, 14..26 mirrored, 13 = identity (build_map_sym_kernel)
@@ -1647,8 +1935,12 @@ int fcgf_forward(yoho_ctx* ctx, const FcgfNet* net, const int* coords0, int n0, 
         if (L[l].n == 0) continue;
         HIPCHK(hipMemsetAsync(Msame[l] + (size_t)14 * L[l].n, 0xFF, sizeof(int) * (size_t)13 * L[l].n, s));
         const bool filter = map_bm && L[l].ts == 1;
-        hipLaunchKernelGGL(build_map_sym_kernel, dim3((L[l].n + 255) / 256, 14), dim3(256), 0, s, L[l].coords, L[l].n, L[l].keys, L[l].vals, L[l].mask,
-                           L[l].ts, filter ? map_desc : nullptr, filter ? map_bm : nullptr, Msame[l]);
+        if (rank_mode)
+            hipLaunchKernelGGL(build_map_sym_kernel, dim3((L[l].n + 255) / 256, 14), dim3(256), 0, s, L[l].coords, L[l].n, (const u64*)nullptr, (const int*)nullptr, 0u,
+                               L[l].ts, (const BmDesc*)nullptr, (const unsigned*)rkbm[l], Msame[l], (const RkDesc*)rkd[l], (const int*)rkrank[l], l);
+        else
+            hipLaunchKernelGGL(build_map_sym_kernel, dim3((L[l].n + 255) / 256, 14), dim3(256), 0, s, L[l].coords, L[l].n, L[l].keys, L[l].vals, L[l].mask,
+                               L[l].ts, filter ? map_desc : nullptr, filter ? map_bm : nullptr, Msame[l], (const RkDesc*)nullptr, (const int*)nullptr, 0);
     }
     for (int l = 0; l < 3; ++l) {
         Mdown[l] = make_map(L[l + 1], L[l], 3, L[l].ts, +1);           // strided conv: offsets on the input (finer) stride
@@ -1689,6 +1981,7 @@ int fcgf_forward(yoho_ctx* ctx, const FcgfNet* net, const int* coords0, int n0, 
     if (ar.off > ar.cap) { set_error("fcgf_forward: workspace estimate too small (%zu > %zu)", ar.off, ar.cap); return YOHO_ENOMEM; }
 
     int conv_cat = -1;                          // phase category of the next conv() calls (yoho_phase_read)
+    int conv_norm = 0;                          // > 0: the next conv() normalises its output rows in its epilogue (and hands them back in the caller's order)
     auto conv = [&](const float* in, int ldin, int cin, const int* map, int K, int nout, const ConvW& W, int cout, float* o, int ldout,
                     int ocoff, const BnAff* bn, const float* bias, const float* res, int ldres, int rcoff, int relu,
                     const int* rowperm = nullptr, int nslots = 0) -> int {
@@ -1701,6 +1994,7 @@ int fcgf_forward(yoho_ctx* ctx, const FcgfNet* net, const int* coords0, int n0, 
         a.in = in; a.ldin = ldin; a.cin = cin; a.map = map; a.K = K; a.nout = nout; a.W = W.w; a.Wh = W.wh; a.descale = W.descale; a.cout = cout;
         a.out = o; a.ldout = ldout; a.ocoff = ocoff; a.aff_s = bn ? bn->s : nullptr; a.aff_t = bn ? bn->t : bias;
         a.res = res; a.ldres = ldres; a.rcoff = rcoff; a.relu = relu;
+        a.norm = conv_norm; a.operm = conv_norm ? operm : nullptr;
         return launch_spconv(a, s);
     };
     // BasicBlockBN: out = relu(bn2(conv2(relu(bn1(conv1(x))))) + x), written at column `ocoff` of `o`
@@ -1758,9 +2052,17 @@ int fcgf_forward(yoho_ctx* ctx, const FcgfNet* net, const int* coords0, int n0, 
     if (ar.off > ar.cap) { set_error("fcgf_forward: workspace estimate too small"); return YOHO_ENOMEM; }
     conv_cat = 14;
     if ((rc = conv(cat[0], catw[0], catw[0], nullptr, 1, n0, net->conv1_tr, T[1], f1, T[1], 0, nullptr, nullptr, nullptr, 0, 0, 1))) return rc;
-    if ((rc = conv(f1, T[1], T[1], nullptr, 1, n0, net->final_k, net->out_ch, f2, net->out_ch, 0, nullptr, net->final_b, nullptr, 0, 0, 0))) return rc;
-    hipLaunchKernelGGL(row_normalize_kernel, dim3(net->out_ch <= 32 ? (n0 + 31) / 32 : (n0 + 3) / 4), dim3(256), 0, s, f2, n0, net->out_ch, out,
-                       net->normalize ? 1 : 0, operm);
+    // the feature head: 1 x 1 convolution to out_ch, rows /= |row| (once more for fcgf_feat.py:48), the caller's row order.  Fused into
+    // the convolution's epilogue where that kernel exists (32 features, fp16x2 fine-level kernel: passes of >= 32768 voxels); the
+    // pass over the (n0, 32) matrix was 0.16 ms per 15-copy pass
+    static const bool no_fuse_norm = [] { const char* e = std::getenv("YOHO_FCGF_NORM"); return e && std::strcmp(e, "staged") == 0; }();    // A/B
+    const bool fuse_norm = !no_fuse_norm && net->out_ch == 32 && net->final_k.wh && T[1] % 32 == 0 && (n0 + 31) / 32 >= 1024;
+    conv_norm = fuse_norm ? (net->normalize ? 2 : 1) : 0;
+    if ((rc = conv(f1, T[1], T[1], nullptr, 1, n0, net->final_k, net->out_ch, fuse_norm ? out : f2, net->out_ch, 0, nullptr, net->final_b, nullptr, 0, 0, 0))) return rc;
+    conv_norm = 0;
+    if (!fuse_norm)
+        hipLaunchKernelGGL(row_normalize_kernel, dim3(net->out_ch == 32 ? (n0 + 127) / 128 : (net->out_ch < 32 ? (n0 + 31) / 32 : (n0 + 3) / 4)), dim3(256), 0, s, f2, n0, net->out_ch, out,
+                           net->normalize ? 1 : 0, operm);
     HIPCHK(hipGetLastError());
     phase_mark(ctx, -1, s);
     return 0;

@@ -722,7 +722,8 @@ class Context:
 
     def set_fcgf_sort(self, parity=True, cells=1):
         """internal row orders of the FCGF backbone: transposed convolutions over parity-sorted rows (default on), level-0 rows
-        grouped by 8^3-voxel cell (0 never, 1 = default: passes of >= 2^18 voxels, 2 always); identical outputs in the
+        grouped by 8^3-voxel cell (0 never, 1 = default: passes of >= 2^18 voxels, 2 always; + 4: coordinate maps through hash
+        tables even when the clouds fit rank-ordered bitmaps - the cell sort only exists on that path); identical outputs in the
         caller's row order either way"""
         _check(self._lib.yoho_set_fcgf_sort(self._h, 1 if parity else 0, int(cells)))
 
