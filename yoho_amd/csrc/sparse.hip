@@ -386,7 +386,11 @@ __global__ void vox_fill_kernel(VoxBatch a, unsigned* bm) {
     const int X = x - d.x0, Y = y - d.y0, Z = z - d.z0;
     if (X < 0 || X >= d.wx * 32 || Y < 0 || Y >= d.ny || Z < 0 || Z >= d.nz || x < -VOX_LIM || x > VOX_LIM || y < -VOX_LIM || y > VOX_LIM ||
         z < -VOX_LIM || z > VOX_LIM) { atomicOr(a.dcount + 2 * b + 1, 1); return; }
-    atomicOr(bm + d.base + ((long long)Z * d.ny + Y) * d.wx + (X >> 5), 1u << (X & 31));
+    // ~3.4 points share a voxel: most find their bit set already and skip the atomic (a stale read only costs a redundant one) -
+    // the pass is bound by the rate of device atomics (~22 G/s), not by its bytes
+    unsigned* wp = bm + d.base + ((long long)Z * d.ny + Y) * d.wx + (X >> 5);
+    const unsigned bit = 1u << (X & 31);
+    if (!(__builtin_nontemporal_load(wp) & bit)) atomicOr(wp, bit);
 }
 // rank mode, pass 2 (ranks finished): first[row of the voxel] = smallest point index
 __global__ void vox_first_kernel(VoxBatch a) {
@@ -395,7 +399,9 @@ __global__ void vox_first_kernel(VoxBatch a) {
     double p0, p1, p2;
     vox_point(a, b, i, p0, p1, p2);
     const int r = rk_lookup(a.rk[a.b0 + b], a.bm, a.rank, voxel_index(p0, a.voxel), voxel_index(p1, a.voxel), voxel_index(p2, a.voxel), 0);
-    if (r >= 0) atomicMin(a.first + r, i);
+    // points are visited roughly in index order, so most find a smaller index stored already: any value ever stored is >= the final
+    // minimum, so skipping on i >= (possibly stale) value is safe, and a stale larger value only costs a redundant atomic
+    if (r >= 0 && __builtin_nontemporal_load(a.first + r) > i) atomicMin(a.first + r, i);
 }
 // rank[] += scanned block offsets (rk_rows_kernel does this for the coordinate maps, where it also writes the rows)
 __global__ void rk_finish_kernel(const RkDesc* __restrict__ desc, int* __restrict__ rank, const int* __restrict__ bscan) {
@@ -1241,7 +1247,7 @@ __global__ __launch_bounds__(256) void conv1_ones_kernel(const int* __restrict__
 
 // A workgroup scans a contiguous run of rows (rows of a cloud are contiguous, so it almost always sees one cloud) and
 // issues one set of atomics per (workgroup, cloud): a few hundred atomics per pass instead of one set per wave.
-__global__ __launch_bounds__(256) void bbox_kernel(const int* __restrict__ coords, int n, int rows_per_wg, int* __restrict__ bb) {
+__global__ __launch_bounds__(256) void bbox_kernel(const int* __restrict__ coords, int n, int rows_per_wg, int* __restrict__ bb, int* __restrict__ part) {
     __shared__ int red[4][7];
     const int r0 = blockIdx.x * rows_per_wg, r1 = min(n, r0 + rows_per_wg);
     auto flush = [&](int cloud, const int (&lo)[3], const int (&hi)[3]) {
@@ -1278,10 +1284,32 @@ __global__ __launch_bounds__(256) void bbox_kernel(const int* __restrict__ coord
     const int w = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) { red[w][0] = lo[0]; red[w][1] = lo[1]; red[w][2] = lo[2]; red[w][3] = hi[0]; red[w][4] = hi[1]; red[w][5] = hi[2]; }
     __syncthreads();
-    if (threadIdx.x == 0 && last >= 0) {
+    if (threadIdx.x == 0) {
+        // the box of the run's last cloud goes to part[block] = (cloud, lo, hi); bbox_reduce_kernel combines the blocks (a thousand
+        // workgroups hitting the same six words of a cloud with atomics was most of this kernel's 0.1 ms)
         for (int ww = 1; ww < 4; ++ww)
             for (int a = 0; a < 3; ++a) { lo[a] = min(lo[a], red[ww][a]); hi[a] = max(hi[a], red[ww][3 + a]); }
-        if (lo[0] <= hi[0]) flush(last, lo, hi);
+        int* p = part + 7 * blockIdx.x;
+        p[0] = (last >= 0 && lo[0] <= hi[0]) ? last : -1;
+        p[1] = lo[0]; p[2] = lo[1]; p[3] = lo[2]; p[4] = hi[0]; p[5] = hi[1]; p[6] = hi[2];
+    }
+}
+
+__global__ __launch_bounds__(1024) void bbox_reduce_kernel(const int* __restrict__ part, int nblocks, int nb, int* __restrict__ bb) {
+    __shared__ int lb[64 * 6];
+    for (int i = threadIdx.x; i < 64 * 6; i += 1024) lb[i] = (i % 6) < 3 ? 0x7FFFFFFF : (int)0x80000000;
+    __syncthreads();
+    for (int b = threadIdx.x; b < nblocks; b += 1024) {
+        const int* p = part + 7 * b;
+        const int cl = p[0];
+        if (cl >= 0 && cl < 64) {
+            atomicMin(&lb[cl * 6 + 0], p[1]); atomicMin(&lb[cl * 6 + 1], p[2]); atomicMin(&lb[cl * 6 + 2], p[3]);
+            atomicMax(&lb[cl * 6 + 3], p[4]); atomicMax(&lb[cl * 6 + 4], p[5]); atomicMax(&lb[cl * 6 + 5], p[6]);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nb * 6; i += 1024) {       // joins what the (rare) cloud boundaries inside a run flushed directly
+        if ((i % 6) < 3) atomicMin(bb + i, lb[i]); else atomicMax(bb + i, lb[i]);
     }
 }
 
@@ -1773,12 +1801,15 @@ int fcgf_forward(yoho_ctx* ctx, const FcgfNet* net, const int* coords0, int n0, 
     }
     const bool conv1_fused = net->in_ch == 1 && C[1] == 32 && net->k1 * net->k1 * net->k1 <= C1O_MAXK;
     int* dbb = ar.take<int>(64 * 6);
+    int* dbbpart = ar.take<int>(7 * 1100);               // per-workgroup partial boxes of bbox_kernel (<= 1024 + 1 runs)
     int hbb[64 * 6];
     auto bounding_boxes = [&](const int* c4) -> int {      // per-cloud boxes of the voxel indices -> hbb (waits for the stream)
         hipLaunchKernelGGL(bbox_init_kernel, dim3(2), dim3(256), 0, s, dbb, nb);
         // <= 1024 workgroups: a run is a few iterations of dependent loads per thread
         const int rpw = std::max(1024, (n0 + 1023) / 1024);
-        hipLaunchKernelGGL(bbox_kernel, dim3((n0 + rpw - 1) / rpw), dim3(256), 0, s, c4, n0, rpw, dbb);
+        const int nblk = (n0 + rpw - 1) / rpw;
+        hipLaunchKernelGGL(bbox_kernel, dim3(nblk), dim3(256), 0, s, c4, n0, rpw, dbb, dbbpart);
+        hipLaunchKernelGGL(bbox_reduce_kernel, dim3(1), dim3(1024), 0, s, dbbpart, nblk, nb, dbb);
         HIPCHK(hipMemcpyAsync(hbb, dbb, sizeof(int) * 6 * nb, hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
         // the packed 64-bit voxel keys hold 19 bits per axis: indices outside +-(2^18 - 16) (16 = reach of the coarsest kernel
