@@ -386,11 +386,9 @@ __global__ void vox_fill_kernel(VoxBatch a, unsigned* bm) {
     const int X = x - d.x0, Y = y - d.y0, Z = z - d.z0;
     if (X < 0 || X >= d.wx * 32 || Y < 0 || Y >= d.ny || Z < 0 || Z >= d.nz || x < -VOX_LIM || x > VOX_LIM || y < -VOX_LIM || y > VOX_LIM ||
         z < -VOX_LIM || z > VOX_LIM) { atomicOr(a.dcount + 2 * b + 1, 1); return; }
-    // ~3.4 points share a voxel: most find their bit set already and skip the atomic (a stale read only costs a redundant one) -
-    // the pass is bound by the rate of device atomics (~22 G/s), not by its bytes
-    unsigned* wp = bm + d.base + ((long long)Z * d.ny + Y) * d.wx + (X >> 5);
-    const unsigned bit = 1u << (X & 31);
-    if (!(__builtin_nontemporal_load(wp) & bit)) atomicOr(wp, bit);
+    // (bound by the rate of device atomics, ~22 G/s: 0.2 ms for the 4.5 M points of a 15-copy pass.  Reading the word first and skipping
+    // the atomic when the bit is there was measured: 3 x SLOWER - 0.60 ms - the read goes to memory and sees the bit too rarely)
+    atomicOr(bm + d.base + ((long long)Z * d.ny + Y) * d.wx + (X >> 5), 1u << (X & 31));
 }
 // rank mode, pass 2 (ranks finished): first[row of the voxel] = smallest point index
 __global__ void vox_first_kernel(VoxBatch a) {
@@ -399,9 +397,7 @@ __global__ void vox_first_kernel(VoxBatch a) {
     double p0, p1, p2;
     vox_point(a, b, i, p0, p1, p2);
     const int r = rk_lookup(a.rk[a.b0 + b], a.bm, a.rank, voxel_index(p0, a.voxel), voxel_index(p1, a.voxel), voxel_index(p2, a.voxel), 0);
-    // points are visited roughly in index order, so most find a smaller index stored already: any value ever stored is >= the final
-    // minimum, so skipping on i >= (possibly stale) value is safe, and a stale larger value only costs a redundant atomic
-    if (r >= 0 && __builtin_nontemporal_load(a.first + r) > i) atomicMin(a.first + r, i);
+    if (r >= 0) atomicMin(a.first + r, i);                  // (a read-and-skip in front of it: 0.18 -> 0.55 ms, as in vox_fill_kernel)
 }
 // rank[] += scanned block offsets (rk_rows_kernel does this for the coordinate maps, where it also writes the rows)
 __global__ void rk_finish_kernel(const RkDesc* __restrict__ desc, int* __restrict__ rank, const int* __restrict__ bscan) {
