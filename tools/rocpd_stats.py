@@ -35,6 +35,39 @@ def main(path):
                                   "having sum(duration) > 0 order by name, grid_x"):
         nm = nm if len(nm) < 70 else nm[:67] + "..."
         print(f"| `{nm}` | {g} | {n} | {a / 1e3:.1f} |")
+    # bench.py's roofline reads the GEMM launches of the LAST of nine back-to-back PartI passes, three times (27 passes at the end of
+    # the run when the dataset / raw-cloud / CPU legs are off): the same launches from this trace, so that the line can be recomputed
+    # from the file - the table above averages every launch of the run, those of the timed steps (pipeline clocks) included
+    try:
+        cols = [r[1] for r in db.execute("pragma table_info(kernels)")]
+        tcol = "start" if "start" in cols else ("start_time" if "start_time" in cols else None)
+        if tcol:
+            print("\nThe GEMM / transform launches of the last 27 PartI passes (bench.py's profiled passes: 3 x 9 back to back), by launch order in a pass; "
+                  "'every ninth' = the launches bench.py's roofline reads:\n")
+            print("| kernel | grid (threads) | launches per pass | avg us, all 27 passes | avg us, every ninth pass (9th, 18th, 27th) |")
+            print("|---|---|---|---|---|")
+            tot_all = tot_9 = 0.0
+            for pat, per in (("fgemm3_kernel", None), ("fgemm3s_kernel", None), ("gft16x_kernel", None)):
+                grids = [g for (g,) in db.execute(f"select distinct grid_x from kernels where name like '%{pat}%'")]
+                for g in sorted(grids):
+                    rows = db.execute(f"select duration from kernels where name like '%{pat}%' and grid_x = ? order by {tcol}", (g,)).fetchall()
+                    npass = 27
+                    # launches per pass: fgemm3 runs 32 -> 256 and 512 -> 256 on the smaller of its two grids, 256 -> 512 on the larger
+                    k = 3 if pat == "gft16x_kernel" else (2 if (pat == "fgemm3_kernel" and len(grids) > 1 and g == min(grids)) else 1)
+                    tail = [r[0] for r in rows[-npass * k:]]
+                    if len(tail) < npass * k:
+                        continue
+                    ninth = [v for i, v in enumerate(tail) if (i // k) % 9 == 8]
+                    a_all, a_9 = sum(tail) / len(tail) / 1e3, sum(ninth) / len(ninth) / 1e3
+                    print(f"| `{pat}` | {g} | {k} | {a_all:.1f} | {a_9:.1f} |")
+                    if pat != "gft16x_kernel":
+                        tot_all += a_all * k
+                        tot_9 += a_9 * k
+            if tot_9 > 0:
+                print(f"\nsum over the four GEMM launches of a pass: {tot_all / 1e3:.4f} ms (all 27), {tot_9 / 1e3:.4f} ms (every ninth) -> 4.078 TFLOP / that / 2500 TFLOP/s = "
+                      f"{4.078 / (tot_all / 1e3) / 2500 * 1e3:.4f} / {4.078 / (tot_9 / 1e3) / 2500 * 1e3:.4f} of the fp16 peak")
+    except Exception as e:
+        print("\n(no tail table:", e, ")")
 
 
 if __name__ == "__main__":
