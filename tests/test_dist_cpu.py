@@ -61,6 +61,35 @@ def test_single_process_noops():
     assert ydist.max_over_ranks(3.5) == 3.5 and ydist.gather_results([1]) == [[1]]
 
 
+def _launched_world1(port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    from yoho_amd import dist as ydist, weights as W
+    r, w, _ = ydist.init_from_env("gloo")
+    sd = W.synth_state_dict(W.PARTII_SPEC, 3)
+    got = ydist.broadcast_state_dict(sd, W.PARTII_SPEC, device=torch.device("cpu"))
+    same = all(np.array_equal(got[k], np.asarray(v, np.float32)) for k, v in sd.items() if not k.endswith("num_batches_tracked"))
+    out = (r, w, ydist.active(), torch.distributed.is_initialized(), got is not sd, same,
+           ydist.all_ranks(1.25, device=torch.device("cpu")), ydist.max_over_ranks(2.5, device=torch.device("cpu")),
+           ydist.gather_results({"a": 1}))
+    ydist.barrier()
+    q.put(out)
+    torch.distributed.destroy_process_group()
+
+
+def test_launched_with_one_rank_still_goes_through_the_backend():
+    """Under a launcher (RANK / WORLD_SIZE / MASTER_* set) a one-rank job creates its process group and its helpers call the backend:
+    the code between `torch.distributed.run` and the first timed step is the same at N = 1 and N = 8 (tests/test_gpu_rccl.py runs
+    this with "nccl" on the GPU box)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_launched_world1, args=(_free_port(), q))
+    p.start()
+    out = q.get(timeout=120)
+    p.join(30)
+    assert p.exitcode == 0
+    assert out == (0, 1, True, True, True, True, [1.25], 2.5, [{"a": 1}])
+
+
 # ---- dataset-level driver (yoho_amd/run_dataset.py): plan, ordering, completeness ------------------------------------
 class _FakeScene:
     def __init__(self, name, nfrag, npairs, seed):
