@@ -984,8 +984,8 @@ __global__ __launch_bounds__(256) void spconv16s_kernel(SpConvArgs a) {
 // ahead, they go through a double-buffered LDS stage (one barrier per step) and each wave reads its fragments from
 // there - the vector-memory pipe only carries the gathers (a quarter of the bytes of the per-wave weight loads).
 // The gathered rows run NA - 1 steps ahead in a register ring.
-template <int NCB, int DBG = 0>
-__global__ __launch_bounds__(256) void spconv16w_kernel(SpConvArgs a) {
+template <int NCB, int DBG, int NA>
+__device__ __forceinline__ void spconv16w_body(const SpConvArgs& a) {
     // one LDS block: region rows of the four waves | double-buffered weight stage; the epilogue lays its output tiles over it
     constexpr int SRCL_INTS = 4 * SP_MAXK * 32, BST_FRAGS = 2 * 4 * NCB * 64, EPI_LD = 36;       // EPI_LD: padded row of 32 floats
     static_assert(SRCL_INTS * 4 + BST_FRAGS * 16 >= 4 * 32 * EPI_LD * 4, "epilogue tiles must fit");
@@ -1098,7 +1098,7 @@ __global__ __launch_bounds__(256) void spconv16w_kernel(SpConvArgs a) {
                 }
             }
         };
-        constexpr int NA = 4;                                                 // even: the stage parity of ring slot j is j & 1
+        static_assert(NA % 2 == 0, "the stage parity of ring slot j is j & 1");
         float av[NA][16];
         uintx4s br[2][NCB];
         loadB(br[0]);
@@ -1175,6 +1175,26 @@ __global__ __launch_bounds__(256) void spconv16w_kernel(SpConvArgs a) {
         }
     }
 }
+
+// Ring depth and register budget per variant, measured on the 15-copy pass (tools/ab_spconv_occ.sh, round 4: 8.61 -> 8.36 ms, same bits):
+// with the gathers only one step ahead (ring 2) the 64-channel kernel fits 4 waves per SIMD (102 registers instead of 148 -> 3) and
+// the 128-channel one 3 (156 instead of 204 -> 2), and the extra resident workgroup hides more than the deeper ring did; forcing the
+// budget with the ring of 4 spills (9.36 ms), a ring of 6 at 3 waves is slower too (8.76), the 32-channel kernel does not care
+// (ring 2 at 5 waves 8.60, ring 4 at 4 waves as it was)
+constexpr int sp_ring(int ncb) { return ncb == 1 ? 4 : 2; }
+constexpr int sp_wpe(int ncb) { return ncb == 4 ? 3 : 4; }
+template <int NCB, int DBG = 0>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sp_wpe(NCB), sp_wpe(NCB)))) void spconv16w_kernel(SpConvArgs a) {
+    spconv16w_body<NCB, DBG, sp_ring(NCB)>(a);
+}
+#ifdef YOHO_EXPERIMENTS
+// occupancy experiments (YOHO_SPCONV_VAR, experiments build only): the same body under a register budget of WPE waves per SIMD
+// (0 = none), with a gather ring of NA steps
+template <int NCB, int NA, int WPE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void spconv16w_occ_kernel(SpConvArgs a) { spconv16w_body<NCB, 0, NA>(a); }
+template <int NCB>
+__global__ __launch_bounds__(256) void spconv16w_ring4_kernel(SpConvArgs a) { spconv16w_body<NCB, 0, 4>(a); }      // the kernels up to round 4
+#endif
 
 // Cin < 32 (the first convolution: one input channel, 5^3 / 7^3 offsets): plain fp32, one thread per (row, channel)
 __global__ __launch_bounds__(256) void spconv_small_kernel(SpConvArgs a) {
@@ -1482,6 +1502,21 @@ static int launch_spconv(const SpConvArgs& a_in, hipStream_t s) {
 #endif
             // 128 output channels: all four channel blocks in one wave, so every row is gathered once instead of twice (the gathers'
             // lane requests are what bounds these kernels; measured -0.25 ms on a 1.3 M-voxel pass, no gain at 256 channels)
+#ifdef YOHO_EXPERIMENTS
+            // low nibble: the 64-channel kernel, second nibble: the 32-channel one, third: the 128-channel one; 0 = as shipped
+            static const int var = [] { const char* e = experiment_env("YOHO_SPCONV_VAR"); return e ? std::atoi(e) : 0; }();
+            const bool four = a.Wh && ncb == 2 && ncbt == 4 && rowtiles >= 1024;
+            if (four && (var & 0xF00) == 0x100) hipLaunchKernelGGL((spconv16w_ring4_kernel<4>), dim3(grid.x, 1), blk, 0, s, a);
+            else if (four) hipLaunchKernelGGL((spconv16w_kernel<4>), dim3(grid.x, 1), blk, 0, s, a);
+            else if (a.Wh && ncb == 2 && (var & 0xF) == 1) hipLaunchKernelGGL((spconv16w_ring4_kernel<2>), grid, blk, 0, s, a);
+            else if (a.Wh && ncb == 2 && (var & 0xF) == 2) hipLaunchKernelGGL((spconv16w_occ_kernel<2, 4, 4>), grid, blk, 0, s, a);
+            else if (a.Wh && ncb == 2 && (var & 0xF) == 3) hipLaunchKernelGGL((spconv16w_occ_kernel<2, 6, 3>), grid, blk, 0, s, a);
+            else if (a.Wh && ncb == 2 && (var & 0xF) == 4) hipLaunchKernelGGL((spconv16w_occ_kernel<2, 2, 5>), grid, blk, 0, s, a);
+            else if (a.Wh && ncb == 1 && (var & 0xF0) == 0x10) hipLaunchKernelGGL((spconv16w_occ_kernel<1, 2, 5>), grid, blk, 0, s, a);
+            else if (a.Wh && ncb == 1 && (var & 0xF0) == 0x20) hipLaunchKernelGGL((spconv16w_occ_kernel<1, 4, 5>), grid, blk, 0, s, a);
+            else if (a.Wh && ncb == 1 && (var & 0xF0) == 0x30) hipLaunchKernelGGL((spconv16w_occ_kernel<1, 6, 4>), grid, blk, 0, s, a);
+            else
+#endif
             if (a.Wh && ncb == 2 && ncbt == 4 && rowtiles >= 1024)
                 hipLaunchKernelGGL((spconv16w_kernel<4>), dim3(grid.x, 1), blk, 0, s, a);
             else if (a.Wh && ncb == 2) hipLaunchKernelGGL((spconv16w_kernel<2>), grid, blk, 0, s, a);
