@@ -38,6 +38,16 @@ def main(commit):
         head = head.replace("--no-cpu-baseline --steps 10", "--no-cpu-baseline --no-dataset --repeats 1 --steps 10")
         head = re.sub(r"commit [0-9a-f]{7}", "commit " + commit, head)
         body = body_of(src)
+        if name in ("kernel_trace_bench", "kernel_trace_bench_seq"):
+            # the numbers the header quotes for "this very run": the bench line of the profiled run and the file's own last table
+            bj = os.path.join(SRC, "bench.json" if name == "kernel_trace_bench" else "bench_seq.json")
+            try:
+                rf = json.loads(open(bj).read().strip().splitlines()[-1])["roofline"]
+                tab = re.search(r"= ([0-9.]+) / ([0-9.]+) of the fp16 peak", body)
+                head = re.sub(r"\(frac [0-9.]+, launch sum [0-9.]+ ms; the table gives [0-9.]+\)",
+                              "(frac %.4f, launch sum %.3f ms; the table gives %s)" % (rf["frac"], rf["launch_ms_sum"], tab.group(2) if tab else "n/a"), head)
+            except Exception as e:                 # a missing leg must not stop the publication of the others
+                print("header numbers of", name, "not refreshed:", e)
         if name == "pmc_traffic":                 # the generated file carries its own header
             body = body[body.index("|"):] if head else body
         open(dst, "w").write(head + body)
