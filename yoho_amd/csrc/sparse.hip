@@ -585,16 +585,9 @@ __global__ void invert_map_kernel(const int* __restrict__ down, int ncoarse, int
     if (f >= 0) up[(size_t)k * nfine + f] = c;
 }
 
-// (n,3) voxel rows of `nb` concatenated clouds (row ranges off[0..nb]) -> (n,4) rows with the cloud index
-struct CloudOff { int off[65]; };             // row offsets of the clouds of a pass, in the kernel arguments
-__global__ void coords4_kernel(const int* c3, int n, CloudOff o, int nb, int* c4) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const int* off = o.off;
-    int b = 0;
-    while (b + 1 < nb && i >= off[b + 1]) ++b;
-    reinterpret_cast<int4*>(c4)[i] = make_int4(c3[3 * (size_t)i], c3[3 * (size_t)i + 1], c3[3 * (size_t)i + 2], b);
-}
+// row offsets of the concatenated clouds of a pass (row ranges off[0..nb]), in the kernel arguments: bbox_kernel<true> turns the (n,3)
+// voxel rows into (n,4) rows with the cloud index
+struct CloudOff { int off[65]; };
 
 // Rows of a level sorted by the parity class of their coordinates on the next coarser stride (8 classes, each padded with
 // -1 to a multiple of 128 slots = one workgroup of the fine-level kernel).  A transposed convolution reaches a fine row
@@ -604,12 +597,19 @@ __global__ void coords4_kernel(const int* c3, int n, CloudOff o, int nb, int* c4
 constexpr int PAR_PAD = 128;
 __device__ __forceinline__ int parity_class(int4 c, int sh) { return ((c.x >> sh) & 1) | (((c.y >> sh) & 1) << 1) | (((c.z >> sh) & 1) << 2); }
 
+// A workgroup takes PAR_ROWS rows (eight per thread) and adds its class counts to the global counters once: with one row per
+// thread the 8 atomics per workgroup on ONE cache line - 41 k of them on a 1.3 M-row level, serialised in the L2 - were most of
+// the 60 us either kernel took (the same finding as bbox_kernel's).
+constexpr int PAR_ROWS = 2048;
 __global__ __launch_bounds__(256) void parity_count_kernel(const int* __restrict__ coords, int n, int sh, int* __restrict__ cnt) {
     __shared__ int lc[8];
     if (threadIdx.x < 8) lc[threadIdx.x] = 0;
     __syncthreads();
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n) atomicAdd(&lc[parity_class(reinterpret_cast<const int4*>(coords)[i], sh)], 1);
+#pragma unroll
+    for (int u = 0; u < PAR_ROWS / 256; ++u) {
+        const int i = blockIdx.x * PAR_ROWS + u * 256 + threadIdx.x;
+        if (i < n) atomicAdd(&lc[parity_class(reinterpret_cast<const int4*>(coords)[i], sh)], 1);
+    }
     __syncthreads();
     if (threadIdx.x < 8 && lc[threadIdx.x]) atomicAdd(&cnt[threadIdx.x], lc[threadIdx.x]);
 }
@@ -620,11 +620,15 @@ __global__ __launch_bounds__(256) void parity_scatter_kernel(const int* __restri
     __shared__ int lc[8], lbase[8];
     if (threadIdx.x < 8) lc[threadIdx.x] = 0;
     __syncthreads();
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    int cls = 0, pos = 0;
-    if (i < n) {
-        cls = parity_class(reinterpret_cast<const int4*>(coords)[i], sh);
-        pos = atomicAdd(&lc[cls], 1);
+    int cls[PAR_ROWS / 256], pos[PAR_ROWS / 256];
+#pragma unroll
+    for (int u = 0; u < PAR_ROWS / 256; ++u) {
+        const int i = blockIdx.x * PAR_ROWS + u * 256 + threadIdx.x;
+        cls[u] = 0; pos[u] = 0;
+        if (i < n) {
+            cls[u] = parity_class(reinterpret_cast<const int4*>(coords)[i], sh);
+            pos[u] = atomicAdd(&lc[cls[u]], 1);
+        }
     }
     __syncthreads();
     if (threadIdx.x < 8) {
@@ -633,7 +637,11 @@ __global__ __launch_bounds__(256) void parity_scatter_kernel(const int* __restri
         lbase[threadIdx.x] = base + (lc[threadIdx.x] ? atomicAdd(&cnt[8 + threadIdx.x], lc[threadIdx.x]) : 0);
     }
     __syncthreads();
-    if (i < n) perm[lbase[cls] + pos] = i;
+#pragma unroll
+    for (int u = 0; u < PAR_ROWS / 256; ++u) {
+        const int i = blockIdx.x * PAR_ROWS + u * 256 + threadIdx.x;
+        if (i < n) perm[lbase[cls[u]] + pos[u]] = i;
+    }
 }
 
 // Level-0 rows grouped by the 8^3-voxel cell they lie in (cells in Morton order inside a cloud, 16 cells per axis with
@@ -1261,52 +1269,51 @@ __global__ __launch_bounds__(256) void conv1_ones_kernel(const int* __restrict__
     if (valid) out[(size_t)row * 32 + l32] = acc * (aff_s ? aff_s[l32] : 1.f) + (aff_t ? aff_t[l32] : 0.f);
 }
 
-// A workgroup scans a contiguous run of rows (rows of a cloud are contiguous, so it almost always sees one cloud) and
-// issues one set of atomics per (workgroup, cloud): a few hundred atomics per pass instead of one set per wave.
-__global__ __launch_bounds__(256) void bbox_kernel(const int* __restrict__ coords, int n, int rows_per_wg, int* __restrict__ bb, int* __restrict__ part) {
-    __shared__ int red[4][7];
-    const int r0 = blockIdx.x * rows_per_wg, r1 = min(n, r0 + rows_per_wg);
-    auto flush = [&](int cloud, const int (&lo)[3], const int (&hi)[3]) {
-        int* b = bb + 6 * cloud;
-        atomicMin(b + 0, lo[0]); atomicMin(b + 1, lo[1]); atomicMin(b + 2, lo[2]);
-        atomicMax(b + 3, hi[0]); atomicMax(b + 4, hi[1]); atomicMax(b + 5, hi[2]);
-    };
-    int cur = -1;
+// Bounding boxes of the clouds of a pass.  A workgroup scans a run of <= rows_per_wg rows of ONE cloud (the clouds' row ranges are in
+// the kernel arguments; workgroup -> (cloud, run) by walking the clouds' run counts) and leaves its box in part[block] = (cloud, lo,
+// hi); bbox_reduce_kernel combines the blocks.  No atomics here: the first version let a run straddle clouds and flushed a thread's
+// box with six atomics at the boundary - 256 threads x 6 atomics on one cache line per boundary, serialised at ~50 ns each, were
+// 75 of the kernel's 80 us on a 15-cloud pass (the row loop without them: 5 us).
+// FROM3: the rows come from the caller's (n,3) matrix and the (n,4) rows with the cloud index are written on the way.
+template <bool FROM3>
+__global__ __launch_bounds__(256) void bbox_kernel(const int* __restrict__ coords, int rows_per_wg, int* __restrict__ part, CloudOff o, int nb,
+                                                   int* __restrict__ c4) {
+    __shared__ int red[4][6];
+    int b = 0, base = 0;
+    for (; b < nb; ++b) {
+        const int runs = (o.off[b + 1] - o.off[b] + rows_per_wg - 1) / rows_per_wg;
+        if ((int)blockIdx.x < base + runs) break;
+        base += runs;
+    }
+    int* p = part + 7 * blockIdx.x;
+    if (b == nb) { if (threadIdx.x == 0) p[0] = -1; return; }
+    const int r0 = o.off[b] + ((int)blockIdx.x - base) * rows_per_wg, r1 = min(o.off[b + 1], r0 + rows_per_wg);
     int lo[3] = {0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF}, hi[3] = {(int)0x80000000, (int)0x80000000, (int)0x80000000};
     for (int i = r0 + threadIdx.x; i < r1; i += 256) {
-        const int4 c = reinterpret_cast<const int4*>(coords)[i];
-        if (c.w != cur) {
-            if (cur >= 0) flush(cur, lo, hi);                       // cloud boundary inside this run (rare)
-            cur = c.w;
-            lo[0] = hi[0] = c.x; lo[1] = hi[1] = c.y; lo[2] = hi[2] = c.z;
+        int x, y, z;
+        if constexpr (FROM3) {
+            x = coords[3 * (size_t)i]; y = coords[3 * (size_t)i + 1]; z = coords[3 * (size_t)i + 2];
+            reinterpret_cast<int4*>(c4)[i] = make_int4(x, y, z, b);
         } else {
-            lo[0] = min(lo[0], c.x); lo[1] = min(lo[1], c.y); lo[2] = min(lo[2], c.z);
-            hi[0] = max(hi[0], c.x); hi[1] = max(hi[1], c.y); hi[2] = max(hi[2], c.z);
+            const int4 c = reinterpret_cast<const int4*>(coords)[i];
+            x = c.x; y = c.y; z = c.z;
         }
-    }
-    // the cloud of the run's last row; lanes still holding another cloud (or nothing) flush on their own
-    const int last = r1 > r0 ? coords[4 * (size_t)(r1 - 1) + 3] : -1;
-    if (cur >= 0 && cur != last) flush(cur, lo, hi);
-    if (cur != last) {
-        lo[0] = lo[1] = lo[2] = 0x7FFFFFFF;
-        hi[0] = hi[1] = hi[2] = (int)0x80000000;
+        lo[0] = min(lo[0], x); lo[1] = min(lo[1], y); lo[2] = min(lo[2], z);
+        hi[0] = max(hi[0], x); hi[1] = max(hi[1], y); hi[2] = max(hi[2], z);
     }
 #pragma unroll
     for (int a = 0; a < 3; ++a)
-        for (int o = 32; o >= 1; o >>= 1) {
-            lo[a] = min(lo[a], __shfl_xor(lo[a], o));
-            hi[a] = max(hi[a], __shfl_xor(hi[a], o));
+        for (int o2 = 32; o2 >= 1; o2 >>= 1) {
+            lo[a] = min(lo[a], __shfl_xor(lo[a], o2));
+            hi[a] = max(hi[a], __shfl_xor(hi[a], o2));
         }
     const int w = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) { red[w][0] = lo[0]; red[w][1] = lo[1]; red[w][2] = lo[2]; red[w][3] = hi[0]; red[w][4] = hi[1]; red[w][5] = hi[2]; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        // the box of the run's last cloud goes to part[block] = (cloud, lo, hi); bbox_reduce_kernel combines the blocks (a thousand
-        // workgroups hitting the same six words of a cloud with atomics was most of this kernel's 0.1 ms)
         for (int ww = 1; ww < 4; ++ww)
             for (int a = 0; a < 3; ++a) { lo[a] = min(lo[a], red[ww][a]); hi[a] = max(hi[a], red[ww][3 + a]); }
-        int* p = part + 7 * blockIdx.x;
-        p[0] = (last >= 0 && lo[0] <= hi[0]) ? last : -1;
+        p[0] = lo[0] <= hi[0] ? b : -1;
         p[1] = lo[0]; p[2] = lo[1]; p[3] = lo[2]; p[4] = hi[0]; p[5] = hi[1]; p[6] = hi[2];
     }
 }
@@ -1324,14 +1331,7 @@ __global__ __launch_bounds__(1024) void bbox_reduce_kernel(const int* __restrict
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < nb * 6; i += 1024) {       // joins what the (rare) cloud boundaries inside a run flushed directly
-        if ((i % 6) < 3) atomicMin(bb + i, lb[i]); else atomicMax(bb + i, lb[i]);
-    }
-}
-
-__global__ void bbox_init_kernel(int* bb, int nb) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < nb * 6) bb[i] = (i % 6) < 3 ? 0x7FFFFFFF : (int)0x80000000;
+    for (int i = threadIdx.x; i < nb * 6; i += 1024) bb[i] = lb[i];
 }
 
 __global__ void bitmap_fill_kernel(const int* __restrict__ coords, int n, const BmDesc* __restrict__ desc, unsigned* __restrict__ bm) {
@@ -1824,23 +1824,27 @@ int fcgf_forward(yoho_ctx* ctx, const FcgfNet* net, const int* coords0, int n0, 
     phase_mark(ctx, 1, s);
     // ---- coordinate maps
     L[0].n = n0; L[0].ts = 1; L[0].coords = ar.take<int>((size_t)n0 * 4);
-    {
-        CloudOff ho;
-        ho.off[0] = 0; ho.off[1] = n0;
-        if (off_host) for (int b = 0; b <= nb; ++b) ho.off[b] = off_host[b];
-        hipLaunchKernelGGL(coords4_kernel, dim3((n0 + 255) / 256), dim3(256), 0, s, coords0, n0, ho, nb, L[0].coords);
-    }
-    const bool conv1_fused = net->in_ch == 1 && C[1] == 32 && net->k1 * net->k1 * net->k1 <= C1O_MAXK;
     int* dbb = ar.take<int>(64 * 6);
-    int* dbbpart = ar.take<int>(7 * 1100);               // per-workgroup partial boxes of bbox_kernel (<= 1024 + 1 runs)
+    int* dbbpart = ar.take<int>(7 * 1100);               // per-workgroup partial boxes of bbox_kernel (<= 1024 + nb <= 1088 runs)
+    // <= 1024 + nb workgroups, each a run of rows of one cloud
+    CloudOff ho;
+    ho.off[0] = 0; ho.off[1] = n0;
+    if (off_host) for (int b = 0; b <= nb; ++b) ho.off[b] = off_host[b];
+    const int bb_rpw = std::max(1024, (n0 + 1023) / 1024);
+    int bb_nblk = 0;
+    for (int b = 0; b < nb; ++b) bb_nblk += (ho.off[b + 1] - ho.off[b] + bb_rpw - 1) / bb_rpw;
+    // (n,3) -> (n,4) rows with the cloud index, and the partial bounding boxes of the clouds on the way
+    if (bb_nblk) hipLaunchKernelGGL(bbox_kernel<true>, dim3(bb_nblk), dim3(256), 0, s, coords0, bb_rpw, dbbpart, ho, nb, L[0].coords);
+    HIPCHK(hipGetLastError());
+    bool boxes_pending = true;                           // dbbpart holds the partial boxes of the rows as they are now
+    const bool conv1_fused = net->in_ch == 1 && C[1] == 32 && net->k1 * net->k1 * net->k1 <= C1O_MAXK;
     int hbb[64 * 6];
     auto bounding_boxes = [&](const int* c4) -> int {      // per-cloud boxes of the voxel indices -> hbb (waits for the stream)
-        hipLaunchKernelGGL(bbox_init_kernel, dim3(2), dim3(256), 0, s, dbb, nb);
-        // <= 1024 workgroups: a run is a few iterations of dependent loads per thread
-        const int rpw = std::max(1024, (n0 + 1023) / 1024);
-        const int nblk = (n0 + rpw - 1) / rpw;
-        hipLaunchKernelGGL(bbox_kernel, dim3(nblk), dim3(256), 0, s, c4, n0, rpw, dbb, dbbpart);
-        hipLaunchKernelGGL(bbox_reduce_kernel, dim3(1), dim3(1024), 0, s, dbbpart, nblk, nb, dbb);
+        // the boxes do not depend on the order of the rows: the partials taken while the rows were written serve the first call,
+        // a second one (the table path behind a bitmap path that handed over) reduces the rows again
+        if (!boxes_pending && bb_nblk) hipLaunchKernelGGL(bbox_kernel<false>, dim3(bb_nblk), dim3(256), 0, s, c4, bb_rpw, dbbpart, ho, nb, nullptr);
+        boxes_pending = false;
+        hipLaunchKernelGGL(bbox_reduce_kernel, dim3(1), dim3(1024), 0, s, dbbpart, bb_nblk, nb, dbb);
         HIPCHK(hipMemcpyAsync(hbb, dbb, sizeof(int) * 6 * nb, hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
         // the packed 64-bit voxel keys hold 19 bits per axis: indices outside +-(2^18 - 16) (16 = reach of the coarsest kernel
@@ -2084,8 +2088,8 @@ int fcgf_forward(yoho_ctx* ctx, const FcgfNet* net, const int* coords0, int n0, 
         if (L[l].n == 0) continue;
         HIPCHK(hipMemsetAsync(perm[l], 0xFF, sizeof(int) * (size_t)nperm[l], s));
         HIPCHK(hipMemsetAsync(pc, 0, sizeof(int) * 16, s));
-        hipLaunchKernelGGL(parity_count_kernel, dim3((L[l].n + 255) / 256), dim3(256), 0, s, L[l].coords, L[l].n, l, pc);
-        hipLaunchKernelGGL(parity_scatter_kernel, dim3((L[l].n + 255) / 256), dim3(256), 0, s, L[l].coords, L[l].n, l, pc, perm[l]);
+        hipLaunchKernelGGL(parity_count_kernel, dim3((L[l].n + PAR_ROWS - 1) / PAR_ROWS), dim3(256), 0, s, L[l].coords, L[l].n, l, pc);
+        hipLaunchKernelGGL(parity_scatter_kernel, dim3((L[l].n + PAR_ROWS - 1) / PAR_ROWS), dim3(256), 0, s, L[l].coords, L[l].n, l, pc, perm[l]);
     }
     HIPCHK(hipGetLastError());
     // ---- features
