@@ -51,6 +51,7 @@ BF16_MFMA_PEAK = 2500.0         # TFLOP/s dense, MI355X_MICROARCH.md (v_mfma_f32
 BF16X3_EXEC_PER_ALG = 6.0 * 14.0 / 13.0   # bf16 MFMA flops issued per algorithmic flop: 6 cross products, 13 taps in 7 pairs
 FOURIER_EXEC_PER_ALG = 244.0 / 780.0      # slab products per 8-channel chunk: sum_rho d^3 = 244 vs 60 x 13 = 780
 FP16_MFMA_PEAK = 2500.0         # TFLOP/s dense (v_mfma_f32_32x32x16_f16, same rate as bf16)
+NOMINAL_MHZ = 2400.0            # shader clock the peaks are quoted at (MI355X_MICROARCH.md)
 
 
 def _issued_rows(d, cout, mode):
@@ -290,11 +291,14 @@ def main():
         pr = synth.make_pair(KP, seed=10 + rank)
         mine = [(cu(pr["feat0"]), cu(pr["feat1"]), cu(pr["keys0"]), cu(pr["keys1"]))]
         pairs_per_step = world
+        full_plan = plan_cost = None
     else:
         # a fixed list of 64 pairs = 8 scenes x 8 pairs, dealt to the ranks by the dataset driver's plan (scenes whole, a
         # scene larger than a rank's share cut round-robin).  8 distinct synthetic pairs, each listed 8 times.
-        from yoho_amd.run_dataset import plan_shards
-        plan = plan_shards({f"scene{i}": 8 for i in range(8)}, world)[rank]
+        from yoho_amd.run_dataset import plan_shards, plan_loads
+        full_plan = plan_shards({f"scene{i}": 8 for i in range(8)}, world)
+        plan_cost = plan_loads(full_plan)
+        plan = full_plan[rank]
         distinct = {}
         mine = []
         for scene, positions in plan:
@@ -568,12 +572,12 @@ def main():
         M = int(res.match.shape[0])
         if args.gconv == "f32":
             roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK, "unit": "TFLOP/s",
-                    "frac": round(achieved / FP32_MFMA_PEAK, 4), "traffic": pmc_traffic("f32")[0],
+                    "frac": round(achieved / FP32_MFMA_PEAK, 4), "traffic": None, "traffic_replayed": pmc_traffic("f32")[0],
                     "kernel": "gconv_kernel<15,false> (4 launches = 4 PartI layers, 2.1725 algorithmic TFLOP per 5000 kp)"}
             dtype = "f32"
         elif args.gconv == "bf16x3":
             roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": BF16_MFMA_PEAK, "unit": "TFLOP/s",
-                    "frac": round(achieved / BF16_MFMA_PEAK, 4), "traffic": pmc_traffic("bf16x3")[0],
+                    "frac": round(achieved / BF16_MFMA_PEAK, 4), "traffic": None, "traffic_replayed": pmc_traffic("bf16x3")[0],
                     "kernel": "gconv16_kernel<15,2> + <8,1> (4 launches = 4 PartI layers, 2.1725 algorithmic TFLOP per 5000 kp)",
                     "executed_tflops": round(achieved * BF16X3_EXEC_PER_ALG, 1),
                     "executed_frac": round(achieved * BF16X3_EXEC_PER_ALG / BF16_MFMA_PEAK, 4),
@@ -582,7 +586,7 @@ def main():
             dtype = "bf16x3 split (fp32-accurate, fp32 accumulate)"
         elif args.gconv == "fp16x2":
             roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": BF16_MFMA_PEAK, "unit": "TFLOP/s",
-                    "frac": round(achieved / BF16_MFMA_PEAK, 4), "traffic": pmc_traffic("fp16x2")[0],
+                    "frac": round(achieved / BF16_MFMA_PEAK, 4), "traffic": None, "traffic_replayed": pmc_traffic("fp16x2")[0],
                     "kernel": "gconv16_kernel<15,2,2> + <8,1,2> (4 launches = 4 PartI layers, 2.1725 algorithmic TFLOP per 5000 kp)",
                     "executed_tflops": round(achieved * BF16X3_EXEC_PER_ALG / 2, 1),
                     "executed_frac": round(achieved * BF16X3_EXEC_PER_ALG / 2 / BF16_MFMA_PEAK, 4),
@@ -599,8 +603,23 @@ def main():
             step_ms = dt / args.steps * 1e3 / (len(mine) if args.scaling == "strong" else 1)
             ach = useful / (gconv_total_ms * 1e-3) / 1e12
             traffic, tsrc = pmc_traffic(args.gconv)
+            # the box's state beside the fraction (a slow box and a slow build must be told apart from this one object):
+            # the clock the GEMM launches of the profiled passes ran at, and the fraction against the peak AT THAT CLOCK
+            cp_prof = power_prof.get("clock_probe") or {}
+            cp_step = power_steps.get("clock_probe") or {}
+            mhz_prof = cp_prof.get("shader_mhz_mean")
+            mhz_step = cp_step.get("shader_mhz_mean")
+            at_clock = lambda frac, mhz: round(frac / (mhz / NOMINAL_MHZ), 4) if mhz else None
             roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": FP16_MFMA_PEAK, "unit": "TFLOP/s",
                     "frac": round(ach / FP16_MFMA_PEAK, 4),
+                    "shader_mhz_mean": mhz_prof, "shader_mhz_nominal": NOMINAL_MHZ,
+                    "frac_at_clock": at_clock(ach / FP16_MFMA_PEAK, mhz_prof),
+                    "power_w": power_prof.get("power_w_after"), "power_cap_w": power_steps.get("power_cap_w"),
+                    "timed_steps": {"shader_mhz_mean": mhz_step, "power_w": power_steps.get("power_w_after_last_region"),
+                                    "frac_step_at_clock": at_clock(useful / (step_ms * 1e-3) / 1e12 / FP16_MFMA_PEAK, mhz_step)},
+                    "clock_note": "shader_mhz_mean = mean of the one-wave clock probes queued with the profiled PartI passes `achieved` is measured on "
+                                  "(timed_steps: with the timed steps); frac_at_clock = achieved / (peak x shader_mhz_mean / 2400): the fraction of what the "
+                                  "matrix cores could do at the clock the power limit left them - comparable across boxes, `frac` is not",
                     "frac_pass": round(useful / (pass_ms * 1e-3) / 1e12 / FP16_MFMA_PEAK, 4),
                     "frac_step": round(useful / (step_ms * 1e-3) / 1e12 / FP16_MFMA_PEAK, 4),
                     "definition": "achieved = useful issued fp16 MFMA flops / time of the four GEMM launches of one PartI pass over both fragments; "
@@ -609,10 +628,12 @@ def main():
                                   f"(GEMMs + transforms + head + tail, {pass_ms:.3f} ms), frac_step over the timed step ({step_ms:.3f} ms)",
                     "frac_per_launch": [round(f / (ms * 1e-3) / 1e12 / FP16_MFMA_PEAK, 4) for f, ms in zip(useful_layer, conv_ms[:4])],
                     "launch_ms_sum": round(gconv_total_ms, 4), "pass_ms": round(pass_ms, 4), "step_ms": round(step_ms, 4),
-                    "traffic": traffic, "traffic_measured_in_this_run": False,
-                    "traffic_source": dict(tsrc or {}, note="REPLAYED from the committed PMC file (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate "
-                                                            "passes, tools/collect_profiles.sh): counters cannot be read inside a timed run; per-launch "
-                                                            "average of the four GEMM launches"),
+                    "traffic": None,
+                    "traffic_replayed": dict(tsrc or {}, bytes_per_launch=traffic,
+                                             note="NOT measured in this run (counters cannot be read inside a timed run, so `traffic` is null): the figure "
+                                                  "of the committed PMC file (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, "
+                                                  "tools/collect_profiles.sh, gfx950 corrections of MI355X_MICROARCH.md), per-launch average of the four "
+                                                  "GEMM launches of the same command"),
                     "kernel": {"fgemm": "fgemm3_kernel (fgemm3s_kernel for the 32-channel layer)", "fgemm128": "fgemm2_kernel", "fgemm256": "fgemm_kernel"}[args.gconv] +
                               " (4 launches = 4 PartI layers over both fragments)",
                     "issued_with_padding": {"tflops": round(issued, 1), "frac": round(issued / FP16_MFMA_PEAK, 4),
@@ -627,7 +648,7 @@ def main():
         else:
             ex = achieved * FOURIER_EXEC_PER_ALG
             roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK, "unit": "TFLOP/s",
-                    "frac": round(achieved / FP32_MFMA_PEAK, 4), "traffic": pmc_traffic("fourier")[0],
+                    "frac": round(achieved / FP32_MFMA_PEAK, 4), "traffic": None, "traffic_replayed": pmc_traffic("fourier")[0],
                     "kernel": "gconvf_kernel (4 launches = 4 PartI layers, 2.1725 algorithmic TFLOP per 5000 kp)",
                     "executed_tflops": round(ex, 2), "executed_frac": round(ex / FP32_MFMA_PEAK, 4),
                     "note": "achieved = algorithmic FLOP/s of the reference's direct 13-tap formulation (SURVEY 8d) over the 4 "
@@ -649,12 +670,19 @@ def main():
             "ranks": {"world_size_seen": world, "process_group": bool(ydist.active()),
                       "backend": (torch.distributed.get_backend() if ydist.active() else None),
                       "ms_per_step_per_rank": {"min": round(min(rank_dts) / args.steps * 1e3, 3), "mean": round(float(np.mean(rank_dts)) / args.steps * 1e3, 3),
-                                               "max": round(max(rank_dts) / args.steps * 1e3, 3), "all": [round(v / args.steps * 1e3, 3) for v in rank_dts]}},
+                                               "max": round(max(rank_dts) / args.steps * 1e3, 3), "all": [round(v / args.steps * 1e3, 3) for v in rank_dts]},
+                      # what every rank was given and how long its share took (one step = one sweep over its pairs); under --scaling strong the
+                      # shares come from run_dataset.plan_shards, whose predicted max / mean load is printed beside the measured one
+                      "pairs_per_rank": [sum(len(pos) for _, pos in part) for part in full_plan] if full_plan else [1] * world,
+                      "ms_per_rank": [round(v / args.steps * 1e3, 3) for v in rank_dts],
+                      "plan_predicted_imbalance": round(max(plan_cost) / (sum(plan_cost) / len(plan_cost)), 4) if plan_cost else 1.0,
+                      "measured_imbalance": round(max(rank_dts) / (sum(rank_dts) / len(rank_dts)), 4)},
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": dtype, "data": "synthetic",
             "config": {"workload": "one synthetic scene pair per step per GPU: 2 fragments x 5000 keypoints x 60 rotations x 32-D "
                                    "-> PartI group conv + invariant pooling -> mutual NN -> Des2R -> PartII -> YOHO-O (<=1000 hypotheses); "
                                    "random-init weights (seeded), inputs resident in HBM",
+                       "ms_per_step_repeats": {"min": round(min(dts) / args.steps * 1e3, 3), "max": round(max(dts) / args.steps * 1e3, 3), "n": len(dts)},
                        "keypoints_per_fragment": KP, "partI_batch": nkp, "matches": M, "hypotheses": min(1000, M), "gconv": args.gconv, "partII": args.partII,
                        "pairs_per_step": pairs_per_step, "pairs_in_flight": args.in_flight,
                        "partI_schedule": ("breadth-first (every layer over the whole pass)" if sched_chunk == 0 else

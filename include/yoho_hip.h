@@ -43,6 +43,18 @@
  *     several on one device, also on different group tables - are independent: the library has no global mutable state.
  *   - tensors use the reference's layouts: group features (K,32,60) f32 with the group axis
  *     innermost, keypoints (K,3) f64, transforms (.,3,4) f64, indices int64.
+ *   - environment: yoho_ctx_create is the ONLY place the library reads the environment (every variable once, into the new context);
+ *     no other entry point does, so what a context computes and how is fixed at its creation and two contexts of a process may differ.
+ *     Defaults of settings that also have a setter:   YOHO_GCONV, YOHO_PARTII (yoho_set_gconv_mode / yoho_set_partII_mode),
+ *     YOHO_PARTI_CHUNK (yoho_set_partI_schedule), YOHO_NN=brute (yoho_set_nn_prefilter), YOHO_FCGF_SORT, YOHO_FCGF_CELLS,
+ *     YOHO_FCGF_COORDS=hash (yoho_set_fcgf_sort).   A/B and diagnostic switches without a setter (struct yoho_env_switches in
+ *     csrc/common.h; every value gives valid results):   YOHO_PARTII_TAIL=staged, YOHO_TRANSFER=staged, YOHO_XF_STEAL=0,
+ *     YOHO_NN_SPLITS=<n>, YOHO_FCGF=f32 (takes effect at the context's yoho_load_fcgf), YOHO_FCGF_MAPS=full, YOHO_FCGF_NORM=staged,
+ *     YOHO_SPCONV_DEBUG=<bits> (only in a -DYOHO_SPCONV_ABLATE build).   The timing experiments YOHO_PARTI_DEBUG / YOHO_FGEMM_DEBUG /
+ *     YOHO_SPCONV_VAR exist only in the separate -DYOHO_EXPERIMENTS library, which no product code loads.
+ *   - argument checks: a NULL context, a NULL required pointer, a negative count or a count beyond a stated capacity returns
+ *     YOHO_EINVAL with a message naming the entry point (tests/test_gpu_abi.py drives every entry point that way); a count of 0 is
+ *     valid wherever it is meaningful (no rows: nothing is launched).
  */
 #ifndef YOHO_HIP_H
 #define YOHO_HIP_H

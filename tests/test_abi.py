@@ -51,5 +51,6 @@ def test_gft16x_hidden_ticket_register_is_untouched():
     import sys
     sys.path.insert(0, os.path.join(REPO, "tools"))
     import check_isa
-    ok, msg = check_isa.check()
-    assert ok, msg
+    for experiments in (False, True):            # the shipped flags and the YOHO_EXPERIMENTS ones (yoho_amd.build audits its own on every build)
+        ok, msg = check_isa.check(experiments)
+        assert ok, (experiments, msg)

@@ -440,6 +440,111 @@ def test_3dLomatch_through_the_dataset_driver(gold, tmp_path, sd1, sd2):
     assert not (w.cache / "Testset" / "3dmatch/room" / "Match").exists()
 
 
+def _lay_out_r5(tmp_path, g, sd1, sd2):
+    """sceneWHU.npz / sceneETH.npz as the reference saw them (oracle/gen_golden_r5.py): origin/{whole}/{scene} with the fixture's pair
+    list as gt.log, FCGF group features under Testset/{whole}/{scene}, PartII weights with the near-identity quaternion head."""
+    from yoho_amd import store
+    from yoho_amd.dataset import ThrDMatchPartDataset
+    store.clear()
+    whole, scene = str(g["whole"]), str(g["scene"])
+    pairs = [tuple(int(v) for v in p) for p in g["pairs"]]
+    nfrag = int(g["nfrag"])
+    sc = synth.make_scene(nfrag, int(g["K"]), seed=int(g["seed"]), res_deg=[float(v) for v in g["res_deg"]])
+    sc["pairs"] = pairs
+    sroot = tmp_path / "origin" / whole / scene
+    cache = tmp_path / "cache"
+    synth.write_scene_files(sc, str(sroot), str(cache / "Testset" / f"{whole}/{scene}"))
+    model_fn = tmp_path / "model"
+    for sub, sd in (("PartI_train", sd1), ("PartII_train", W.identity_head(sd2))):
+        os.makedirs(model_fn / sub)
+        W.save_checkpoint(str(model_fn / sub / "model_best.pth"), sd, 0.5)
+    ds = ThrDMatchPartDataset(str(sroot), nfrag)       # utils/dataset.py:195-215 builds the set's scenes like this (the table itself: tests/test_rr_cpu.py)
+    ds.name = f"{whole}/{scene}"
+    assert ds.name == f"{whole}/{scene}" and [tuple(int(v) for v in p) for p in ds.pair_ids] == pairs
+
+    def cfg(p):
+        return types.SimpleNamespace(
+            SO3_related_files=None, model_fn=str(model_fn), output_cache_fn=str(cache), origin_data_dir=str(tmp_path / "origin"),
+            test_network_type=f"{p}_test", train_network_type=f"{p}_train", test_batch_size=40 if p == "PartI" else 50,
+            ransac_c_inlinerdist=0.07, ransac_o_inlinerdist=0.09, extractor=p, matcher="Match",
+            estimator="yohoc" if p == "PartI" else "yohoo", descriptor="YOHO", fmr_ratio=0.05,
+            ok_match_dist_threshold=0.1, RR_dist_threshold=0.2, testset_name=whole)
+    return types.SimpleNamespace(sc=sc, ds=ds, cfg=cfg, cache=cache, pairs=pairs, whole=whole, scene=scene, name=ds.name,
+                                 datasets={"wholesetname": whole, scene: ds})
+
+
+@pytest.mark.parametrize("fixture", ["sceneWHU.npz", "sceneETH.npz"])
+@pytest.mark.parametrize("part,sign", [("PartI", "YOHO_C"), ("PartII", "YOHO_O")])
+def test_whu_tls_and_eth_evaluators_match_reference(gold, tmp_path, sd1, sd2, fixture, part, sign):
+    """BASELINE config 5's ETH / WHU-TLS halves at the reference's own settings (1000 iterations).  Evaluator_PartI swaps in
+    `yohoc_mul` above 500 iterations (tests/evaluator.py:37-38): the reference forks one process per pair, so EVERY pair draws from
+    the np.random state the parent had (tests/estimator.py:255-275) - several pairs here, where yohoc and yohoc_mul differ; golden =
+    the files the reference's Pool wrote.  'WHU-TLS' is scored by the consecutive protocol (utils/RR_cal.py:329-331, :262-285), 'ETH'
+    by 3DMatch's.  Compared: match lists, coarse rotations, per-pair transforms / winning iteration / winning triple, FMR, flags, RR,
+    pre.log, result.txt."""
+    from yoho_amd import evaluator, extractor, estimator, RR_cal
+    g = gold(fixture)
+    w = _lay_out_r5(tmp_path, g, sd1, sd2)
+    it = int(g["iters"])
+    cdir = w.cache / "Testset" / w.name
+    ev = evaluator.name2evaluator[part](w.cfg(part), it)
+    if part == "PartI":
+        assert type(ev.estimator) is estimator.yohoc_mul and type(evaluator.Evaluator_PartI(w.cfg(part), 500).estimator) is estimator.yohoc
+    else:
+        extractor.extractor_PartI(w.cfg("PartI")).Extract(w.ds)       # the PartII evaluator assumes cached PartI descriptors
+    np.random.seed(int(g["seed_c" if part == "PartI" else "seed_o"]))
+    state = np.random.get_state()
+    RR, FMRS, pair_fmrs = ev.eval(w.datasets, results_log=str(tmp_path / "results.log"))
+    if part == "PartI":                                               # the forks leave the parent's stream where it was
+        assert all(np.array_equal(a, b) for a, b in zip(np.random.get_state()[1:], state[1:]))
+    for (a, b) in w.pairs:
+        assert np.array_equal(np.load(cdir / "Match" / f"{a}-{b}.npy"), g[f"match_{a}_{b}"])
+        assert np.array_equal(np.load(cdir / "Match" / "DR_index" / f"{a}-{b}.npy"), g[f"dr_{a}_{b}"])
+        key = "yohoc" if part == "PartI" else "yohoo"
+        z = np.load(cdir / "Match" / sign / f"{it}iters" / f"{a}-{b}.npz")
+        assert int(z["recalltime"]) == int(g[f"{key}_recall_{a}_{b}"]), (a, b)
+        assert rel(z["trans"], g[f"{key}_trans_{a}_{b}"]) < 1e-4
+        if part == "PartI":
+            assert np.array_equal(z["center"], g[f"yohoc_center_{a}_{b}"])       # the winning triple's six keypoints
+    assert np.array_equal(pair_fmrs, g[f"{part}_pair_fmrs"]) and FMRS[0] == float(g[f"{part}_FMR"])
+    assert RR == float(g[f"{part}_RR"])
+    _, flags, errors = RR_cal.benchmark(w.cfg(part), w.datasets, it, yoho_sign=sign)
+    assert flags[w.name] == list(g[f"{part}_flags"])
+    assert np.allclose(errors[w.name], g[f"{part}_errors"], rtol=1e-3, atol=1e-6)
+    txt = (w.cache / "Testset" / w.whole / "Eval_results" / f"{sign}_RR" / f"{it}iters" / "result.txt").read_text()
+    ref_txt = str(g[f"{part}_result_txt"])
+    assert txt.splitlines()[0] == ref_txt.splitlines()[0] and w.name in txt
+    assert [ln for ln in txt.splitlines() if "Registration Recall" in ln] == [ln for ln in ref_txt.splitlines() if "Registration Recall" in ln]
+    _, mine = RR_cal.read_pre_trajectory(str(cdir / "Match" / sign / f"{it}iters" / "pre.log"))
+    ref_log = tmp_path / "ref_pre.log"
+    ref_log.write_text(str(g[f"{part}_prelog"]))
+    _, ref = RR_cal.read_pre_trajectory(str(ref_log))
+    assert rel(mine, ref) < 1e-4
+    print("%s %s: RR %.3f (reference %.3f), FMR %.3f" % (fixture, part, RR, float(g[f"{part}_RR"]), FMRS[0]))
+
+
+@pytest.mark.parametrize("fixture", ["sceneWHU.npz", "sceneETH.npz"])
+def test_whu_tls_and_eth_through_the_dataset_driver(gold, tmp_path, sd1, sd2, fixture):
+    """The sharded driver on the same files: run_dataset.eval_sharded (YOHO-O, and YOHO-C with the sampling on the device) on a
+    'WHU-TLS/..' / 'ETH/..' scene gets the reference's flags and RR under that set's protocol, pre.log in gt.log's pair order."""
+    from yoho_amd import run_dataset, RR_cal
+    g = gold(fixture)
+    it = int(g["iters"])
+    for estimator, part, sign in (("yohoo", "PartII", "YOHO_O"), ("yohoc", "PartI", "YOHO_C")):
+        w = _lay_out_r5(tmp_path / estimator, g, sd1, sd2)
+        stats = {}
+        rr = run_dataset.eval_sharded(w.cfg(part), max_iter=it, estimator=estimator, datasets=w.datasets, base_seed=3,
+                                      results_log=str(tmp_path / "results.log"), stats_out=stats)
+        _, flags, _ = RR_cal.benchmark(w.cfg(part), w.datasets, it, yoho_sign=sign)
+        assert flags[w.name] == list(g[f"{part}_flags"]) and rr == float(g[f"{part}_RR"]), (estimator, flags[w.name])
+        assert stats["pairs"] == len(w.pairs) and stats["fragments"] == int(g["nfrag"])
+        sdir = w.cache / "Testset" / w.name / "Match" / sign / f"{it}iters"
+        est_pairs, _ = RR_cal.read_pre_trajectory(str(sdir / "pre.log"))
+        assert [tuple(int(v) for v in p[:2]) for p in est_pairs] == w.pairs
+        txt = (w.cache / "Testset" / w.whole / "Eval_results" / f"{sign}_RR" / f"{it}iters" / "result.txt").read_text()
+        assert txt.splitlines()[0] == str(g[f"{part}_result_txt"]).splitlines()[0]
+
+
 def test_testset_create_from_point_clouds(tmp_path, tables):
     """YOHO_testset.py drop-in: fragment point clouds + keypoints -> FCGF_Input_Group_feature/{id}.npy; three of the
     sixty group elements are checked against the oracle chain (voxelise, backbone, f64 NN gather)."""

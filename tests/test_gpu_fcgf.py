@@ -230,3 +230,98 @@ def test_voxel_indices_outside_the_key_range_are_refused(hip, fsd):
     with pytest.raises(hip.YohoError, match="voxel index"):
         c.fcgf_forward(far)
     assert c.fcgf_forward(coords).shape[0] == coords.shape[0]
+
+
+# ---- the backbone at the size it is benchmarked at (bench.py's `fcgf` leg, tools/bench_fcgf.py: 300 k points, extent 3 m, voxel 0.025,
+# the 15-copy pass yoho_extractor.run makes four of per fragment) ----------------------------------------------------------------------
+def _full_size_pass(fx, pc_d, Rs):
+    res = fx.extract_rotated_batch(pc_d, Rs, 0.025)
+    return res
+
+
+def test_backbone_fifteen_copy_pass_at_benchmarked_size_vs_oracle(hip, fsd, tables):
+    """What only exists at 300 k points x 15 copies (1.3 M voxels in one pass): runs and 2048-row workgroups that straddle cloud
+    boundaries (copy sizes are no multiples of anything), 15 clouds sharing every launch, rank-ordered bitmaps of 15 boxes, the
+    1024-entry scan blocks of a level with > 1 M rows.  Copies 0, 7 and 14 of the first pass of yoho_extractor.run are compared with the
+    oracle ROW FOR ROW (selected points and voxel coordinates bit-exact, features to 1e-5), through the same calls the extractor makes
+    (fcgf_extractor.extract_rotated_batch = yoho_fcgf_voxelize_rotated_batch -> yoho_fcgf_forward_batch); the hash-table coordinate maps
+    give the same bits as the default bitmaps at this size, and five repeats of the pass are bit-identical."""
+    from yoho_amd.fcgf_feat import fcgf_extractor
+    pc = synth.surface_cloud(300000, seed=1, extent=3.0)
+    ctx = hip.Context()
+    ck = {"config": {"model": "ResUNetBN2C", "model_n_out": 32, "normalize_feature": True, "conv1_kernel_size": 7},
+          "state_dict": {k: torch.from_numpy(np.array(v)) for k, v in fsd.items()}}
+    fx = fcgf_extractor(ck, ctx=ctx)
+    pc_d = torch.from_numpy(pc).cuda()
+    Rs = [tables.R64[g] for g in range(15)]
+    res = _full_size_pass(fx, pc_d, Rs)
+    sizes = [int(sel.shape[0]) for sel, _, _ in res]
+    total = sum(sizes)
+    assert total > 1_000_000 and len(set(sizes)) > 1
+    # cloud boundaries inside the 2048-row workgroups / 1024-row runs of the internal sorts and reductions
+    bounds = np.cumsum(sizes)[:-1]
+    assert all(b % 2048 != 0 for b in bounds) and all(b % 1024 != 0 for b in bounds)
+    worst = 0.0
+    for j in (0, 7, 14):
+        rot = pc @ Rs[j].T
+        s0, c0 = fo.voxelize(rot, 0.025)
+        sel, F, ps = res[j]
+        assert np.array_equal(sel.cpu().numpy(), s0), j
+        assert np.allclose(ps.cpu().numpy(), rot[s0].astype(np.float32), rtol=0, atol=5e-7)
+        F0 = fo.extract_features(rot, 0.025, fsd)[1]
+        Fj = F.cpu().numpy()
+        assert Fj.shape == F0.shape and np.isfinite(Fj).all()
+        e = rel(Fj, F0)
+        worst = max(worst, e)
+        assert e < TOL, (j, e)
+        assert np.abs(Fj - F0).max(axis=1).max() < 5e-6               # row for row (rows are unit vectors: absolute = relative)
+    print("fcgf backbone, 15-copy pass, %d voxels (copies %d..%d): worst rel err of copies 0/7/14 vs the oracle %.3g" % (total, min(sizes), max(sizes), worst))
+    # the same pass: five repeats, and once with hash-table coordinate maps - identical bits
+    for _ in range(5):
+        again = _full_size_pass(fx, pc_d, Rs)
+        for (s1, f1, p1), (s2, f2, p2) in zip(res, again):
+            assert torch.equal(s1, s2) and torch.equal(f1, f2) and torch.equal(p1, p2)
+    try:
+        ctx.set_fcgf_sort(True, 4 | 1)
+        hashed = _full_size_pass(fx, pc_d, Rs)
+    finally:
+        ctx.set_fcgf_sort(True, 1)
+    for (s1, f1, _), (s2, f2, _) in zip(res, hashed):
+        assert torch.equal(s1, s2) and torch.equal(f1, f2)
+
+
+def test_backbone_wide_and_sparse_clouds_share_a_pass(hip, fsd):
+    """A cloud far wider than one brick of the rank-ordered bitmaps / the 128-voxel cell wrap (9 m = 360 voxels per axis), a 37-point
+    cloud and a mid-sized one in one pass, against the oracle; and the case ADVICE r4 found: clouds that are SPARSE in LARGE boxes
+    (15 x 5 k voxels over 800 x 800 x 240 cells: 660 MB of rank arrays against a 670 MB workspace estimate that only knows the voxel
+    count) - the pass must grow its workspace (or fall back to the hash tables), never return YOHO_ENOMEM, and give the hash path's bits."""
+    ctx = hip.Context()
+    ctx.load_fcgf(fsd)
+    pcs = [synth.surface_cloud(30000, seed=21, extent=9.0), synth.surface_cloud(37, seed=22), synth.surface_cloud(9000, seed=23, extent=1.5)]
+    vox = [fo.voxelize(p, 0.025) for p in pcs]
+    clouds = [torch.from_numpy(c).cuda() for _, c in vox]
+    assert (vox[0][1].max(0) - vox[0][1].min(0)).max() > 320
+    outs = ctx.fcgf_forward_batch(clouds)
+    for p, F in zip(pcs, outs):
+        F0 = fo.extract_features(p, 0.025, fsd)[1]
+        assert rel(F.cpu().numpy(), F0) < TOL
+    # sparse clouds in large boxes, fresh context (small workspace)
+    rs = np.random.RandomState(5)
+    sparse = []
+    for b in range(15):
+        c = np.unique(np.stack([rs.randint(0, 800, 5200), rs.randint(0, 800, 5200), rs.randint(0, 240, 5200)], 1).astype(np.int32), axis=0)
+        c = c[rs.permutation(len(c))] + np.array([-400 + 7 * b, -123, 50 * b], np.int32)
+        sparse.append(torch.from_numpy(np.ascontiguousarray(c)).cuda())
+    fresh = hip.Context()
+    fresh.load_fcgf(fsd)
+    got = fresh.fcgf_forward_batch(sparse)
+    again = fresh.fcgf_forward_batch(sparse)                  # second pass of the same shape: the grown workspace is kept
+    hashed_ctx = hip.Context()
+    hashed_ctx.load_fcgf(fsd)
+    hashed_ctx.set_fcgf_sort(True, 4 | 1)
+    hashed = hashed_ctx.fcgf_forward_batch(sparse)
+    for a, b, c in zip(got, again, hashed):
+        assert torch.equal(a, b) and torch.equal(a, c)
+    F0 = fo.resunet_forward(sparse[3].cpu().numpy(), fsd)
+    F0 = F0 / np.linalg.norm(F0, axis=1, keepdims=True)
+    assert rel(got[3].cpu().numpy(), F0) < TOL

@@ -90,3 +90,72 @@ def test_bench_under_the_launcher_with_one_rank():
     d = json.loads(line)
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["value"] > 0
     assert d["ranks"]["backend"] == "nccl" and d["ranks"]["process_group"] is True and len(d["ranks"]["ms_per_step_per_rank"]["all"]) == 1
+
+
+# ---- more than one rank: ready to fire on any box with two devices -----------------------------------------------------------------
+_WORKER2 = r"""
+import hashlib, json, os, sys
+import numpy as np, torch, torch.distributed as dist
+from yoho_amd import dist as ydist, weights as W
+rank, world, local = ydist.init_from_env("nccl")
+assert world == 2 and local == rank and dist.get_backend() == "nccl" and torch.cuda.current_device() == rank
+sd = W.synth_state_dict(W.PARTI_SPEC, 7)
+# rank 1 starts from DIFFERENT weights: whatever it holds after the broadcast came over xGMI from rank 0's device
+mine = sd if rank == 0 else W.synth_state_dict(W.PARTI_SPEC, 99)
+got = ydist.broadcast_state_dict(mine, W.PARTI_SPEC)
+for k, v in sd.items():                                      # tensor by tensor, on both ranks
+    if not k.endswith("num_batches_tracked"):
+        assert np.array_equal(got[k], np.asarray(v, np.float32)), (rank, k)
+ydist.barrier()
+assert ydist.all_ranks(10.0 + rank) == [10.0, 11.0] and ydist.max_over_ranks(float(rank)) == 1.0
+g = ydist.gather_results({f"{rank}-9": {"trans": np.full((3, 4), float(rank)), "recalltime": rank}})
+if rank == 0:
+    assert len(g) == 2 and g[1]["1-9"]["recalltime"] == 1 and float(g[1]["1-9"]["trans"][0, 0]) == 1.0
+# the sharded dataset driver over the two devices (tools/bench_dataset.run: scene cut over both ranks, one weight broadcast, host gather)
+sys.path.insert(0, os.path.join(os.environ["YOHO_REPO"], "tools"))
+import bench_dataset
+out = bench_dataset.run(nfrag=10, kp=600, span=4, estimator="yohoo", workdir=os.environ["YOHO_WORKDIR"], runs=1, max_iter=100)
+if rank == 0:
+    print("RCCL_WORLD2 " + json.dumps({"sha": out.get("trans_sha256"), "pairs": out["pairs"], "rr": [r["registration_recall"] for r in out["runs"]]}))
+ydist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def test_rccl_world2_broadcast_and_sharded_driver(tmp_path):
+    """Two ranks on two devices over RCCL: the weight broadcast compared tensor by tensor on rank 1 (which starts from
+    different weights), barrier / all-ranks / max / host gather across the ranks, and the sharded dataset driver over both devices
+    = the world-1 digest (every pair's transform and recalltime).  A one-GPU box reports the skip with its reason; any box with two
+    devices runs it - nothing else in the tree would put an ncclBroadcast between two GPUs before the driver's scaling run does."""
+    import torch
+    ndev = torch.cuda.device_count()
+    if ndev < 2:
+        pytest.skip(f"skipped: {ndev} device - the world-2 RCCL test needs two (it runs unchanged on any multi-GPU box)")
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import bench_dataset
+    one = bench_dataset.run(nfrag=10, kp=600, span=4, estimator="yohoo", workdir=str(tmp_path / "w1"), runs=1, max_iter=100)
+    script = tmp_path / "worker2.py"
+    script.write_text(_WORKER2)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), str(script)]
+    p = subprocess.run(cmd, cwd=REPO, env=_env(YOHO_REPO=REPO, YOHO_WORKDIR=str(tmp_path / "w2")), capture_output=True, text=True, timeout=1200)
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-4000:])
+    line = [ln for ln in p.stdout.splitlines() if ln.startswith("RCCL_WORLD2 ")][-1]
+    d = json.loads(line[len("RCCL_WORLD2 "):])
+    assert d["pairs"] == one["pairs"] == 30 and d["sha"] == one["trans_sha256"], "world-2 transforms over RCCL differ from world-1"
+    assert d["rr"] == [r["registration_recall"] for r in one["runs"]]
+
+
+def test_bench_strong_scaling_line_reports_per_rank_work_and_plan():
+    """`bench.py --scaling strong` (fixed total work cut over the ranks by the dataset driver's plan): the line carries every rank's
+    pair count and time and the plan's predicted imbalance, so that a scaling run explains itself.  World 1 here; the same keys at N > 1."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), "bench.py", "--gpus", "1", "--steps", "2", "--warmup", "1", "--repeats", "1", "--scaling", "strong",
+           "--no-cpu-baseline", "--no-dataset", "--no-yohoc", "--no-fcgf", "--no-sustained"]
+    p = subprocess.run(cmd, cwd=REPO, env=_env(), capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-4000:])
+    d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["scaling"] == "strong" and d["n_gpus"] == 1
+    r = d["ranks"]
+    assert len(r["pairs_per_rank"]) == 1 and len(r["ms_per_rank"]) == 1 and r["pairs_per_rank"][0] > 0 and r["ms_per_rank"][0] > 0
+    assert r["plan_predicted_imbalance"] >= 1.0

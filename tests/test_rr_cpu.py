@@ -91,6 +91,47 @@ def test_benchmark_on_3dLomatch_matches_reference(gold, tmp_path, part, sign, it
     assert txt == str(g[f"{part}_result_txt"])
 
 
+@pytest.mark.parametrize("fixture", ["sceneWHU.npz", "sceneETH.npz"])
+@pytest.mark.parametrize("part,sign", [("PartI", "YOHO_C"), ("PartII", "YOHO_O")])
+def test_benchmark_on_whu_tls_and_eth_matches_reference(gold, tmp_path, fixture, part, sign):
+    """BASELINE config 5's other two test sets.  'WHU-TLS' switches utils/RR_cal.benchmark to the CONSECUTIVE protocol
+    (utils/RR_cal.py:329-331 -> :262-285: every gt row counts, the first estimate is scored against gt row 0 directly,
+    n_gt = table entries + 1); 'ETH' keeps the 3DMatch protocol (the pair that is gt row 0 can never be looked up: flag 2).
+    Golden: the reference's benchmark on the pre.log its own estimators wrote (oracle/gen_golden_r5.py) - flags, RR, errors, result.txt."""
+    g = gold(fixture)
+    whole, scene, it = str(g["whole"]), str(g["scene"]), int(g["iters"])
+    pairs = [tuple(int(v) for v in p) for p in g["pairs"]]
+    sc = synth.make_scene(int(g["nfrag"]), int(g["K"]), seed=int(g["seed"]), res_deg=[float(v) for v in g["res_deg"]])
+    sc["pairs"] = pairs
+    scenes, counts = {"WHU-TLS": (['Park', 'Mountain', 'Campus', 'RiverBank', 'UndergroundExcavation', 'Tunnel'], [32, 6, 10, 7, 12, 7]),
+                      "ETH": (['gazebo_summer', 'gazebo_winter', 'wood_autumn', 'wood_summer'], [32, 31, 32, 37])}[whole]   # utils/dataset.py:195-208
+    for s in scenes:
+        synth.write_scene_files(sc, str(tmp_path / "origin" / whole / s))
+    dss = get_dataset_name(whole, str(tmp_path / "origin"))
+    assert dss["wholesetname"] == whole and list(dss)[1:] == scenes and [len(dss[s].pc_ids) for s in scenes] == counts
+    ds = dss[scene]
+    assert ds.name == f"{whole}/{scene}" and [tuple(int(v) for v in p) for p in ds.pair_ids] == pairs
+    cache = tmp_path / "cache"
+    pre_dir = cache / "Testset" / ds.name / "Match" / sign / f"{it}iters"
+    os.makedirs(pre_dir)
+    (pre_dir / "pre.log").write_text(str(g[f"{part}_prelog"]))
+    cfg = types.SimpleNamespace(output_cache_fn=str(cache), RR_dist_threshold=0.2)
+    RR, flags, errors = RR_cal.benchmark(cfg, {"wholesetname": whole, scene: ds}, it, yoho_sign=sign)
+    assert RR == float(g[f"{part}_RR"]) and flags[ds.name] == list(g[f"{part}_flags"])
+    assert np.allclose(errors[ds.name], g[f"{part}_errors"], rtol=1e-9, atol=1e-12)
+    txt = (cache / "Testset" / whole / "Eval_results" / f"{sign}_RR" / f"{it}iters" / "result.txt").read_text()
+    assert txt == str(g[f"{part}_result_txt"])
+    if whole == "WHU-TLS":
+        assert 2 not in flags[ds.name] and len(flags[ds.name]) == len(pairs)       # consecutive pairs are all scored, row 0 included
+        # the same pre.log under the 3DMatch protocol would score nothing: every pair is consecutive
+        ds3 = types.SimpleNamespace(name=ds.name, gt_dir=ds.gt_dir)
+        with np.errstate(invalid="ignore"):
+            rr3, f3, _ = RR_cal.benchmark(cfg, {"wholesetname": "other", scene: ds3}, it, yoho_sign=sign)
+        assert f3[ds.name] == [2] * len(pairs) and np.isnan(rr3)                   # 0 / 0 as in the reference (numpy integer n_gt)
+    else:
+        assert flags[ds.name][0] == 2                                              # gt row 0: table entry 0 = "empty" (:250-256)
+
+
 def test_ply_reader(tmp_path):
     pts = np.random.RandomState(1).rand(11, 3).astype(np.float32)
     hdr = "ply\nformat binary_little_endian 1.0\nelement vertex 11\nproperty float x\nproperty float y\nproperty float z\nproperty uchar red\nend_header\n"

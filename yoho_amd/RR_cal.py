@@ -140,7 +140,9 @@ def evaluate_registration(num_fragment, result, result_pairs, gt_pairs, gt, gt_i
         else:
             score(result[k], row)
     precision = good * 1.0 / (scored if scored else 1e6)
-    return precision, good * 1.0 / n_gt, flags, errors
+    # n_gt is a numpy integer in the reference (np.sum of the mask): a scene without a scorable gt pair gives nan (0/0, numpy
+    # warning), not a ZeroDivisionError
+    return precision, good * 1.0 / np.int64(n_gt), flags, errors
 
 
 def benchmark(cfg, datasets, max_iter, yoho_sign='YOHO_O'):

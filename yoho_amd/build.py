@@ -40,12 +40,20 @@ def _stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _hipcc():
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    return hipcc if os.path.exists(hipcc) else "hipcc"
+
+
+def asm_command(src, out, flags=None):
+    """the device assembly of one source with the flags its object is compiled with (yoho_amd.isa_audit, tools/check_isa.py)"""
+    return [_hipcc()] + list(FLAGS if flags is None else flags) + EXTRA.get(src, []) + ["--cuda-device-only", "-S", os.path.join(CSRC, src), "-o", out]
+
+
 def build(force=False, verbose=True):
     if not force and not _stale():
         return LIB
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    if not os.path.exists(hipcc):
-        hipcc = "hipcc"
+    hipcc = _hipcc()
     os.makedirs(OBJDIR, exist_ok=True)
     objs = []
     procs = []
@@ -56,9 +64,18 @@ def build(force=False, verbose=True):
             print(" ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd)))
         objs.append(obj)
+    # the ISA audit of gft16x_kernel's hidden ticket request runs on assembly made with THESE flags, as part of the build
+    asm = os.path.join(OBJDIR, "gft16.s")
+    procs.append(("gft16.hip (assembly for the ISA audit)", subprocess.Popen(asm_command("gft16.hip", asm), stderr=subprocess.DEVNULL)))
     for src, p in procs:
         if p.wait() != 0:
             raise RuntimeError(f"hipcc failed on {src}")
+    from .isa_audit import audit_file
+    ok, msg = audit_file(asm)
+    if verbose:
+        print("ISA audit:", msg, flush=True)
+    if not ok:
+        raise RuntimeError("ISA audit of gft16x_kernel failed (the library was NOT linked): " + msg)
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     if verbose:
         print(" ".join(cmd), flush=True)

@@ -339,6 +339,19 @@ int yoho_ctx_create(int device, const float* R, const uint8_t* N, const uint8_t*
     }
     c->gconv_mode = 4;      // default: group-Fourier irrep GEMMs on the fp16x2 split MFMA; YOHO_GCONV=f32 | bf16x3 | fourier | fp16x2 | fgemm
     c->partII_mode = 2;     // default: fp16x2 cone layers; YOHO_PARTII=f32 | bf16x3 | fp16x2
+    // ---- the environment is read HERE and nowhere else (include/yoho_hip.h lists the variables)
+    {
+        auto is = [](const char* name, const char* val) { const char* e = std::getenv(name); return e && std::strcmp(e, val) == 0; };
+        auto num = [](const char* name) { const char* e = std::getenv(name); return e ? std::atoi(e) : 0; };
+        c->env.partII_tail_staged = is("YOHO_PARTII_TAIL", "staged");
+        c->env.transfer_staged = is("YOHO_TRANSFER", "staged");
+        c->env.xf_steal = !is("YOHO_XF_STEAL", "0");
+        c->env.nn_splits = num("YOHO_NN_SPLITS");
+        c->env.spconv_debug = num("YOHO_SPCONV_DEBUG");
+        c->env.fcgf_f32 = is("YOHO_FCGF", "f32");
+        c->env.fcgf_full_maps = is("YOHO_FCGF_MAPS", "full");
+        c->env.fcgf_norm_staged = is("YOHO_FCGF_NORM", "staged");
+    }
     if (const char* m = std::getenv("YOHO_FCGF_CELLS")) c->fcgf_cell_sort = std::atoi(m);
     if (const char* m = std::getenv("YOHO_FCGF_SORT")) c->fcgf_parity_sort = std::strcmp(m, "0") == 0 ? 0 : 1;
     if (const char* m = std::getenv("YOHO_FCGF_COORDS")) c->fcgf_hash_coords = std::strcmp(m, "hash") == 0 ? 1 : 0;
@@ -704,7 +717,7 @@ static int partI_passG_chunk(yoho_ctx* c, char* ws, int evbase, const float* x, 
     const Layer* L = c->p1;
     mark(0);
     int* rf = c->d_rflag;
-    int* xc = c->d_xfctr + (size_t)slot * 8;     // ticket counters of this stream slot's three transform launches (a launch leaves them at zero)
+    int* xc = c->env.xf_steal ? c->d_xfctr + (size_t)slot * 8 : nullptr;     // ticket counters of this stream slot's three transform launches (a launch leaves them at zero)
     if ((rc = launch_head16(x, B, nT, bP32, kppad, c->dF16, s, x1, B0, rf))) return rc;
     mark(1);
     if ((rc = launch_fgemm(L[0], bP32, kppad, nT, nullptr, bH0, 0, s, rf, gv))) return rc;
@@ -713,11 +726,11 @@ static int partI_passG_chunk(yoho_ctx* c, char* ws, int evbase, const float* x, 
     mark(3);
     if ((rc = launch_fgemm(L[1], bP256, kppad, nT, nullptr, bM, 0, s, rf, gv))) return rc;
     mark(4);
-    if ((rc = launch_gft16(bM, nullptr, bP512, kppad, c->dF16, L[1].bn_s, L[1].bn_t, nT, 64, c->nCU, s, 0, rf, gv, xc + 2))) return rc;
+    if ((rc = launch_gft16(bM, nullptr, bP512, kppad, c->dF16, L[1].bn_s, L[1].bn_t, nT, 64, c->nCU, s, 0, rf, gv, xc ? xc + 2 : nullptr))) return rc;
     mark(5);
     if ((rc = launch_fgemm(L[2], bP512, kppad, nT, bH0, bA, EPI_RES, s, rf, gv))) return rc;
     mark(6);
-    if ((rc = launch_gft16(bA, nullptr, bP256, kppad, c->dF16, L[2].bn_s, L[2].bn_t, nT, 32, c->nCU, s, 0, rf, gv, xc + 4))) return rc;
+    if ((rc = launch_gft16(bA, nullptr, bP256, kppad, c->dF16, L[2].bn_s, L[2].bn_t, nT, 32, c->nCU, s, 0, rf, gv, xc ? xc + 4 : nullptr))) return rc;
     mark(7);
     if ((rc = launch_fgemm(L[3], bP256, kppad, nT, nullptr, bY, 0, s, rf, gv))) return rc;
     mark(8);
@@ -823,6 +836,7 @@ static int partI_pass(yoho_ctx* c, const float* x, int B, float* eqv, float* inv
 int yoho_partI_forward(yoho_ctx* c, const float* x, int B, float* eqv, float* inv, float* inv_np, void* stream) {
     if (!c || !x || !eqv || B < 1) { set_error("yoho_partI_forward: bad argument (B=%d)", B); return YOHO_EINVAL; }
     if (!c->has_partI) { set_error("yoho_partI_forward: PartI weights not loaded"); return YOHO_ENOWEIGHTS; }
+    YOHO_NEED_ALIGNED("yoho_partI_forward", 15, x, eqv, inv, inv_np);
     HIPCHK(hipSetDevice(c->device));
     hipStream_t s = (hipStream_t)stream;
     const int MAXB = 16384;                      // bounds the workspace to ~4.5 GB
@@ -838,6 +852,7 @@ int yoho_partI_forward(yoho_ctx* c, const float* x, int B, float* eqv, float* in
 int yoho_group_mean_np(yoho_ctx* c, const float* eqv, int B, float* out, void* stream) {
     if (!c || !eqv || !out || B < 0) { set_error("yoho_group_mean_np: bad argument"); return YOHO_EINVAL; }
     if (B == 0) return 0;
+    YOHO_NEED_ALIGNED("yoho_group_mean_np", 15, eqv, out);
     HIPCHK(hipSetDevice(c->device));
     return launch_group_mean_np(eqv, B, out, (hipStream_t)stream);
 }
@@ -892,8 +907,7 @@ static int partII_pass16(yoho_ctx* c, const float* s0, const float* s1, const fl
         if ((rc = launch_gconv16(c->p2[1], bA0, nT16, nullptr, nullptr, bA1p, EPI_ACT, s, 2, nullptr, nullptr, npl, rf))) return rc;
         // with the one-launch tail behind it the layer runs its K over two workgroups per tile and the tail adds the halves (bF0,
         // the staged tail's 512-channel buffer, holds them)
-        static const bool staged_tail16 = [] { const char* e = std::getenv("YOHO_PARTII_TAIL"); return e && std::strcmp(e, "staged") == 0; }();
-        if (!staged_tail16 && mlp_head_supported(c->p2[3], c->p2[4], c->p2[5])) {
+        if (!c->env.partII_tail_staged && mlp_head_supported(c->p2[3], c->p2[4], c->p2[5])) {
             if ((rc = launch_cone1(c->p2[2], bA1p, nT, nT16, nullptr, nullptr, n0, s, bF0))) return rc;
             return launch_mlp_head(c->p2[3], c->p2[4], c->p2[5], nullptr, nT, M, quat, s, bF0, &c->p2[2], bH0);
         }
@@ -902,8 +916,7 @@ static int partII_pass16(yoho_ctx* c, const float* s0, const float* s1, const fl
         if ((rc = launch_gconv16(c->p2[1], bA0, nT16, nullptr, nullptr, nullptr, EPI_ACT32, s, 2, nullptr, bA1, npl))) return rc;
         if ((rc = launch_gconv(conv_args(c->p2[2], bA1, nT, bH0, bF, nullptr, true), -1, EPI_RES | EPI_RAW, s))) return rc;
     }
-    static const bool staged_tail = [] { const char* e = std::getenv("YOHO_PARTII_TAIL"); return e && std::strcmp(e, "staged") == 0; }();
-    if (!staged_tail && mlp_head_supported(c->p2[3], c->p2[4], c->p2[5])) return launch_mlp_head(c->p2[3], c->p2[4], c->p2[5], bF, nT, M, quat, s);
+    if (!c->env.partII_tail_staged && mlp_head_supported(c->p2[3], c->p2[4], c->p2[5])) return launch_mlp_head(c->p2[3], c->p2[4], c->p2[5], bF, nT, M, quat, s);
     if ((rc = launch_gconv(conv_args(c->p2[3], bF, nT, nullptr, nullptr, bF0, true), -1, EPI_ACT, s))) return rc;
     if ((rc = launch_gconv(conv_args(c->p2[4], bF0, nT, nullptr, nullptr, bF1, true), -1, EPI_ACT, s))) return rc;
     if ((rc = launch_gconv(conv_args(c->p2[5], bF1, nT, nullptr, bQ, nullptr, false), 1, EPI_RAW, s))) return rc;
@@ -932,8 +945,7 @@ static int partII_pass(yoho_ctx* c, const float* s0, const float* s1, const floa
     if ((rc = launch_gconv(conv_args(c->p2[0], bX, nT, nullptr, bH0, bA0, false), 12, EPI_RAW | EPI_ACT, s))) return rc;
     if ((rc = launch_gconv(conv_args(c->p2[1], bA0, nT, nullptr, nullptr, bA1, false), 4, EPI_ACT, s))) return rc;
     if ((rc = launch_gconv(conv_args(c->p2[2], bA1, nT, bH0, bF, nullptr, true), -1, EPI_RES | EPI_RAW, s))) return rc;
-    static const bool staged_tail = [] { const char* e = std::getenv("YOHO_PARTII_TAIL"); return e && std::strcmp(e, "staged") == 0; }();
-    if (!staged_tail && mlp_head_supported(c->p2[3], c->p2[4], c->p2[5])) return launch_mlp_head(c->p2[3], c->p2[4], c->p2[5], bF, nT, M, quat, s);
+    if (!c->env.partII_tail_staged && mlp_head_supported(c->p2[3], c->p2[4], c->p2[5])) return launch_mlp_head(c->p2[3], c->p2[4], c->p2[5], bF, nT, M, quat, s);
     if ((rc = launch_gconv(conv_args(c->p2[3], bF, nT, nullptr, nullptr, bF0, true), -1, EPI_ACT, s))) return rc;
     if ((rc = launch_gconv(conv_args(c->p2[4], bF0, nT, nullptr, nullptr, bF1, true), -1, EPI_ACT, s))) return rc;
     if ((rc = launch_gconv(conv_args(c->p2[5], bF1, nT, nullptr, bQ, nullptr, false), 1, EPI_RAW, s))) return rc;
@@ -948,6 +960,8 @@ int yoho_partII_forward(yoho_ctx* c, const float* before_eqv0, const float* befo
     if (!before_eqv0 || !before_eqv1 || !after_eqv0 || !after_eqv1 || !pre_idx || !quat) {
         set_error("yoho_partII_forward: bad argument"); return YOHO_EINVAL;
     }
+    YOHO_NEED_ALIGNED("yoho_partII_forward", 15, before_eqv0, before_eqv1, after_eqv0, after_eqv1, quat);
+    YOHO_NEED_ALIGNED("yoho_partII_forward", 7, pre_idx);
     HIPCHK(hipSetDevice(c->device));
     hipStream_t s = (hipStream_t)stream;
     const int MAXM = 8192;
@@ -971,6 +985,8 @@ int yoho_partII_forward_indexed(yoho_ctx* c, const float* s0, const int64_t* i0,
         set_error("yoho_partII_forward_indexed: bad argument"); return YOHO_EINVAL;
     }
     if (!partII_fourier_head(c)) { set_error("yoho_partII_forward_indexed: needs the default PartII mode (fp16x2, Fourier first layer)"); return YOHO_EINVAL; }
+    YOHO_NEED_ALIGNED("yoho_partII_forward_indexed", 15, s0, s1, s2, s3, quat);
+    YOHO_NEED_ALIGNED("yoho_partII_forward_indexed", 7, i0, i1, i2, i3, pre_idx);
     HIPCHK(hipSetDevice(c->device));
     hipStream_t s = (hipStream_t)stream;
     const int MAXM = 8192;
@@ -989,7 +1005,7 @@ int yoho_load_fcgf(yoho_ctx* c, const yoho_fcgf_config* cfg, const float* const*
     for (int i = 0; i < ntensors; ++i) if (!tensors[i]) { set_error("yoho_load_fcgf: null tensor %d", i); return YOHO_EINVAL; }
     HIPCHK(hipSetDevice(c->device));
     FcgfNet* n = nullptr;
-    int rc = fcgf_load(&n, cfg, tensors, ntensors);
+    int rc = fcgf_load(&n, cfg, tensors, ntensors, c->env.fcgf_f32);
     if (rc) return rc;
     if (c->fcgf) fcgf_free(c->fcgf);
     c->fcgf = n;
@@ -1000,6 +1016,8 @@ int yoho_fcgf_voxelize(yoho_ctx* c, const double* pts, int n, double voxel_size,
     if (!c || !count || n < 0 || !(voxel_size > 0)) { set_error("yoho_fcgf_voxelize: bad argument"); return YOHO_EINVAL; }
     if (n == 0) { *count = 0; return 0; }
     if (!pts || !sel || !coords) { set_error("yoho_fcgf_voxelize: bad argument"); return YOHO_EINVAL; }
+    YOHO_NEED_ALIGNED("yoho_fcgf_voxelize", 7, pts, sel);
+    YOHO_NEED_ALIGNED("yoho_fcgf_voxelize", 3, coords);
     HIPCHK(hipSetDevice(c->device));
     return fcgf_voxelize(c, pts, n, nullptr, voxel_size, sel, coords, nullptr, count, (hipStream_t)stream);
 }
@@ -1009,6 +1027,8 @@ int yoho_fcgf_voxelize_rotated(yoho_ctx* c, const double* pts, int n, const doub
     if (!c || !count || !R_host || n < 0 || !(voxel_size > 0)) { set_error("yoho_fcgf_voxelize_rotated: bad argument"); return YOHO_EINVAL; }
     if (n == 0) { *count = 0; return 0; }
     if (!pts || !sel || !coords) { set_error("yoho_fcgf_voxelize_rotated: bad argument"); return YOHO_EINVAL; }
+    YOHO_NEED_ALIGNED("yoho_fcgf_voxelize_rotated", 7, pts, sel);
+    YOHO_NEED_ALIGNED("yoho_fcgf_voxelize_rotated", 3, coords, pts_sel);
     HIPCHK(hipSetDevice(c->device));
     return fcgf_voxelize(c, pts, n, R_host, voxel_size, sel, coords, pts_sel, count, (hipStream_t)stream);
 }
@@ -1017,6 +1037,8 @@ int yoho_fcgf_voxelize_rotated_batch(yoho_ctx* c, const double* pts, int n, cons
                                      int32_t* coords, float* pts_sel, int* counts, void* stream) {
     if (!c || !counts || !R_host || n < 0 || nb < 1 || !(voxel_size > 0)) { set_error("yoho_fcgf_voxelize_rotated_batch: bad argument"); return YOHO_EINVAL; }
     if (n > 0 && (!pts || !sel || !coords)) { set_error("yoho_fcgf_voxelize_rotated_batch: bad argument"); return YOHO_EINVAL; }
+    YOHO_NEED_ALIGNED("yoho_fcgf_voxelize_rotated_batch", 7, pts, sel);
+    YOHO_NEED_ALIGNED("yoho_fcgf_voxelize_rotated_batch", 3, coords, pts_sel);
     HIPCHK(hipSetDevice(c->device));
     return fcgf_voxelize_batch(c, pts, n, R_host, nb, voxel_size, sel, coords, pts_sel, counts, (hipStream_t)stream);
 }
@@ -1025,6 +1047,8 @@ int yoho_rotate_select(yoho_ctx* c, const double* pts, const double* R_host, con
     if (!c || m < 0) { set_error("yoho_rotate_select: bad argument"); return YOHO_EINVAL; }
     if (m == 0) return 0;
     if (!pts || !sel || !out) { set_error("yoho_rotate_select: bad argument"); return YOHO_EINVAL; }
+    YOHO_NEED_ALIGNED("yoho_rotate_select", 7, pts, sel);
+    YOHO_NEED_ALIGNED("yoho_rotate_select", 3, out);
     HIPCHK(hipSetDevice(c->device));
     return fcgf_rotate_select(pts, R_host, sel, m, out, (hipStream_t)stream);
 }
@@ -1037,10 +1061,11 @@ int yoho_group_transfer_batch(yoho_ctx* c, const double* pts, const int64_t* kid
     if (!pts || !kidx || !R_host || !ds || !feat || !m || !out || !q_scratch || !idx_scratch) { set_error("yoho_group_transfer_batch: null argument"); return YOHO_EINVAL; }
     for (int b = 0; b < nb; ++b)
         if (!ds[b] || !feat[b] || m[b] < 1) { set_error("yoho_group_transfer_batch: copy %d has no down-sampled points", b); return YOHO_EINVAL; }
+    YOHO_NEED_ALIGNED("yoho_group_transfer_batch", 7, pts, kidx, idx_scratch);
+    YOHO_NEED_ALIGNED("yoho_group_transfer_batch", 15, out);
     int rc;
     phase_mark(c, 15, (hipStream_t)stream);
-    static const bool staged_transfer = [] { const char* e = std::getenv("YOHO_TRANSFER"); return e && std::strcmp(e, "staged") == 0; }();   // A/B
-    if (c->nn_cell > 0.0 && !staged_transfer) {
+    if (c->nn_cell > 0.0 && !c->env.transfer_staged) {                 // (YOHO_TRANSFER=staged: A/B)
         // with a cell-size hint: all copies of the pass through the hash grid in four launches (gridnn.hip), the keypoints rotated and
         // the feature rows written by the query kernel itself; q_scratch / idx_scratch stay unused
         HIPCHK(hipSetDevice(c->device));
@@ -1065,6 +1090,8 @@ int yoho_fcgf_forward(yoho_ctx* c, const int32_t* coords, int n, float* out, voi
     if (!c->fcgf) { set_error("yoho_fcgf_forward: backbone weights not loaded"); return YOHO_ENOWEIGHTS; }
     if (n == 0) return 0;
     if (!coords || !out) { set_error("yoho_fcgf_forward: bad argument"); return YOHO_EINVAL; }
+    YOHO_NEED_ALIGNED("yoho_fcgf_forward", 15, out);
+    YOHO_NEED_ALIGNED("yoho_fcgf_forward", 3, coords);
     HIPCHK(hipSetDevice(c->device));
     return fcgf_forward(c, c->fcgf, coords, n, nullptr, 1, out, (hipStream_t)stream);
 }
@@ -1077,6 +1104,8 @@ int yoho_fcgf_forward_batch(yoho_ctx* c, const int32_t* coords, const int32_t* o
     const int n = offsets[nb];
     if (n == 0) return 0;
     if (!coords || !out) { set_error("yoho_fcgf_forward_batch: bad argument"); return YOHO_EINVAL; }
+    YOHO_NEED_ALIGNED("yoho_fcgf_forward_batch", 15, out);
+    YOHO_NEED_ALIGNED("yoho_fcgf_forward_batch", 3, coords);
     HIPCHK(hipSetDevice(c->device));
     return fcgf_forward(c, c->fcgf, coords, n, offsets, nb, out, (hipStream_t)stream);
 }
@@ -1086,6 +1115,7 @@ int yoho_partI_forward_pair(yoho_ctx* c, const float* x0, int B0, const float* x
     if (!c || !x0 || !x1 || !eqv || B0 < 1 || B1 < 1) { set_error("yoho_partI_forward_pair: bad argument"); return YOHO_EINVAL; }
     if (!c->has_partI) { set_error("yoho_partI_forward_pair: PartI weights not loaded"); return YOHO_ENOWEIGHTS; }
     if (c->gconv_mode < 4 || B0 + B1 > 16384) { set_error("yoho_partI_forward_pair: default arithmetic mode and at most 16384 keypoints"); return YOHO_EINVAL; }
+    YOHO_NEED_ALIGNED("yoho_partI_forward_pair", 15, x0, x1, eqv, inv, inv_np);
     HIPCHK(hipSetDevice(c->device));
     return partI_passG(c, x0, B0 + B1, eqv, inv, inv_np, (hipStream_t)stream, x1, B0);
 }
@@ -1096,6 +1126,7 @@ int yoho_gconv_layer(yoho_ctx* c, const float* x, int B, int cin, int cout, cons
     if (B == 0) return 0;
     if (!x || !weight || !y) { set_error("yoho_gconv_layer: bad argument"); return YOHO_EINVAL; }
     if (transpose && c->tap_inv[0] < 0) { set_error("yoho_gconv_layer: the neighbour table is not closed under inversion"); return YOHO_EINVAL; }
+    YOHO_NEED_ALIGNED("yoho_gconv_layer", 15, x, weight, y);
     HIPCHK(hipSetDevice(c->device));
     hipStream_t s = (hipStream_t)stream;
     const int xc = transpose ? cout : cin, yc = transpose ? cin : cout;
@@ -1110,12 +1141,14 @@ int yoho_gconv_layer(yoho_ctx* c, const float* x, int B, int cin, int cout, cons
 
 int yoho_bn_stats(yoho_ctx* c, const float* x, int B, int C, float* mean, float* var, void* stream) {
     if (!c || !x || !mean || !var || B < 1 || C < 1) { set_error("yoho_bn_stats: bad argument"); return YOHO_EINVAL; }
+    YOHO_NEED_ALIGNED("yoho_bn_stats", 15, x);
     HIPCHK(hipSetDevice(c->device));
     return bn_stats(x, B, C, mean, var, (hipStream_t)stream);
 }
 
 int yoho_bn_relu_apply(yoho_ctx* c, const float* x, int B, int C, const float* scale, const float* shift, float* y, void* stream) {
     if (!c || !x || !scale || !shift || !y || B < 1 || C < 1) { set_error("yoho_bn_relu_apply: bad argument"); return YOHO_EINVAL; }
+    YOHO_NEED_ALIGNED("yoho_bn_relu_apply", 15, x, y);
     HIPCHK(hipSetDevice(c->device));
     return bn_relu_apply(x, B, C, scale, shift, y, (hipStream_t)stream);
 }
@@ -1125,12 +1158,14 @@ int yoho_bn_relu_backward(yoho_ctx* c, const float* x, const float* y, const flo
     if (!c || !x || !y || !dy || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || B < 1 || C < 1) {
         set_error("yoho_bn_relu_backward: bad argument"); return YOHO_EINVAL;
     }
+    YOHO_NEED_ALIGNED("yoho_bn_relu_backward", 15, x, y, dy, dx);
     HIPCHK(hipSetDevice(c->device));
     return bn_relu_backward(x, y, dy, B, C, gamma, mean, rstd, batch_stats, dx, dgamma, dbeta, (hipStream_t)stream);
 }
 
 int yoho_gconv_wgrad(yoho_ctx* c, const float* x, const float* dy, int B, int cin, int cout, float* dW, float* db, void* stream) {
     if (!c || B < 1 || cin < 1 || cout < 1 || !x || !dy || !dW) { set_error("yoho_gconv_wgrad: bad argument"); return YOHO_EINVAL; }
+    YOHO_NEED_ALIGNED("yoho_gconv_wgrad", 15, x, dy, dW);
     HIPCHK(hipSetDevice(c->device));
     return gconv_wgrad(c, x, dy, B, cin, cout, dW, db, (hipStream_t)stream);
 }

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
+#include <initializer_list>
 #include "yoho_hip.h"
 
 namespace yoho {
@@ -17,6 +18,19 @@ constexpr int SLAB_FLOATS = 2 * TILE * 4;          // 256 floats = 1 KiB
 constexpr int CHUNK_FLOATS = G * SLAB_FLOATS;      // 15360 floats = 60 KiB
 
 void set_error(const char* fmt, ...);
+// device tensors at the ABI are read with 16-byte vector loads and LDS DMA (include/yoho_hip.h: "contiguous, 16-byte aligned"); f64 /
+// int64 arrays that are only ever read element-wise need their natural 8 bytes.  Null pointers pass (optional arguments).
+inline bool yoho_misaligned(std::initializer_list<const void*> ps, unsigned mask) {
+    for (const void* p : ps) if ((reinterpret_cast<uintptr_t>(p) & mask) != 0) return true;
+    return false;
+}
+#define YOHO_NEED_ALIGNED(fn, mask, ...)                                                                                  \
+    do {                                                                                                                  \
+        if (::yoho::yoho_misaligned({__VA_ARGS__}, (mask))) {                                                             \
+            ::yoho::set_error(fn ": a device pointer is not %d-byte aligned", (int)(mask) + 1);                           \
+            return YOHO_EINVAL;                                                                                           \
+        }                                                                                                                 \
+    } while (0)
 int hip_fail(hipError_t e, const char* what, const char* file, int line);
 
 #define HIPCHK(expr)                                                         \
@@ -127,7 +141,7 @@ int bn_relu_backward(const float* x, const float* y, const float* dy, int B, int
                      int batch_stats, float* dx, float* dgamma, float* dbeta, hipStream_t s);
 int gconv_wgrad(yoho_ctx* c, const float* x, const float* dy, int B, int cin, int cout, float* dW, float* db, hipStream_t s);
 struct FcgfNet;
-int fcgf_load(FcgfNet** out, const yoho_fcgf_config* cfg, const float* const* t, int ntensors);
+int fcgf_load(FcgfNet** out, const yoho_fcgf_config* cfg, const float* const* t, int ntensors, bool f32_kernels);
 void fcgf_free(FcgfNet* n);
 int fcgf_forward(yoho_ctx* ctx, const FcgfNet* net, const int* coords0, int n0, const int* off_host, int nb, float* out, hipStream_t s);
 int fcgf_voxelize(yoho_ctx* ctx, const double* pts, int n, const double* R_host, double voxel, int64_t* sel, int* coords, float* pts_sel,
@@ -163,7 +177,7 @@ int launch_quat_norm(const float* y, int M, float* quat, hipStream_t s);
 
 size_t mutual_prefilter_ws_bytes(int Na, int Nb);
 int launch_mutual_prefilter(const float* a, int Na, const float* b, int Nb, void* ws, unsigned long long** keysA, unsigned long long** keysB,
-                            int nCU, hipStream_t s);
+                            int nCU, hipStream_t s, int nn_splits = 0);
 size_t grid_transfer_ws_bytes(int K, int nb, int mmax);
 int launch_grid_transfer_batch(const double* pts, const int64_t* kidx, int K, const double* R_host, int nb, const float* const* ds,
                                const float* const* feat, const int* m, int g0, float* out, double cell, void* ws, int nCU, hipStream_t s);
@@ -214,8 +228,23 @@ struct PhaseProf {
 
 }  // namespace yoho
 
+// A/B and diagnostic switches of the environment.  They are read ONCE, in yoho_ctx_create, into the context (the list is in
+// include/yoho_hip.h); no entry point reads the environment afterwards, so what a context does is fixed when it is created, two
+// contexts of one process can differ, and a test can pin every switch.
+struct yoho_env_switches {
+    bool partII_tail_staged = false;   // YOHO_PARTII_TAIL=staged: PartII's 1x1 tail as three gconv launches + quat_norm instead of mlp_head
+    bool transfer_staged = false;      // YOHO_TRANSFER=staged: the feature transfer of a pass copy by copy instead of the batched grid kernels
+    bool xf_steal = true;              // YOHO_XF_STEAL=0: gft16x walks its chunks by static striding instead of tickets
+    int nn_splits = 0;                 // YOHO_NN_SPLITS=<n>: column splits of the matcher's Gram passes (0 = two workgroups per CU)
+    int spconv_debug = 0;              // YOHO_SPCONV_DEBUG=<bits>: ablations of the fine-level sparse conv (a -DYOHO_SPCONV_ABLATE build only)
+    bool fcgf_f32 = false;             // YOHO_FCGF=f32: the backbone's weights are packed for the fp32-MFMA kernels at yoho_load_fcgf
+    bool fcgf_full_maps = false;       // YOHO_FCGF_MAPS=full: every kernel map by its own probes (no mirrored / inverted maps)
+    bool fcgf_norm_staged = false;     // YOHO_FCGF_NORM=staged: row normalisation as its own kernel behind the last convolution
+};
+
 struct yoho_ctx {
     int device = 0;
+    yoho_env_switches env;
     // tables
     float* dR32 = nullptr;       // (60,9)
     double* dR64 = nullptr;      // (60,9) widened from f32 exactly as the reference's f64 @ f32 promotes

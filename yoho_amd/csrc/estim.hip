@@ -548,6 +548,8 @@ int yoho_group_scatter(yoho_ctx* c, const float* feat, int n, const int64_t* idx
     if (!c || K < 0 || n < 1 || g < 0 || g >= G) { set_error("yoho_group_scatter: bad argument"); return YOHO_EINVAL; }
     if (K == 0) return 0;
     if (!feat || !idx || !out) { set_error("yoho_group_scatter: bad argument"); return YOHO_EINVAL; }
+    YOHO_NEED_ALIGNED("yoho_group_scatter", 15, feat, out);
+    YOHO_NEED_ALIGNED("yoho_group_scatter", 7, idx);
     HIPCHK(hipSetDevice(c->device));
     hipLaunchKernelGGL(group_scatter_kernel, dim3((K + 15) / 16), dim3(256), 0, (hipStream_t)stream, feat, idx, K, n, g, out);
     HIPCHK(hipGetLastError());
@@ -558,6 +560,8 @@ int yoho_hyp_from_quat(yoho_ctx* c, const float* quat, const int64_t* idx, const
                        void* stream) {
     if (!c || !quat || !idx || !k0 || !k1 || !T || M < 0) { set_error("yoho_hyp_from_quat: bad argument"); return YOHO_EINVAL; }
     if (M == 0) return 0;
+    YOHO_NEED_ALIGNED("yoho_hyp_from_quat", 15, quat);
+    YOHO_NEED_ALIGNED("yoho_hyp_from_quat", 7, idx, k0, k1, T);
     HIPCHK(hipSetDevice(c->device));
     hipLaunchKernelGGL(hyp_kernel, dim3((M + 255) / 256), dim3(256), 0, (hipStream_t)stream, quat, idx, k0, k1, c->dR64, M, T);
     HIPCHK(hipGetLastError());
@@ -567,6 +571,8 @@ int yoho_hyp_from_quat(yoho_ctx* c, const float* quat, const int64_t* idx, const
 int yoho_o_score(yoho_ctx* c, const double* k0, const double* k1, int M, const double* T, const int64_t* order, int H, double d,
                  int* best_h, int* best_count, int32_t* counts, void* stream) {
     if (!c || !k0 || !k1 || !T || !best_h || !best_count || M < 1 || H < 1) { set_error("yoho_o_score: bad argument"); return YOHO_EINVAL; }
+    YOHO_NEED_ALIGNED("yoho_o_score", 7, k0, k1, T, order);
+    YOHO_NEED_ALIGNED("yoho_o_score", 3, best_h, best_count, counts);
     HIPCHK(hipSetDevice(c->device));
     hipStream_t s = (hipStream_t)stream;
     int rc;
@@ -587,6 +593,8 @@ int yoho_c_ransac(yoho_ctx* c, const double* k0, const double* k1, int M, const 
     if (!c || !k0 || !k1 || !triples || !best_T || !best_iter || !best_count || M < 1 || I < 1) {
         set_error("yoho_c_ransac: bad argument"); return YOHO_EINVAL;
     }
+    YOHO_NEED_ALIGNED("yoho_c_ransac", 7, k0, k1, triples, best_T, T_out);
+    YOHO_NEED_ALIGNED("yoho_c_ransac", 3, best_iter, best_count, counts);
     HIPCHK(hipSetDevice(c->device));
     hipStream_t s = (hipStream_t)stream;
     int rc;
@@ -611,6 +619,8 @@ int yoho_c_ransac_device(yoho_ctx* c, const double* keys0, const int64_t* i0, co
     if (!c || !keys0 || !keys1 || !dr_index || !best_T || !best_iter || !best_count || M < 1 || max_iter < 1 || istride < 1) {
         set_error("yoho_c_ransac_device: bad argument"); return YOHO_EINVAL;
     }
+    YOHO_NEED_ALIGNED("yoho_c_ransac_device", 7, keys0, keys1, i0, i1, dr_index, best_T, triples_out);
+    YOHO_NEED_ALIGNED("yoho_c_ransac_device", 3, best_iter, best_count);
     HIPCHK(hipSetDevice(c->device));
     hipStream_t s = (hipStream_t)stream;
     int rc;
@@ -647,6 +657,9 @@ int yoho_group_gather(yoho_ctx* c, const double* keys, int K, const float* pts, 
     if (!c || !keys || !pts || !feat || !Rg_host || !out || K < 1 || n < 1 || g < 0 || g >= G) {
         set_error("yoho_group_gather: bad argument"); return YOHO_EINVAL;
     }
+    YOHO_NEED_ALIGNED("yoho_group_gather", 7, keys, nn_idx);
+    YOHO_NEED_ALIGNED("yoho_group_gather", 15, feat, out);
+    YOHO_NEED_ALIGNED("yoho_group_gather", 3, pts);
     HIPCHK(hipSetDevice(c->device));
     hipStream_t s = (hipStream_t)stream;
     Mat3 R;

@@ -389,17 +389,19 @@ __global__ __launch_bounds__(512, 2) void gft16x_kernel(Gft16Args a) {
     // read at the top of the next one where the counted wait for that DMA has covered it (vector-memory operations complete in issue
     // order), handed to the other waves through LDS at the barrier that is there anyway.  A chunk's arithmetic does not depend on who
     // takes it: same bits.  The last workgroup to finish zeroes the counters for the next launch.
-    int* ids = reinterpret_cast<int*>(smem + 2 * GB + 768);      // [2]: ticket slots, written by thread 0 in front of a barrier
+    int* ids = reinterpret_cast<int*>(smem + 2 * GB + 768);      // [0], [1]: ticket slots of the loop, written by thread 0 in front of a barrier; [2]: the prologue's
     const bool steal = a.ctr != nullptr;
     int chunk = blockIdx.x, nxt = blockIdx.x + gridDim.x;
     int ticket = 0;
     if (steal) {
+        // the prologue's pair of tickets travels through a slot of its own: iteration 0 writes slot 0 in front of its first barrier, and
+        // nothing orders the other waves' read below before that write (only the latency of wave 0's DMA wait did)
         if (tid == 0) {
             const int t0 = __hip_atomic_fetch_add(a.ctr, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            ids[0] = t0;
+            ids[2] = t0;
         }
         __syncthreads();
-        chunk = ids[0];
+        chunk = ids[2];
         nxt = chunk + 1;
     }
     if (chunk < a.nChunks) stage(chunk, smem);
@@ -615,8 +617,7 @@ int launch_gft16(const float* in, float* out32, char* planes, int kppad, const v
                  int C8, int nCU, hipStream_t s, int B, int* rflag, int variant, int* ctr) {
     Gft16Args a;
     a.B = B; a.res0 = nullptr; a.nTiles16 = 0; a.rflag = rflag;
-    static const bool no_steal = [] { const char* e = std::getenv("YOHO_XF_STEAL"); return e && std::strcmp(e, "0") == 0; }();    // A/B: static striding
-    a.ctr = no_steal ? nullptr : ctr;
+    a.ctr = ctr;                       // null: static striding (the caller's context was created with YOHO_XF_STEAL=0, or the pass is small)
     a.in = in; a.out32 = out32; a.planes = planes; a.Ffrag = reinterpret_cast<const uintx4*>(Ffrag); a.bn_s = bn_s; a.bn_t = bn_t;
     a.nChunks = nTiles * C8; a.C8 = C8;
     static const int dbg_drain = [] { const char* e = experiment_env("YOHO_PARTI_DEBUG"); return (e && std::strstr(e, "drain")) ? 1 : 0; }();
@@ -633,6 +634,9 @@ int launch_gft16(const float* in, float* out32, char* planes, int kppad, const v
     const int want = nCU * (gmult > 0 ? gmult : 1);
     const int grid = a.nChunks < want ? a.nChunks : want;
     if (grid == 0) return 0;
+    // every workgroup draws TWO tickets up front: with fewer than two chunks per workgroup half of them would get nothing and the rest
+    // two each (a pass of <= 256 keypoints, the tail of a chunked pass) - static striding deals those one each
+    if (a.nChunks <= 2 * grid) a.ctr = nullptr;
     if (planes && variant != 1 && a.C8 * 8 <= G16X_MAXC) hipLaunchKernelGGL(gft16x_kernel, dim3(grid), dim3(512), G16X_LDS, s, a);       // two waves per SIMD
     else if (planes) hipLaunchKernelGGL(gft16_kernel<G16_ACTP>, dim3(grid), dim3(256), G16_LDS, s, a);
     else if (bn_s) hipLaunchKernelGGL(gft16_kernel<G16_ACT32>, dim3(grid), dim3(256), G16_LDS, s, a);

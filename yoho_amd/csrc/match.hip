@@ -352,6 +352,9 @@ int yoho_nn_search(yoho_ctx* c, const float* src, int Ns, const float* tgt, int 
                    void* stream) {
     if (!c || !src || !tgt || !idx || Ns < 0 || Nt < 1) { set_error("yoho_nn_search: bad argument"); return YOHO_EINVAL; }
     if (Ns == 0) return 0;
+    YOHO_NEED_ALIGNED("yoho_nn_search", (D == 32 ? 15 : 3), src, tgt);
+    YOHO_NEED_ALIGNED("yoho_nn_search", 7, idx);
+    YOHO_NEED_ALIGNED("yoho_nn_search", 3, dist);
     HIPCHK(hipSetDevice(c->device));
     if (D == 3 && c->nn_cell > 0.0 && (size_t)Ns * Nt >= (1u << 20) && (dist_type == YOHO_DIST_L2 || dist_type == YOHO_DIST_SQUARE_L2)) {
         int rc;
@@ -371,6 +374,8 @@ int yoho_nn_search(yoho_ctx* c, const float* src, int Ns, const float* tgt, int 
 
 int yoho_mutual_nn(yoho_ctx* c, const float* a, int Na, const float* b, int Nb, int64_t* pairs, int* M_out, void* stream) {
     if (!c || !a || !b || !pairs || !M_out || Na < 1 || Nb < 1) { set_error("yoho_mutual_nn: bad argument"); return YOHO_EINVAL; }
+    YOHO_NEED_ALIGNED("yoho_mutual_nn", 15, a, b, pairs);
+    YOHO_NEED_ALIGNED("yoho_mutual_nn", 3, M_out);
     HIPCHK(hipSetDevice(c->device));
     hipStream_t s = (hipStream_t)stream;
     // workspace: fwd (Na) + back (Nb) int64, placed after everything the descriptor passes use
@@ -383,7 +388,7 @@ int yoho_mutual_nn(yoho_ctx* c, const float* a, int Na, const float* b, int Nb, 
         // MFMA pre-filter + exact evaluation of the candidates (matchf.hip): the same packed keys as the segmented search below
         if ((rc = ensure_ws(c, mutual_prefilter_ws_bytes(Na, Nb), s))) return rc;
         unsigned long long *kA = nullptr, *kB = nullptr;
-        if ((rc = launch_mutual_prefilter(a, Na, b, Nb, c->ws.p, &kA, &kB, c->nCU, s))) return rc;
+        if ((rc = launch_mutual_prefilter(a, Na, b, Nb, c->ws.p, &kA, &kB, c->nCU, s, c->env.nn_splits))) return rc;
         return launch_mutual_compact((const int64_t*)kA, (const int64_t*)kB, Na, pairs, M_out, s, true);
     }
     if ((size_t)Na * Nb >= (1u << 20)) {
@@ -400,6 +405,9 @@ int yoho_mutual_nn(yoho_ctx* c, const float* a, int Na, const float* b, int Nb, 
 int yoho_des2r(yoho_ctx* c, const float* d1, const float* d2, int M, int64_t* idx, float* cor, void* stream) {
     if (!c || !d1 || !d2 || !idx || M < 0) { set_error("yoho_des2r: bad argument"); return YOHO_EINVAL; }
     if (M == 0) return 0;
+    YOHO_NEED_ALIGNED("yoho_des2r", 15, d1, d2);
+    YOHO_NEED_ALIGNED("yoho_des2r", 7, idx);
+    YOHO_NEED_ALIGNED("yoho_des2r", 3, cor);
     HIPCHK(hipSetDevice(c->device));
     return launch_des2r(d1, nullptr, d2, nullptr, 1, c->dPq, M, idx, cor, (hipStream_t)stream);
 }
@@ -408,6 +416,9 @@ int yoho_des2r_indexed(yoho_ctx* c, const float* e1, const int64_t* i1, const fl
                        int64_t* idx, float* cor, void* stream) {
     if (!c || !e1 || !e2 || !i1 || !i2 || !idx || M < 0 || istride < 1) { set_error("yoho_des2r_indexed: bad argument"); return YOHO_EINVAL; }
     if (M == 0) return 0;
+    YOHO_NEED_ALIGNED("yoho_des2r_indexed", 15, e1, e2);
+    YOHO_NEED_ALIGNED("yoho_des2r_indexed", 7, i1, i2, idx);
+    YOHO_NEED_ALIGNED("yoho_des2r_indexed", 3, cor);
     HIPCHK(hipSetDevice(c->device));
     return launch_des2r(e1, i1, e2, i2, istride, c->dPq, M, idx, cor, (hipStream_t)stream);
 }

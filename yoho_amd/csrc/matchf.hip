@@ -271,7 +271,7 @@ size_t mutual_prefilter_ws_bytes(int Na, int Nb) {
 
 // keysA (Na) / keysB (Nb) receive the packed winners (the layout launch_mutual_compact<PACKED> reads); ws as sized above
 int launch_mutual_prefilter(const float* a, int Na, const float* b, int Nb, void* ws, unsigned long long** keysA, unsigned long long** keysB,
-                            int nCU, hipStream_t s) {
+                            int nCU, hipStream_t s, int nn_splits) {
     MfArgs p;
     char* w = (char*)ws;
     p.a = a; p.b = b; p.Na = Na; p.Nb = Nb;
@@ -296,8 +296,7 @@ int launch_mutual_prefilter(const float* a, int Na, const float* b, int Nb, void
     // grid: (128-row blocks of the larger set, splits of the other set, 2 directions), about two workgroups per CU
     const int nmax = Na > Nb ? Na : Nb, nmin = Na < Nb ? Na : Nb;
     const int rb = (nmax + 127) / 128, tiles = (nmax + 31) / 32;
-    static const int segmult = [] { const char* e = std::getenv("YOHO_NN_SPLITS"); return e ? std::atoi(e) : 0; }();
-    int splits = segmult > 0 ? segmult : (2 * nCU + 2 * rb - 1) / (2 * rb);
+    int splits = nn_splits > 0 ? nn_splits : (2 * nCU + 2 * rb - 1) / (2 * rb);
     splits = splits < 1 ? 1 : (splits > tiles ? tiles : splits);
     p.tilesPer = (tiles + splits - 1) / splits;
     splits = (tiles + p.tilesPer - 1) / p.tilesPer;

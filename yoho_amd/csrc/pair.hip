@@ -181,6 +181,8 @@ int yoho_register_pair(yoho_ctx* c, const float* feat0, const float* feat1, cons
         set_error("yoho_register_pair: YOHO-O runs in the default PartII arithmetic mode only (the caller composes the staged entries otherwise)");
         return YOHO_EINVAL;
     }
+    YOHO_NEED_ALIGNED("yoho_register_pair", 15, feat0, feat1, eqv0, eqv1, inv0, inv1);
+    YOHO_NEED_ALIGNED("yoho_register_pair", 7, keys0, keys1);
     HIPCHK(hipSetDevice(c->device));
     hipStream_t s = (hipStream_t)stream;
     std::memset(out, 0, sizeof(*out));

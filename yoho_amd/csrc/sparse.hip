@@ -1469,8 +1469,6 @@ __global__ __launch_bounds__(256) void conv1_mfma_kernel(const int* __restrict__
 static int launch_spconv(const SpConvArgs& a_in, hipStream_t s) {
     if (a_in.nout == 0) return 0;
     SpConvArgs a = a_in;
-    static const int dbg = [] { const char* e = std::getenv("YOHO_SPCONV_DEBUG"); return e ? std::atoi(e) : 0; }();
-    a.debug = dbg;
     if (!a.Wh || !a.rowperm) { a.rowperm = nullptr; a.nslots = a.nout; }     // the permutation is an optimisation of the fp16x2 kernels
     if (a.norm && !(a.Wh && a.cout == 32 && a.cin % 32 == 0 && (a.nslots + 31) / 32 >= 1024)) {
         set_error("sparse conv: the fused row normalisation exists in the 32-channel fine-level kernel only"); return YOHO_EINVAL;
@@ -1678,7 +1676,7 @@ void fcgf_free(FcgfNet* n) {
 }
 
 // tensors: host pointers in the order of yoho_amd.weights.fcgf_spec() with the num_batches_tracked entries left out
-int fcgf_load(FcgfNet** out, const yoho_fcgf_config* cfg, const float* const* t, int ntensors) {
+int fcgf_load(FcgfNet** out, const yoho_fcgf_config* cfg, const float* const* t, int ntensors, bool f32_kernels) {
     FcgfNet* n = new FcgfNet();
     for (int i = 1; i < 5; ++i) { n->C[i] = cfg->channels[i]; n->T[i] = cfg->tr_channels[i]; }
     n->out_ch = cfg->out_channels; n->k1 = cfg->conv1_kernel_size; n->in_ch = cfg->in_channels; n->normalize = cfg->normalize_feature;
@@ -1687,8 +1685,7 @@ int fcgf_load(FcgfNet** out, const yoho_fcgf_config* cfg, const float* const* t,
     if (n->k1 % 2 == 0 || n->out_ch > 64 || n->in_ch > 31) { fcgf_free(n); set_error("yoho_load_fcgf: unsupported configuration"); return YOHO_EINVAL; }
     int ti = 0, rc = 0;
     auto fail = [&](int r) { fcgf_free(n); return r; };
-    const char* am = std::getenv("YOHO_FCGF");
-    const bool use16 = !(am && std::strcmp(am, "f32") == 0);      // default: fp16x2 split MFMA; YOHO_FCGF=f32 keeps the fp32 MFMA kernels
+    const bool use16 = !f32_kernels;                              // default: fp16x2 split MFMA; a context created under YOHO_FCGF=f32 keeps the fp32 MFMA kernels
     const int* C = n->C; const int* T = n->T;
     const int cin_enc[4] = {n->in_ch, C[1], C[2], C[3]};
     for (int l = 0; l < 4 && !rc; ++l) {
@@ -1799,9 +1796,13 @@ size_t fcgf_workspace_bytes(const FcgfNet* net, int n0) {
 
 // coords0: (n0,3) int32 device, the distinct voxels of nb clouds stored one after the other (host row offsets off[0..nb],
 // null = one cloud); out: (n0, out_ch).  The clouds share every launch (cloud index = 4th key component).
-int fcgf_forward(yoho_ctx* ctx, const FcgfNet* net, const int* coords0, int n0, const int* off_host, int nb, float* out, hipStream_t s) {
-    if (nb < 1 || nb > 64) { set_error("fcgf_forward: 1..64 clouds per call"); return YOHO_EINVAL; }
-    if (n0 == 0) return 0;
+// One attempt.  ws_extra: bytes on top of fcgf_workspace_bytes (the rank-ordered bitmaps of a pass whose clouds are sparse in large
+// boxes: their size hangs on the bounding boxes, which are only known once the pass has started).  Returns FCGF_RETRY with *rank_need
+// set when the bitmaps would eat into the budget of the maps and features behind them - nothing of the pass has been kept then, and
+// the caller starts it again on a workspace grown by that much (or on the hash-table path when allow_rank is false).
+static constexpr int FCGF_RETRY = 2;
+static int fcgf_forward_attempt(yoho_ctx* ctx, const FcgfNet* net, const int* coords0, int n0, const int* off_host, int nb, float* out, hipStream_t s,
+                                size_t ws_extra, bool allow_rank, size_t* rank_need) {
     // The gathers address a feature matrix through a 2 GiB buffer window.  Level l's widest gathered matrix has ld[l] columns; level 0
     // is known now, the coarser levels are checked as their sizes come back (they hold a fraction of the rows, so in practice the
     // level-0 matrices - 96 columns: 5.5 M voxels - are what limits a pass).
@@ -1816,7 +1817,8 @@ int fcgf_forward(yoho_ctx* ctx, const FcgfNet* net, const int* coords0, int n0, 
     };
     if (!window_ok(0, n0)) return YOHO_EINVAL;
     int rc;
-    if ((rc = ensure_ws(ctx, fcgf_workspace_bytes(net, n0), s))) return rc;
+    const size_t ws_base = fcgf_workspace_bytes(net, n0);
+    if ((rc = ensure_ws(ctx, ws_base + ws_extra, s))) return rc;
     Arena ar{(char*)ctx->ws.p, 0, ctx->ws.bytes};
     const int* C = net->C; const int* T = net->T;
     Level L[4];
@@ -1863,7 +1865,7 @@ int fcgf_forward(yoho_ctx* ctx, const FcgfNet* net, const int* coords0, int n0, 
     };
     int* operm = nullptr;                          // internal level-0 row -> caller's row (null: same order)
     // ---- rank-ordered bitmaps (see RkDesc): every level's coordinate map without a hash table, when every cloud fits one
-    const bool force_hash = ctx->fcgf_hash_coords != 0;
+    const bool force_hash = ctx->fcgf_hash_coords != 0 || !allow_rank;
     bool rank_mode = false;
     bool has_dups = false;                         // the caller's rows repeat voxels: every row is then mapped by its own probes (full maps)
     RkDesc* rkd[4] = {nullptr, nullptr, nullptr, nullptr};      // device descriptors per level [nb]
@@ -1900,6 +1902,17 @@ int fcgf_forward(yoho_ctx* ctx, const FcgfNet* net, const int* coords0, int n0, 
         }
         const size_t mark = ar.off;
         int* btot[4]; int* lcoords[4];
+        if (ok) {
+            // The estimate behind the workspace knows n0 only; the bitmaps and rank arrays follow the VOLUME of the boxes (sparse clouds
+            // in large boxes: 15 copies of 5 k voxels over 800 x 800 x 240 cells are 660 MB of ranks).  They must fit ON TOP of that
+            // estimate, or the kernel maps and features taken later run out of room: ask for a larger workspace and start again.
+            size_t rb = 22 * 256 + 2 * sizeof(RkDesc) * 64 + sizeof(BmDesc) * 64 + (size_t)n0 * 4;
+            for (int l = 0; l < 4; ++l) rb += ((size_t)words[l] + 2) * 4 + ((size_t)ranks[l] + 1) * 4 + ((size_t)blocks[l] + 2) * 4 + (size_t)n0 * 16 + sizeof(RkDesc) * 64;
+            if (ws_base + rb > ar.cap) {
+                if (rank_need) { *rank_need = rb; return FCGF_RETRY; }
+                ok = false;
+            }
+        }
         if (ok) {
             for (int l = 0; l < 4; ++l) {
                 rkd[l] = reinterpret_cast<RkDesc*>(ar.take<char>(sizeof(RkDesc) * 64));
@@ -2050,8 +2063,7 @@ int fcgf_forward(yoho_ctx* ctx, const FcgfNet* net, const int* coords0, int n0, 
     int* Msame[4]; int* Mdown[3]; int* Mup[3];
     // every map by its own probes: A/B switch, and whenever the caller's rows repeat voxels - the mirrored entries of the symmetric
     // build and the inverted maps are only ever written for the FIRST row of a voxel
-    static const bool full_maps_env = [] { const char* e = std::getenv("YOHO_FCGF_MAPS"); return e && std::strcmp(e, "full") == 0; }();
-    const bool full_maps = full_maps_env || has_dups;
+    const bool full_maps = ctx->env.fcgf_full_maps || has_dups;
     for (int l = 0; l < 4; ++l) {
         if (full_maps) { Msame[l] = make_map(L[l], L[l], 3, L[l].ts, +1); continue; }
         // symmetric 3^3 map: offsets 0..12 looked up, 14..26 mirrored, 13 = identity (build_map_sym_kernel)
@@ -2120,6 +2132,7 @@ int fcgf_forward(yoho_ctx* ctx, const FcgfNet* net, const int* coords0, int n0, 
         a.out = o; a.ldout = ldout; a.ocoff = ocoff; a.aff_s = bn ? bn->s : nullptr; a.aff_t = bn ? bn->t : bias;
         a.res = res; a.ldres = ldres; a.rcoff = rcoff; a.relu = relu;
         a.norm = conv_norm; a.operm = conv_norm ? operm : nullptr;
+        a.debug = ctx->env.spconv_debug;
         return launch_spconv(a, s);
     };
     // BasicBlockBN: out = relu(bn2(conv2(relu(bn1(conv1(x))))) + x), written at column `ocoff` of `o`
@@ -2180,8 +2193,7 @@ int fcgf_forward(yoho_ctx* ctx, const FcgfNet* net, const int* coords0, int n0, 
     // the feature head: 1 x 1 convolution to out_ch, rows /= |row| (once more for fcgf_feat.py:48), the caller's row order.  Fused into
     // the convolution's epilogue where that kernel exists (32 features, fp16x2 fine-level kernel: passes of >= 32768 voxels); the
     // pass over the (n0, 32) matrix was 0.16 ms per 15-copy pass
-    static const bool no_fuse_norm = [] { const char* e = std::getenv("YOHO_FCGF_NORM"); return e && std::strcmp(e, "staged") == 0; }();    // A/B
-    const bool fuse_norm = !no_fuse_norm && net->out_ch == 32 && net->final_k.wh && T[1] % 32 == 0 && (n0 + 31) / 32 >= 1024;
+    const bool fuse_norm = !ctx->env.fcgf_norm_staged && net->out_ch == 32 && net->final_k.wh && T[1] % 32 == 0 && (n0 + 31) / 32 >= 1024;
     conv_norm = fuse_norm ? (net->normalize ? 2 : 1) : 0;
     if ((rc = conv(f1, T[1], T[1], nullptr, 1, n0, net->final_k, net->out_ch, fuse_norm ? out : f2, net->out_ch, 0, nullptr, net->final_b, nullptr, 0, 0, 0))) return rc;
     conv_norm = 0;
@@ -2191,6 +2203,19 @@ int fcgf_forward(yoho_ctx* ctx, const FcgfNet* net, const int* coords0, int n0, 
     HIPCHK(hipGetLastError());
     phase_mark(ctx, -1, s);
     return 0;
+}
+
+int fcgf_forward(yoho_ctx* ctx, const FcgfNet* net, const int* coords0, int n0, const int* off_host, int nb, float* out, hipStream_t s) {
+    if (nb < 1 || nb > 64) { set_error("fcgf_forward: 1..64 clouds per call"); return YOHO_EINVAL; }
+    if (n0 == 0) return 0;
+    size_t need = 0;
+    int rc = fcgf_forward_attempt(ctx, net, coords0, n0, off_host, nb, out, s, 0, true, &need);
+    if (rc != FCGF_RETRY) return rc;
+    // the bitmaps of this pass do not fit beside the budget of the maps and features: once more on a workspace with room for both (it
+    // stays that size, so the next pass of the same shape starts there), and on the hash tables if even that cannot be had
+    rc = fcgf_forward_attempt(ctx, net, coords0, n0, off_host, nb, out, s, need, true, nullptr);
+    if (rc != YOHO_ENOMEM) return rc;
+    return fcgf_forward_attempt(ctx, net, coords0, n0, off_host, nb, out, s, 0, false, nullptr);
 }
 
 // voxelisation (fcgf_feat.py:33-43): first point of every voxel in input order -> sel (ascending), integer coordinates
@@ -2300,7 +2325,7 @@ static int voxelize_batch_rank(yoho_ctx* ctx, const double* pts, int n, const do
     }
     const int nblk = (n + 1023) / 1024;
     const size_t need = (size_t)words * 4 + (size_t)ranks * 4 + (size_t)blocks * 4 + (size_t)nb * n * 4 + ((size_t)nblk + 1) * 4 * nb + sizeof(RkDesc) * 64 + 65536;
-    if ((rc = ensure_ws(ctx, need, s))) return rc;
+    if ((rc = ensure_ws(ctx, need, s))) return rc == YOHO_ENOMEM ? 1 : rc;      // multi-GB ranks that cannot be had: the table path needs 12 bytes per point and copy
     Arena ar{(char*)ctx->ws.p, 0, ctx->ws.bytes};
     int* dcount = ar.take<int>(2 * (size_t)nb + 2);      // per copy: [0] number of voxels, [1] flag: a voxel outside the bitmap / the key range
     RkDesc* dd = reinterpret_cast<RkDesc*>(ar.take<char>(sizeof(RkDesc) * 64));
