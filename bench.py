@@ -75,7 +75,7 @@ def fgemm_issued_flops(nkp, mode="fgemm"):
     return sum(fgemm_issued_flops_per_layer(nkp, mode))
 
 
-PMC_FILES = ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")     # newest first
+PMC_FILES = ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")     # newest first
 
 
 def pmc_traffic(mode):

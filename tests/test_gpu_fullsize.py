@@ -368,3 +368,35 @@ def test_register_pair_one_call_equals_python_composition(dctx, sd1, sd2):
     assert f["matches"] == M
     if M == 0:
         assert f["best_count"] == 0 and np.array_equal(f["trans"], np.eye(4))
+
+
+def test_transform_ticket_stealing_equals_static_striding_under_a_coresident_probe(hip, sd1, monkeypatch):
+    """gft16x takes its chunks from a ticket counter through a returning atomic the compiler does not see (csrc/gft16.hip; the register
+    discipline is audited on the assembly at build time, yoho_amd/isa_audit.py).  What the audit cannot show is that a pass computes the
+    same planes whoever takes which chunk: 10000 keypoints (20032 / 10016 chunks per launch on 256 persistent workgroups) with tickets
+    against a context created under YOHO_XF_STEAL=0 (static striding), bit for bit - alone, and with 1 ms clock probes co-resident on
+    another stream (workgroups of the transform then start late on the CUs the probe occupies: the hand-out differs from run to run).
+    Also the small passes where the launcher itself falls back to static striding (fewer than two chunks per workgroup)."""
+    x = torch.from_numpy(np.concatenate([synth.unit_features(5000, seed=31), synth.unit_features(5000, seed=32)])).cuda()
+    monkeypatch.setenv("YOHO_XF_STEAL", "0")
+    static = hip.Context()
+    monkeypatch.delenv("YOHO_XF_STEAL")
+    steal = hip.Context()
+    for c in (static, steal):
+        c.load_partI(sd1)
+        assert c.gconv_mode == "fgemm"
+    ref = static.partI_forward(x, want_inv=False, want_inv_np=True)
+    side = torch.cuda.Stream()
+    prober = hip.Context()
+    buf = torch.zeros(3, dtype=torch.int64, device="cuda")
+    for rep in range(6):
+        if rep >= 2:                                        # four of the six passes run beside a train of 1 ms one-wave probes
+            for _ in range(8):
+                prober.clock_probe(1000, stream=side, out=buf)
+        got = steal.partI_forward(x, want_inv=False, want_inv_np=True)
+        torch.cuda.synchronize()
+        for k in ("eqv", "inv_np"):
+            assert torch.equal(got[k], ref[k]), (rep, k)
+    for B in (1, 31, 256, 700):                             # nChunks <= 2 x grid for the 32-channel transforms: static striding in both contexts
+        a, b = static.partI_forward(x[:B].contiguous(), want_inv=True), steal.partI_forward(x[:B].contiguous(), want_inv=True)
+        assert torch.equal(a["eqv"], b["eqv"]) and torch.equal(a["inv"], b["inv"])

@@ -31,7 +31,7 @@ rocprofv3 --kernel-trace --stats -d $O/prof_extract -- python $R/tools/bench_ext
 python $R/tools/rocpd_stats.py $O/prof_extract > $O/kernel_trace_extract.md 2>&1
 # 6. L2 hit rate of the sparse-convolution row gathers with / without cell-sorted level-0 rows
 bash $R/tools/pmc_l2_fcgf.sh $O > $O/pmc_l2.log 2>&1
-# 7. the fused all-60-coefficient tile, K loop only (tools/fused_tile_probe.hip)
+# 7. (round 4 only: the fused all-60-coefficient tile probe, tools/archive/fused_tile_probe.hip - run when its binary is present)
 [ -x $R/tools/_fused_tile_probe ] && $R/tools/_fused_tile_probe 10000 512 > $O/fused_tile_probe.log 2>&1
 cd $R
 # 8. the dataset-scale rows (profiles/rNN_dataset.md)

@@ -1777,6 +1777,7 @@ static int build_table(const CoordSrc& src, int n, Level& L, hipStream_t s) {
     return 0;
 }
 
+constexpr size_t C1BM_BUDGET = (size_t)64 << 20;
 size_t fcgf_workspace_bytes(const FcgfNet* net, int n0) {
     // generous bound: every level sized like level 0
     const size_t N = (size_t)n0 + 256;
@@ -1790,7 +1791,7 @@ size_t fcgf_workspace_bytes(const FcgfNet* net, int n0) {
     size_t feat = 1 + 2 * C[1] + (T[2] + C[1]) + 2 * T[2] + T[1] + net->out_ch;
     feat += 2 * C[2] + (T[3] + C[2]) + 2 * T[3] + 2 * C[3] + (T[4] + C[3]) + 2 * T[4] + 3 * C[4];
     b += feat * N * 4 + 64 * 256;
-    b += (size_t)64 << 20;                                                    // occupancy bitmaps of the first convolution
+    b += C1BM_BUDGET;                                                         // occupancy bitmaps of the first convolution (hash-table path)
     return b;
 }
 
@@ -2049,7 +2050,13 @@ static int fcgf_forward_attempt(yoho_ctx* ctx, const FcgfNet* net, const int* co
             hdesc[b] = BmDesc{words, bb[0] - hk, bb[1] - hk, bb[2] - hk, (int)wx, (int)dy, (int)dz};
             words += wx * dy * dz;
         }
-        if (ok && words > 0 && ar.off + (size_t)words * 4 + 8192 < ar.cap) {
+        // optional, and budgeted: fcgf_workspace_bytes reserves 64 MiB for these bitmaps (C1BM_BUDGET).  Sparse clouds in large boxes
+        // need more than that (15 x 5 k voxels over 800 x 800 x 240 cells: 310 MB) - they are taken only if the workspace has that much
+        // ON TOP of the estimate, or the maps and features allocated below would run out of room ("workspace estimate too small")
+        const size_t bm_bytes = (size_t)words * 4 + 8192 + sizeof(BmDesc) * 64 + 512;
+        const bool fits = bm_bytes <= C1BM_BUDGET || ws_base + (bm_bytes - C1BM_BUDGET) <= ar.cap;
+        if (ok && words > 0 && !fits && rank_need) { *rank_need = bm_bytes - C1BM_BUDGET; return FCGF_RETRY; }      // once more on a workspace with room for them
+        if (ok && words > 0 && fits) {
             dbm_words = words;
             dbm = ar.take<unsigned>((size_t)words + 2);            // + spare words: conv1_mfma_kernel reads word pairs
             ddesc = reinterpret_cast<BmDesc*>(ar.take<char>(sizeof(BmDesc) * 64));

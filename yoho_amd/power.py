@@ -1,4 +1,4 @@
-"""Clock / power sampling beside a measurement (bench.py, tools/sweep_partI_chunk.py).
+"""Clock / power sampling beside a measurement (bench.py, tools/archive/sweep_partI_chunk.py).
 
 The irrep GEMMs of PartI are limited by the package power budget, not by their schedule: the evidence so far was
 GRBM_GUI_ACTIVE / duration from PMC runs.  This module gives the two independent readings the bench line carries:
