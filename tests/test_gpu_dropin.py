@@ -256,6 +256,41 @@ def test_yoho_extractor_with_stub_backbone(sd1, tables):
         yoho_extractor(fcgf_ckpt=None, yoho_ckpt=sd1).run(pc)
 
 
+def test_extractor_outputs_stop_being_pinned_beyond_the_budget(sd1, monkeypatch):
+    """yoho_extractor.run returns page-locked CPU tensors only while the pinned bytes still alive in the caller's hands stay under
+    yoho_extract.PIN_OUTPUT_BYTES (a caller that keeps a scene's descriptors must not pin GBs of host RAM); values are the
+    same either way, dropping results gives the budget back."""
+    import gc
+    from yoho_amd import yoho_extract as ye
+
+    class Stub:
+        def run(self, pc, voxel_size):
+            f = torch.from_numpy(synth.unit_features(len(pc), seed=1)[:, :, 0].copy())
+            return pc, f / f.norm(dim=1, keepdim=True)
+    pc = synth.surface_cloud(600, seed=2)
+    ex = ye.yoho_extractor(fcgf_ckpt=None, yoho_ckpt=sd1, fcgf=Stub())
+    gc.collect()
+    base = ye._pinned_alive[0]
+    per_call = 200 * 32 * 61 * 4                                   # inv (200,32) + eqv (200,32,60)
+    monkeypatch.setattr(ye, "PIN_OUTPUT_BYTES", base + 2 * per_call + 64)
+    kept = []
+    for i in range(4):
+        np.random.seed(3)
+        kept.append(ex.run(pc, voxel_size=0.025, nkpts=200))
+    assert [k[2].is_pinned() for k in kept] == [True, True, False, False] and [k[1].is_pinned() for k in kept] == [True, True, False, False]
+    for k in kept[1:]:
+        assert torch.equal(k[1], kept[0][1]) and torch.equal(k[2], kept[0][2])
+    assert ye._pinned_alive[0] == base + 2 * per_call
+    del kept, k
+    gc.collect()
+    assert ye._pinned_alive[0] == base
+    np.random.seed(3)
+    assert ex.run(pc, voxel_size=0.025, nkpts=200)[2].is_pinned()
+    monkeypatch.setattr(ye, "PIN_OUTPUT_BYTES", 0)
+    np.random.seed(3)
+    assert not ex.run(pc, voxel_size=0.025, nkpts=200)[2].is_pinned()
+
+
 def test_fcgf_extractor_dropin_and_full_yoho_extractor(sd1, tables):
     """simple_yoho/fcgf_feat.py + yoho_extract.py with the HIP backbone: checkpoint dict in the FCGF format"""
     import fcgf_oracle as fo

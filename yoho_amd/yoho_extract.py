@@ -24,13 +24,34 @@ from . import weights as W
 from .utils import transform_points
 
 
+# Page-locked result tensors are handed out only while the pinned bytes still ALIVE in the caller's hands stay under this budget
+# (YOHO_PIN_OUTPUT_BYTES, default 2 GiB; 0 = always pageable, as the reference returns them).  A caller that streams fragments
+# (describe, consume, drop) keeps the fast copy; one that keeps the descriptors of a whole scene or test set - 38 MB per fragment,
+# the testset and cache writers do - gets ordinary pageable tensors once the budget is used up instead of pinning GBs of host RAM
+# that torch's caching host allocator never gives back to the OS.
+PIN_OUTPUT_BYTES = int(os.environ.get("YOHO_PIN_OUTPUT_BYTES", str(2 << 30)))
+_pinned_alive = [0]
+
+
+def _unpin(nbytes):
+    _pinned_alive[0] -= nbytes
+
+
 def _to_host(*tensors):
-    """device tensors -> CPU tensors, as the reference API returns them (simple_yoho/yoho_extract.py:72-77), through page-locked memory:
-    a pageable 38 MB copy of the descriptors took 2.5 ms of a 48 ms fragment, the same copy into a pinned tensor 0.8 ms.  The pinned
-    blocks come from torch's caching host allocator (no hipHostMalloc per call after the first); every call gets tensors of its own."""
-    outs = [torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for t in tensors]
+    """device tensors -> CPU tensors, as the reference API returns them (simple_yoho/yoho_extract.py:72-77), through page-locked memory
+    while the budget above allows: a pageable 38 MB copy of the descriptors took 2.5 ms of a 48 ms fragment, the same copy into a pinned
+    tensor 0.8 ms.  The pinned blocks come from torch's caching host allocator (no hipHostMalloc per call after the first); every call
+    gets tensors of its own."""
+    import weakref
+    need = sum(t.numel() * t.element_size() for t in tensors)
+    pin = need > 0 and _pinned_alive[0] + need <= PIN_OUTPUT_BYTES
+    outs = [torch.empty(t.shape, dtype=t.dtype, pin_memory=pin) for t in tensors]
     for o, t in zip(outs, tensors):
-        o.copy_(t, non_blocking=True)
+        o.copy_(t, non_blocking=pin)
+        if pin:
+            nbytes = o.numel() * o.element_size()
+            _pinned_alive[0] += nbytes
+            weakref.finalize(o, _unpin, nbytes)
     torch.cuda.current_stream().synchronize()
     return tuple(outs)
 
