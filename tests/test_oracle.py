@@ -180,3 +180,58 @@ def test_philox_known_answers_and_device_sampler_statistic():
     assert (prob[np.bincount(dr, minlength=60) < 2] == 0).all() and (freq[prob == 0] == 0).all()
     assert orc.yohoc_device_triples(np.arange(60), 10, 1) is None                # no bucket with two matches
     assert np.array_equal(tri, orc.yohoc_device_triples(dr, 4000, seed=2024)) and not np.array_equal(tri, orc.yohoc_device_triples(dr, 4000, seed=2025))
+
+
+def test_device_sampler_follows_the_reference_sampling_law():
+    """Statistical parity of YOHO-C's device mode, pinned as a distribution: the library's sampler is bit-exact against
+    orc.yohoc_device_triples (tests/test_gpu_dropin.py), and that restatement is tested here against the law the reference draws from
+    (tests/estimator.py:119-128: a coarse rotation with probability p_b ~ n (n - .01)(n - .02), then three members of its bucket uniformly
+    WITH replacement, independently): chi-square of the bucket counts against p, of the member counts of the largest bucket against
+    uniform, of the (first, second) member pairs against the product law, and a two-sample chi-square against draws made by numpy
+    exactly as the reference makes them.  Thresholds are the 99.9 % quantiles (Wilson-Hilferty); the seed is fixed, so the test is
+    deterministic."""
+    def chi2_crit(dof, z=3.09):                                  # upper 0.1 % quantile of chi-square(dof)
+        return dof * (1.0 - 2.0 / (9.0 * dof) + z * np.sqrt(2.0 / (9.0 * dof))) ** 3
+
+    rs = np.random.RandomState(5)
+    dr = rs.randint(0, 60, 900)
+    dr[:200] = 17
+    dr[200:290] = 42
+    dr[290:330] = 3
+    n_it = 20000
+    tri = orc.yohoc_device_triples(dr, n_it, seed=0x1234567890ABCDEF)
+    buckets, prob = orc.dr_statistic(dr)
+    live = np.nonzero(prob > 0)[0]
+    rot = dr[tri[:, 0]]
+    obs = np.bincount(rot, minlength=60)[live].astype(np.float64)
+    exp = prob[live] * n_it
+    big = exp >= 5                                               # pool the rare buckets
+    o = np.append(obs[big], obs[~big].sum())
+    e = np.append(exp[big], exp[~big].sum())
+    keep = e > 0
+    stat = ((o[keep] - e[keep]) ** 2 / e[keep]).sum()
+    assert stat < chi2_crit(keep.sum() - 1), (stat, keep.sum())
+    # members of the largest bucket: uniform, with replacement, the three positions independent
+    b17 = np.asarray(buckets[17])
+    in17 = tri[rot == 17]
+    assert len(in17) > 5000
+    pos = np.searchsorted(b17, in17)                             # index of every drawn match inside its bucket
+    for col in range(3):
+        c = np.bincount(pos[:, col], minlength=len(b17)).astype(np.float64)
+        ee = len(in17) / len(b17)
+        assert ((c - ee) ** 2 / ee).sum() < chi2_crit(len(b17) - 1)
+    assert (pos[:, 0] == pos[:, 1]).mean() > 0.5 / len(b17)     # repeats do occur: with replacement (expected 1 / 200 of the draws)
+    q = 10                                                       # coarse 10 x 10 table of (first, second)
+    cell = (pos[:, 0] * q // len(b17)) * q + pos[:, 1] * q // len(b17)
+    c = np.bincount(cell, minlength=q * q).astype(np.float64)
+    ee = len(in17) / (q * q)
+    assert ((c - ee) ** 2 / ee).sum() < chi2_crit(q * q - 1)
+    # two-sample: the same number of draws made by numpy as the reference makes them
+    np_state = np.random.get_state()
+    np.random.seed(11)
+    ref_rot = np.array([np.random.choice(range(60), p=prob) for _ in range(n_it)])
+    np.random.set_state(np_state)
+    a, b = np.bincount(rot, minlength=60).astype(np.float64), np.bincount(ref_rot, minlength=60).astype(np.float64)
+    both = (a + b) >= 10
+    stat2 = (((a - b) ** 2) / (a + b))[both].sum()
+    assert stat2 < chi2_crit(both.sum() - 1), stat2
