@@ -37,6 +37,7 @@ def main(commit):
         head = header_of(dst) or header_of(os.path.join(DST, PREV + "_" + name + ".md")).replace("Round %d" % int(PREV[1:]), "Round %d" % int(RND[1:]))
         head = head.replace("--no-cpu-baseline --steps 10", "--no-cpu-baseline --no-dataset --repeats 1 --steps 10")
         head = re.sub(r"commit [0-9a-f]{7}", "commit " + commit, head)
+        head = head.replace(f"gpurun_out/{PREV}p/", f"gpurun_out/{RND}p/").replace(f"profiles/{PREV}_bench_profiled.json", f"profiles/{RND}_bench_profiled.json")
         body = body_of(src)
         if name in ("kernel_trace_bench", "kernel_trace_bench_seq"):
             # the numbers the header quotes for "this very run": the bench line of the profiled run and the file's own last table
