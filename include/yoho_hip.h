@@ -298,7 +298,10 @@ int yoho_group_transfer_batch(yoho_ctx* ctx, const double* pts, const int64_t* k
 int yoho_fcgf_forward(yoho_ctx* ctx, const int32_t* coords, int n, float* out, void* stream);
 /* several clouds in one pass (the 60 rotated copies of a fragment, or the reference's DataLoader batch, YOHO_testset.py:172-180):
  * coords = the clouds' voxel rows one after the other, offsets (host, nb+1 entries, offsets[0] = 0) their row ranges,
- * nb <= 64.  Same result per cloud as nb separate yoho_fcgf_forward calls. */
+ * nb <= 64.  Same result per cloud as nb separate yoho_fcgf_forward calls.  The workspace is sized from the voxel count; clouds that are
+ * sparse in large bounding boxes need more for their occupancy bitmaps, which the library only learns once the pass has started: it
+ * then restarts the pass once on a workspace grown by that much (and keeps it), or runs the hash-table coordinate maps if the
+ * allocation fails - the caller sees one call with the same result either way, never YOHO_ENOMEM for a pass that fits the device. */
 int yoho_fcgf_forward_batch(yoho_ctx* ctx, const int32_t* coords, const int32_t* offsets, int nb, float* out, void* stream);
 
 /* PartI group-conv formulation: 0 = direct 13-tap conv on fp32 MFMA (v_mfma_f32_32x32x2_f32), 1 = direct conv with an
