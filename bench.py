@@ -251,7 +251,7 @@ def main():
     ap.add_argument("--in-flight", type=int, choices=[1, 2], default=2,
                     help="pairs in flight: 2 (default) queues the descriptor pass of the next pair on a second HIP stream before waiting for "
                          "the current pair's read-backs (pipeline.PairStreamer); 1 runs the pairs strictly one after the other")
-    ap.add_argument("--gconv", choices=["f32", "bf16x3", "fourier", "fp16x2", "fgemm", "fgemm256", "fgemm128"], default=os.environ.get("YOHO_GCONV", "fgemm"),
+    ap.add_argument("--gconv", choices=["f32", "bf16x3", "fourier", "fp16x2", "fgemm", "fgemm256", "fgemm128", "fgemm8"], default=os.environ.get("YOHO_GCONV", "fgemm"),
                     help="PartI group conv: group-Fourier domain (fp32 MFMA), direct fp32 MFMA, direct 3-way bf16 split MFMA, "
                          "or direct 2-way fp16 split MFMA")
     ap.add_argument("--partII", choices=["f32", "bf16x3", "fp16x2"], default=os.environ.get("YOHO_PARTII", "fp16x2"),
@@ -552,7 +552,7 @@ def main():
     def add(name, ms, nbytes, note):
         hbm[name] = {"ms": round(float(ms), 4), "bytes": int(nbytes), "TBps": round(nbytes / (ms * 1e-3) / 1e12, 3) if ms > 0 else None,
                      "frac_of_8TBps": round(nbytes / (ms * 1e-3) / 8e12, 4) if ms > 0 else None, "what": note}
-    if args.gconv in ("fgemm", "fgemm256", "fgemm128"):
+    if args.gconv in ("fgemm", "fgemm256", "fgemm128", "fgemm8"):
         add("head16_kernel", conv_ms[4], 2 * coef(32), "x (B,32,60) f32 in, cin=32 operand planes out")
         for i, ch in ((7, 256), (8, 512), (9, 256)):
             add(f"gft16_kernel<ACTP> {ch}ch", conv_ms[i], 2 * coef(ch), "fp32 coefficients in, BN+ReLU in the group domain, fp16x2 operand planes out")
@@ -593,16 +593,16 @@ def main():
                     "note": "achieved = algorithmic fp32-equivalent FLOP/s; the 2-way fp16 split (x = hi + lo, 3 products, error "
                             "<= 3*2^-22 per product) issues 3.23 fp16 MFMA flops per algorithmic flop, so frac <= 0.31"}
             dtype = "fp16x2 split (2^-22-accurate products, fp32 accumulate)"
-        elif args.gconv in ("fgemm", "fgemm256", "fgemm128"):
+        elif args.gconv in ("fgemm", "fgemm256", "fgemm128", "fgemm8"):
             # ONE definition: the fp16 MFMA flops the formulation needs - the irrep GEMMs (244 / 780 of the direct
             # multiply-adds), every product as 3 fp16 MFMA products, NO padding rows or columns - over the dense fp16 peak
             useful = FLOP_PER_KP * nkp * FOURIER_EXEC_PER_ALG * 3.0
             useful_layer = [2.0 * 244 * cin * cout * nkp * 3.0 for cin, cout in ((32, 256), (256, 512), (512, 256), (256, 32))]
-            issued = fgemm_issued_flops(nkp, args.gconv) / (gconv_total_ms * 1e-3) / 1e12
+            issued = fgemm_issued_flops(nkp, "fgemm" if args.gconv == "fgemm8" else args.gconv) / (gconv_total_ms * 1e-3) / 1e12
             pass_ms = float(conv_ms[12])
             step_ms = dt / args.steps * 1e3 / (len(mine) if args.scaling == "strong" else 1)
             ach = useful / (gconv_total_ms * 1e-3) / 1e12
-            traffic, tsrc = pmc_traffic(args.gconv)
+            traffic, tsrc = pmc_traffic("fgemm" if args.gconv == "fgemm8" else args.gconv)
             # the box's state beside the fraction (a slow box and a slow build must be told apart from this one object):
             # the clock the GEMM launches of the profiled passes ran at, and the fraction against the peak AT THAT CLOCK
             cp_prof = power_prof.get("clock_probe") or {}
@@ -634,11 +634,12 @@ def main():
                                                   "of the committed PMC file (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, "
                                                   "tools/collect_profiles.sh, gfx950 corrections of MI355X_MICROARCH.md), per-launch average of the four "
                                                   "GEMM launches of the same command"),
-                    "kernel": {"fgemm": "fgemm3_kernel (fgemm3s_kernel for the 32-channel layer)", "fgemm128": "fgemm2_kernel", "fgemm256": "fgemm_kernel"}[args.gconv] +
+                    "kernel": {"fgemm": "fgemm3_kernel (fgemm3s_kernel for the 32-channel layer)", "fgemm128": "fgemm2_kernel", "fgemm256": "fgemm_kernel",
+                               "fgemm8": "fgemm3c_kernel for 256 -> 512 and 512 -> 256 (fp16 main product + fp8 e4m3 corrections: 2 / 3 of the matrix time the `useful` count assumes), fgemm3 / fgemm3s for the 32-channel layers"}[args.gconv] +
                               " (4 launches = 4 PartI layers over both fragments)",
                     "issued_with_padding": {"tflops": round(issued, 1), "frac": round(issued / FP16_MFMA_PEAK, 4),
                                             "frac_per_launch": [round(f / (ms * 1e-3) / 1e12 / FP16_MFMA_PEAK, 4)
-                                                                for f, ms in zip(fgemm_issued_flops_per_layer(nkp, args.gconv), conv_ms[:4])]},
+                                                                for f, ms in zip(fgemm_issued_flops_per_layer(nkp, "fgemm" if args.gconv == "fgemm8" else args.gconv), conv_ms[:4])]},
                     "direct_form": {"tflops": round(achieved, 2), "frac_of_fp16_peak": round(achieved / FP16_MFMA_PEAK, 4),
                                     "frac_of_fp32_mfma_peak": round(achieved / FP32_MFMA_PEAK, 3),
                                     "note": "the reference's direct 13-tap flop count (4.345 TFLOP per 10000 kp) over the same launches: what rounds 1-3 "

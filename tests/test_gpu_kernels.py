@@ -151,6 +151,59 @@ def test_partI_group_fourier_mode(hip, ctx, gold, sd1, tables, fmode):
     assert d < 1e-5
 
 
+def test_partI_fp8_correction_mode(hip, ctx, gold, sd1, tables):
+    """gconv mode 'fgemm8' (opt-in, round 5): the irrep GEMMs of the two large layers evaluate the main product a_h w_h on the fp16 pipe and
+    BOTH correction products (a_h w_l + a_l w_h, 2^-11 of the main term) in fp8 e4m3 on v_mfma_scale_f32_32x32x64_f8f6f4, two K16 steps per
+    instruction - 2 / 3 of the matrix time.  The activation operand is scaled by the largest magnitude the transform in front of the GEMM
+    wrote (a device word, no host round trip).  Tolerance: BASELINE's 1e-4; expected ~1.5e-5 (tools/fp8_correction_study.py: CPU emulation
+    of exactly this arithmetic), asserted < 5e-5 so that a broken scale (corrections lost: 3e-4) cannot pass.  Deterministic; pair pass equal
+    to the two single passes; and faster than the default mode on the 10 000-keypoint pair pass."""
+    c = hip.Context()
+    c.load_partI(sd1)
+    c.set_gconv_mode("fgemm8")
+    g = gold("partI.npz")
+    out = c.partI_forward(cu(g["x"]), want_inv=True, want_inv_np=True)
+    e_g, i_g = rel(out["eqv"].cpu().numpy(), g["eqv"]), rel(out["inv"].cpu().numpy(), g["inv"])
+    print("fgemm8 golden: rel err eqv %.3g inv %.3g" % (e_g, i_g))
+    assert e_g < 5e-5 and i_g < 5e-5
+    worst = 0.0
+    for B in (1, 31, 33, 100, 257, 1000):
+        x = synth.unit_features(B, seed=300 + B)
+        o = c.partI_forward(cu(x))
+        e, i = orc.partI_forward(x, sd1, tables.N)
+        worst = max(worst, rel(o["eqv"].cpu().numpy(), e), rel(o["inv"].cpu().numpy(), i))
+    print("fgemm8 vs oracle, B = 1 .. 1000: worst rel err %.3g" % worst)
+    assert worst < 5e-5
+    x0, x1 = cu(synth.unit_features(5000, seed=41)), cu(synth.unit_features(4999, seed=42))
+    d_ = c.partI_forward(x0)["eqv"]
+    ref = ctx.partI_forward(x0)["eqv"]                                           # direct fp32 MFMA
+    dd = (d_ - ref).abs().max().item()
+    shipped = hip.Context()
+    shipped.load_partI(sd1)
+    ds = (shipped.partI_forward(x0)["eqv"] - ref).abs().max().item()
+    print("at 5000 kp vs the direct fp32 kernel: fgemm8 max abs diff %.3g, default fgemm %.3g" % (dd, ds))
+    assert dd < 5e-5 and ds < 1e-5 and dd > ds                                    # the new mode really runs a different arithmetic
+    assert torch.equal(c.partI_forward(x0)["eqv"], d_)                            # deterministic
+    # pair pass: one launch over both fragments; the activation scale is then the maximum over BOTH, so the bits may differ from the
+    # single passes in the fp8 rounding of the corrections - the values may not
+    pp = c.partI_forward_pair(x0, x1, want_inv=False, want_inv_np=True)
+    s0, s1 = c.partI_forward(x0)["eqv"], c.partI_forward(x1)["eqv"]
+    assert (pp["eqv"][:5000] - s0).abs().max().item() < 3e-5 and (pp["eqv"][5000:] - s1).abs().max().item() < 3e-5
+    assert torch.equal(c.partI_forward_pair(x0, x1, want_inv=False, want_inv_np=True)["eqv"], pp["eqv"])
+    # time of the GEMM launches of the pair pass, both modes (HIP events recorded by the library)
+    ms = {}
+    for name, cc in (("fgemm", shipped), ("fgemm8", c)):
+        cc.set_profiling(True)
+        for _ in range(4):
+            cc.partI_forward_pair(x0, x1, want_inv=False, want_inv_np=True, check_range=False)
+        torch.cuda.synchronize()
+        ms[name] = [cc.kernel_ms(i) for i in range(4)] + [cc.kernel_ms(12)]
+        cc.set_profiling(False)
+    print("GEMM launches of a 9999-keypoint pair pass (ms): fgemm %s pass %.3f | fgemm8 %s pass %.3f" %
+          ([round(v, 3) for v in ms["fgemm"][:4]], ms["fgemm"][4], [round(v, 3) for v in ms["fgemm8"][:4]], ms["fgemm8"][4]))
+    assert ms["fgemm8"][1] < ms["fgemm"][1] and ms["fgemm8"][2] < ms["fgemm"][2]
+
+
 def test_fgemm_tile_variants_are_bit_identical(hip, sd1):
     """the three GEMM blockings of the default mode (256 x 256 tile with eight waves, two per SIMD | 256 x 256 with four waves |
     256 x 128 tiles, two workgroups per CU) and the two transform kernels (two waves per SIMD | one) issue the same products in

@@ -361,7 +361,7 @@ int yoho_ctx_create(int device, const float* R, const uint8_t* N, const uint8_t*
         int ck = 0, ns = 1;
         if (std::sscanf(m, "%dx%d", &ck, &ns) >= 1 && ck >= 0 && (ns == 1 || ns == 2)) { c->partI_chunk = (ck + 255) / 256 * 256; c->partI_streams = ns; }
     }
-    if (const char* m = std::getenv("YOHO_GCONV")) c->gconv_mode = std::strcmp(m, "f32") == 0 ? 0 : (std::strcmp(m, "bf16x3") == 0 ? 1 : (std::strcmp(m, "fp16x2") == 0 ? 3 : (std::strcmp(m, "fgemm") == 0 ? 4 : (std::strcmp(m, "fgemm256") == 0 ? 5 : (std::strcmp(m, "fgemm128") == 0 ? 6 : 2)))));
+    if (const char* m = std::getenv("YOHO_GCONV")) c->gconv_mode = std::strcmp(m, "f32") == 0 ? 0 : (std::strcmp(m, "bf16x3") == 0 ? 1 : (std::strcmp(m, "fp16x2") == 0 ? 3 : (std::strcmp(m, "fgemm") == 0 ? 4 : (std::strcmp(m, "fgemm256") == 0 ? 5 : (std::strcmp(m, "fgemm128") == 0 ? 6 : (std::strcmp(m, "fgemm8") == 0 ? 7 : 2))))));
     // group-Fourier basis (irreps of the table's group)
     c->fb = new FourierBasis();
     if ((rc = build_fourier(N, P, *c->fb))) { delete c->fb; delete c; return rc; }
@@ -381,6 +381,8 @@ int yoho_ctx_create(int device, const float* R, const uint8_t* N, const uint8_t*
     }
     HIPCHK(hipMalloc((void**)&c->d_rflag, 4 * sizeof(int)));
     HIPCHK(hipMemset(c->d_rflag, 0, 4 * sizeof(int)));
+    HIPCHK(hipMalloc((void**)&c->d_amax, 8 * sizeof(unsigned)));
+    HIPCHK(hipMemset(c->d_amax, 0, 8 * sizeof(unsigned)));
     HIPCHK(hipMalloc((void**)&c->d_xfctr, 16 * sizeof(int)));
     HIPCHK(hipMemset(c->d_xfctr, 0, 16 * sizeof(int)));
     *out = c;
@@ -409,6 +411,7 @@ int yoho_ctx_destroy(yoho_ctx* c) {
     if (c->d_tap_inv) (void)hipFree(c->d_tap_inv);
     if (c->d_rflag) (void)hipFree(c->d_rflag);
     if (c->d_xfctr) (void)hipFree(c->d_xfctr);
+    if (c->d_amax) (void)hipFree(c->d_amax);
     for (int* t : {c->tabs.slabtab, c->tabs.outg, c->tabs.slab4, c->tabs.unitg}) if (t) (void)hipFree(t);
     delete c->fb;
     for (auto& e : c->ev) (void)hipEventDestroy(e);
@@ -460,7 +463,7 @@ int yoho_load_partII(yoho_ctx* c, const yoho_partII_weights* w) {
 }
 
 int yoho_set_gconv_mode(yoho_ctx* c, int mode) {
-    if (!c || mode < 0 || mode > 6) { set_error("yoho_set_gconv_mode: mode must be 0 (fp32 MFMA), 1 (bf16x3 MFMA), 2 (group-Fourier fp32 MFMA), 3 (fp16x2 MFMA), 4 (group-Fourier irrep GEMMs, fp16x2 MFMA), 5 or 6 (4 with the other two GEMM blockings)"); return YOHO_EINVAL; }
+    if (!c || mode < 0 || mode > 7) { set_error("yoho_set_gconv_mode: mode must be 0 (fp32 MFMA), 1 (bf16x3 MFMA), 2 (group-Fourier fp32 MFMA), 3 (fp16x2 MFMA), 4 (group-Fourier irrep GEMMs, fp16x2 MFMA), 5 or 6 (4 with the other two GEMM blockings), 7 (4 with fp8 correction products)"); return YOHO_EINVAL; }
     c->gconv_mode = mode;
     return 0;
 }
@@ -718,17 +721,21 @@ static int partI_passG_chunk(yoho_ctx* c, char* ws, int evbase, const float* x, 
     mark(0);
     int* rf = c->d_rflag;
     int* xc = c->env.xf_steal ? c->d_xfctr + (size_t)slot * 8 : nullptr;     // ticket counters of this stream slot's three transform launches (a launch leaves them at zero)
+    // gconv_mode 7: the two large GEMMs take their correction products on the fp8 pipe and scale their activation operand by the largest
+    // magnitude the transform in front of them wrote (am[0]: planes of act(h0) for 256 -> 512, am[1]: planes of act(mid) for 512 -> 256)
+    unsigned* am = c->gconv_mode == 7 ? c->d_amax + (size_t)slot * 4 : nullptr;
+    if (am) HIPCHK(hipMemsetAsync(am, 0, 4 * sizeof(unsigned), s));
     if ((rc = launch_head16(x, B, nT, bP32, kppad, c->dF16, s, x1, B0, rf))) return rc;
     mark(1);
     if ((rc = launch_fgemm(L[0], bP32, kppad, nT, nullptr, bH0, 0, s, rf, gv))) return rc;
     mark(2);
-    if ((rc = launch_gft16(bH0, nullptr, bP256, kppad, c->dF16, L[0].bn_s, L[0].bn_t, nT, 32, c->nCU, s, 0, rf, gv, xc))) return rc;
+    if ((rc = launch_gft16(bH0, nullptr, bP256, kppad, c->dF16, L[0].bn_s, L[0].bn_t, nT, 32, c->nCU, s, 0, rf, gv, xc, am))) return rc;
     mark(3);
-    if ((rc = launch_fgemm(L[1], bP256, kppad, nT, nullptr, bM, 0, s, rf, gv))) return rc;
+    if ((rc = launch_fgemm(L[1], bP256, kppad, nT, nullptr, bM, 0, s, rf, gv, am))) return rc;
     mark(4);
-    if ((rc = launch_gft16(bM, nullptr, bP512, kppad, c->dF16, L[1].bn_s, L[1].bn_t, nT, 64, c->nCU, s, 0, rf, gv, xc ? xc + 2 : nullptr))) return rc;
+    if ((rc = launch_gft16(bM, nullptr, bP512, kppad, c->dF16, L[1].bn_s, L[1].bn_t, nT, 64, c->nCU, s, 0, rf, gv, xc ? xc + 2 : nullptr, am ? am + 1 : nullptr))) return rc;
     mark(5);
-    if ((rc = launch_fgemm(L[2], bP512, kppad, nT, bH0, bA, EPI_RES, s, rf, gv))) return rc;
+    if ((rc = launch_fgemm(L[2], bP512, kppad, nT, bH0, bA, EPI_RES, s, rf, gv, am ? am + 1 : nullptr))) return rc;
     mark(6);
     if ((rc = launch_gft16(bA, nullptr, bP256, kppad, c->dF16, L[2].bn_s, L[2].bn_t, nT, 32, c->nCU, s, 0, rf, gv, xc ? xc + 4 : nullptr))) return rc;
     mark(7);

@@ -131,7 +131,7 @@ void fgemm_qinfo(int* qi);
 void fgemm_plane_offsets(int kppad, int cin, long long* off);
 int pack_fgemm_weights(const FourierBasis& fb, const float* W, int cin, int cout, std::vector<unsigned short>& out, float* descale);
 int launch_fgemm(const Layer& L, const char* Bplanes, int kppad, int nT32, const float* res, float* out, int flags, hipStream_t s,
-                 int* rflag = nullptr, int variant = 2);
+                 int* rflag = nullptr, int variant = 2, const unsigned* amax = nullptr);
 void build_gft16_frags(const FourierBasis& fb, std::vector<unsigned short>& out);
 int gconv_layer(yoho_ctx* c, const float* x, int B, int cin, int cout, const float* W, const float* bias, int transpose, float* y,
                 hipStream_t s);
@@ -152,7 +152,7 @@ int fcgf_voxelize_batch(yoho_ctx* ctx, const double* pts, int n, const double* R
 int launch_cone1(const Layer& L, const char* X, int nTiles32, int nTiles16, const float* res, float* out, const int* n0, hipStream_t s, float* part = nullptr);
 int gft16_init();
 int launch_gft16(const float* in, float* out32, char* planes, int kppad, const void* Ffrag, const float* bn_s, const float* bn_t, int nTiles,
-                 int C8, int nCU, hipStream_t s, int B = 0, int* rflag = nullptr, int variant = 2, int* ctr = nullptr);
+                 int C8, int nCU, hipStream_t s, int B = 0, int* rflag = nullptr, int variant = 2, int* ctr = nullptr, unsigned* amax = nullptr);
 int launch_gft16_invp(const float* in, float* res0, char* planes16, int nTiles16, const void* Ffrag, const float* bn_s, const float* bn_t,
                       int nTiles, int C8, int nCU, hipStream_t s, int* rflag = nullptr);
 int launch_head2(const float* s0, const float* s1, const float* s2, const float* s3, const int64_t* pre_idx, const int* P, const float* bn_s,
@@ -261,7 +261,8 @@ struct yoho_ctx {
     float *p2_init_bn_s = nullptr, *p2_init_bn_t = nullptr;  // BN(128) applied by the PartII pack kernel
     int partII_mode = 2;         // cone layers: 0 fp32 MFMA, 1 bf16x3 split MFMA, 2 fp16x2 split MFMA (default)
     int gconv_mode = 4;          // 0 direct fp32 MFMA, 1 direct bf16x3 split, 2 group-Fourier fp32 MFMA, 3 direct fp16x2 split,
-                                 // 4 group-Fourier irrep GEMMs on the fp16x2 split MFMA (default)
+                                 // 4 group-Fourier irrep GEMMs on the fp16x2 split MFMA (default); 5 / 6 its other blockings; 7 = 4 with the
+                                 // correction products of the two large layers on the fp8 matrix pipe (fgemm3c, opt-in)
     yoho::FourierBasis* fb = nullptr;
     float* dFpad = nullptr;      // F padded to 64 x 64 (device)
     void* dF16 = nullptr;        // fp16x2 MFMA fragments of F^T and F (gft16.hip)
@@ -271,6 +272,7 @@ struct yoho_ctx {
     int nCU = 256;
     yoho::SlotTables tabs;       // direct-conv slot tables (device)
     int* d_rflag = nullptr;      // fp16 range words (note_range): [0] PartI, [1] PartII; read and cleared by yoho_range_status
+    unsigned* d_amax = nullptr;  // gconv_mode 7: largest |plane value| the transforms wrote, per stream slot and layer ([2][4], float bit patterns; zeroed at the head of a pass)
     int* d_xfctr = nullptr;      // chunk tickets of the persistent transform kernel (gft16x work stealing): [stream slot 2][launch 4][2], zero between launches
     int fcgf_cell_sort = 1;      // FCGF backbone: level-0 rows grouped by 8^3-voxel cell inside the pass (gather locality): 0 never, 1 passes of >= 2^18 rows, 2 always
     int fcgf_hash_coords = 0;    // 1: coordinate maps through hash tables even when the clouds fit rank-ordered bitmaps (YOHO_FCGF_COORDS=hash, yoho_set_fcgf_sort cell_sort | 4)

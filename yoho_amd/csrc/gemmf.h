@@ -35,6 +35,7 @@ struct FGemmArgs {
     int cin, cout, kppad, nT32;
     float descale;
     int* rflag;           // fp16 range flag: raised when an output coefficient will not fit the consumer's fp16 planes (x HF_ASCALE)
+    const unsigned* amax; // gconv_mode 7 (fgemm3c): largest |value| of the B planes as a float bit pattern, left by their producer; null = fgemm3
 };
 
 template <int I, int N, typename Fn>

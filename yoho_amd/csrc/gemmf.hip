@@ -331,7 +331,7 @@ int pack_fgemm_weights(const FourierBasis& fb, const float* W, int cin, int cout
 }
 
 void fgemm_fill_args(FGemmArgs& a, const Layer& L, const char* Bplanes, int kppad, int nT32, const float* res, float* out, int* rflag) {
-    a.rflag = rflag;
+    a.rflag = rflag; a.amax = nullptr;
     a.A = reinterpret_cast<const char*>(L.wpg); a.B = Bplanes; a.bias = L.bias; a.res = res; a.out = out;
     a.cin = L.cin; a.cout = L.cout; a.kppad = kppad; a.nT32 = nT32; a.descale = L.wpg_descale;
     static const int ROT[NIR_ORD] = {0, 0, 4, 4, 2};
@@ -348,9 +348,10 @@ void fgemm_fill_args(FGemmArgs& a, const Layer& L, const char* Bplanes, int kppa
 
 // variant 2 (default): 256 x 128 tiles, two workgroups per CU (gemmf2.hip); variant 1: 256 x 256 tiles, one workgroup per CU
 int launch_fgemm(const Layer& L, const char* Bplanes, int kppad, int nT32, const float* res, float* out, int flags, hipStream_t s, int* rflag,
-                 int variant) {
+                 int variant, const unsigned* amax) {
     FGemmArgs a;
     fgemm_fill_args(a, L, Bplanes, kppad, nT32, res, out, rflag);
+    a.amax = variant == 3 ? amax : nullptr;
     static const int dbg_gemm1 = [] { const char* e = experiment_env("YOHO_PARTI_DEBUG"); return (e && std::strstr(e, "gemm1")) ? 1 : 0; }();
     if (dbg_gemm1) variant = 1;
     if (variant == 3) return launch_fgemm3(a, flags, s);

@@ -504,6 +504,237 @@ __global__ __launch_bounds__(512, 2) void fgemm3_kernel(FGemmArgs a, int flags) 
 
 
 // ---------------------------------------------------------------------------------------------------------------
+// fgemm3c (gconv_mode 7, "fgemm8"; round 5, opt-in): fgemm3 with the two CORRECTION products of the fp16 split on the fp8 matrix pipe.
+// A product a * w is a_h w_h + a_h w_l + a_l w_h; the corrections are 2^-11 of the main term and survive e4m3 (3 mantissa bits: 2^-15
+// of the sum; tools/fp8_correction_study.py: 1.5e-5 worst relative error of the descriptor against 1.4e-6 and a tolerance of 1e-4).
+// v_mfma_scale_f32_32x32x64_f8f6f4 does K = 64 at twice the fp16 rate, and ONE such MFMA takes both corrections of TWO K16 steps by
+// K-concatenation:  A' = [a_h(s0) | a_l(s0) | a_h(s1) | a_l(s1)],  B' = [w_l(s0) | w_h(s0) | w_l(s1) | w_h(s1)]  (32 fp8 per lane; the
+// lane's eight values of a fragment keep their place, so A' and B' pair element by element exactly like the fp16 fragments do).
+// Per K16 step: 8 fp16 MFMAs + 4 fp8 MFMAs of twice the length = 2 / 3 of fgemm3's matrix time, plus 48 v_cvt_scalef32_pk_fp8_f16
+// (two values each) on fragments that are in registers anyway.  The K loop is the one tools/fp8_corr_probe.hip measured (1.23-1.32 x over
+// the same loop with three fp16 products): fragments of the CURRENT step read at its head, DMA two steps ahead, no hand interleaving.
+// Tile shape, operand packs, LDS image, work map, residual start and epilogue are fgemm3's; the sums differ from fgemm3's in the last
+// bits by construction.
+// ---------------------------------------------------------------------------------------------------------------
+typedef int intx8 __attribute__((ext_vector_type(8)));
+typedef short shortx2 __attribute__((ext_vector_type(2)));
+typedef _Float16 halfx2 __attribute__((ext_vector_type(2)));
+struct Frags8 {
+    intx8 a[4], b[2];          // dwords [4 p .. 4 p + 1] = hi plane (A) / lo plane (B) of the pair's step p, [4 p + 2 .. 4 p + 3] = lo (A) / hi (B)
+};
+struct C8Scales {
+    float ah, al, bh, bl;
+    int mfma_b;
+};
+struct Int2 { int x, y; };
+// eight fp16 (one fragment) / scale -> eight fp8 e4m3 (two dwords)
+__device__ __forceinline__ Int2 frag_to_fp8(uintx4 f, float scale) {
+    union { unsigned u; halfx2 h; } p0, p1, p2, p3;
+    p0.u = f[0]; p1.u = f[1]; p2.u = f[2]; p3.u = f[3];
+    shortx2 r = {0, 0}, q = {0, 0};
+    r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(r, p0.h, scale, false);
+    r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(r, p1.h, scale, true);
+    q = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(q, p2.h, scale, false);
+    q = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(q, p3.h, scale, true);
+    Int2 o;
+    __builtin_memcpy(&o.x, &r, 4);
+    __builtin_memcpy(&o.y, &q, 4);
+    return o;
+}
+
+// the products of one K16 step of a pair (PAR = 0, 1) on its fragments: main product on the fp16 pipe, the fragments into half PAR of the
+// fp8 operands, and behind the pair's second step the eight fp8 MFMAs that take both corrections of both steps
+template <int PAR>
+__device__ __forceinline__ void step3c(const Frags2& f, floatx16 (&acc)[4][2], Frags8& c8, const C8Scales& sc) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = mfma_h(f.ah[i], f.bh[j], acc[i][j]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const Int2 h = frag_to_fp8(f.ah[i], sc.ah), l = frag_to_fp8(f.al[i], sc.al);
+        c8.a[i][4 * PAR] = h.x; c8.a[i][4 * PAR + 1] = h.y; c8.a[i][4 * PAR + 2] = l.x; c8.a[i][4 * PAR + 3] = l.y;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const Int2 l = frag_to_fp8(f.bl[j], sc.bl), h = frag_to_fp8(f.bh[j], sc.bh);
+        c8.b[j][4 * PAR] = l.x; c8.b[j][4 * PAR + 1] = l.y; c8.b[j][4 * PAR + 2] = h.x; c8.b[j][4 * PAR + 3] = h.y;
+    }
+    if constexpr (PAR == 1) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(c8.a[i], c8.b[j], acc[i][j], 0, 0, 0, 127 + 2 - 11, 0, sc.mfma_b);
+    }
+}
+
+__global__ __launch_bounds__(512, 2) void fgemm3c_kernel(FGemmArgs a, int flags) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w8 = __builtin_amdgcn_readfirstlane(tid >> 6);             // 8 waves: waves 0-3 own the left 128 columns, 4-7 the right
+    const int w = w8 & 3;
+    int t = 0, local = 0, r = 0;
+    if (!fg3_map(a, blockIdx.x & 7, blockIdx.x >> 3, t, local, r)) return;
+    const int d = a.dim[t], qbase = a.qbase[t];
+    const int MT = a.MT[t], KS = d * a.cin / 32, KT = 2 * KS;
+    const int nh = w8 >> 2, pair = local;
+    const int cg = pair / MT, mtile = pair - cg * MT;
+    const int ntile = r + 8 * cg;
+    const char* Ag = a.A + a.a_off[t] + (size_t)mtile * KS * FG_STAGE;
+    const char* Bg = a.B + a.b_off[t] + (size_t)ntile * KS * FG_STAGE;
+    const int wm = w >> 1, wn = w & 1;
+    const int wkg = w8 >> 2, wcb = w8 & 3;                               // this wave's DMA pieces: k-group, 64-row / 64-column block
+    const int la = wkg * 4096 + wcb * 1024 + lane * 16;                  // DMA source offset inside a step (same for the A and the B piece)
+    const int lb = la;
+
+    floatx16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // fp8 conversion scales (the conversion DIVIDES by its scale operand; powers of two throughout).  Weights: max |What| * wscale is in
+    // [2^9, 2^10) (pack_fgemm_weights) -> / 4 puts the hi plane below 256 (e4m3 tops out at 448); their lo plane is 2^-11 of that.
+    // Activations: the producer of the planes left the largest magnitude it wrote in *a.amax (bit pattern of a non-negative float):
+    // 2^k with k = floor(log2(amax)) - 7 puts it into [128, 256).  Both correction products then carry 1 / (4 * 2^k * 2^-11), undone by
+    // the block scales of the MFMA (E8M0, 127 = 2^0).
+    const unsigned amax_bits = __builtin_amdgcn_readfirstlane(*a.amax);
+    int kexp = (int)(amax_bits >> 23) - 127 - 7;
+    kexp = kexp < -60 ? -60 : (kexp > 9 ? 9 : kexp);
+    C8Scales sc;
+    sc.ah = 4.f; sc.al = 4.f / 2048.f;
+    sc.bh = __uint_as_float((unsigned)(kexp + 127) << 23); sc.bl = __uint_as_float((unsigned)(kexp - 11 + 127) << 23);
+    sc.mfma_b = 127 + kexp;
+    const int lane_a = (lane >> 5) * 4096 + (wm * 128 + (lane & 31)) * 16;
+    const int lane_b = 16384 + (lane >> 5) * 4096 + (nh * 128 + wn * 64 + (lane & 31)) * 16;
+
+    // prologue: steps 0 and 1 (the loop stages two steps ahead of the one it multiplies)
+    dma_step3(Ag, Bg, smem, la, lb, w, wkg, wcb);
+    dma_step3(Ag + step_off(1), Bg + step_off(1), smem + F3_BUF, la, lb, w, wkg, wcb);
+    const bool rows_live = (mtile * 256 + wm * 128) < d * a.cout;       // else: all 128 rows of this wave are padding (cout = 32)
+    const int colbase = ntile * 256 + nh * 128 + wn * 64;
+    const int jidx = colbase / a.kppad, kp0 = colbase - jidx * a.kppad;
+    if ((flags & EPI_RES) && rows_live) {
+        // the accumulators start from the residual (x 1 / descale, a power of two): its loads fly with the first DMA stages
+        const float inv = 1.f / a.descale;
+        const int half = lane >> 5, kp32 = lane & 31, cout8 = a.cout >> 3;
+#pragma unroll
+        for (int bi = 0; bi < 2; ++bi) {
+            const int tile32 = (kp0 >> 5) + bi;
+#pragma unroll
+            for (int ai = 0; ai < 4; ++ai) {
+                const int rowb = mtile * 256 + wm * 128 + ai * 32;
+                const int iidx = rowb / a.cout, o0 = rowb - iidx * a.cout;
+                const bool ok = tile32 < a.nT32 && iidx < d;
+                const int q = qbase + iidx * d + jidx;
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const int o = o0 + q4 * 8 + half * 4;
+                    const size_t off = (((((size_t)tile32 * G + q) * cout8 + (o >> 3)) * 2 + half) * TILE + kp32) * 4;
+                    const floatx4 v = *reinterpret_cast<const floatx4*>(a.res + (ok ? off : 0)) * (ok ? inv : 0.f);     // branch-free
+                    acc[ai][bi][4 * q4 + 0] = v.x; acc[ai][bi][4 * q4 + 1] = v.y;
+                    acc[ai][bi][4 * q4 + 2] = v.z; acc[ai][bi][4 * q4 + 3] = v.w;
+                }
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    Frags8 c8;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) c8.a[i][e] = 0;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) c8.b[j][e] = 0;
+    // Step s lives in ring buffer s % 3.  At the head of step s: its DMA (issued two steps ago) has landed - the four pieces issued one
+    // step ago may stay in flight -, one barrier, then the DMA of step s + 2 goes into the buffer every wave finished reading BEFORE that
+    // barrier (step s - 1's), the twelve fragments of step s are read, and the products are issued: the two waves of a SIMD cover each
+    // other's fragment latency (tools/fp8_corr_probe.hip: this plain loop runs the three-product arithmetic as fast as fgemm3's
+    // hand-interleaved one).  Past the end the last step is staged again (into a buffer nobody reads any more): uniform counted waits.
+    int cur = 0, stg = 2 * F3_BUF;                // buffer of step s, buffer the DMA of step s + 2 goes to
+    int s = 0;
+    auto one_step = [&](auto parity) {
+        constexpr int PAR = decltype(parity)::value;
+        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            const int s2 = s + 2 < KT ? s + 2 : KT - 1;
+            dma_step3(uniform_ptr(Ag + step_off(s2)), uniform_ptr(Bg + step_off(s2)), smem + stg, la, lb, w, wkg, wcb);
+        }
+        Frags2 f;
+        sfor<0, 12>([&](auto rc) { read_frag3<decltype(rc)::value>(smem + cur + lane_a, smem + cur + lane_b, f); });
+        step3c<PAR>(f, acc, c8, sc);
+        stg = cur;                               // (s + 3) % 3 == s % 3
+        cur = cur == 2 * F3_BUF ? 0 : cur + F3_BUF;
+        ++s;
+    };
+    if (rows_live) {
+        for (int it = 0; it < KT; it += 2) {     // KT = 2 KS is even
+            one_step(std::integral_constant<int, 0>{});
+            one_step(std::integral_constant<int, 1>{});
+        }
+    } else {
+        // all 128 rows of this wave are padding: keep its share of the DMA and the barriers going
+        for (int it = 0; it < KT; ++it) {
+            asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            const int s2 = s + 2 < KT ? s + 2 : KT - 1;
+            dma_step3(uniform_ptr(Ag + step_off(s2)), uniform_ptr(Bg + step_off(s2)), smem + stg, la, lb, w, wkg, wcb);
+            stg = cur;
+            cur = cur == 2 * F3_BUF ? 0 : cur + F3_BUF;
+            ++s;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the re-staged tail pieces must not land in the LDS of the next workgroup
+    if (!rows_live) return;
+
+    // ---- epilogue: D[row][col]: lane (col = lane & 31, half = lane >> 5), reg e -> row = (e & 3) + 8 * (e >> 2) + 4 * half
+    const int half = lane >> 5, kp32 = lane & 31;
+    const int cout8 = a.cout >> 3;
+    const bool addb = (d == 1);                              // trivial irrep: coefficient 0 carries sqrt(60) * bias
+        unsigned top = 0u;                                       // largest |coefficient| written (bit pattern; inf / NaN order above)
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, 0x7FFFFFFF, 0x00020000);
+#pragma unroll
+    for (int bi = 0; bi < 2; ++bi) {
+        const int tile32 = (kp0 >> 5) + bi;
+        if (tile32 >= a.nT32) continue;
+#pragma unroll
+        for (int ai = 0; ai < 4; ++ai) {
+            const int rowb = mtile * 256 + wm * 128 + ai * 32;     // the 32 rows of an MFMA tile share i (cout is a multiple of 32)
+            const int iidx = rowb / a.cout, o0 = rowb - iidx * a.cout;
+            if (iidx >= d) continue;
+            const int q = qbase + iidx * d + jidx;
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const int o = o0 + q4 * 8 + half * 4;
+                floatx4 val;
+                val.x = acc[ai][bi][4 * q4 + 0]; val.y = acc[ai][bi][4 * q4 + 1];
+                val.z = acc[ai][bi][4 * q4 + 2]; val.w = acc[ai][bi][4 * q4 + 3];
+                val *= a.descale;
+                if (addb) val += *reinterpret_cast<const floatx4*>(a.bias + o) * 7.745966692414834f;
+                const size_t off = (((((size_t)tile32 * G + q) * cout8 + (o >> 3)) * 2 + half) * TILE + kp32) * 4;
+                if (flags & F2_ST_SC1) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uintx4, val), orsrc, (int)(off * 4), 0, 16);
+                else if (flags & F2_ST_NT) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uintx4, val), orsrc, (int)(off * 4), 0, 2);
+                else if (!(flags & F2_NOSTORE)) *reinterpret_cast<floatx4*>(a.out + off) = val;
+                top = max(max(top, __float_as_uint(val.x) & 0x7FFFFFFFu), __float_as_uint(val.y) & 0x7FFFFFFFu);
+                top = max(max(top, __float_as_uint(val.z) & 0x7FFFFFFFu), __float_as_uint(val.w) & 0x7FFFFFFFu);
+            }
+        }
+    }
+    note_range_bits(a.rflag, top, FP16_MAX / HF_ASCALE);     // the consumer multiplies by HF_ASCALE and converts to fp16
+}
+
+
+
+// ---------------------------------------------------------------------------------------------------------------
 // fgemm3s: fgemm3's staging and K loop for layers with 32 output channels (32 d <= 160 live rows of the 256-row A tile).  In
 // fgemm3 the waves are arranged 2 (rows) x 4 (columns): the lower row half is padding, so half the waves - two of the four
 // SIMDs - idle and the other two issue 24 MFMAs per step on 128 rows of which 32 d are real.  Here the eight waves split the
@@ -685,6 +916,7 @@ __global__ __launch_bounds__(512, 2) void fgemm3s_kernel(FGemmArgs a, int flags)
 int fgemm3_init() {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&fgemm3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, F3_LDS));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&fgemm3s_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, F3_LDS));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&fgemm3c_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, F3_LDS));
     return 0;
 }
 
@@ -705,6 +937,7 @@ int launch_fgemm3(const FGemmArgs& a, int flags, hipStream_t s) {
     // 32 output channels, no residual: all 32 d live rows in every wave (fgemm3s); YOHO_FGEMM_DEBUG=nosmall keeps fgemm3
     static const bool small_ok = [] { const char* e = experiment_env("YOHO_FGEMM_DEBUG"); return !(e && std::strstr(e, "nosmall")); }();
     if (small_ok && a.cout == 32 && !(flags & EPI_RES)) hipLaunchKernelGGL(fgemm3s_kernel, dim3(tot), dim3(512), F3_LDS, s, a, flags);
+    else if (a.amax) hipLaunchKernelGGL(fgemm3c_kernel, dim3(tot), dim3(512), F3_LDS, s, a, flags);      // gconv_mode 7: corrections on the fp8 pipe
     else hipLaunchKernelGGL(fgemm3_kernel, dim3(tot), dim3(512), F3_LDS, s, a, flags);
     HIPCHK(hipGetLastError());
     return 0;

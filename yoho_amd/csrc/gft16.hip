@@ -50,6 +50,7 @@ struct Gft16Args {
     int* rflag;               // fp16 range flag of the context (note_range)
     int drain;                // experiment (YOHO_PARTI_DEBUG=drain): wait for every outstanding vector-memory operation instead of the counted wait
     int* ctr;                 // gft16x work stealing: [0] next chunk ticket, [1] finished workgroups (both 0 between launches), or null = static striding
+    unsigned* amax;           // gft16x, gconv_mode 7: atomicMax of the largest |value| written to the planes (float bit pattern), or null
 };
 
 __device__ __forceinline__ floatx16 mfma_hh(uintx4 a, uintx4 b, floatx16 c) {
@@ -539,6 +540,12 @@ __global__ __launch_bounds__(512, 2) void gft16x_kernel(Gft16Args a) {
         if (!steal) nxt = next + gridDim.x;
     }
     note_range_bits(a.rflag, top);
+    if (a.amax) {                                            // the consumer GEMM scales its fp8 correction operands by this (fgemm3c)
+        unsigned t = top;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) t = max(t, (unsigned)__shfl_xor((int)t, o));
+        if (lane == 0) atomicMax(a.amax, t);
+    }
     if (steal && tid == 0) {
         // every ticket this workgroup requested has been answered before it reports (the adds complete in issue order, the last one
         // is waited for by using its value); the last workgroup to report leaves the counters at zero for the next launch
@@ -614,9 +621,9 @@ static void fill_qtables(int kppad, int cin, long long* qbase, int* qstride) {
 // else bn_s != null: BN + ReLU, fp32 chunks to out32 (may alias in);
 // else: inverse transform only, out32 = group-domain values (B,32,60) (C8 must be 4)
 int launch_gft16(const float* in, float* out32, char* planes, int kppad, const void* Ffrag, const float* bn_s, const float* bn_t, int nTiles,
-                 int C8, int nCU, hipStream_t s, int B, int* rflag, int variant, int* ctr) {
+                 int C8, int nCU, hipStream_t s, int B, int* rflag, int variant, int* ctr, unsigned* amax) {
     Gft16Args a;
-    a.B = B; a.res0 = nullptr; a.nTiles16 = 0; a.rflag = rflag;
+    a.B = B; a.res0 = nullptr; a.nTiles16 = 0; a.rflag = rflag; a.amax = amax;
     a.ctr = ctr;                       // null: static striding (the caller's context was created with YOHO_XF_STEAL=0, or the pass is small)
     a.in = in; a.out32 = out32; a.planes = planes; a.Ffrag = reinterpret_cast<const uintx4*>(Ffrag); a.bn_s = bn_s; a.bn_t = bn_t;
     a.nChunks = nTiles * C8; a.C8 = C8;
@@ -755,7 +762,7 @@ int launch_head16(const float* x, int B, int nTiles, char* planes, int kppad, co
 int launch_gft16_invp(const float* in, float* res0, char* planes16, int nTiles16, const void* Ffrag, const float* bn_s, const float* bn_t,
                       int nTiles, int C8, int nCU, hipStream_t s, int* rflag) {
     Gft16Args a;
-    a.rflag = rflag; a.drain = 0;
+    a.rflag = rflag; a.drain = 0; a.ctr = nullptr; a.amax = nullptr;
     a.in = in; a.out32 = nullptr; a.planes = planes16; a.Ffrag = reinterpret_cast<const uintx4*>(Ffrag); a.bn_s = bn_s; a.bn_t = bn_t;
     a.nChunks = nTiles * C8; a.C8 = C8; a.B = 0; a.res0 = res0; a.nTiles16 = nTiles16;
     for (int q = 0; q < G; ++q) { a.qbase[q] = 0; a.qstride[q] = 0; }

@@ -146,9 +146,9 @@ class YohoError(RuntimeError):
         self.code = code
 
 
-GCONV_MODES = {"f32": 0, "bf16x3": 1, "fourier": 2, "fp16x2": 3, "fgemm": 4, "fgemm256": 5, "fgemm128": 6}
+GCONV_MODES = {"f32": 0, "bf16x3": 1, "fourier": 2, "fp16x2": 3, "fgemm": 4, "fgemm256": 5, "fgemm128": 6, "fgemm8": 7}
 PARTII_MODES = {"f32": 0, "bf16x3": 1, "fp16x2": 2}
-FP16_GCONV_MODES = ("fp16x2", "fgemm", "fgemm256", "fgemm128")      # arithmetic with fp16 planes: guarded by the range flag (yoho_range_status)
+FP16_GCONV_MODES = ("fp16x2", "fgemm", "fgemm256", "fgemm128", "fgemm8")      # arithmetic with fp16 planes: guarded by the range flag (yoho_range_status)
 MAX_PAIR_KEYPOINTS = 16384                  # yoho_partI_forward_pair takes both fragments in one pass up to this many rows
 
 
@@ -458,7 +458,7 @@ class Context:
 
     def supports_pair(self, n_rows):
         """yoho_partI_forward_pair (no concatenation copy) exists for the default arithmetic mode and one pass"""
-        return self.gconv_mode in ("fgemm", "fgemm256", "fgemm128") and n_rows <= MAX_PAIR_KEYPOINTS
+        return self.gconv_mode in ("fgemm", "fgemm256", "fgemm128", "fgemm8") and n_rows <= MAX_PAIR_KEYPOINTS
 
     def supports_matched(self):
         """row-indexed PartII (yoho_partII_forward_indexed) exists for the default PartII mode"""
