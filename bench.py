@@ -248,6 +248,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--no-yohoc", action="store_true", help="skip the YOHO-C leg")
+    ap.add_argument("--no-fgemm8", action="store_true", help="skip the leg with the opt-in fp8-correction arithmetic (gconv mode 'fgemm8')")
     ap.add_argument("--in-flight", type=int, choices=[1, 2], default=2,
                     help="pairs in flight: 2 (default) queues the descriptor pass of the next pair on a second HIP stream before waiting for "
                          "the current pair's read-backs (pipeline.PairStreamer); 1 runs the pairs strictly one after the other")
@@ -444,6 +445,32 @@ def main():
         rs_ = pipeline.run_pair(ctx, f0, f1, k0, k1, max_iter=1000, order_rng=np.random.RandomState(7), eqv=ra_.eqv, hypotheses="selected")
         sel_leg["same_winner_and_transform_as_all"] = bool((ra_.best_h, ra_.best_count) == (rs_.best_h, rs_.best_count) and
                                                            np.array_equal(np.asarray(ra_.trans), np.asarray(rs_.trans)))
+    # the same step in the opt-in arithmetic of round 5 (gconv mode 'fgemm8': the two correction products of the fp16 split of the two large
+    # PartI layers in fp8 e4m3 on v_mfma_scale_f32_32x32x64_f8f6f4): time, and what it does to this pair's results.  Reported
+    # beside the headline, which stays on the default arithmetic (~1e-6 of the fp32 reference; this mode ~1e-5, tolerance 1e-4)
+    fgemm8 = None
+    if not args.no_fgemm8 and args.gconv == "fgemm":
+        g1 = guard_total()
+        ctx.set_gconv_mode("fgemm8")
+        if streamer is not None:
+            streamer.set_modes("fgemm8", None)
+        try:
+            dt8, dts8, _, res8, pw8 = timed("yohoo", args.steps, max(min(args.warmup, 2), 1), 1)
+            ra8 = pipeline.run_pair(ctx, f0, f1, k0, k1, max_iter=1000, order_rng=np.random.RandomState(7))
+        finally:
+            ctx.set_gconv_mode(args.gconv)
+            if streamer is not None:
+                streamer.set_modes(args.gconv, None)
+        rd8 = pipeline.run_pair(ctx, f0, f1, k0, k1, max_iter=1000, order_rng=np.random.RandomState(7))
+        e8 = torch.cat([ra8.eqv[0]["eqv"], ra8.eqv[1]["eqv"]])
+        ed = torch.cat([rd8.eqv[0]["eqv"], rd8.eqv[1]["eqv"]])
+        fgemm8 = {"metric": "keypoints/sec (5000 kp x60 rot desc + YOHO-O), PartI with fp8 correction products (opt-in gconv mode 'fgemm8')",
+                  "value": round(pairs_per_step * 2 * KP * args.steps / dt8, 1), "ms_per_step": round(dt8 / args.steps * 1e3, 3),
+                  "vs_headline_ms_per_step": round(dt8 / dt, 4),
+                  "descriptor_max_abs_diff_vs_default": float((e8 - ed).abs().max().item()),
+                  "same_match_list_as_default": bool(ra8.match.shape == rd8.match.shape and torch.equal(ra8.match, rd8.match)),
+                  "same_winner_as_default": bool((ra8.best_h, ra8.best_count) == (rd8.best_h, rd8.best_count)),
+                  "matches": int(ra8.match.shape[0]), "clock_probe": (pw8 or {}).get("clock_probe"), "range_repeats": guard_total() - g1}
     yohoc = None
     if not args.no_yohoc:
         g1 = guard_total()
@@ -712,6 +739,8 @@ def main():
             out["yohoc"] = yohoc
         if sel_leg is not None:
             out["yohoo_selected_hypotheses"] = sel_leg
+        if fgemm8 is not None:
+            out["fgemm8"] = fgemm8
     # dataset-scale leg (BASELINE configs 3 / 5): 60 fragments x 5000 keypoints from .npy files on disk, ~500 pairs, through the
     # dataset driver; with N ranks the scene's pairs are dealt to them by run_dataset.plan_shards.  Never part of `value`.
     dataset = None
