@@ -26,6 +26,20 @@ for rep in range(reps):
         print("PartI mismatch at rep", rep, "B", B, (a["eqv"] - b["eqv"]).abs().max().item())
 ctx.set_gconv_mode("fgemm")
 print("PartI: %d reps, %d mismatches" % (reps, bad))
+# the opt-in fp8-correction arithmetic (fgemm3c: counted waits across barriers too, plus a device-side scale word): run-to-run determinism
+bad8 = 0
+ctx.set_gconv_mode("fgemm8")
+for rep in range(reps):
+    B = [10000, 5000, 4097, 777][rep % 4]
+    x = torch.from_numpy(synth.unit_features(B, seed=100 + rep)).cuda()
+    a = ctx.partI_forward(x, want_inv=True)
+    a2 = ctx.partI_forward(x, want_inv=True)
+    ok = torch.equal(a["eqv"], a2["eqv"]) and torch.equal(a["inv"], a2["inv"]) and bool(torch.isfinite(a["eqv"]).all())
+    bad8 += 0 if ok else 1
+    if not ok:
+        print("PartI fgemm8 nondeterminism at rep", rep, "B", B, (a["eqv"] - a2["eqv"]).abs().max().item())
+ctx.set_gconv_mode("fgemm")
+print("PartI fgemm8: %d reps, %d mismatches" % (reps, bad8))
 
 # PartII determinism on a pair's matches
 pr = synth.make_pair(5000, seed=3)
