@@ -15,5 +15,6 @@ d=json.loads(open("$O/bench_final.json").read().strip().splitlines()[-1])
 print("value", d["value"], d["ms_per_step"], d["ms_per_step_repeats"]["all_in_order"], "sustained", d["sustained"]["ms_per_step"], d["sustained"]["clock_probe"]["shader_mhz_mean"])
 r=d["roofline"]; print("roof", r["achieved"], r["frac"], r["frac_at_clock"], r["shader_mhz_mean"], r["power_w"], r["frac_pass"], r["frac_step"], r["frac_per_launch"])
 f=d["fcgf"]; print("fcgf", f.get("ms_per_fragment"), f.get("ms_per_fragment_all"), json.dumps(f.get("split_ms")))
+f8=d.get("fgemm8") or {}; print("fgemm8", f8.get("ms_per_step"), f8.get("vs_headline_ms_per_step"), f8.get("descriptor_max_abs_diff_vs_default"), f8.get("same_match_list_as_default"), f8.get("same_winner_as_default"))
 print("dataset", [x["total_s"] for x in d["dataset"]["runs"]], "cpu", d["cpu_baseline"]["value"], d["cpu_baseline"]["cores"], "yohoc", d["yohoc"]["ms_per_step"], "sel", d["yohoo_selected_hypotheses"]["ms_per_step"])
 PY
