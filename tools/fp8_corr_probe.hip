@@ -11,7 +11,8 @@
 //
 // This file measures what that buys BEFORE touching fgemm3: a K loop with fgemm3's shape (256 x 256 tile, eight waves of 128 x 64, K16 steps
 // of 16 KiB A + 16 KiB B staged by LDS DMA through a ring of three buffers, one barrier per step, two workgroups' worth of registers per CU) in
-// three arithmetic variants - 0: three fp16 products (shipped), 1: fp16 main + fp8 corrections, 2: main product only (the floor) - timed back
+// arithmetic variants - 0: three fp16 products (shipped), 1: fp16 main + fp8 corrections, 2: main product only (the floor), 3: as 1 with the
+// weight operand's fp8 fragments read ready-made instead of converted (timing only: what a pre-packed weight plane would buy) - timed back
 // to back under sustained load, and the accumulators of one tile compared with an fp64 evaluation on the host.
 //
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/fp8_corr_probe.hip -o tools/_fp8_corr_probe && tools/_fp8_corr_probe [row tiles 16] [col tiles 32] [K16 steps 416]
@@ -141,6 +142,28 @@ __global__ __launch_bounds__(512, 2) void kloop(Args a) {
             for (int r = 0; r < 4; ++r)
 #pragma unroll
                 for (int c = 0; c < 2; ++c) acc[r][c] = mfma16(f[4 + r], f[8 + c], acc[r][c]);
+        } else if constexpr (V == 3) {
+            // timing only (values meaningless): the WEIGHT operand's fp8 fragments come pre-packed from memory - here the raw bytes of
+            // the step's two A planes stand in for them - so only the activation fragments are converted (16 instead of 48 per step)
+            if constexpr (P == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { a8[r][e] = (int)f[r][e]; a8[r][4 + e] = (int)f[4 + r][e]; }
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const I2 l = to_fp8(f[10 + c], a.cvt_lo), h = to_fp8(f[8 + c], a.cvt_hi);
+                b8[c][4 * P] = l.x; b8[c][4 * P + 1] = l.y; b8[c][4 * P + 2] = h.x; b8[c][4 * P + 3] = h.y;
+            }
+            if constexpr (P == 1) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int c = 0; c < 2; ++c)
+                        acc[r][c] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8[r], b8[c], acc[r][c], 0, 0, 0, 127 - 11, 0, 127);
+            }
         } else if constexpr (V == 1) {
             // A' dwords [4P .. 4P+1] = a_h, [4P+2 .. 4P+3] = a_l x 2^11;  B' = w_l x 2^11, w_h: element by element the pairs of the two corrections
 #pragma unroll
@@ -250,8 +273,8 @@ int main(int argc, char** argv) {
     CHK(hipMemcpy(A, hA.data(), szA, hipMemcpyHostToDevice));
     CHK(hipMemcpy(B, hB.data(), szB, hipMemcpyHostToDevice));
     typedef void (*kern_t)(Args);
-    kern_t kerns[3] = {kloop<0>, kloop<1>, kloop<2>};
-    for (int v = 0; v < 3; ++v) CHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kerns[v]), hipFuncAttributeMaxDynamicSharedMemorySize, RING * PBUF));
+    kern_t kerns[4] = {kloop<0>, kloop<1>, kloop<2>, kloop<3>};
+    for (int v = 0; v < 4; ++v) CHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kerns[v]), hipFuncAttributeMaxDynamicSharedMemorySize, RING * PBUF));
     Args a{A, B, out, ntm, ntn, nsteps, cvt_hi, cvt_lo};
     const int grid = ntm * ntn;
     std::printf("K loop of a 256 x 256 irrep-GEMM tile (8 waves of 128 x 64, K16 steps of 32 KiB by LDS DMA, ring of 3): %d x %d tiles, %d K16 steps (K = %d)\n",
@@ -279,12 +302,12 @@ int main(int argc, char** argv) {
     double rmax = 0.0;
     for (double v : ref) rmax = std::fmax(rmax, std::fabs(v));
     std::vector<float> hout((size_t)8 * 4 * 2 * 64 * 16);
-    const char* names[3] = {"3 fp16 products (shipped arithmetic)", "fp16 main + fp8 e4m3 corrections", "main product only"};
+    const char* names[4] = {"3 fp16 products (shipped arithmetic)", "fp16 main + fp8 e4m3 corrections", "main product only", "(timing only) weights pre-packed in fp8"};
     hipEvent_t e0, e1;
     CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
-    double ms_of[3] = {0, 0, 0};
+    double ms_of[4] = {0, 0, 0, 0};
     for (int round = 0; round < 2; ++round)
-        for (int v = 0; v < 3; ++v) {
+        for (int v = 0; v < 4; ++v) {
             for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kerns[v], dim3(grid), dim3(512), RING * PBUF, 0, a);
             CHK(hipDeviceSynchronize());
             CHK(hipEventRecord(e0, 0));
@@ -312,6 +335,6 @@ int main(int argc, char** argv) {
             std::printf("  run %d  %-38s %8.3f ms per launch  (%.0f TFLOP/s in units of the shipped 3-product count)   tile (0,0): max |error| / max |C| = %.2e\n",
                         round, names[v], ms, flops3 / (ms * 1e-3) / 1e12, err / rmax);
         }
-    std::printf("speed-up of the fp8-corrected loop over the shipped one: %.3f x (floor = main product only: %.3f x)\n", ms_of[0] / ms_of[1], ms_of[0] / ms_of[2]);
+    std::printf("speed-up of the fp8-corrected loop over the shipped one: %.3f x (floor = main product only: %.3f x; with the weight operand pre-packed in fp8: %.3f x)\n", ms_of[0] / ms_of[1], ms_of[0] / ms_of[2], ms_of[0] / ms_of[3]);
     return 0;
 }

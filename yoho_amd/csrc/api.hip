@@ -35,6 +35,7 @@ static void free_layer(Layer& L) {
     if (L.wp16) (void)hipFree(L.wp16);
     if (L.wph) (void)hipFree(L.wph);
     if (L.wpg) (void)hipFree(L.wpg);
+    if (L.wpg8) (void)hipFree(L.wpg8);
     if (L.wpf) (void)hipFree(L.wpf);
     if (L.bias) (void)hipFree(L.bias);
     if (L.bn_s) (void)hipFree(L.bn_s);
@@ -165,9 +166,11 @@ static int build_layer(Layer& L, const yoho_conv_w& cw, int cin, int cout, int n
         pack_fourier_weights(*fb, cw.weight, cin, cout, L.cout_pad, wf);
         if ((rc = upload(wf.data(), wf.size() * sizeof(float), (void**)&L.wpf))) return rc;
         if ((cout % 256 == 0 || cout == 32) && cin % 32 == 0) {
-            std::vector<unsigned short> wg;
-            if (pack_fgemm_weights(*fb, cw.weight, cin, cout, wg, &L.wpg_descale)) { set_error("irrep-GEMM weight packing failed"); return YOHO_EINVAL; }
+            std::vector<unsigned short> wg, wg8;
+            const bool big = cin >= 256 && cout >= 256;                  // the layers fgemm3c (gconv_mode 7) takes
+            if (pack_fgemm_weights(*fb, cw.weight, cin, cout, wg, &L.wpg_descale, big ? &wg8 : nullptr)) { set_error("irrep-GEMM weight packing failed"); return YOHO_EINVAL; }
             if ((rc = upload(wg.data(), wg.size() * sizeof(unsigned short), &L.wpg))) return rc;
+            if (big && (rc = upload(wg8.data(), wg8.size() * sizeof(unsigned short), &L.wpg8))) return rc;
         }
     }
     if ((rc = upload(bias.data(), bias.size() * sizeof(float), (void**)&L.bias))) return rc;

@@ -77,6 +77,8 @@ struct Layer {
     void* wph = nullptr;      // fp16x2 planes [ob][c8][tap-pair 7][plane 2][lane64][8] (13-tap layers only)
     float* wpf = nullptr;
     void* wpg = nullptr;      // irrep-GEMM A operand: fp16x2 planes of What (gemmf.hip), 13-tap layers with cout % 256 == 0
+    void* wpg8 = nullptr;     // the same pack for fgemm3c (gconv_mode 7): hi plane as in wpg, the lo plane's 16-byte units replaced by the unit's fp8 e4m3
+                              // operand [hi / 4 (8 values) | lo * 512 (8 values)]; layers with cin and cout >= 256 only
     float wpg_descale = 1.f;     // group-Fourier weights [ob][c8][frag 60][lane64][4] (13-tap layers only)
     float* bias = nullptr;    // [cout_pad]
     float* bn_s = nullptr;    // [cout_pad] scale of the BN that FOLLOWS this conv (applied with ReLU in the epilogue)
@@ -129,7 +131,8 @@ int fgemm_init();
 size_t fgemm_planes_bytes(int kppad, int cin);
 void fgemm_qinfo(int* qi);
 void fgemm_plane_offsets(int kppad, int cin, long long* off);
-int pack_fgemm_weights(const FourierBasis& fb, const float* W, int cin, int cout, std::vector<unsigned short>& out, float* descale);
+int pack_fgemm_weights(const FourierBasis& fb, const float* W, int cin, int cout, std::vector<unsigned short>& out, float* descale,
+                       std::vector<unsigned short>* out8 = nullptr);
 int launch_fgemm(const Layer& L, const char* Bplanes, int kppad, int nT32, const float* res, float* out, int flags, hipStream_t s,
                  int* rflag = nullptr, int variant = 2, const unsigned* amax = nullptr);
 void build_gft16_frags(const FourierBasis& fb, std::vector<unsigned short>& out);

@@ -279,8 +279,35 @@ static inline unsigned short half_bits_h(float x) {
     return u;
 }
 
+// OCP fp8 E4M3 (bias 7, largest finite 448, no infinities) of x: round to nearest even, saturating
+static unsigned char e4m3_bits(float x) {
+    const unsigned sgn = std::signbit(x) ? 0x80u : 0u;
+    const float a = std::fabs(x);
+    if (!(a == a)) return 0x7F;
+    if (a >= 464.f) return (unsigned char)(sgn | 0x7E);                       // 448 (464 is half way to the next step)
+    if (a < std::ldexp(1.f, -6)) {                                            // subnormal: quantum 2^-9
+        const int r = (int)std::nearbyint(std::ldexp(a, 9));                  // 0 .. 8 (8 = the smallest normal)
+        return (unsigned char)(sgn | (r == 8 ? 0x08 : r));
+    }
+    int e;
+    (void)std::frexp(a, &e);                                                  // a = m 2^e, 0.5 <= m < 1
+    int r = (int)std::nearbyint(std::ldexp(a, 3 - (e - 1)));                  // a / 2^(e-1) in [1, 2) -> 8 .. 16
+    if (r == 16) { r = 8; ++e; }
+    const int E = e - 1 + 7;
+    if (E > 15 || (E == 15 && r - 8 > 6)) return (unsigned char)(sgn | 0x7E);
+    return (unsigned char)(sgn | (E << 3) | (r - 8));
+}
+static inline float half_value_h(unsigned short u) {
+    _Float16 h;
+    std::memcpy(&h, &u, 2);
+    return (float)h;
+}
+
 // What(r,i,m)[o][c] = sum_k W[o][c][k] rho_r(n_k)[m][i]  ->  A pack (fp16x2 planes of What * 2^s)
-int pack_fgemm_weights(const FourierBasis& fb, const float* W, int cin, int cout, std::vector<unsigned short>& out, float* descale) {
+// out8 (optional): the pack fgemm3c reads - the hi plane as in `out`; every 16-byte unit of the lo plane (the 8 K-values of one row and
+// k-group) replaced by the unit's fp8 operand: bytes 0-7 = e4m3(hi / 4), bytes 8-15 = e4m3(lo * 512)   (|hi| < 1024, |lo| <= 0.5)
+int pack_fgemm_weights(const FourierBasis& fb, const float* W, int cin, int cout, std::vector<unsigned short>& out, float* descale,
+                       std::vector<unsigned short>* out8) {
     if ((cout % 256 && cout != 32) || cin % 32) return -1;     // row tiles must not straddle i unless the whole irrep fits one tile
     std::vector<float> what((size_t)60 * cout * cin);
     std::vector<double> coef(60 * NTAP);
@@ -327,6 +354,19 @@ int pack_fgemm_weights(const FourierBasis& fb, const float* W, int cin, int cout
                 }
             }
     }
+    if (out8) {
+        *out8 = out;
+        const size_t nblk = out.size() / (FG_STAGE / 2);
+        for (size_t b = 0; b < nblk; ++b) {
+            const unsigned short* src = out.data() + b * (FG_STAGE / 2);
+            unsigned char* dst = reinterpret_cast<unsigned char*>(out8->data() + b * (FG_STAGE / 2) + 8192);
+            for (int u = 0; u < 1024; ++u)                                     // 16-byte units of the plane
+                for (int e = 0; e < 8; ++e) {
+                    dst[u * 16 + e] = e4m3_bits(half_value_h(src[u * 8 + e]) * 0.25f);
+                    dst[u * 16 + 8 + e] = e4m3_bits(half_value_h(src[8192 + u * 8 + e]) * 512.f);
+                }
+        }
+    }
     return 0;
 }
 
@@ -351,7 +391,7 @@ int launch_fgemm(const Layer& L, const char* Bplanes, int kppad, int nT32, const
                  int variant, const unsigned* amax) {
     FGemmArgs a;
     fgemm_fill_args(a, L, Bplanes, kppad, nT32, res, out, rflag);
-    a.amax = variant == 3 ? amax : nullptr;
+    if (variant == 3 && amax && L.wpg8) { a.amax = amax; a.A = reinterpret_cast<const char*>(L.wpg8); }      // fgemm3c and its weight pack
     static const int dbg_gemm1 = [] { const char* e = experiment_env("YOHO_PARTI_DEBUG"); return (e && std::strstr(e, "gemm1")) ? 1 : 0; }();
     if (dbg_gemm1) variant = 1;
     if (variant == 3) return launch_fgemm3(a, flags, s);

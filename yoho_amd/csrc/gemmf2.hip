@@ -510,8 +510,8 @@ __global__ __launch_bounds__(512, 2) void fgemm3_kernel(FGemmArgs a, int flags) 
 // v_mfma_scale_f32_32x32x64_f8f6f4 does K = 64 at twice the fp16 rate, and ONE such MFMA takes both corrections of TWO K16 steps by
 // K-concatenation:  A' = [a_h(s0) | a_l(s0) | a_h(s1) | a_l(s1)],  B' = [w_l(s0) | w_h(s0) | w_l(s1) | w_h(s1)]  (32 fp8 per lane; the
 // lane's eight values of a fragment keep their place, so A' and B' pair element by element exactly like the fp16 fragments do).
-// Per K16 step: 8 fp16 MFMAs + 4 fp8 MFMAs of twice the length = 2 / 3 of fgemm3's matrix time, plus 48 v_cvt_scalef32_pk_fp8_f16
-// (two values each) on fragments that are in registers anyway.  The K loop is the one tools/fp8_corr_probe.hip measured (1.23-1.32 x over
+// Per K16 step: 8 fp16 MFMAs + 4 fp8 MFMAs of twice the length = 2 / 3 of fgemm3's matrix time, plus 16 v_cvt_scalef32_pk_fp8_f16
+// (two values each) on the activation fragments; the weight operand's fp8 fragments are packed on the host (Layer::wpg8).  The K loop is the one tools/fp8_corr_probe.hip measured (1.23-1.32 x over
 // the same loop with three fp16 products): fragments of the CURRENT step read at its head, DMA two steps ahead, no hand interleaving.
 // Tile shape, operand packs, LDS image, work map, residual start and epilogue are fgemm3's; the sums differ from fgemm3's in the last
 // bits by construction.
@@ -550,11 +550,12 @@ __device__ __forceinline__ void step3c(const Frags2& f, floatx16 (&acc)[4][2], F
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = mfma_h(f.ah[i], f.bh[j], acc[i][j]);
+    // the weight operand's fp8 fragments come ready-made: fgemm3c's weight pack (Layer::wpg8) carries, in the place of the lo plane, the
+    // 16 bytes [e4m3(hi / 4) x 8 | e4m3(lo * 512) x 8] of every (row, k-group) unit - exactly this step's four dwords of A'
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const Int2 h = frag_to_fp8(f.ah[i], sc.ah), l = frag_to_fp8(f.al[i], sc.al);
-        c8.a[i][4 * PAR] = h.x; c8.a[i][4 * PAR + 1] = h.y; c8.a[i][4 * PAR + 2] = l.x; c8.a[i][4 * PAR + 3] = l.y;
-    }
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) c8.a[i][4 * PAR + e] = (int)f.al[i][e];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const Int2 l = frag_to_fp8(f.bl[j], sc.bl), h = frag_to_fp8(f.bh[j], sc.bh);
