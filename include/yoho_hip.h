@@ -311,8 +311,8 @@ int yoho_fcgf_forward_batch(yoho_ctx* ctx, const int32_t* coords, const int32_t*
  * magnitude, beyond that the result is inf/NaN), 4 = group-Fourier domain with every layer as five dense irrep GEMMs on
  * the fp16x2 split MFMA and fp16x2 transform kernels between them (default); 5 / 6 = the same arithmetic with the other two GEMM
  * blockings; 7 (opt-in, YOHO_GCONV=fgemm8) = 4 with the two correction products of the split of the two large layers evaluated in fp8
- * e4m3 on v_mfma_scale_f32_32x32x64_f8f6f4 (2 / 3 of the matrix time of those layers; descriptors within ~2e-5 of the fp32 reference
- * instead of ~1e-6).  All meet the 1e-4 parity tolerance. */
+ * e4m3 on v_mfma_scale_f32_32x32x64_f8f6f4 (2 / 3 of the matrix time of those layers: ~7 % per pair; descriptors within ~1e-5 of the fp32
+ * reference instead of ~1e-6, i.e. nearest-neighbour near-ties may resolve differently from the reference's).  All meet the 1e-4 parity tolerance. */
 int yoho_set_gconv_mode(yoho_ctx* ctx, int mode);
 
 /* 3-D nearest-neighbour searches (yoho_nn_search with D = 3, yoho_group_gather) through a uniform hash grid of the given
