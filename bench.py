@@ -249,6 +249,9 @@ def main():
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--no-yohoc", action="store_true", help="skip the YOHO-C leg")
     ap.add_argument("--no-fgemm8", action="store_true", help="skip the leg with the opt-in fp8-correction arithmetic (gconv mode 'fgemm8')")
+    ap.add_argument("--staged", action="store_true",
+                    help="compose the estimator side of every pair from the staged entries in Python (pipeline.run_pair: tensor-library index "
+                         "kernels between the stages) instead of one yoho_register_pair call per pair")
     ap.add_argument("--in-flight", type=int, choices=[1, 2], default=2,
                     help="pairs in flight: 2 (default) queues the descriptor pass of the next pair on a second HIP stream before waiting for "
                          "the current pair's read-backs (pipeline.PairStreamer); 1 runs the pairs strictly one after the other")
@@ -324,8 +327,10 @@ def main():
         todo = [p for _ in range(n) for p in mine]
         dist = 0.09 if estimator == "yohoo" else 0.07
         if streamer is not None:
+            # default: the estimator side of a pair is ONE library call (yoho_register_pair; vote order = RandomState(seed).shuffle restated
+            # in C) - between the descriptor pass and the winner no tensor-library kernel runs (profiles/r06_kernel_trace_bench.md)
             return streamer.run(todo, inlier_dist=dist, max_iter=1000, order_rng=rng, estimator=estimator,
-                                seeds=[seed0 + i for i in range(len(todo))], hypotheses=hypotheses, keep="last")[-1]
+                                seeds=[seed0 + i for i in range(len(todo))], hypotheses=hypotheses, keep="last", fused=not args.staged)[-1]
         r = None
         for i, (a0, a1, b0, b1) in enumerate(todo):
             r = pipeline.run_pair(ctx, a0, a1, b0, b1, inlier_dist=dist, max_iter=1000, order_rng=rng, estimator=estimator, seed=seed0 + i,
@@ -384,8 +389,18 @@ def main():
         return int(ctx.range_fallbacks + (sum(c.range_fallbacks for c in streamer.desc + [streamer.est]) if streamer else 0))
 
     g0 = guard_total()
-    dt, dts, rank_dts, res, power_steps = timed("yohoo", args.steps, max(args.warmup, 1), args.repeats)
+    dt, dts, rank_dts, res_timed, power_steps = timed("yohoo", args.steps, max(args.warmup, 1), args.repeats)
     headline_range_repeats = guard_total() - g0
+    # the last timed pair once more through the staged entries (untimed) with the vote order of its seed: the stage outputs the legs
+    # below need (match list, coarse rotations, descriptors), and the check that the one-call pair of the timed steps picked the same
+    # winner and transform
+    last_seed = 1000 + 100000 * (max(1, args.repeats) - 1) + args.steps * len(mine) - 1
+    res = pipeline.run_pair(ctx, *mine[-1], inlier_dist=0.09, max_iter=1000, order_rng=np.random.RandomState(last_seed & 0xFFFFFFFF))
+    one_call = {"estimator_side": "staged entries composed in Python (pipeline.run_pair)" if (args.staged or streamer is None) else
+                                  "one library call per pair (yoho_register_pair)",
+                "matches_winner_count_transform_equal_staged_composition":
+                    bool(res_timed.matches == res.matches and (res_timed.best_h, res_timed.best_count) == (res.best_h, res.best_count) and
+                         np.array_equal(np.asarray(res_timed.trans), np.asarray(res.trans)))}
 
     # sustained leg: the headline's timed region is 0.1 s behind a few warm-up steps, i.e. a burst at boost clock.  Here the same
     # steps run for >= 1 s untimed (the part reaches the clock its power budget allows) and then >= 2 s timed, with clock probes
@@ -509,7 +524,7 @@ def main():
         yohoc = {"metric": "keypoints/sec (5000 kp x60 rot desc + YOHO-C, 1000 iterations sampled on the device)",
                  "value": round(pairs_per_step * 2 * KP * args.steps / dtc, 1), "ms_per_step": round(dtc / args.steps * 1e3, 3),
                  "iterations": 1000, "estimator_host_ms_per_pair": round(host_ms, 4),
-                 "winner_inliers": int(resc.best_count), "matches": int(resc.match.shape[0]), "range_repeats": guard_total() - g1,
+                 "winner_inliers": int(resc.best_count), "matches": int(resc.matches), "range_repeats": guard_total() - g1,
                  "modes": {
                      "device_sampling": {"contract": "statistical parity: Philox-sampled triples, proper rotations, no host work (pipeline.run_pair, "
                                                      "run_dataset, cfg.yohoc_device_sampling); bit-exact vs oracle/yoho_oracle.yohoc_device_triples",
@@ -712,7 +727,7 @@ def main():
                                    "random-init weights (seeded), inputs resident in HBM",
                        "ms_per_step_repeats": {"min": round(min(dts) / args.steps * 1e3, 3), "max": round(max(dts) / args.steps * 1e3, 3), "n": len(dts)},
                        "keypoints_per_fragment": KP, "partI_batch": nkp, "matches": M, "hypotheses": min(1000, M), "gconv": args.gconv, "partII": args.partII,
-                       "pairs_per_step": pairs_per_step, "pairs_in_flight": args.in_flight,
+                       "pairs_per_step": pairs_per_step, "pairs_in_flight": args.in_flight, "pair_call": one_call,
                        "partI_schedule": ("breadth-first (every layer over the whole pass)" if sched_chunk == 0 else
                                           f"depth-first, chunks of {sched_chunk} keypoints on {sched_streams} stream(s)"),
                        "parallelism": (f"one pair per GPU per step, {world} GPU(s), no data-path collective" if args.scaling == "weak" else

@@ -29,6 +29,7 @@
  *   yoho_group_transfer_batch                                     the feature-transfer body of those loops for the copies of a pass
  *   yoho_register_pair           one iteration of the pair loop  tests/evaluator.py:112-117 / :41-47 (matcher -> Des2R -> PartII + vote | YOHO-C)
  *   yoho_vote_order              np.random.shuffle(index)        tests/estimator.py:321-323 (seeded RandomState, host code)
+ *   yoho_c_draw_np               the np.random.choice draws      tests/estimator.py:113-128 (numpy's legacy stream continued in C, host code)
  *
  * Conventions
  *   - return 0 on success, a negative YOHO_E* code on error; yoho_last_error() gives a
@@ -50,6 +51,7 @@
  *     YOHO_FCGF_COORDS=hash (yoho_set_fcgf_sort).   A/B and diagnostic switches without a setter (struct yoho_env_switches in
  *     csrc/common.h; every value gives valid results):   YOHO_PARTII_TAIL=staged, YOHO_TRANSFER=staged, YOHO_XF_STEAL=0,
  *     YOHO_NN_SPLITS=<n>, YOHO_FCGF=f32 (takes effect at the context's yoho_load_fcgf), YOHO_FCGF_MAPS=full, YOHO_FCGF_NORM=staged,
+ *     YOHO_WS_LIMIT_MB=<n> (workspace requests above n MiB fail with YOHO_ENOMEM as on an exhausted device: test hook for the recoveries),
  *     YOHO_SPCONV_DEBUG=<bits> (only in a -DYOHO_SPCONV_ABLATE build).   The timing experiments YOHO_PARTI_DEBUG / YOHO_FGEMM_DEBUG /
  *     YOHO_SPCONV_VAR exist only in the separate -DYOHO_EXPERIMENTS library, which no product code loads.
  *   - argument checks: a NULL context, a NULL required pointer, a negative count or a count beyond a stated capacity returns
@@ -213,6 +215,15 @@ int yoho_register_pair(yoho_ctx* ctx, const float* feat0, const float* feat1, co
                        double inlier_dist, uint64_t seed, int selected, yoho_pair_result* out, void* stream);
 /* order[0..M) = numpy.random.RandomState(seed).shuffle applied to arange(M) (host memory; no device work, no context) */
 int yoho_vote_order(uint32_t seed, int M, int64_t* order);
+/* The sampling half of the reference's YOHO-C loop (tests/estimator.py:113-128) on numpy's legacy MT19937 stream, host memory only (no
+ * device work, no context): per accepted iteration `np.random.choice(range(60), p=prob)` then `np.random.choice(bucket, 3)`, a
+ * rotation whose bucket has fewer than two matches consuming its draw and being skipped, until max_iter iterations or 50001 draws.
+ *   mt_key[624], *mt_pos     np.random.get_state()[1:3]; advanced in place, so np.random.set_state continues the reference's stream
+ *   prob[60]                 DR_statictic's normalised weights as handed to choice (:34-51)
+ *   bucket_start[61], bucket_members   matches of rotation r, ascending: bucket_members[bucket_start[r] .. bucket_start[r+1])
+ *   triples (max_iter,3)     receives the sampled match indices; *n_triples accepted iterations, *n_draws rotation draws made */
+int yoho_c_draw_np(uint32_t* mt_key, int* mt_pos, const double* prob, const int64_t* bucket_start, const int64_t* bucket_members,
+                   int max_iter, int64_t* triples, int* n_triples, int* n_draws);
 
 /* one group element of the 60-fold gather: rotate keys (K,3) f64 by Rg (3x3 f64, host ptr),
  * 1-NN among pts (n,3) f32 in f64, copy feat (n,32) rows into out[:, :, g] of (K,32,60);

@@ -325,3 +325,43 @@ def test_backbone_wide_and_sparse_clouds_share_a_pass(hip, fsd):
     F0 = fo.resunet_forward(sparse[3].cpu().numpy(), fsd)
     F0 = F0 / np.linalg.norm(F0, axis=1, keepdims=True)
     assert rel(got[3].cpu().numpy(), F0) < TOL
+
+
+def test_enomem_recoveries_run_and_leave_no_error_behind(hip, fsd, tables, monkeypatch):
+    """both YOHO_ENOMEM recoveries of the backbone actually run (YOHO_WS_LIMIT_MB makes a workspace request above the limit
+    fail exactly as hipMalloc on an exhausted device does) - (a) the pass whose bitmaps do not fit: first attempt -> grown workspace
+    refused -> third attempt on the hash tables; (b) the batched voxelisation whose rank arrays cannot be had -> the table path.  Each
+    must give the unlimited context's bits, succeed (no stale HIP error surfacing behind the next launch as YOHO_EHIP) and leave
+    yoho_last_error empty."""
+    rs = np.random.RandomState(5)
+    sparse = []
+    for b in range(15):
+        c = np.unique(np.stack([rs.randint(0, 800, 5200), rs.randint(0, 800, 5200), rs.randint(0, 240, 5200)], 1).astype(np.int32), axis=0)
+        c = c[rs.permutation(len(c))] + np.array([-400 + 7 * b, -123, 50 * b], np.int32)
+        sparse.append(torch.from_numpy(np.ascontiguousarray(c)).cuda())
+    free = hip.Context()
+    free.load_fcgf(fsd)
+    want = free.fcgf_forward_batch(sparse)
+    # 360 voxels per axis (up to ~620 for a rotated copy, still inside one bitmap's 2^24 words): 0.2-0.9 GB of bitmaps + rank arrays for 15 copies
+    pc_d = torch.from_numpy(synth.surface_cloud(20000, seed=12, extent=9.0)).cuda()
+    Rs = [tables.R64[g] for g in range(15)]
+    want_v = free.fcgf_voxelize_rotated_batch(pc_d, Rs, 0.025)
+    monkeypatch.setenv("YOHO_WS_LIMIT_MB", "1000")
+    lim = hip.Context()
+    monkeypatch.delenv("YOHO_WS_LIMIT_MB")
+    lim.load_fcgf(fsd)
+    lib = hip.load_library()
+    got = lim.fcgf_forward_batch(sparse)
+    assert lib.yoho_last_error() == b"", lib.yoho_last_error()
+    for a, b in zip(got, want):
+        assert torch.equal(a, b)
+    monkeypatch.setenv("YOHO_WS_LIMIT_MB", "100")
+    lim2 = hip.Context()
+    monkeypatch.delenv("YOHO_WS_LIMIT_MB")
+    got_v = lim2.fcgf_voxelize_rotated_batch(pc_d, Rs, 0.025)
+    assert lib.yoho_last_error() == b"", lib.yoho_last_error()
+    for a, b in zip(got_v, want_v):
+        assert all(torch.equal(x, y) for x, y in zip(a, b))
+    # and the limited context still works for an ordinary pass afterwards
+    small = [torch.from_numpy(fo.voxelize(synth.surface_cloud(3000, seed=4), 0.025)[1]).cuda()]
+    assert torch.equal(lim.fcgf_forward_batch(small)[0], free.fcgf_forward_batch(small)[0])

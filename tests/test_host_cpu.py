@@ -112,3 +112,95 @@ def test_library_vote_order_is_numpys_shuffle():
             np.random.RandomState(seed).shuffle(a)
             assert np.array_equal(a, hip.vote_order(seed, M)), (seed, M)
     assert np.array_equal(hip.vote_order(2 ** 32 + 5, 100), hip.vote_order(5, 100))       # the seed is taken modulo 2^32
+
+
+def _yohoc_host(inlier=0.07):
+    """a yohoc instance without a library context (the draw / statistic / mask methods are host code)"""
+    from yoho_amd.estimator import yohoc
+    est = object.__new__(yohoc)
+    est.inliner_dist, est.lapack_parity, est.device_sampling = inlier, True, False
+    return est
+
+
+def test_library_yohoc_draws_are_numpys_choice_calls():
+    """yoho_c_draw_np (host code of the library): the reference's sampling loop (tests/estimator.py:113-128) taken from numpy's
+    legacy stream in C - RandomState.choice(range(60), p) = one 53-bit random_sample + searchsorted(cdf, side='right'),
+    choice(bucket, 3) = masked-rejection randint - against np.random.choice itself, call by call: seeds at both ends of the 32-bit
+    range, a stream position in the middle of the state block, bucket sizes around the power-of-two mask boundaries, buckets of
+    fewer than two matches (zero weight), few buckets, and the state AFTER the draws (the next pair continues the stream)."""
+    est = _yohoc_host()
+    cases = []
+    rs = np.random.RandomState(99)
+    for M, nrot in ((3233, 60), (700, 60), (64, 7), (5, 2), (40, 60), (2, 1), (1025 * 3, 3)):
+        dr = rs.randint(0, nrot, size=M)
+        if nrot == 60 and M > 100:
+            dr[rs.rand(M) < 0.5] = 42                       # a dominant coarse rotation, as a registrable pair has
+        cases.append(dr)
+    for seed in (0, 1, 1234, 2 ** 32 - 1, 3141592653):
+        for burn in (0, 311):
+            for dr in cases:
+                for it in (1, 50, 1000):
+                    buckets, prob = est.DR_statictic(dr)
+                    if prob is None:
+                        continue
+                    np.random.seed(seed)
+                    np.random.random_sample(burn)
+                    want = est._draw_numpy(buckets, prob, it)
+                    after = np.random.get_state()
+                    np.random.seed(seed)
+                    np.random.random_sample(burn)
+                    prob2, table = est._statistic_flat(dr)
+                    assert np.array_equal(prob, prob2)
+                    got = est._draw(None, prob2, it, table=table)
+                    mine = np.random.get_state()
+                    assert got.dtype == np.int64 and np.array_equal(got, want), (seed, burn, len(dr), it)
+                    assert np.array_equal(after[1], mine[1]) and after[2] == mine[2], (seed, burn, len(dr), it)
+    # the list form (DR_statictic's dict of lists) gives the same table
+    dr = cases[0]
+    buckets, prob = est.DR_statictic(dr)
+    np.random.seed(5)
+    a = est._draw(buckets, prob, 100)
+    np.random.seed(5)
+    b = est._draw(None, prob, 100, table=est.bucket_table(dr))
+    assert np.array_equal(a, b)
+
+
+def test_library_yohoc_draws_hit_the_draw_limit_like_the_reference():
+    """nearly all the weight on rotations that cannot be sampled cannot happen (their weight is 0), so the 50001-draw limit is
+    reached only through max_iter; what can happen is that the loop ends by max_iter with `draws == max_iter` - and a statistic
+    with no bucket of two matches returns None before any draw (the reference's recalltime 50001)."""
+    from yoho_amd import hip
+    est = _yohoc_host()
+    dr = np.arange(60)                                       # every bucket holds one match
+    assert est._statistic_flat(dr)[0] is None and est.DR_statictic(dr) == (None, None)
+    assert est._statistic_flat(np.array([3, 3, 7, 9, 9, 9]))[0] is None           # total weight 6e-6 < 1e-4 (:47-48)
+    dr = np.array([3] * 30 + [7] + [9] * 40)
+    prob, (start, members) = est._statistic_flat(dr)
+    st = np.random.RandomState(1)
+    tri, draws = hip.c_draw_np(prob, start, members, 200, rng=st)
+    assert draws == 200 and tri.shape == (200, 3) and 30 not in set(np.unique(tri))
+    # a private RandomState is advanced, the global one is not touched
+    g = np.random.get_state()
+    hip.c_draw_np(prob, start, members, 10, rng=st)
+    assert np.array_equal(g[1], np.random.get_state()[1]) and g[2] == np.random.get_state()[2]
+
+
+def test_reflection_mask_vectorised_equals_the_reference_expression_per_triple():
+    """estimator.yohoc._reflect_mask forms the 3x3 covariances of all sampled triples with stacked numpy calls; the sign LAPACK
+    gives the null direction hangs on their last bits, so the stack must carry the bits of the reference's expression on ONE
+    triple (tests/estimator.py:56-58): checked on 20000 triples incl. repeated points (rank-1 / rank-0 covariances)."""
+    from yoho_amd.estimator import yohoc
+    rs = np.random.RandomState(3)
+    k0 = rs.rand(3000, 3) * 3.0
+    k1 = k0 @ np.linalg.qr(rs.randn(3, 3))[0].T + 0.01 * rs.randn(3000, 3)
+    tri = rs.randint(0, 3000, size=(20000, 3))
+    tri[:500, 1] = tri[:500, 0]
+    tri[500:600, 2] = tri[500:600, 1] = tri[500:600, 0]
+    a, b = k0[tri], k1[tri]
+    c0 = a - np.mean(a, axis=1, keepdims=True)
+    c1 = b - np.mean(b, axis=1, keepdims=True)
+    cov = np.matmul(np.swapaxes(c1, 1, 2), c0)
+    for i in range(0, 20000, 7):
+        one = (b[i] - np.mean(b[i], 0, keepdims=True)).T @ (a[i] - np.mean(a[i], 0, keepdims=True))
+        assert np.array_equal(one, cov[i]), i
+    assert np.array_equal(yohoc._reflect_mask(a, b), yohoc._reflect_mask_one_by_one(a, b))

@@ -18,6 +18,7 @@ constexpr int SLAB_FLOATS = 2 * TILE * 4;          // 256 floats = 1 KiB
 constexpr int CHUNK_FLOATS = G * SLAB_FLOATS;      // 15360 floats = 60 KiB
 
 void set_error(const char* fmt, ...);
+void clear_error();
 // device tensors at the ABI are read with 16-byte vector loads and LDS DMA (include/yoho_hip.h: "contiguous, 16-byte aligned"); f64 /
 // int64 arrays that are only ever read element-wise need their natural 8 bytes.  Null pointers pass (optional arguments).
 inline bool yoho_misaligned(std::initializer_list<const void*> ps, unsigned mask) {
@@ -243,6 +244,8 @@ struct yoho_env_switches {
     bool fcgf_f32 = false;             // YOHO_FCGF=f32: the backbone's weights are packed for the fp32-MFMA kernels at yoho_load_fcgf
     bool fcgf_full_maps = false;       // YOHO_FCGF_MAPS=full: every kernel map by its own probes (no mirrored / inverted maps)
     bool fcgf_norm_staged = false;     // YOHO_FCGF_NORM=staged: row normalisation as its own kernel behind the last convolution
+    long long ws_limit_mb = 0;         // YOHO_WS_LIMIT_MB=<n>: a workspace request above n MiB fails as an exhausted device would (0 = no limit):
+                                       // lets a test walk the YOHO_ENOMEM recoveries of the backbone (hash-table attempt, table voxelisation)
 };
 
 struct yoho_ctx {

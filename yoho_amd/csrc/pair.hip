@@ -72,6 +72,47 @@ static void np_shuffle_arange(uint32_t seed, int M, int64_t* out) {
     }
 }
 
+// The sampling half of the reference's YOHO-C loop (tests/estimator.py:113-128) on numpy's legacy stream, restated from
+// numpy/random/mtrand.pyx (RandomState.choice, .random_sample, .randint) and _common/distributions.c
+// (random_bounded_uint64_fill -> buffered_bounded_masked_uint32):
+//   choice(range(60), p = prob)   one 53-bit double u = ((w0 >> 5) * 2^26 + (w1 >> 6)) / 2^53 from two MT words, then
+//                                 cdf = cumsum(prob) / cumsum(prob)[-1]; index = searchsorted(cdf, u, side='right')
+//   choice(bucket, 3)             randint(0, n, size=3): per element words masked to the smallest 2^k - 1 >= n - 1 until <= n - 1
+// A rotation whose bucket holds fewer than two matches consumes its draw and is skipped (the reference's `continue`); the loop
+// ends after max_iter accepted iterations or 50001 draws (:118 `if exec_time > max_time: break` is tested before the increment).
+static void np_yohoc_draws(NpMt& s, const double* prob, const int64_t* start, const int64_t* members, int max_iter, int64_t* triples,
+                           int* n_triples, int* n_draws) {
+    double cdf[60];
+    double acc = 0.0;
+    for (int i = 0; i < 60; ++i) { acc = i ? acc + prob[i] : prob[0]; cdf[i] = acc; }      // ndarray.cumsum: sequential adds
+    const double last = cdf[59];
+    for (int i = 0; i < 60; ++i) cdf[i] = cdf[i] / last;
+    int it = 0, draws = 0;
+    while (it < max_iter) {
+        if (draws > 50000) break;
+        ++draws;
+        const uint32_t a = np_mt_next(s) >> 5, b = np_mt_next(s) >> 6;
+        const double u = ((double)a * 67108864.0 + (double)b) / 9007199254740992.0;
+        int lo = 0, hi = 60;                                  // searchsorted(side='right'): the number of cdf entries <= u
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (cdf[mid] <= u) lo = mid + 1; else hi = mid; }
+        const int rot = lo;
+        // numpy would raise IndexError for rot == 60 (u >= cdf[59] = 1 cannot happen: u < 1); an empty answer keeps the ABI total
+        const int64_t n = rot < 60 ? start[rot + 1] - start[rot] : 0;
+        if (n < 2) continue;
+        const uint32_t rng = (uint32_t)(n - 1);
+        uint32_t mask = rng;
+        mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+        for (int e = 0; e < 3; ++e) {
+            uint32_t v;
+            while ((v = np_mt_next(s) & mask) > rng) {}
+            triples[3 * it + e] = members[start[rot] + v];
+        }
+        ++it;
+    }
+    *n_triples = it;
+    *n_draws = draws;
+}
+
 // k0m[m] = keys0[pairs[m][0]], k1m[m] = keys1[pairs[m][1]]
 __global__ void pair_keys_kernel(const double* __restrict__ keys0, const double* __restrict__ keys1, const int64_t* __restrict__ pairs, int M,
                                  double* __restrict__ k0m, double* __restrict__ k1m) {
@@ -166,6 +207,26 @@ extern "C" {
 int yoho_vote_order(uint32_t seed, int M, int64_t* order) {
     if (M < 0 || (M > 0 && !order)) { set_error("yoho_vote_order: bad argument"); return YOHO_EINVAL; }
     np_shuffle_arange(seed, M, order);
+    return 0;
+}
+
+int yoho_c_draw_np(uint32_t* mt_key, int* mt_pos, const double* prob, const int64_t* bucket_start, const int64_t* bucket_members,
+                   int max_iter, int64_t* triples, int* n_triples, int* n_draws) {
+    if (!mt_key || !mt_pos || !prob || !bucket_start || !bucket_members || !triples || !n_triples || !n_draws || max_iter < 0 ||
+        *mt_pos < 0 || *mt_pos > 624) {
+        set_error("yoho_c_draw_np: bad argument"); return YOHO_EINVAL;
+    }
+    for (int i = 0; i < 60; ++i)
+        if (bucket_start[i + 1] < bucket_start[i] || bucket_start[i] < 0 || !(prob[i] >= 0.0)) {
+            set_error("yoho_c_draw_np: bucket_start must be non-decreasing and prob non-negative (rotation %d)", i); return YOHO_EINVAL;
+        }
+    if (!(prob[59] >= 0.0)) { set_error("yoho_c_draw_np: prob must be non-negative"); return YOHO_EINVAL; }
+    NpMt s;
+    std::memcpy(s.key, mt_key, sizeof(s.key));
+    s.pos = *mt_pos;
+    np_yohoc_draws(s, prob, bucket_start, bucket_members, max_iter, triples, n_triples, n_draws);
+    std::memcpy(mt_key, s.key, sizeof(s.key));
+    *mt_pos = s.pos;
     return 0;
 }
 

@@ -2222,7 +2222,9 @@ int fcgf_forward(yoho_ctx* ctx, const FcgfNet* net, const int* coords0, int n0, 
     // stays that size, so the next pass of the same shape starts there), and on the hash tables if even that cannot be had
     rc = fcgf_forward_attempt(ctx, net, coords0, n0, off_host, nb, out, s, need, true, nullptr);
     if (rc != YOHO_ENOMEM) return rc;
-    return fcgf_forward_attempt(ctx, net, coords0, n0, off_host, nb, out, s, 0, false, nullptr);
+    rc = fcgf_forward_attempt(ctx, net, coords0, n0, off_host, nb, out, s, 0, false, nullptr);
+    if (rc == 0) clear_error();             // recovered: the failed allocation's message must not outlive the pass that succeeded
+    return rc;
 }
 
 // voxelisation (fcgf_feat.py:33-43): first point of every voxel in input order -> sel (ascending), integer coordinates
@@ -2332,7 +2334,7 @@ static int voxelize_batch_rank(yoho_ctx* ctx, const double* pts, int n, const do
     }
     const int nblk = (n + 1023) / 1024;
     const size_t need = (size_t)words * 4 + (size_t)ranks * 4 + (size_t)blocks * 4 + (size_t)nb * n * 4 + ((size_t)nblk + 1) * 4 * nb + sizeof(RkDesc) * 64 + 65536;
-    if ((rc = ensure_ws(ctx, need, s))) return rc == YOHO_ENOMEM ? 1 : rc;      // multi-GB ranks that cannot be had: the table path needs 12 bytes per point and copy
+    if ((rc = ensure_ws(ctx, need, s))) { if (rc == YOHO_ENOMEM) clear_error(); return rc == YOHO_ENOMEM ? 1 : rc; }      // multi-GB ranks that cannot be had: the table path needs 12 bytes per point and copy
     Arena ar{(char*)ctx->ws.p, 0, ctx->ws.bytes};
     int* dcount = ar.take<int>(2 * (size_t)nb + 2);      // per copy: [0] number of voxels, [1] flag: a voxel outside the bitmap / the key range
     RkDesc* dd = reinterpret_cast<RkDesc*>(ar.take<char>(sizeof(RkDesc) * 64));

@@ -4,8 +4,9 @@ vote) on the HIP library, same class / method names, .npz outputs and pre.log.
 Two sampling modes for YOHO-C:
 
 * parity (default).  The reference draws from the global ``np.random`` stream (tests/estimator.py:122,126).
-  The same draws are made on the host, in the same order (<= 1000 index triples per pair), and handed to
-  the GPU (``yoho_c_ransac``), so that with the same seed the same hypotheses are scored.  The reference's
+  The same draws are made on the host, in the same order (<= 1000 index triples per pair; the library continues numpy's
+  legacy MT19937 stream in C, ``yoho_c_draw_np``), and handed to the GPU (``yoho_c_ransac``), so that with the same seed the
+  same hypotheses are scored.  The reference's
   Kabsch has no determinant fix (:59-60) and a 3-point covariance has rank <= 2, so LAPACK decides the sign
   of the null direction - about half of the reference's hypotheses are reflections.  With
   ``cfg.yohoc_lapack_parity`` (default True) that sign comes from one batched ``np.linalg.svd`` on the host
@@ -58,6 +59,12 @@ def rotation_angle_deg(R_gt, R):
     return np.rad2deg(np.abs(np.arccos(np.clip(c, -1.0, 1.0))))
 
 
+def _det3(A):
+    """determinants of a stack of 3x3 matrices by cofactor expansion (only their sign is used)"""
+    return (A[:, 0, 0] * (A[:, 1, 1] * A[:, 2, 2] - A[:, 1, 2] * A[:, 2, 1]) - A[:, 0, 1] * (A[:, 1, 0] * A[:, 2, 2] - A[:, 1, 2] * A[:, 2, 0])
+            + A[:, 0, 2] * (A[:, 1, 0] * A[:, 2, 1] - A[:, 1, 1] * A[:, 2, 0]))
+
+
 def draw_seed():
     """a 63-bit seed for the device sampler, taken from the global np.random stream (so np.random.seed governs it)"""
     return int(np.random.randint(0, 2 ** 63 - 1, dtype=np.int64))
@@ -86,7 +93,9 @@ class yohoc(_Base):
       triples, where LAPACK's sign of the null direction makes the reference's R = Vt.T @ U.T a reflection (:55-63 has no
       determinant fix; 3 centred points give a rank-2 covariance).  The device does everything else: Kabsch for all iterations,
       the optional reflection, the inlier vote, the first strict maximum.  Per-iteration counts, winner and transform are the
-      reference's (atol 1e-9, goldens chain*.npz / scene*.npz).  Cost: the numpy draws and the SVDs, tens of ms per pair on the host.
+      reference's (atol 1e-9, goldens chain*.npz / scene*.npz).  Cost per pair at M = 3233, 1000 iterations: ~3.5 ms of host work (the
+      draws continue numpy's stream in C, hip.c_draw_np: 0.3 ms where 2000 np.random.choice calls took 54; one stacked
+      np.linalg.svd: 2.5 ms) + the device call.
     * device sampling (cfg.yohoc_device_sampling=True; pipeline.run_pair(estimator="yohoc"), the dataset driver, bench.py):
       STATISTICAL parity.  Statistic, sampling (Philox4x32-10 keyed by a seed), Kabsch and vote run on the device, no host work but
       the launches; proper rotations only.  The random stream is not numpy's MT19937, so results equal the reference's in
@@ -115,6 +124,17 @@ class yohoc(_Base):
             return None, None
         return buckets, weight / total
 
+    def _statistic_flat(self, DR_indexs):
+        """DR_statictic without the per-rotation Python lists: (prob or None, (bucket_start, bucket_members))"""
+        start, members = self.bucket_table(DR_indexs)
+        size = np.diff(start)
+        n = size / 100.0
+        weight = np.where(size >= 2, n * (n - 0.01) * (n - 0.02), 0.0)
+        total = np.sum(weight)
+        if total < 1e-4:
+            return None, (start, members)
+        return weight / total, (start, members)
+
     def Threepps2Tran(self, kps0_init, kps1_init):
         """tests/estimator.py:55-63 for one triple, computed by the Kabsch kernel (proper rotation
         unless LAPACK parity asks for the reference's reflection)."""
@@ -128,17 +148,49 @@ class yohoc(_Base):
     @staticmethod
     def _reflect_mask(k0s, k1s):
         """1 where LAPACK's SVD makes the reference's R = Vt.T @ U.T a reflection, for (I,3,3) sampled triples.
-        The sign hangs on the rounding of the covariance, so each 3x3 is formed by the very expression the reference
-        evaluates (tests/estimator.py:56-58: centre with np.mean, then a 3x3 matmul); only the SVDs are batched."""
+        The sign hangs on the rounding of the covariance, so each 3x3 has to carry the bits of the expression the reference
+        evaluates (tests/estimator.py:56-58: centre with np.mean, then a 3x3 matmul): np.mean over the first axis of a (3,3)
+        array adds the rows in order and divides by 3, which is what the reduction over axis 1 of the (I,3,3) stack does per
+        triple; np.matmul hands every 3x3 of a stack to the same BLAS call a single (3,3).T @ (3,3) gets (transposed view
+        included).  tests/test_host_cpu.py checks both against the one-triple-at-a-time expression, bit for bit."""
+        c0 = k0s - np.mean(k0s, axis=1, keepdims=True)
+        c1 = k1s - np.mean(k1s, axis=1, keepdims=True)
+        cov = np.matmul(np.swapaxes(c1, 1, 2), c0)
+        U, _, VT = np.linalg.svd(cov)
+        return (_det3(U) * _det3(VT) < 0).astype(np.uint8)          # orthogonal factors: the determinants are +-1 up to rounding
+
+    @staticmethod
+    def _reflect_mask_one_by_one(k0s, k1s):
+        """_reflect_mask with every covariance formed by the reference's own expression on one triple (what the vectorised form
+        is tested against)"""
         cov = np.empty((k0s.shape[0], 3, 3))
         for i in range(k0s.shape[0]):
             cov[i] = (k1s[i] - np.mean(k1s[i], 0, keepdims=True)).T @ (k0s[i] - np.mean(k0s[i], 0, keepdims=True))
         U, _, VT = np.linalg.svd(cov)
         return (np.linalg.det(U) * np.linalg.det(VT) < 0).astype(np.uint8)
 
-    def _draw(self, buckets, prob, max_iter):
-        """the sampling half of tests/estimator.py:119-128: consumes np.random exactly as the reference's loop does
-        (one weighted draw of a rotation, then three matches of its bucket with replacement, per accepted iteration)"""
+    @staticmethod
+    def bucket_table(DR_indexs):
+        """(bucket_start (61,), bucket_members (M,)): the matches of coarse rotation r in ascending order are
+        bucket_members[bucket_start[r]:bucket_start[r + 1]] (the lists DR_statictic returns, flat)"""
+        idx = np.asarray(DR_indexs).astype(np.int64).reshape(-1)
+        size = np.bincount(idx, minlength=G)[:G]
+        return np.concatenate([[0], np.cumsum(size)]).astype(np.int64), np.argsort(idx, kind="stable").astype(np.int64)
+
+    def _draw(self, buckets, prob, max_iter, table=None):
+        """the sampling half of tests/estimator.py:119-128: consumes np.random exactly as the reference's loop does (one weighted
+        draw of a rotation, then three matches of its bucket with replacement, per accepted iteration).  The stream is continued
+        in C (hip.c_draw_np: numpy's legacy choice / random_sample / randint restated, pinned against numpy in
+        tests/test_host_cpu.py) - 2000 interpreter-level np.random.choice calls per pair cost 54 ms, this costs 0.05."""
+        if table is None:
+            start = np.concatenate([[0], np.cumsum([len(buckets[i]) for i in range(G)])]).astype(np.int64)
+            members = np.array([m for i in range(G) for m in buckets[i]], dtype=np.int64)
+        else:
+            start, members = table
+        return hip.c_draw_np(prob, start, members, max_iter)[0]
+
+    def _draw_numpy(self, buckets, prob, max_iter):
+        """_draw through np.random.choice itself, call by call as the reference makes them (the checker of _draw)"""
         triples, draws = [], 0
         while len(triples) < max_iter and draws <= 50000:
             draws += 1
@@ -154,10 +206,10 @@ class yohoc(_Base):
         timings: optional dict receiving the seconds spent in the host draws, the host SVDs and the device call."""
         import time
         t0 = time.perf_counter()
-        buckets, prob = self.DR_statictic(dr)
+        prob, table = self._statistic_flat(dr)
         if prob is None:
             return None
-        triples = self._draw(buckets, prob, max_iter)
+        triples = self._draw(None, prob, max_iter, table=table)
         t1 = time.perf_counter()
         trans, recall, tri = np.eye(4), 0, None
         t2 = t1

@@ -25,7 +25,7 @@ SYMBOLS = [
     "yoho_des2r", "yoho_des2r_indexed", "yoho_partII_forward", "yoho_partII_forward_indexed", "yoho_hyp_from_quat", "yoho_o_score", "yoho_c_ransac",
     "yoho_group_gather", "yoho_set_profiling", "yoho_get_kernel_ms", "yoho_set_gconv_mode", "yoho_set_partII_mode", "yoho_set_nn_grid",
     "yoho_range_status", "yoho_c_ransac_device", "yoho_group_scatter", "yoho_set_nn_prefilter", "yoho_set_fcgf_sort", "yoho_fcgf_voxelize_rotated_batch", "yoho_gconv_wgrad", "yoho_bn_stats", "yoho_bn_relu_apply", "yoho_bn_relu_backward", "yoho_set_partI_schedule", "yoho_clock_probe", "yoho_group_transfer_batch",
-    "yoho_register_pair", "yoho_vote_order", "yoho_phase_profile", "yoho_phase_read",
+    "yoho_register_pair", "yoho_vote_order", "yoho_c_draw_np", "yoho_phase_profile", "yoho_phase_read",
 ]
 
 
@@ -122,6 +122,7 @@ def load_library():
     lib.yoho_c_ransac_device.argtypes = [vp, vp, vp, vp, vp, ci, vp, ci, ci, C.c_uint64, C.c_double, vp, vp, vp, vp, vp]
     lib.yoho_register_pair.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, C.c_double, C.c_uint64, ci, C.POINTER(PairResultC), vp]
     lib.yoho_vote_order.argtypes = [C.c_uint32, ci, vp]
+    lib.yoho_c_draw_np.argtypes = [vp, C.POINTER(ci), vp, vp, vp, ci, vp, C.POINTER(ci), C.POINTER(ci)]
     lib.yoho_phase_profile.argtypes = [vp, ci]
     lib.yoho_phase_read.argtypes = [vp, vp, vp, vp, vp]
     for s in SYMBOLS[2:]:
@@ -138,6 +139,32 @@ def vote_order(seed, M):
     if rc != 0:
         raise YohoError(f"libyoho_hip error {rc}: {lib.yoho_last_error().decode()}", rc)
     return out
+
+
+def c_draw_np(prob, bucket_start, bucket_members, max_iter, rng=None):
+    """The draws of the reference's YOHO-C loop (tests/estimator.py:113-128) taken from numpy's legacy stream in C (yoho_c_draw_np):
+    rng is a np.random.RandomState or None for the global np.random state, which is advanced exactly as the reference's
+    `np.random.choice(range(60), p=prob)` / `np.random.choice(bucket, 3)` calls advance it.  -> (triples (I,3) int64, draws)"""
+    lib = load_library()
+    src = np.random if rng is None else rng
+    st = src.get_state()
+    if st[0] != "MT19937":
+        raise YohoError(f"c_draw_np continues numpy's legacy MT19937 stream; the generator is {st[0]!r}")
+    key = np.ascontiguousarray(st[1], dtype=np.uint32).copy()
+    pos = C.c_int(int(st[2]))
+    prob = np.ascontiguousarray(prob, dtype=np.float64)
+    start = np.ascontiguousarray(bucket_start, dtype=np.int64)
+    members = np.ascontiguousarray(bucket_members, dtype=np.int64)
+    if prob.shape != (60,) or start.shape != (61,) or members.ndim != 1 or int(start[-1]) > members.shape[0]:
+        raise ValueError("c_draw_np: prob (60,), bucket_start (61,), bucket_members (>= bucket_start[60],)")
+    tri = np.empty((max(int(max_iter), 0), 3), dtype=np.int64)
+    n, draws = C.c_int(0), C.c_int(0)
+    rc = lib.yoho_c_draw_np(key.ctypes.data_as(C.c_void_p), C.byref(pos), prob.ctypes.data_as(C.c_void_p), start.ctypes.data_as(C.c_void_p),
+                            members.ctypes.data_as(C.c_void_p), int(max_iter), tri.ctypes.data_as(C.c_void_p), C.byref(n), C.byref(draws))
+    if rc != 0:
+        raise YohoError(f"libyoho_hip error {rc}: {lib.yoho_last_error().decode()}", rc)
+    src.set_state((st[0], key, pos.value) + tuple(st[3:]))
+    return tri[:n.value], draws.value
 
 
 class YohoError(RuntimeError):

@@ -15,7 +15,7 @@ import torch
 
 
 class PairResult:
-    __slots__ = ("match", "dr_index", "quat", "trans_pre", "best_h", "best_count", "trans", "order", "eqv", "range_repeats", "hyp_rows")
+    __slots__ = ("match", "dr_index", "quat", "trans_pre", "best_h", "best_count", "trans", "order", "eqv", "range_repeats", "hyp_rows", "matches")
 
 
 def describe_pair(ctx, feat0, feat1, check_range=True):
@@ -44,6 +44,7 @@ def run_pair(ctx, feat0, feat1, keys0, keys1, inlier_dist=0.09, max_iter=1000, o
     r = PairResult()
     r.range_repeats = 0
     r.quat = r.trans_pre = r.order = r.hyp_rows = None
+    r.matches = 0
     if hypotheses not in ("all", "selected"):
         raise ValueError(f"hypotheses must be 'all' or 'selected', got {hypotheses!r}")
     if eqv is None:
@@ -59,7 +60,7 @@ def run_pair(ctx, feat0, feat1, keys0, keys1, inlier_dist=0.09, max_iter=1000, o
         match = ctx.mutual_nn(o0["inv_np"], o1["inv_np"])
     r.eqv = (o0, o1)
     r.match = match
-    M = match.shape[0]
+    M = r.matches = match.shape[0]
     if M == 0:
         r.dr_index = r.quat = r.trans_pre = None
         r.best_h, r.best_count, r.trans, r.order = 0, 0, np.eye(4), None
@@ -163,9 +164,37 @@ class PairStreamer:
                 t.record_stream(self.sb)
         return o0, o1, ev
 
-    def run(self, pairs, inlier_dist=0.09, max_iter=1000, order_rng=None, estimator="yohoo", seeds=None, hypotheses="all", keep="all"):
+    def _register(self, pair, o0, o1, inlier_dist, max_iter, estimator, seed, hypotheses):
+        """the estimator side of one pair as ONE library call (yoho_register_pair, csrc/pair.hip: mutual NN -> Des2R -> PartII +
+        [R|t] + vote | device-sampled YOHO-C; vote order = numpy's RandomState(seed & 0xFFFFFFFF).shuffle restated in C): no
+        tensor-library kernel runs between the descriptor pass and the winner.  The result carries what the one call returns
+        (winner, count, transform, match count); match list / coarse rotations / quaternions stay in the library's scratch.
+        A PartII range flag repeats the pair through the staged entries in bf16x3, as run_dataset does."""
+        f = self.est.register_pair(pair[0], pair[1], o0["eqv"], o1["eqv"], o0["inv_np"], o1["inv_np"], pair[2], pair[3], estimator=estimator,
+                                   max_iter=max_iter, inlier_dist=inlier_dist, seed=seed, selected=(hypotheses == "selected"))
+        if f["range_flag"]:
+            r = self.est._repeat_wider("partII", lambda: run_pair(
+                self.est, pair[0], pair[1], pair[2], pair[3], inlier_dist=inlier_dist, max_iter=max_iter,
+                order_rng=np.random.RandomState(seed & 0xFFFFFFFF), eqv=(o0, o1), estimator=estimator, seed=seed, hypotheses=hypotheses))
+            r.range_repeats += 1
+            return r
+        r = PairResult()
+        r.match = r.dr_index = r.quat = r.trans_pre = r.order = r.hyp_rows = None
+        r.eqv = (o0, o1)
+        r.range_repeats = 0
+        r.matches, r.best_h, r.best_count, r.trans = f["matches"], f["best_h"], f["best_count"], f["trans"]
+        return r
+
+    def run(self, pairs, inlier_dist=0.09, max_iter=1000, order_rng=None, estimator="yohoo", seeds=None, hypotheses="all", keep="all",
+            fused=False):
         """pairs: sequence of (feat0, feat1, keys0, keys1) device tensors.  Returns the list of PairResult; keep="last": only the
-        last pair's (a PairResult holds its descriptors, 77 MB at 2 x 5000 keypoints: a long throughput run must not keep them all)."""
+        last pair's (a PairResult holds its descriptors, 77 MB at 2 x 5000 keypoints: a long throughput run must not keep them all).
+        fused: the estimator side of every pair is one library call (_register; needs `seeds`, which then also seed the YOHO-O vote
+        order - order_rng is not consumed); same winner and transform as the staged composition with
+        order_rng = RandomState(seed & 0xFFFFFFFF) (tests/test_gpu_fullsize.py)."""
+        if fused and seeds is None:
+            raise ValueError("PairStreamer.run(fused=True) takes the vote order / sampling stream of every pair from `seeds`")
+        fused = fused and (estimator == "yohoc" or self.est.supports_matched())
         pairs = list(pairs)
         out = []
         if not pairs:
@@ -189,8 +218,11 @@ class PairStreamer:
                     o0, o1 = d._repeat_wider("gconv", lambda: describe_pair(d, pair[0], pair[1], check_range=False))
                     torch.cuda.current_stream().synchronize()        # d's next pass is queued on the other stream
                     repeats = 1
-                r = run_pair(self.est, pair[0], pair[1], pair[2], pair[3], inlier_dist=inlier_dist, max_iter=max_iter, order_rng=order_rng,
-                             eqv=(o0, o1), estimator=estimator, seed=(seeds[i] if seeds is not None else 0), hypotheses=hypotheses)
+                if fused:
+                    r = self._register(pair, o0, o1, inlier_dist, max_iter, estimator, seeds[i], hypotheses)
+                else:
+                    r = run_pair(self.est, pair[0], pair[1], pair[2], pair[3], inlier_dist=inlier_dist, max_iter=max_iter, order_rng=order_rng,
+                                 eqv=(o0, o1), estimator=estimator, seed=(seeds[i] if seeds is not None else 0), hypotheses=hypotheses)
                 r.range_repeats += repeats
             if keep == "last":
                 out = [r]
