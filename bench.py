@@ -252,6 +252,9 @@ def main():
     ap.add_argument("--staged", action="store_true",
                     help="compose the estimator side of every pair from the staged entries in Python (pipeline.run_pair: tensor-library index "
                          "kernels between the stages) instead of one yoho_register_pair call per pair")
+    ap.add_argument("--timed-only", action="store_true",
+                    help="warm-up and the headline's timed regions only, then a short JSON line: the kernel trace of this command contains "
+                         "nothing but what the timed steps launch (profiles/rNN_kernel_trace_bench_timed.md)")
     ap.add_argument("--in-flight", type=int, choices=[1, 2], default=2,
                     help="pairs in flight: 2 (default) queues the descriptor pass of the next pair on a second HIP stream before waiting for "
                          "the current pair's read-backs (pipeline.PairStreamer); 1 runs the pairs strictly one after the other")
@@ -391,6 +394,14 @@ def main():
     g0 = guard_total()
     dt, dts, rank_dts, res_timed, power_steps = timed("yohoo", args.steps, max(args.warmup, 1), args.repeats)
     headline_range_repeats = guard_total() - g0
+    if args.timed_only:
+        if rank == 0:
+            print(json.dumps({"metric": "keypoints/sec (5000 kp x60 rot desc+YOHO-O)", "value": round(pairs_per_step * 2 * KP * args.steps / dt, 1),
+                              "unit": "keypoints/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+                              "timed_only": True, "staged": bool(args.staged), "matches": int(res_timed.matches), "winner": int(res_timed.best_h),
+                              "range_repeats": headline_range_repeats}), flush=True)
+        ydist.barrier()
+        return
     # the last timed pair once more through the staged entries (untimed) with the vote order of its seed: the stage outputs the legs
     # below need (match list, coarse rotations, descriptors), and the check that the one-call pair of the timed steps picked the same
     # winner and transform

@@ -372,7 +372,9 @@ int yoho_range_status(yoho_ctx* ctx, int* partI_overflow, int* partII_overflow, 
  * running head -> 4 irrep GEMMs + 3 transforms -> tail on its own workspace slice, so a chunk's intermediates (0.5 MB per
  * keypoint) can stay in the 256 MB Infinity Cache between layers.  streams = 2: chunks alternate between the caller's stream and
  * a stream owned by the context, forked from / joined into the caller's stream with events, so the call keeps its contract
- * (asynchronous, ordered on the caller's stream).  Results are bit-identical for every schedule. */
+ * (asynchronous, ordered on the caller's stream).  Results are bit-identical for every schedule in every arithmetic mode except the
+ * opt-in mode 7 ('fgemm8'): its fp8 correction planes are scaled by one amax word per launch, so there a keypoint's bits depend on
+ * which keypoints share its launch (differences within the mode's 1e-5 of the fp32 reference). */
 int yoho_set_partI_schedule(yoho_ctx* ctx, int chunk_kp, int streams);
 
 /* timing hook for bench.py: device time (ms) of the stages of the last yoho_partI_forward pass, measured with hipEvents

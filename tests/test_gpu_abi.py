@@ -61,6 +61,12 @@ def test_every_entry_point_refuses_bad_arguments(env, hip):
     ms = C.c_float(0)
 
     # (entry point, arguments, expected code, text the message must contain)
+    # host-side arguments of yoho_c_draw_np (numpy arrays kept alive by these names)
+    _key = np.zeros(624, np.uint32); _prob = np.full(60, 1.0 / 60); _start = np.arange(61, dtype=np.int64) * 2
+    _start_bad = _start.copy(); _start_bad[7] = 99
+    _members = np.arange(120, dtype=np.int64); _tri = np.zeros((4, 3), np.int64)
+    hkey, hprob, hstart, hstart_bad, hmembers, htri = (C.c_void_p(a_.ctypes.data) for a_ in (_key, _prob, _start, _start_bad, _members, _tri))
+    mtpos, badpos = C.c_int(624), C.c_int(700)
     cases = [
         ("yoho_ctx_create", (0, N, N, N, C.byref(C.c_void_p())), EINVAL, "yoho_ctx_create"),
         ("yoho_load_partI", (N, N), EINVAL, "yoho_load_partI"),
@@ -142,6 +148,10 @@ def test_every_entry_point_refuses_bad_arguments(env, hip):
         ("yoho_register_pair", (h, p(x), p(x), p(eqv), p(eqv), p(inv), p(inv), p(k0), p(k1), 8, 8, 0, 100, 0.09, 1, 1, N, N), EINVAL, "yoho_register_pair"),
         ("yoho_vote_order", (1, -1, N), EINVAL, "yoho_vote_order"),
         ("yoho_vote_order", (1, 5, N), EINVAL, "yoho_vote_order"),
+        ("yoho_c_draw_np", (N, C.byref(mtpos), hprob, hstart, hmembers, 4, htri, C.byref(one), C.byref(one)), EINVAL, "yoho_c_draw_np"),
+        ("yoho_c_draw_np", (hkey, C.byref(badpos), hprob, hstart, hmembers, 4, htri, C.byref(one), C.byref(one)), EINVAL, "yoho_c_draw_np"),
+        ("yoho_c_draw_np", (hkey, C.byref(mtpos), hprob, hstart_bad, hmembers, 4, htri, C.byref(one), C.byref(one)), EINVAL, "non-decreasing"),
+        ("yoho_c_draw_np", (hkey, C.byref(mtpos), hprob, hstart, hmembers, -1, htri, C.byref(one), C.byref(one)), EINVAL, "yoho_c_draw_np"),
         ("yoho_set_gconv_mode", (h, 9), EINVAL, "yoho_set_gconv_mode"),
         ("yoho_set_gconv_mode", (N, 4), EINVAL, "yoho_set_gconv_mode"),
         ("yoho_set_partII_mode", (h, -1), EINVAL, "yoho_set_partII_mode"),

@@ -264,9 +264,13 @@ def test_extractor_outputs_stop_being_pinned_beyond_the_budget(sd1, monkeypatch)
     from yoho_amd import yoho_extract as ye
 
     class Stub:
+        feats = {}                                                     # the 60 rotated copies of a call share one feature table (360 calls here)
+
         def run(self, pc, voxel_size):
-            f = torch.from_numpy(synth.unit_features(len(pc), seed=1)[:, :, 0].copy())
-            return pc, f / f.norm(dim=1, keepdim=True)
+            if len(pc) not in self.feats:
+                f = torch.from_numpy(synth.unit_features(len(pc), seed=1)[:, :, 0].copy())
+                self.feats[len(pc)] = f / f.norm(dim=1, keepdim=True)
+            return pc, self.feats[len(pc)]
     pc = synth.surface_cloud(600, seed=2)
     ex = ye.yoho_extractor(fcgf_ckpt=None, yoho_ckpt=sd1, fcgf=Stub())
     gc.collect()

@@ -242,8 +242,9 @@ def _full_size_pass(fx, pc_d, Rs):
 def test_backbone_fifteen_copy_pass_at_benchmarked_size_vs_oracle(hip, fsd, tables):
     """What only exists at 300 k points x 15 copies (1.3 M voxels in one pass): runs and 2048-row workgroups that straddle cloud
     boundaries (copy sizes are no multiples of anything), 15 clouds sharing every launch, rank-ordered bitmaps of 15 boxes, the
-    1024-entry scan blocks of a level with > 1 M rows.  Copies 0, 7 and 14 of the first pass of yoho_extractor.run are compared with the
-    oracle ROW FOR ROW (selected points and voxel coordinates bit-exact, features to 1e-5), through the same calls the extractor makes
+    1024-entry scan blocks of a level with > 1 M rows.  Copy 7 of the first pass of yoho_extractor.run is compared with the
+    oracle ROW FOR ROW (selected points and voxel coordinates bit-exact, features to 1e-5), copies 0 and 14 with the oracle's voxelisation
+    and with a pass of that copy alone (bit for bit), through the same calls the extractor makes
     (fcgf_extractor.extract_rotated_batch = yoho_fcgf_voxelize_rotated_batch -> yoho_fcgf_forward_batch); the hash-table coordinate maps
     give the same bits as the default bitmaps at this size, and five repeats of the pass are bit-identical."""
     from yoho_amd.fcgf_feat import fcgf_extractor
@@ -262,12 +263,20 @@ def test_backbone_fifteen_copy_pass_at_benchmarked_size_vs_oracle(hip, fsd, tabl
     bounds = np.cumsum(sizes)[:-1]
     assert all(b % 2048 != 0 for b in bounds) and all(b % 1024 != 0 for b in bounds)
     worst = 0.0
+    # The oracle (a CPU pass of ~70 s per copy on the GPU box) pins an INTERIOR copy row for row; the first and the last copy - whose
+    # rows sit at the two ends of every shared launch - are pinned to it through the library itself: their voxelisation against the
+    # oracle's, their features against a pass of that copy ALONE (bit for bit: a cloud's rows do not depend on which clouds share its
+    # pass, test_batched_clouds_equal_separate_passes at small size), which the oracle pins at 1.5 k - 6 k points (test_backbone_vs_oracle).
     for j in (0, 7, 14):
         rot = pc @ Rs[j].T
         s0, c0 = fo.voxelize(rot, 0.025)
         sel, F, ps = res[j]
         assert np.array_equal(sel.cpu().numpy(), s0), j
         assert np.allclose(ps.cpu().numpy(), rot[s0].astype(np.float32), rtol=0, atol=5e-7)
+        if j != 7:
+            alone = fx.extract_rotated_batch(pc_d, [Rs[j]], 0.025)[0]
+            assert torch.equal(alone[0], sel) and torch.equal(alone[1], F) and torch.equal(alone[2], ps), j
+            continue
         F0 = fo.extract_features(rot, 0.025, fsd)[1]
         Fj = F.cpu().numpy()
         assert Fj.shape == F0.shape and np.isfinite(Fj).all()
@@ -275,7 +284,7 @@ def test_backbone_fifteen_copy_pass_at_benchmarked_size_vs_oracle(hip, fsd, tabl
         worst = max(worst, e)
         assert e < TOL, (j, e)
         assert np.abs(Fj - F0).max(axis=1).max() < 5e-6               # row for row (rows are unit vectors: absolute = relative)
-    print("fcgf backbone, 15-copy pass, %d voxels (copies %d..%d): worst rel err of copies 0/7/14 vs the oracle %.3g" % (total, min(sizes), max(sizes), worst))
+    print("fcgf backbone, 15-copy pass, %d voxels (copies %d..%d): worst rel err of copy 7 vs the oracle (copies 0 / 14: bit-identical to their single-cloud passes) %.3g" % (total, min(sizes), max(sizes), worst))
     # the same pass: five repeats, and once with hash-table coordinate maps - identical bits
     for _ in range(5):
         again = _full_size_pass(fx, pc_d, Rs)
@@ -331,8 +340,10 @@ def test_enomem_recoveries_run_and_leave_no_error_behind(hip, fsd, tables, monke
     """both YOHO_ENOMEM recoveries of the backbone actually run (YOHO_WS_LIMIT_MB makes a workspace request above the limit
     fail exactly as hipMalloc on an exhausted device does) - (a) the pass whose bitmaps do not fit: first attempt -> grown workspace
     refused -> third attempt on the hash tables; (b) the batched voxelisation whose rank arrays cannot be had -> the table path.  Each
-    must give the unlimited context's bits, succeed (no stale HIP error surfacing behind the next launch as YOHO_EHIP) and leave
-    yoho_last_error empty."""
+    must succeed (no stale HIP error surfacing behind the next launch as YOHO_EHIP), leave yoho_last_error empty and give the unlimited
+    context's result: (b) bit for bit (integers); (a) to the backbone's tolerance - the last-resort attempt cannot grow the workspace for
+    the first convolution's occupancy bitmaps either, so that layer runs on its hash-probe kernel, whose sums differ from the bitmap
+    kernel's in the last bit (measured 1.2e-7 - 1.8e-7 absolute on unit rows)."""
     rs = np.random.RandomState(5)
     sparse = []
     for b in range(15):
@@ -346,7 +357,7 @@ def test_enomem_recoveries_run_and_leave_no_error_behind(hip, fsd, tables, monke
     pc_d = torch.from_numpy(synth.surface_cloud(20000, seed=12, extent=9.0)).cuda()
     Rs = [tables.R64[g] for g in range(15)]
     want_v = free.fcgf_voxelize_rotated_batch(pc_d, Rs, 0.025)
-    monkeypatch.setenv("YOHO_WS_LIMIT_MB", "1000")
+    monkeypatch.setenv("YOHO_WS_LIMIT_MB", "1300")       # first attempt asks for 1.13 GB, the grown one for 1.8
     lim = hip.Context()
     monkeypatch.delenv("YOHO_WS_LIMIT_MB")
     lim.load_fcgf(fsd)
@@ -354,7 +365,8 @@ def test_enomem_recoveries_run_and_leave_no_error_behind(hip, fsd, tables, monke
     got = lim.fcgf_forward_batch(sparse)
     assert lib.yoho_last_error() == b"", lib.yoho_last_error()
     for a, b in zip(got, want):
-        assert torch.equal(a, b)
+        assert rel(a.cpu().numpy(), b.cpu().numpy()) < TOL
+    assert any(not torch.equal(a, b) for a, b in zip(got, want)), "the limit did not force the last-resort attempt (its first layer differs in the last bit)"
     monkeypatch.setenv("YOHO_WS_LIMIT_MB", "100")
     lim2 = hip.Context()
     monkeypatch.delenv("YOHO_WS_LIMIT_MB")

@@ -1,4 +1,4 @@
-// Timing + numerics probe for the lever DESIGN section 8 names for the next round: the two CORRECTION products of the fp16x2 split on the
+// Timing + numerics probe for the lever NOTEBOOK.md section 8 names for the next round: the two CORRECTION products of the fp16x2 split on the
 // fp8 matrix pipe.
 //
 // The irrep GEMMs evaluate a * w as a_h w_h + a_h w_l + a_l w_h on v_mfma_f32_32x32x16_f16 (3 MFMAs per term).  The corrections are

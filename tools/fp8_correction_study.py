@@ -1,4 +1,4 @@
-"""Would the two CORRECTION products of the fp16x2 split survive fp8?  (CPU, numpy)
+"""Would the two CORRECTION products of the fp16x2 split survive fp8?  (CPU, numpy; NOTEBOOK.md section 8)
 
 The irrep GEMMs evaluate every product a * w as a_h w_h + a_h w_l + a_l w_h (a = a_h + a_l, two fp16 planes; 3 MFMAs per term at the fp16
 rate).  The two correction terms are 2^-11 of the main one; on gfx950 an fp8 MFMA runs at twice the fp16 rate, so evaluating them in fp8

@@ -66,16 +66,31 @@ def build(force=False, verbose=True):
         objs.append(obj)
     # the ISA audit of gft16x_kernel's hidden ticket request runs on assembly made with THESE flags, as part of the build
     asm = os.path.join(OBJDIR, "gft16.s")
-    procs.append(("gft16.hip (assembly for the ISA audit)", subprocess.Popen(asm_command("gft16.hip", asm), stderr=subprocess.DEVNULL)))
+    procs.append(("gft16.hip (assembly for the ISA audit)", subprocess.Popen(asm_command("gft16.hip", asm))))
     for src, p in procs:
         if p.wait() != 0:
             raise RuntimeError(f"hipcc failed on {src}")
-    from .isa_audit import audit_file
-    ok, msg = audit_file(asm)
-    if verbose:
-        print("ISA audit:", msg, flush=True)
-    if not ok:
-        raise RuntimeError("ISA audit of gft16x_kernel failed (the library was NOT linked): " + msg)
+    # The audit matches mnemonics of THIS toolchain's output.  A positive violation (the ticket register referenced elsewhere, scratch,
+    # AGPR copies) always fails the build.  "Pattern not found" - another hipcc spelling or scheduling the request differently - fails it
+    # too unless YOHO_ISA_AUDIT=warn says the builder has looked (then the library is linked with static striding advised:
+    # YOHO_XF_STEAL=0 avoids the audited code path at run time); YOHO_ISA_AUDIT=skip skips the audit.
+    policy = os.environ.get("YOHO_ISA_AUDIT", "strict")
+    if policy != "skip":
+        from .isa_audit import audit_file
+        try:
+            ok, msg = audit_file(asm)
+            found = not msg.startswith(("expected exactly one hidden ticket request", "the ticket register")) or ok
+        except RuntimeError as e:                # the kernel itself was not found in the assembly
+            ok, msg, found = False, str(e), False
+        if verbose:
+            print("ISA audit:", msg, flush=True)
+        if not ok:
+            if policy == "warn" and not found:
+                print("WARNING: the ISA audit did not find the pattern it checks (another toolchain?); linking anyway because YOHO_ISA_AUDIT=warn. "
+                      "Run contexts with YOHO_XF_STEAL=0 unless the assembly has been inspected by hand.", file=sys.stderr, flush=True)
+            else:
+                raise RuntimeError("ISA audit of gft16x_kernel failed (the library was NOT linked; YOHO_ISA_AUDIT=warn links when only the "
+                                   "pattern is missing): " + msg)
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     if verbose:
         print(" ".join(cmd), flush=True)

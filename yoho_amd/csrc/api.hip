@@ -764,8 +764,10 @@ static int partI_passG_chunk(yoho_ctx* c, char* ws, int evbase, const float* x, 
 }
 
 // The pass over B keypoints (rows >= B0 from x1 when set).  Breadth-first (one chunk) unless yoho_set_partI_schedule asked for the
-// depth-first schedule: chunks of partI_chunk keypoints, each with its own workspace slice per stream, results bit-identical
-// (a keypoint's arithmetic does not depend on which other keypoints share its launch).
+// depth-first schedule: chunks of partI_chunk keypoints, each with its own workspace slice per stream.  In every mode but 7 the results are
+// bit-identical (a keypoint's arithmetic does not depend on which other keypoints share its launch).  Mode 7 ('fgemm8') is NOT
+// schedule-invariant: the fp8 scale of a layer's correction planes is ONE amax word per launch, so a keypoint's bits depend on which
+// other keypoints share the launch (pair pass vs single pass, chunked vs breadth-first); the differences stay inside the mode's 1e-5.
 static int partI_passG(yoho_ctx* c, const float* x, int B, float* eqv, float* inv, float* inv_np, hipStream_t s, const float* x1 = nullptr,
                        int B0 = 0) {
     for (int i = 0; i < 4; ++i) if (!c->p1[i].wpg) { set_error("irrep-GEMM weights missing"); return YOHO_ENOWEIGHTS; }

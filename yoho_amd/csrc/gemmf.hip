@@ -391,9 +391,10 @@ int launch_fgemm(const Layer& L, const char* Bplanes, int kppad, int nT32, const
                  int variant, const unsigned* amax) {
     FGemmArgs a;
     fgemm_fill_args(a, L, Bplanes, kppad, nT32, res, out, rflag);
-    if (variant == 3 && amax && L.wpg8) { a.amax = amax; a.A = reinterpret_cast<const char*>(L.wpg8); }      // fgemm3c and its weight pack
     static const int dbg_gemm1 = [] { const char* e = experiment_env("YOHO_PARTI_DEBUG"); return (e && std::strstr(e, "gemm1")) ? 1 : 0; }();
     if (dbg_gemm1) variant = 1;
+    // fgemm3c and its fp8 weight pack - chosen AFTER every override of the variant: the other kernels read A as fp16 planes
+    if (variant == 3 && amax && L.wpg8) { a.amax = amax; a.A = reinterpret_cast<const char*>(L.wpg8); }
     if (variant == 3) return launch_fgemm3(a, flags, s);
     if (variant != 1) return launch_fgemm2(a, flags, s);
     int tot = 0;

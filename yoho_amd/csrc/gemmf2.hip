@@ -924,6 +924,8 @@ int fgemm3_init() {
 int launch_fgemm3(const FGemmArgs& a, int flags, hipStream_t s) {
     if (const char* dbg = experiment_env("YOHO_FGEMM_DEBUG")) {
         if (std::strstr(dbg, "nostore")) flags |= F2_NOSTORE;
+        if (std::strstr(dbg, "sc1")) flags |= F2_ST_SC1;            // round 6: the coefficient stores write-through ...
+        if (std::strstr(dbg, "stnt")) flags |= F2_ST_NT;            // ... or non-temporal: produced once, consumed once by gft16x
     }
     int tot = 0;
     for (int x = 0; x < 8; ++x) {

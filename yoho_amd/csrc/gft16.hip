@@ -49,6 +49,7 @@ struct Gft16Args {
     int qstride[G];           // bytes per 256-column tile of q's irrep (= K stages * 32 KiB)
     int* rflag;               // fp16 range flag of the context (note_range)
     int drain;                // experiment (YOHO_PARTI_DEBUG=drain): wait for every outstanding vector-memory operation instead of the counted wait
+                              // bit 1 (YOHO_PARTI_DEBUG=ldnt): gft16x stages its coefficient chunks with non-temporal LDS-DMA loads
     int* ctr;                 // gft16x work stealing: [0] next chunk ticket, [1] finished workgroups (both 0 between launches), or null = static striding
     unsigned* amax;           // gft16x, gconv_mode 7: atomicMax of the largest |value| written to the planes (float bit pattern), or null
 };
@@ -378,6 +379,12 @@ __global__ __launch_bounds__(512, 2) void gft16x_kernel(Gft16Args a) {
         const int c8 = chunk % a.C8, tile32 = chunk / a.C8;
         const char* src = reinterpret_cast<const char*>(a.in) + ((size_t)tile32 * G * a.C8 + c8) * 1024;
         const size_t rs = (size_t)a.C8 * 1024;
+#ifdef YOHO_EXPERIMENTS
+        if (a.drain & 2) {
+            for (int p = w8; p < G; p += 8) __builtin_amdgcn_global_load_lds((gptr_t)(src + p * rs + lane * 16), (lptr_t)(dst + p * 1024), 16, 0, 2);
+            return;
+        }
+#endif
         for (int p = w8; p < G; p += 8) __builtin_amdgcn_global_load_lds((gptr_t)(src + p * rs + lane * 16), (lptr_t)(dst + p * 1024), 16, 0, 0);
     };
     const int hsel = w8 >> 2, kp = 8 * (w8 & 3) + (n >> 2), e = n & 3;
@@ -414,7 +421,7 @@ __global__ __launch_bounds__(512, 2) void gft16x_kernel(Gft16Args a) {
         // vector-memory operations complete in issue order: behind this chunk's DMA (issued one iteration ago) are only the
         // plane stores of the previous chunk - 8 per thread in waves 0-3, 7 in waves 4-7 - which may stay in flight
         if (it > 0) {
-            if (a.drain) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (a.drain & 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             else if (w8 < 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
         }
@@ -629,7 +636,8 @@ int launch_gft16(const float* in, float* out32, char* planes, int kppad, const v
     a.nChunks = nTiles * C8; a.C8 = C8;
     static const int dbg_drain = [] { const char* e = experiment_env("YOHO_PARTI_DEBUG"); return (e && std::strstr(e, "drain")) ? 1 : 0; }();
     static const int dbg_xf1 = [] { const char* e = experiment_env("YOHO_PARTI_DEBUG"); return (e && std::strstr(e, "xf1")) ? 1 : 0; }();
-    a.drain = dbg_drain;
+    static const int dbg_ldnt = [] { const char* e = experiment_env("YOHO_PARTI_DEBUG"); return (e && std::strstr(e, "ldnt")) ? 2 : 0; }();
+    a.drain = dbg_drain | dbg_ldnt;
     if (dbg_xf1) variant = 1;
     if (planes) {
         fill_qtables(kppad, C8 * 8, a.qbase, a.qstride);

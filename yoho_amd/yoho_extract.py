@@ -15,6 +15,7 @@ Differences from the reference (all deliberate):
   * any number of keypoints works (no "avoid B == 1" last-batch merge needed, :55-58).
 """
 import os
+import threading
 
 import numpy as np
 import torch
@@ -31,10 +32,12 @@ from .utils import transform_points
 # that torch's caching host allocator never gives back to the OS.
 PIN_OUTPUT_BYTES = int(os.environ.get("YOHO_PIN_OUTPUT_BYTES", str(2 << 30)))
 _pinned_alive = [0]
+_pinned_lock = threading.Lock()
 
 
 def _unpin(nbytes):
-    _pinned_alive[0] -= nbytes
+    with _pinned_lock:
+        _pinned_alive[0] -= nbytes
 
 
 def _to_host(*tensors):
@@ -44,14 +47,17 @@ def _to_host(*tensors):
     gets tensors of its own."""
     import weakref
     need = sum(t.numel() * t.element_size() for t in tensors)
-    pin = need > 0 and _pinned_alive[0] + need <= PIN_OUTPUT_BYTES
+    with _pinned_lock:                                 # reserve the whole call's bytes or none (several extractor threads share the budget)
+        pin = need > 0 and _pinned_alive[0] + need <= PIN_OUTPUT_BYTES
+        if pin:
+            _pinned_alive[0] += need
     outs = [torch.empty(t.shape, dtype=t.dtype, pin_memory=pin) for t in tensors]
     for o, t in zip(outs, tensors):
         o.copy_(t, non_blocking=pin)
         if pin:
-            nbytes = o.numel() * o.element_size()
-            _pinned_alive[0] += nbytes
-            weakref.finalize(o, _unpin, nbytes)
+            # released when the page-locked STORAGE dies, not the tensor object: out.numpy(), a view or a slice keep the storage (and
+            # the pinned pages) alive after the tensor the caller was handed is gone (ADVICE r5)
+            weakref.finalize(o.untyped_storage(), _unpin, o.numel() * o.element_size())
     torch.cuda.current_stream().synchronize()
     return tuple(outs)
 
