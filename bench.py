@@ -97,6 +97,53 @@ def pmc_traffic(mode):
     return None, None
 
 
+def measure_traffic(mode, nkp):
+    """Fabric-side bytes of the irrep-GEMM launches MEASURED IN THIS RUN: two child processes of this command on this box run
+    `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, nothing else traced, as MI355X_MICROARCH.md's HBM
+    section prescribes) over tools/pmc_partI.py - two PartI passes of nkp keypoints in `mode` with the checkpoint of the timed steps -
+    while this process waits.  gfx950 correction of the guide: FETCH_SIZE x 2 (16-byte-per-lane streaming reads are tallied at half
+    their bytes; every operand of these kernels arrives by 16-byte LDS DMA), WRITE_SIZE as reported.  Both counters sit on the L2's
+    memory side: Infinity-Cache hits are counted.  -> (dict or None, note)"""
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None, "rocprofv3 not on PATH"
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import pmc_traffic
+    tmp = tempfile.mkdtemp(prefix="yoho_pmc_", dir="/tmp")
+    try:
+        env = dict(os.environ, PMC_B=str(nkp), TMPDIR="/tmp")
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+            env.pop(k, None)
+        for cnt in ("FETCH_SIZE", "WRITE_SIZE"):
+            r = subprocess.run(["rocprofv3", "--kernel-trace", "--pmc", cnt, "--output-format", "csv", "-d", os.path.join(tmp, cnt), "--",
+                                sys.executable, os.path.join(REPO, "tools", "pmc_partI.py"), mode], env=env, cwd=tmp,
+                               stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=240)
+            if r.returncode != 0:
+                return None, f"rocprofv3 --pmc {cnt} exited with {r.returncode}: {r.stderr.decode(errors='replace')[-200:]}"
+        F, Wr = pmc_traffic.load(os.path.join(tmp, "FETCH_SIZE"), "FETCH_SIZE"), pmc_traffic.load(os.path.join(tmp, "WRITE_SIZE"), "WRITE_SIZE")
+        rows, gemm_b, gemm_n, all_b = [], 0.0, 0, 0.0
+        for key, (n, fkib) in F.items():
+            wn, wkib = Wr.get(key, [n, 0.0])
+            b = (2.0 * fkib + wkib * n / max(wn, 1)) * 1024.0           # bytes over all n dispatches of this (kernel, grid)
+            all_b += b
+            if "fgemm" in key[0]:
+                gemm_b += b
+                gemm_n += n
+                rows.append({"kernel": key[0], "grid": key[1], "dispatches": n, "fetch_x2_bytes_per_launch": round(2048.0 * fkib / n),
+                             "write_bytes_per_launch": round(1024.0 * wkib / max(wn, 1))})
+        if gemm_n == 0:
+            return None, "no irrep-GEMM dispatch in the counter files"
+        passes = gemm_n / 4.0
+        return {"bytes_per_launch": round(gemm_b / gemm_n), "gemm_bytes_per_pass": round(gemm_b / passes), "pass_bytes": round(all_b / passes),
+                "passes_profiled": passes, "per_kernel": rows}, "measured in this run"
+    except Exception as e:                                            # the headline must survive a failure of this leg
+        return None, f"{type(e).__name__}: {e}"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def cpu_baseline(pr, e0, e1, match, dr):
     """The oracle (`kind: "port"`: the reference's op sequence on torch-CPU kernels for the networks and Des2R, numpy for matcher and
     YOHO-O) timed on the host cores ON THE BENCHED WORKLOAD - 2 x 5000 keypoints - with the two networks sampled by batch:
@@ -269,6 +316,7 @@ def main():
                     help="PartI pass: '0' breadth-first, 'C' or 'CxS' depth-first over chunks of C keypoints on S (1 or 2) streams")
     ap.add_argument("--no-dataset", action="store_true", help="skip the dataset-scale leg (tools/bench_dataset.py: 60 fragments from disk, ~500 pairs)")
     ap.add_argument("--no-fcgf", action="store_true", help="skip the raw-cloud leg (yoho_extractor.run on a 300 k-point cloud)")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the in-run PMC measurement of roofline.traffic (two short rocprofv3 child processes)")
     ap.add_argument("--no-sustained", action="store_true", help="skip the sustained leg (>= 1 s of load, then >= 2 s of timed steps)")
     args = ap.parse_args()
     sched = [int(v) for v in str(args.partI_schedule).lower().split("x")] + [1]
@@ -621,6 +669,10 @@ def main():
             "%.1f us per pass; brute force (YOHO_NN=brute) evaluates 2 x 5000 x 5000 explicit differences on the vector pipes" % (KP, KP, nn_ms * 500))
     add("des2r_kernel", des_ms, M * (2 * 7680 + 8), "two (32,60) descriptors per match in, index out")
 
+    traffic_meas, traffic_note = (None, "not measured (--no-traffic, or more than one rank)")
+    if rank == 0 and world == 1 and not args.no_traffic:
+        torch.cuda.synchronize()
+        traffic_meas, traffic_note = measure_traffic(args.gconv, nkp)
     if rank == 0:
         M = int(res.match.shape[0])
         if args.gconv == "f32":
@@ -656,6 +708,9 @@ def main():
             step_ms = dt / args.steps * 1e3 / (len(mine) if args.scaling == "strong" else 1)
             ach = useful / (gconv_total_ms * 1e-3) / 1e12
             traffic, tsrc = pmc_traffic("fgemm" if args.gconv == "fgemm8" else args.gconv)
+            # algorithmic bytes of the four GEMM launches of one pass: fp16x2 operand planes in (4 B per value), fp32 coefficients out,
+            # the residual of the third layer in, every weight pack once (244 / 13 of the 13-tap weights, 4 B per value)
+            alg_bytes = sum(60 * 4 * nkp * (cin + cout) + 244 * 4 * cin * cout for cin, cout in ((32, 256), (256, 512), (512, 256), (256, 32))) + 60 * 4 * nkp * 256
             # the box's state beside the fraction (a slow box and a slow build must be told apart from this one object):
             # the clock the GEMM launches of the profiled passes ran at, and the fraction against the peak AT THAT CLOCK
             cp_prof = power_prof.get("clock_probe") or {}
@@ -681,12 +736,22 @@ def main():
                                   f"(GEMMs + transforms + head + tail, {pass_ms:.3f} ms), frac_step over the timed step ({step_ms:.3f} ms)",
                     "frac_per_launch": [round(f / (ms * 1e-3) / 1e12 / FP16_MFMA_PEAK, 4) for f, ms in zip(useful_layer, conv_ms[:4])],
                     "launch_ms_sum": round(gconv_total_ms, 4), "pass_ms": round(pass_ms, 4), "step_ms": round(step_ms, 4),
-                    "traffic": None,
+                    # fabric-side bytes per GEMM launch (average of the four launches of a pass), MEASURED IN THIS RUN by two rocprofv3 child
+                    # processes (measure_traffic); null only when that failed (traffic_note says why)
+                    "traffic": None if traffic_meas is None else traffic_meas["bytes_per_launch"],
+                    "traffic_note": traffic_note,
+                    "traffic_detail": None if traffic_meas is None else dict(
+                        traffic_meas, algorithmic_bytes_per_launch=round(alg_bytes / 4.0),
+                        over_algorithmic=round(traffic_meas["gemm_bytes_per_pass"] / alg_bytes, 2),
+                        definition="(2 x FETCH_SIZE + WRITE_SIZE) x 1024 per dispatch from two separate `rocprofv3 --kernel-trace --pmc` passes over "
+                                   "tools/pmc_partI.py (two PartI passes of the same keypoint count, same checkpoint, same arithmetic mode) run as child "
+                                   "processes of this command; FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 note; the counters sit on the L2's "
+                                   "memory side and count Infinity-Cache hits: the excess over `algorithmic` is the weight panels every column tile "
+                                   "re-streams from the Infinity Cache (31 MB of packs, on die), the activation planes and the coefficient writes are "
+                                   "at their algorithmic volume (profiles/r06_nt_traffic.md); algorithmic = operand planes in + fp32 coefficients out + "
+                                   "residual in + weight packs once, summed over the four launches / 4"),
                     "traffic_replayed": dict(tsrc or {}, bytes_per_launch=traffic,
-                                             note="NOT measured in this run (counters cannot be read inside a timed run, so `traffic` is null): the figure "
-                                                  "of the committed PMC file (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, "
-                                                  "tools/collect_profiles.sh, gfx950 corrections of MI355X_MICROARCH.md), per-launch average of the four "
-                                                  "GEMM launches of the same command"),
+                                             note="the committed PMC file of an earlier run of the same command (tools/collect_profiles.sh), kept for comparison"),
                     "kernel": {"fgemm": "fgemm3_kernel (fgemm3s_kernel for the 32-channel layer)", "fgemm128": "fgemm2_kernel", "fgemm256": "fgemm_kernel",
                                "fgemm8": "fgemm3c_kernel for 256 -> 512 and 512 -> 256 (fp16 main product + fp8 e4m3 corrections: 2 / 3 of the matrix time the `useful` count assumes), fgemm3 / fgemm3s for the 32-channel layers"}[args.gconv] +
                               " (4 launches = 4 PartI layers over both fragments)",

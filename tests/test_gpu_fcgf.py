@@ -244,7 +244,7 @@ def test_backbone_fifteen_copy_pass_at_benchmarked_size_vs_oracle(hip, fsd, tabl
     boundaries (copy sizes are no multiples of anything), 15 clouds sharing every launch, rank-ordered bitmaps of 15 boxes, the
     1024-entry scan blocks of a level with > 1 M rows.  Copy 7 of the first pass of yoho_extractor.run is compared with the
     oracle ROW FOR ROW (selected points and voxel coordinates bit-exact, features to 1e-5), copies 0 and 14 with the oracle's voxelisation
-    and with a pass of that copy alone (bit for bit), through the same calls the extractor makes
+    and with a pass of that copy alone (2e-6), through the same calls the extractor makes
     (fcgf_extractor.extract_rotated_batch = yoho_fcgf_voxelize_rotated_batch -> yoho_fcgf_forward_batch); the hash-table coordinate maps
     give the same bits as the default bitmaps at this size, and five repeats of the pass are bit-identical."""
     from yoho_amd.fcgf_feat import fcgf_extractor
@@ -265,8 +265,11 @@ def test_backbone_fifteen_copy_pass_at_benchmarked_size_vs_oracle(hip, fsd, tabl
     worst = 0.0
     # The oracle (a CPU pass of ~70 s per copy on the GPU box) pins an INTERIOR copy row for row; the first and the last copy - whose
     # rows sit at the two ends of every shared launch - are pinned to it through the library itself: their voxelisation against the
-    # oracle's, their features against a pass of that copy ALONE (bit for bit: a cloud's rows do not depend on which clouds share its
-    # pass, test_batched_clouds_equal_separate_passes at small size), which the oracle pins at 1.5 k - 6 k points (test_backbone_vs_oracle).
+    # oracle's, their features against a pass of that copy ALONE, which the oracle pins at 1.5 k - 6 k points (test_backbone_vs_oracle).
+    # Not bit for bit at this size: a pass picks the first convolution's kernel by what fits its workspace (occupancy-bitmap MFMA kernel or
+    # hash probes; the 7^3 sums then differ in the last bit), and a 1.3 M-row pass and an 87 k-row pass pick differently; at equal kernel
+    # choice a cloud's rows do not depend on which clouds share its pass (test_batched_clouds_equal_separate_passes).
+    ends = []
     for j in (0, 7, 14):
         rot = pc @ Rs[j].T
         s0, c0 = fo.voxelize(rot, 0.025)
@@ -275,7 +278,10 @@ def test_backbone_fifteen_copy_pass_at_benchmarked_size_vs_oracle(hip, fsd, tabl
         assert np.allclose(ps.cpu().numpy(), rot[s0].astype(np.float32), rtol=0, atol=5e-7)
         if j != 7:
             alone = fx.extract_rotated_batch(pc_d, [Rs[j]], 0.025)[0]
-            assert torch.equal(alone[0], sel) and torch.equal(alone[1], F) and torch.equal(alone[2], ps), j
+            assert torch.equal(alone[0], sel) and torch.equal(alone[2], ps), j
+            d_alone = float((alone[1] - F).abs().max())
+            ends.append(d_alone)
+            assert d_alone < 2e-6, (j, d_alone)                       # unit rows: absolute = relative; the oracle bar is 5e-6 per row
             continue
         F0 = fo.extract_features(rot, 0.025, fsd)[1]
         Fj = F.cpu().numpy()
@@ -284,7 +290,7 @@ def test_backbone_fifteen_copy_pass_at_benchmarked_size_vs_oracle(hip, fsd, tabl
         worst = max(worst, e)
         assert e < TOL, (j, e)
         assert np.abs(Fj - F0).max(axis=1).max() < 5e-6               # row for row (rows are unit vectors: absolute = relative)
-    print("fcgf backbone, 15-copy pass, %d voxels (copies %d..%d): worst rel err of copy 7 vs the oracle (copies 0 / 14: bit-identical to their single-cloud passes) %.3g" % (total, min(sizes), max(sizes), worst))
+    print("fcgf backbone, 15-copy pass, %d voxels (copies %d..%d): worst rel err of copy 7 vs the oracle %.3g; copies 0 / 14 vs their single-cloud passes: max abs diff %s" % (total, min(sizes), max(sizes), worst, ["%.2g" % v for v in ends]))
     # the same pass: five repeats, and once with hash-table coordinate maps - identical bits
     for _ in range(5):
         again = _full_size_pass(fx, pc_d, Rs)
