@@ -308,7 +308,7 @@ def main():
     ap.add_argument("--gconv", choices=["f32", "bf16x3", "fourier", "fp16x2", "fgemm", "fgemm256", "fgemm128", "fgemm8"], default=os.environ.get("YOHO_GCONV", "fgemm"),
                     help="PartI group conv: group-Fourier domain (fp32 MFMA), direct fp32 MFMA, direct 3-way bf16 split MFMA, "
                          "or direct 2-way fp16 split MFMA")
-    ap.add_argument("--partII", choices=["f32", "bf16x3", "fp16x2"], default=os.environ.get("YOHO_PARTII", "fp16x2"),
+    ap.add_argument("--partII", choices=["f32", "bf16x3", "fp16x2", "cgemm", "cgemm8"], default=os.environ.get("YOHO_PARTII", "fp16x2"),
                     help="arithmetic of the two PartII cone layers")
     ap.add_argument("--repeats", type=int, default=3, help="the timed region (exactly --steps steps) is run this many times; ms_per_step / value are "
                                                            "the median repeat, min / max are reported beside it")
@@ -519,32 +519,47 @@ def main():
         rs_ = pipeline.run_pair(ctx, f0, f1, k0, k1, max_iter=1000, order_rng=np.random.RandomState(7), eqv=ra_.eqv, hypotheses="selected")
         sel_leg["same_winner_and_transform_as_all"] = bool((ra_.best_h, ra_.best_count) == (rs_.best_h, rs_.best_count) and
                                                            np.array_equal(np.asarray(ra_.trans), np.asarray(rs_.trans)))
-    # the same step in the opt-in arithmetic of round 5 (gconv mode 'fgemm8': the two correction products of the fp16 split of the two large
-    # PartI layers in fp8 e4m3 on v_mfma_scale_f32_32x32x64_f8f6f4): time, and what it does to this pair's results.  Reported
-    # beside the headline, which stays on the default arithmetic (~1e-6 of the fp32 reference; this mode ~1e-5, tolerance 1e-4)
+    # the same step in the opt-in arithmetic with EVERY large split product's corrections on the fp8 pipe (v_mfma_scale_f32_32x32x64_f8f6f4):
+    # gconv mode 'fgemm8' (round 5: the two large PartI layers, NOTEBOOK.md 3.1h) + PartII mode 'cgemm8' (round 6: the 13-element cone layer
+    # as an implicit GEMM with fp8 corrections); also PartII 'cgemm8' alone beside the default PartI.  Time, and what it does to
+    # this pair's results.  Reported beside the headline, which stays on the default arithmetic (~1e-6 of the fp32 reference; these ~1e-5,
+    # tolerance 1e-4; tests/test_gpu_census.py counts what that costs against the reference itself)
     fgemm8 = None
-    if not args.no_fgemm8 and args.gconv == "fgemm":
+    if not args.no_fgemm8 and args.gconv == "fgemm" and args.partII == "fp16x2":
         g1 = guard_total()
-        ctx.set_gconv_mode("fgemm8")
-        if streamer is not None:
-            streamer.set_modes("fgemm8", None)
-        try:
-            dt8, dts8, _, res8, pw8 = timed("yohoo", args.steps, max(min(args.warmup, 2), 1), 1)
-            ra8 = pipeline.run_pair(ctx, f0, f1, k0, k1, max_iter=1000, order_rng=np.random.RandomState(7))
-        finally:
-            ctx.set_gconv_mode(args.gconv)
+
+        def leg(gm, pm):
+            ctx.set_gconv_mode(gm)
+            ctx.set_partII_mode(pm)
             if streamer is not None:
-                streamer.set_modes(args.gconv, None)
+                streamer.set_modes(gm, pm)
+            try:
+                dt_, _, _, _, pw_ = timed("yohoo", args.steps, max(min(args.warmup, 2), 1), 1)
+                ra_ = pipeline.run_pair(ctx, f0, f1, k0, k1, max_iter=1000, order_rng=np.random.RandomState(7))
+            finally:
+                ctx.set_gconv_mode(args.gconv)
+                ctx.set_partII_mode(args.partII)
+                if streamer is not None:
+                    streamer.set_modes(args.gconv, args.partII)
+            return dt_, pw_, ra_
+        dt8, pw8, ra8 = leg("fgemm8", "cgemm8")
+        dtp, _, rap = leg(args.gconv, "cgemm8")
         rd8 = pipeline.run_pair(ctx, f0, f1, k0, k1, max_iter=1000, order_rng=np.random.RandomState(7))
         e8 = torch.cat([ra8.eqv[0]["eqv"], ra8.eqv[1]["eqv"]])
         ed = torch.cat([rd8.eqv[0]["eqv"], rd8.eqv[1]["eqv"]])
-        fgemm8 = {"metric": "keypoints/sec (5000 kp x60 rot desc + YOHO-O), PartI with fp8 correction products (opt-in gconv mode 'fgemm8')",
+        same_list = bool(ra8.match.shape == rd8.match.shape and torch.equal(ra8.match, rd8.match))
+        fgemm8 = {"metric": "keypoints/sec (5000 kp x60 rot desc + YOHO-O), every large split product's corrections in fp8 (opt-in: gconv 'fgemm8' + PartII 'cgemm8')",
                   "value": round(pairs_per_step * 2 * KP * args.steps / dt8, 1), "ms_per_step": round(dt8 / args.steps * 1e3, 3),
                   "vs_headline_ms_per_step": round(dt8 / dt, 4),
                   "descriptor_max_abs_diff_vs_default": float((e8 - ed).abs().max().item()),
-                  "same_match_list_as_default": bool(ra8.match.shape == rd8.match.shape and torch.equal(ra8.match, rd8.match)),
+                  "quaternion_max_abs_diff_vs_default": float((ra8.quat - rd8.quat).abs().max().item()) if same_list else None,
+                  "same_match_list_as_default": same_list,
                   "same_winner_as_default": bool((ra8.best_h, ra8.best_count) == (rd8.best_h, rd8.best_count)),
-                  "matches": int(ra8.match.shape[0]), "clock_probe": (pw8 or {}).get("clock_probe"), "range_repeats": guard_total() - g1}
+                  "matches": int(ra8.match.shape[0]), "clock_probe": (pw8 or {}).get("clock_probe"),
+                  "partII_cgemm8_only": {"ms_per_step": round(dtp / args.steps * 1e3, 3), "vs_headline_ms_per_step": round(dtp / dt, 4),
+                                         "quaternion_max_abs_diff_vs_default": float((rap.quat - rd8.quat).abs().max().item()),
+                                         "same_winner_as_default": bool((rap.best_h, rap.best_count) == (rd8.best_h, rd8.best_count))},
+                  "range_repeats": guard_total() - g1}
     yohoc = None
     if not args.no_yohoc:
         g1 = guard_total()

@@ -352,8 +352,11 @@ int yoho_set_nn_prefilter(yoho_ctx* ctx, int enable);
  *                 tile skips the offsets none of its rows reaches (skipped terms are exact zeros). */
 int yoho_set_fcgf_sort(yoho_ctx* ctx, int parity_sort, int cell_sort);
 
-/* PartII group-conv layers: 0 = fp32 MFMA, 1 = bf16x3 split MFMA, 2 = fp16x2 split MFMA (default; first layer in the
- * group-Fourier domain, 13-rotation cone layer direct, last layer as one dense product at the identity). */
+/* PartII group-conv layers: 0 = fp32 MFMA, 1 = bf16x3 split MFMA, 2 = fp16x2 split MFMA (first layer in the
+ * group-Fourier domain, 13-rotation cone layer direct, last layer as one dense product at the identity), 3 = 2 with the
+ * 13-rotation cone layer as ONE implicit GEMM over (tap, channel) whose B operand stages are picked per tap from the 45 cone
+ * elements (YOHO_PARTII=cgemm), 4 = 3 with the two correction products of the fp16 split on the fp8 matrix pipe
+ * (YOHO_PARTII=cgemm8; quaternions ~1e-5 from the fp32 reference instead of ~1e-6, tolerance 1e-4; PartII feeds no index decision). */
 int yoho_set_partII_mode(yoho_ctx* ctx, int mode);
 
 /* fp16 range guard.  The default arithmetic (PartI mode 4, PartII mode 2; also PartI mode 3) keeps activations and

@@ -400,3 +400,31 @@ def test_transform_ticket_stealing_equals_static_striding_under_a_coresident_pro
     for B in (1, 31, 256, 700):                             # nChunks <= 2 x grid for the 32-channel transforms: static striding in both contexts
         a, b = static.partI_forward(x[:B].contiguous(), want_inv=True), steal.partI_forward(x[:B].contiguous(), want_inv=True)
         assert torch.equal(a["eqv"], b["eqv"]) and torch.equal(a["inv"], b["inv"])
+
+
+def test_partII_cone_gemm_modes_at_full_size(hip, dctx, sd1, sd2):
+    """PartII modes 'cgemm' / 'cgemm8' (opt-in, round 6) on all 3233 matches of the bench pair: quaternions against the default mode's -
+    which test_run_pair_full_size_default_modes_vs_oracle pins to the oracle at 3.4e-6 - within 5e-6 (fp16x2 products, another summation
+    order) and 5e-5 (fp8 correction products; the tolerance of the path is 1e-4), the same YOHO-O winner, inlier count and a transform
+    within 1e-4; through the staged entries and through the one-call pair."""
+    pr = synth.make_pair(5000, seed=10)
+    f0, f1, k0, k1 = cu(pr["feat0"]), cu(pr["feat1"]), cu(pr["keys0"]), cu(pr["keys1"])
+    o0, o1 = pipeline.describe_pair(dctx, f0, f1)
+    o0 = {k: v.contiguous() for k, v in o0.items()}
+    o1 = {k: v.contiguous() for k, v in o1.items()}
+    ref = pipeline.run_pair(dctx, f0, f1, k0, k1, order_rng=np.random.RandomState(1234), eqv=(o0, o1))
+    c = hip.Context()
+    c.load_partII(sd2)
+    for mode, bar in (("cgemm", 5e-6), ("cgemm8", 5e-5)):
+        c.set_partII_mode(mode)
+        r = pipeline.run_pair(c, f0, f1, k0, k1, order_rng=np.random.RandomState(1234), eqv=(o0, o1))
+        assert torch.equal(r.match, ref.match) and torch.equal(r.dr_index, ref.dr_index)
+        dq = float((r.quat - ref.quat).abs().max())
+        print("PartII %s at M=%d: max |q - q_default| %.3g; winner %d (%d inliers), default %d (%d)" % (mode, r.match.shape[0], dq, r.best_h, r.best_count, ref.best_h, ref.best_count))
+        assert dq < bar, (mode, dq)
+        assert (r.best_h, r.best_count) == (ref.best_h, ref.best_count), mode
+        assert np.abs(np.asarray(r.trans) - np.asarray(ref.trans)).max() <= TOL * np.abs(np.asarray(ref.trans)).max()
+        f = c.register_pair(f0, f1, o0["eqv"], o1["eqv"], o0["inv_np"], o1["inv_np"], k0, k1, estimator="yohoo", max_iter=1000, inlier_dist=0.09,
+                            seed=1234, selected=False)
+        assert (f["best_h"], f["best_count"], f["matches"]) == (r.best_h, r.best_count, r.match.shape[0]) and np.array_equal(f["trans"], np.asarray(r.trans))
+        assert r.range_repeats == 0 and not f["range_flag"]

@@ -443,6 +443,48 @@ def test_partII_ragged_match_counts(ctx, ctxh, sd2, tables, M):
     assert rel(q, qo) < TOL and rel(q32, qo) < TOL, (rel(q, qo), rel(q32, qo))
 
 
+@pytest.mark.parametrize("mode,tol", [("cgemm", TOL), ("cgemm8", TOL)])
+def test_partII_cone_gemm_modes(hip, ctx, ctxh, sd1, sd2, tables, mode, tol):
+    """PartII modes 3 / 4: the 13-element cone layer as one implicit GEMM (cgemm_kernel: B-operand stage blocks picked per tap from the 45
+    cone elements the inverse transform leaves, fp16x2 products or fp16 main product + fp8 correction products) against the oracle, the
+    fp32 kernels and the direct cone kernel of mode 2 - at match counts around every tile boundary of the new kernels (32-match transform
+    tiles, 16-match cone1 tiles, 256-match column tiles: the last column tile of a pass is ragged and its unwritten columns must not
+    leak), through the plain and the row-indexed entry, and repeated (workspace reuse with stale column tiles from a larger pass)."""
+    c = hip.Context()
+    c.load_partI(sd1)
+    c.load_partII(sd2)
+    c.set_partII_mode(mode)
+    assert c.supports_matched()
+    worst = 0.0
+    for M in (700, 1, 17, 40, 255, 256, 257, 300):           # the large pass first: the small ones then see its stale stage blocks
+        rs = np.random.RandomState(900 + M)
+        mk = lambda sd: synth.unit_features(M, seed=sd)
+        a, b, c_, d = mk(11), mk(12), mk(13), mk(14)
+        dr = rs.randint(0, 60, size=M).astype(np.int64)
+        args = [cu(x) for x in (a, b, c_, d)]
+        q = c.partII_forward(*args, cu(dr)).cpu().numpy()
+        qo = orc.partII_forward(a, b, c_, d, dr, sd2, tables.N, tables.P)
+        qd = ctxh.partII_forward(*args, cu(dr)).cpu().numpy()
+        assert q.shape == (M, 4) and np.isfinite(q).all()
+        worst = max(worst, rel(q, qo))
+        assert rel(q, qo) < tol and rel(q, qd) < tol, (M, rel(q, qo), rel(q, qd))
+        assert np.array_equal(q, c.partII_forward(*args, cu(dr)).cpu().numpy()), M          # same bits on a repeat
+    print("partII %s: worst rel err vs oracle %.3g" % (mode, worst))
+    # the row-indexed entry (what run_pair / yoho_register_pair use): rows addressed through a match list
+    K = 300
+    pr = synth.make_pair(K, seed=21)
+    f0, f1 = cu(pr["feat0"]), cu(pr["feat1"])
+    o0, o1 = c.partI_forward(f0)["eqv"], c.partI_forward(f1)["eqv"]
+    rs = np.random.RandomState(3)
+    match = torch.from_numpy(np.stack([rs.permutation(K)[:180], rs.permutation(K)[:180]], 1).astype(np.int64)).cuda()
+    dr = torch.from_numpy(rs.randint(0, 60, size=180).astype(np.int64)).cuda()
+    qi = c.partII_forward_matched(f0, f1, o0, o1, match, dr)
+    m0, m1 = match[:, 0], match[:, 1]
+    qg = c.partII_forward(f1[m1].contiguous(), f0[m0].contiguous(), o1[m1].contiguous(), o0[m0].contiguous(), dr)
+    assert torch.equal(qi, qg)
+    assert c.range_status() == (False, False)
+
+
 def test_partII_zero_matches(ctxh):
     e = torch.empty((0, 32, 60), dtype=torch.float32, device="cuda")
     q = ctxh.partII_forward(e, e, e, e, torch.empty((0,), dtype=torch.int64, device="cuda"))

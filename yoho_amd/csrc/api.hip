@@ -38,6 +38,8 @@ static void free_layer(Layer& L) {
     if (L.wph) (void)hipFree(L.wph);
     if (L.wpg) (void)hipFree(L.wpg);
     if (L.wpg8) (void)hipFree(L.wpg8);
+    if (L.wcg) (void)hipFree(L.wcg);
+    if (L.wcg8) (void)hipFree(L.wcg8);
     if (L.wpf) (void)hipFree(L.wpf);
     if (L.bias) (void)hipFree(L.bias);
     if (L.bn_s) (void)hipFree(L.bn_s);
@@ -371,7 +373,7 @@ int yoho_ctx_create(int device, const float* R, const uint8_t* N, const uint8_t*
     if (const char* m = std::getenv("YOHO_FCGF_SORT")) c->fcgf_parity_sort = std::strcmp(m, "0") == 0 ? 0 : 1;
     if (const char* m = std::getenv("YOHO_FCGF_COORDS")) c->fcgf_hash_coords = std::strcmp(m, "hash") == 0 ? 1 : 0;
     if (const char* m = std::getenv("YOHO_NN")) c->nn_prefilter = std::strcmp(m, "brute") == 0 ? 0 : 1;
-    if (const char* m = std::getenv("YOHO_PARTII")) c->partII_mode = std::strcmp(m, "f32") == 0 ? 0 : (std::strcmp(m, "fp16x2") == 0 ? 2 : 1);
+    if (const char* m = std::getenv("YOHO_PARTII")) c->partII_mode = std::strcmp(m, "f32") == 0 ? 0 : (std::strcmp(m, "fp16x2") == 0 ? 2 : (std::strcmp(m, "cgemm") == 0 ? 3 : (std::strcmp(m, "cgemm8") == 0 ? 4 : 1)));
     if (const char* m = std::getenv("YOHO_PARTI_CHUNK")) {       // "1024" or "1024x2" (chunk keypoints x streams), see yoho_set_partI_schedule
         int ck = 0, ns = 1;
         if (std::sscanf(m, "%dx%d", &ck, &ns) >= 1 && ck >= 0 && (ns == 1 || ns == 2)) { c->partI_chunk = (ck + 255) / 256 * 256; c->partI_streams = ns; }
@@ -396,8 +398,21 @@ int yoho_ctx_create(int device, const float* R, const uint8_t* N, const uint8_t*
     }
     HIPCHK(hipMalloc((void**)&c->d_rflag, 4 * sizeof(int)));
     HIPCHK(hipMemset(c->d_rflag, 0, 4 * sizeof(int)));
-    HIPCHK(hipMalloc((void**)&c->d_amax, 8 * sizeof(unsigned)));
-    HIPCHK(hipMemset(c->d_amax, 0, 8 * sizeof(unsigned)));
+    HIPCHK(hipMalloc((void**)&c->d_amax, 12 * sizeof(unsigned)));      // [2][4] PartI, [8] PartII's cone GEMM
+    HIPCHK(hipMemset(c->d_amax, 0, 12 * sizeof(unsigned)));
+    {
+        // receptive cone of group element 0 through two 13-tap layers: outputs of the middle layer at n_j = N[0][j], inputs at N[n_j][k]
+        for (int g = 0; g < G; ++g) c->cone_slot_of[g] = -1;
+        for (int j = 0; j < NTAP; ++j)
+            for (int k = 0; k < NTAP; ++k) c->cone_slot_of[c->hN[c->hN[j] * NTAP + k]] = 0;
+        int ns = 0;
+        for (int g = 0; g < G; ++g) if (c->cone_slot_of[g] == 0) c->cone_slot_of[g] = ns++;
+        c->cone_nslot = ns;
+        for (int j = 0; j < NTAP; ++j) {
+            c->cone_outg[j] = c->hN[j];
+            for (int k = 0; k < NTAP; ++k) c->cone_slot[j * 13 + k] = (unsigned char)c->cone_slot_of[c->hN[c->hN[j] * NTAP + k]];
+        }
+    }
     HIPCHK(hipMalloc((void**)&c->d_xfctr, 16 * sizeof(int)));
     HIPCHK(hipMemset(c->d_xfctr, 0, 16 * sizeof(int)));
     *out = c;
@@ -468,6 +483,13 @@ int yoho_load_partII(yoho_ctx* c, const yoho_partII_weights* w) {
     if ((rc = upload(t.data(), 128 * sizeof(float), (void**)&c->p2_init_bn_t))) return rc;
     if ((rc = build_layer(c->p2[0], w->init, 128, 256, NTAP, &w->res_in_bn, c->fb))) return rc;      // + irrep-GEMM weights
     if ((rc = build_layer(c->p2[1], w->res_in, 256, 512, NTAP, &w->res_out_bn))) return rc;
+    {
+        // the cone layer's weights once more as the A operand of the cone GEMM (PartII modes 3 / 4)
+        std::vector<unsigned short> wc, wc8;
+        if (pack_cgemm_weights(w->res_in.weight, 256, 512, NTAP, wc, &c->p2[1].wcg_descale, wc8)) { set_error("cone-GEMM weight packing failed"); return YOHO_EINVAL; }
+        if ((rc = upload(wc.data(), wc.size() * sizeof(unsigned short), &c->p2[1].wcg))) return rc;
+        if ((rc = upload(wc8.data(), wc8.size() * sizeof(unsigned short), &c->p2[1].wcg8))) return rc;
+    }
     if ((rc = build_layer(c->p2[2], w->res_out, 512, 256, NTAP, nullptr))) return rc;
     if ((rc = build_layer(c->p2[3], w->fc0, 256, 512, 1, &w->fc0_bn))) return rc;
     if ((rc = build_layer(c->p2[4], w->fc1, 512, 128, 1, &w->fc1_bn))) return rc;
@@ -491,7 +513,7 @@ int yoho_set_partI_schedule(yoho_ctx* c, int chunk_kp, int streams) {
 }
 
 int yoho_set_partII_mode(yoho_ctx* c, int mode) {
-    if (!c || mode < 0 || mode > 2) { set_error("yoho_set_partII_mode: mode must be 0 (fp32 MFMA), 1 (bf16x3) or 2 (fp16x2 MFMA for the cone layers)"); return YOHO_EINVAL; }
+    if (!c || mode < 0 || mode > 4) { set_error("yoho_set_partII_mode: mode must be 0 (fp32 MFMA), 1 (bf16x3), 2 (fp16x2 MFMA, direct cone kernels), 3 (fp16x2, 13-element cone layer as an implicit GEMM) or 4 (3 with fp8 correction products)"); return YOHO_EINVAL; }
     c->partII_mode = mode;
     return 0;
 }
@@ -884,7 +906,7 @@ int yoho_group_mean_np(yoho_ctx* c, const float* eqv, int B, float* out, void* s
 // PartII with the two large cone layers (128->256 @45 g, 256->512 @13 g) on the bf16x3 split MFMA; the g = 0 tail
 // (512->256 conv + the 1x1 MLP) stays on the fp32 kernels, fed through fp32 32-tile hand-over buffers.
 static bool partII_fourier_head(const yoho_ctx* c) {
-    return c->partII_mode == 2 && c->p2[0].wpg;
+    return c->partII_mode >= 2 && c->p2[0].wpg;
 }
 
 static int partII_pass16(yoho_ctx* c, const float* s0, const float* s1, const float* s2, const float* s3, const int64_t* idx,
@@ -892,7 +914,9 @@ static int partII_pass16(yoho_ctx* c, const float* s0, const float* s1, const fl
     const int nT16 = (M + 15) / 16, nT = (M + TILE - 1) / TILE;
     const size_t ch = (size_t)CHUNK_FLOATS * sizeof(float), ch16 = (size_t)npl * 15360;
     const size_t n128 = (size_t)nT * 16, n256 = (size_t)nT * 32, n512 = (size_t)nT * 64, n32 = (size_t)nT * 4;
-    const size_t szX = (size_t)nT16 * 16 * ch16, szA0 = (size_t)nT16 * 32 * ch16;
+    // (PartII modes 3 / 4 keep the cone GEMM's stage blocks where the direct kernels keep their 256-channel planes: whole 256-match column tiles)
+    const size_t szG = c->partII_mode >= 3 ? (size_t)((nT + 7) / 8) * c->cone_nslot * 8 * 32768 : 0;
+    const size_t szX = (size_t)nT16 * 16 * ch16, szA0 = std::max((size_t)nT16 * 32 * ch16, szG);
     const size_t szA1p = npl == 2 ? (size_t)nT16 * 64 * ch16 : 0;      // fp16x2: 13-cone activation planes for cone1_kernel
     int rc;
     int* rf = c->d_rflag + 1;                           // PartII's range word
@@ -920,6 +944,23 @@ static int partII_pass16(yoho_ctx* c, const float* s0, const float* s1, const fl
         float* bC = (float*)(bP + szP);                 // raw Fourier coefficients of the first layer
         if ((rc = launch_head2(s0, s1, s2, s3, idx, c->dP, c->p2_init_bn_s, c->p2_init_bn_t, M, nT, bP, kppad, c->dF16, s, ridx, istride, rf))) return rc;
         if ((rc = launch_fgemm(c->p2[0], bP, kppad, nT, nullptr, bC, 0, s, rf))) return rc;
+        if (c->partII_mode >= 3 && c->p2[1].wcg && !c->env.partII_tail_staged && mlp_head_supported(c->p2[3], c->p2[4], c->p2[5])) {
+            // modes 3 / 4: the 13-element cone layer as ONE implicit GEMM (cgemm_kernel, gemmf2.hip).  The inverse transform leaves the 45
+            // cone elements of the first layer's output as B-operand stage blocks [column tile][slot][32-channel block][32 KiB] (in the
+            // region the direct kernels' planes bA0 occupy: 45 of 60 slabs, the same bytes per match), the GEMM writes cone1's planes
+            const int nslot = c->cone_nslot;
+            unsigned* amax = nullptr;
+            if (c->partII_mode == 4) {
+                amax = c->d_amax + 8;                        // slot of its own behind PartI's [2][4] words
+                HIPCHK(hipMemsetAsync(amax, 0, sizeof(unsigned), s));
+            }
+            if ((rc = launch_gft16_invg(bC, bH0, bA0, c->cone_slot_of, nslot, c->dF16, c->p2[0].bn_s, c->p2[0].bn_t, nT, 32, c->nCU, s, rf, amax))) return rc;
+            if ((rc = launch_cgemm(c->p2[1], bA0, nslot, c->cone_slot, c->cone_outg, nT, nT16, bA1p, s, rf, amax))) return rc;
+            int n0[NTAP];
+            for (int k = 0; k < NTAP; ++k) n0[k] = c->hN[k];
+            if ((rc = launch_cone1(c->p2[2], bA1p, nT, nT16, nullptr, nullptr, n0, s, bF0))) return rc;
+            return launch_mlp_head(c->p2[3], c->p2[4], c->p2[5], nullptr, nT, M, quat, s, bF0, &c->p2[2], bH0);
+        }
         if ((rc = launch_gft16_invp(bC, bH0, bA0, nT16, c->dF16, c->p2[0].bn_s, c->p2[0].bn_t, nT, 32, c->nCU, s, rf))) return rc;
     } else {
         if ((rc = launch_pack16_partII(s0, s1, s2, s3, idx, c->dP, c->p2_init_bn_s, c->p2_init_bn_t, M, nT16, bX, s, npl, rf))) return rc;
@@ -949,7 +990,7 @@ static int partII_pass16(yoho_ctx* c, const float* s0, const float* s1, const fl
 
 static int partII_pass(yoho_ctx* c, const float* s0, const float* s1, const float* s2, const float* s3, const int64_t* idx,
                        int M, float* quat, hipStream_t s) {
-    if (c->partII_mode != 0) return partII_pass16(c, s0, s1, s2, s3, idx, M, quat, s, c->partII_mode == 1 ? 3 : 2);
+    if (c->partII_mode != 0) return partII_pass16(c, s0, s1, s2, s3, idx, M, quat, s, c->partII_mode == 1 ? 3 : 2);      // modes 2, 3, 4: two planes
     const int nT = (M + TILE - 1) / TILE;
     const size_t ch = (size_t)CHUNK_FLOATS * sizeof(float);
     const size_t n128 = (size_t)nT * 16, n256 = (size_t)nT * 32, n512 = (size_t)nT * 64, n32 = (size_t)nT * 4;

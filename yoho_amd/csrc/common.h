@@ -81,6 +81,9 @@ struct Layer {
     void* wpg8 = nullptr;     // the same pack for fgemm3c (gconv_mode 7): hi plane as in wpg, the lo plane's 16-byte units replaced by the unit's fp8 e4m3
                               // operand [hi / 4 (8 values) | lo * 512 (8 values)]; layers with cin and cout >= 256 only
     float wpg_descale = 1.f;     // group-Fourier weights [ob][c8][frag 60][lane64][4] (13-tap layers only)
+    void* wcg = nullptr;      // cone GEMM A operand (gemmf2.hip cgemm_kernel; PartII's 13-element cone layer only): the plain [cout][tap * cin + c]
+    void* wcg8 = nullptr;     // matrix in fgemm's A pack - fp16 hi + lo planes (wcg) or hi + fp8 correction operand (wcg8)
+    float wcg_descale = 1.f;
     float* bias = nullptr;    // [cout_pad]
     float* bn_s = nullptr;    // [cout_pad] scale of the BN that FOLLOWS this conv (applied with ReLU in the epilogue)
     float* bn_t = nullptr;    // [cout_pad] shift
@@ -134,6 +137,12 @@ void fgemm_qinfo(int* qi);
 void fgemm_plane_offsets(int kppad, int cin, long long* off);
 int pack_fgemm_weights(const FourierBasis& fb, const float* W, int cin, int cout, std::vector<unsigned short>& out, float* descale,
                        std::vector<unsigned short>* out8 = nullptr);
+int pack_cgemm_weights(const float* W, int cin, int cout, int ntaps, std::vector<unsigned short>& out, float* descale, std::vector<unsigned short>& out8);
+int cgemm_init();
+int launch_cgemm(const Layer& L, const char* Bstages, int nslot, const unsigned char* slot, const unsigned char* outg, int nT32, int nTiles16,
+                 char* out, hipStream_t s, int* rflag, const unsigned* amax);
+int launch_gft16_invg(const float* in, float* res0, char* planesG, const int* slot_of, int nslot, const void* Ffrag, const float* bn_s,
+                      const float* bn_t, int nTiles, int C8, int nCU, hipStream_t s, int* rflag, unsigned* amax);
 int launch_fgemm(const Layer& L, const char* Bplanes, int kppad, int nT32, const float* res, float* out, int flags, hipStream_t s,
                  int* rflag = nullptr, int variant = 2, const unsigned* amax = nullptr);
 void build_gft16_frags(const FourierBasis& fb, std::vector<unsigned short>& out);
@@ -265,7 +274,12 @@ struct yoho_ctx {
     yoho::Layer p1[4];           // conv_in, res_in, res_out, conv_out
     yoho::Layer p2[6];           // init, res_in, res_out, fc0, fc1, fc2
     float *p2_init_bn_s = nullptr, *p2_init_bn_t = nullptr;  // BN(128) applied by the PartII pack kernel
-    int partII_mode = 2;         // cone layers: 0 fp32 MFMA, 1 bf16x3 split MFMA, 2 fp16x2 split MFMA (default)
+    int partII_mode = 2;         // cone layers: 0 fp32 MFMA, 1 bf16x3 split MFMA, 2 fp16x2 split MFMA (direct cone kernels), 3 fp16x2 with the 13-element cone
+                                 // layer as an implicit GEMM (cgemm_kernel), 4 = 3 with fp8 correction products
+    int cone_nslot = 0;          // group elements the middle cone layer reads (45 for the icosahedral tables), their slot (or -1) per element,
+    int cone_slot_of[60];        // the slot of N[n_j][k] per (output element j, tap k), and the output elements n_j = N[0][j]
+    unsigned char cone_slot[13 * 13];
+    unsigned char cone_outg[13];
     int gconv_mode = 4;          // 0 direct fp32 MFMA, 1 direct bf16x3 split, 2 group-Fourier fp32 MFMA, 3 direct fp16x2 split,
                                  // 4 group-Fourier irrep GEMMs on the fp16x2 split MFMA (default); 5 / 6 its other blockings; 7 = 4 with the
                                  // correction products of the two large layers on the fp8 matrix pipe (fgemm3c, opt-in)

@@ -244,6 +244,7 @@ __global__ __launch_bounds__(256, 1) void fgemm_kernel(FGemmArgs a, int flags) {
 
 int fgemm_init() {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&fgemm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, FG_LDS));
+    if (int rc = cgemm_init()) return rc;
     return fgemm2_init();
 }
 
@@ -366,6 +367,45 @@ int pack_fgemm_weights(const FourierBasis& fb, const float* W, int cin, int cout
                     dst[u * 16 + 8 + e] = e4m3_bits(half_value_h(src[8192 + u * 8 + e]) * 512.f);
                 }
         }
+    }
+    return 0;
+}
+
+// the 13-tap weights W[o][c][k] of a direct layer as the plain matrix A[o][k * cin + c] in the same A pack (row tiles of 256 output
+// channels x K32 stages; planes of W * 2^s with max |W| 2^s in [2^9, 2^10)) - the A operand of the cone GEMM (gemmf2.hip); out8 as above
+int pack_cgemm_weights(const float* W, int cin, int cout, int ntaps, std::vector<unsigned short>& out, float* descale, std::vector<unsigned short>& out8) {
+    if (cout % 256 || cin % 32) return -1;
+    float wmax = 0.f;
+    for (size_t i = 0; i < (size_t)cout * cin * ntaps; ++i) wmax = std::fmax(wmax, std::fabs(W[i]));
+    int ex = 0;
+    if (wmax > 0.f && std::isfinite(wmax)) (void)std::frexp(wmax, &ex);
+    const float wscale = std::ldexp(1.f, 10 - ex);
+    *descale = 1.f / (wscale * H2_ASCALE);
+    const int KS = ntaps * cin / 32;
+    out.assign((size_t)(cout / 256) * KS * (FG_STAGE / 2), 0);
+    for (int o = 0; o < cout; ++o) {
+        const int mtile = o >> 8, rr = o & 255;
+        for (int tap = 0; tap < ntaps; ++tap)
+            for (int c = 0; c < cin; ++c) {
+                const int k = tap * cin + c, ks = k >> 5, sub = (k >> 4) & 1, kg = (k >> 3) & 1, e = k & 7;
+                const float x = W[((size_t)o * cin + c) * ntaps + tap] * wscale;
+                const _Float16 hi = (_Float16)x;
+                unsigned short* blk = out.data() + ((size_t)mtile * KS + ks) * (FG_STAGE / 2);
+                const size_t idx = ((size_t)(sub * 2 + kg) * 256 + rr) * 8 + e;
+                blk[0 * 8192 + idx] = half_bits_h(x);
+                blk[1 * 8192 + idx] = half_bits_h(x - (float)hi);
+            }
+    }
+    out8 = out;
+    const size_t nblk = out.size() / (FG_STAGE / 2);
+    for (size_t b = 0; b < nblk; ++b) {
+        const unsigned short* src = out.data() + b * (FG_STAGE / 2);
+        unsigned char* dst = reinterpret_cast<unsigned char*>(out8.data() + b * (FG_STAGE / 2) + 8192);
+        for (int u = 0; u < 1024; ++u)
+            for (int e = 0; e < 8; ++e) {
+                dst[u * 16 + e] = e4m3_bits(half_value_h(src[u * 8 + e]) * 0.25f);
+                dst[u * 16 + 8 + e] = e4m3_bits(half_value_h(src[8192 + u * 8 + e]) * 512.f);
+            }
     }
     return 0;
 }

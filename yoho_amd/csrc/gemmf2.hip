@@ -736,6 +736,217 @@ __global__ __launch_bounds__(512, 2) void fgemm3c_kernel(FGemmArgs a, int flags)
 
 
 // ---------------------------------------------------------------------------------------------------------------
+// cgemm (round 6): PartII's 13-element cone layer (utils/network.py:243-249,23-65 evaluated only where the g = 0 output needs it) as ONE
+// implicit GEMM on fgemm3c's K loop:
+//     y[o, (j, m)] = sum_k sum_c W[o, c, k] * act[c, N[n_j][k], m]        M = cout = 512, N = 13 output elements x matches, K = 13 taps x cin
+// The "gather" of the 13-tap group convolution is a choice of B-operand STAGE BLOCK per (output element j, tap k): the producer
+// (gft16_kernel<G16_INVG>) leaves the activated first-layer output as [column tile of 256 matches][cone slot][32-channel block] x 32 KiB in
+// exactly the image an LDS stage wants, so a K step's B half is still one straight LDS-DMA copy - only its base moves with the tap
+// (a.slot: slot of N[n_j][k], 169 bytes).  A = the layer's weights as a plain [cout][tap * cin + c] matrix in fgemm's A pack (hi plane +
+// fp8 correction operand in place of the lo plane for FP8, hi + lo planes else).  Tile shape, LDS image, DMA, fragment reads and the
+// products are fgemm3c's / fgemm3's (three fp16 products, or one fp16 product + the two corrections on the fp8 pipe); the epilogue
+// applies bias, the next layer's BN + ReLU and writes fp16x2 planes in the layout cone1_kernel stages from
+// ([tile16][c8][plane][60 slabs][16 matches][8 ch], slab n_j).  Replaces gconv16_kernel<7,4,2> in PartII modes 3 / 4: no tap-pair or
+// unit padding (14 / 13 twice), both operands blocked through LDS.
+// ---------------------------------------------------------------------------------------------------------------
+struct CGemmArgs {
+    const char* A;            // [mtile][tap * KSt + cb][32 KiB]
+    const char* B;            // [column tile][slot][cb][32 KiB]
+    const float* bias;
+    const float* bn_s;
+    const float* bn_t;
+    char* out;                // cone1 planes
+    int NTm, MT, KSt, ntap, nj, nslot, c8out, nT32, nTiles16;
+    float descale;
+    int* rflag;
+    const unsigned* amax;     // FP8: largest |B plane value| (float bit pattern) left by the producer
+    unsigned char slot[13 * 13];
+    unsigned char outg[16];
+};
+
+__device__ __forceinline__ void cg_split_pair(float x0, float x1, unsigned& hi, unsigned& lo) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 x;
+    x.x = x0; x.y = x1;
+    const halfx2 h = __builtin_convertvector(x, halfx2);
+    const f2 r = x - __builtin_convertvector(h, f2);
+    const halfx2 l = __builtin_convertvector(r, halfx2);
+    __builtin_memcpy(&hi, &h, 4);
+    __builtin_memcpy(&lo, &l, 4);
+}
+
+template <bool FP8>
+__global__ __launch_bounds__(512, 2) void cgemm_kernel(CGemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ int tapoff[16];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w8 = __builtin_amdgcn_readfirstlane(tid >> 6);             // 8 waves: waves 0-3 own the left 128 columns, 4-7 the right
+    const int w = w8 & 3;
+    // work map: both row tiles of a column tile are neighbours on one XCD (the B panel is served from that XCD's L2 to the second one)
+    const int xcd = blockIdx.x & 7, slot_ = blockIdx.x >> 3;
+    const int ct = xcd + 8 * (slot_ / a.MT), mtile = slot_ % a.MT;
+    if (ct >= a.nj * a.NTm) return;
+    const int j = ct / a.NTm, mt = ct - j * a.NTm;
+    const int SPT = 2 * a.KSt;                                           // K16 steps per tap
+    const int KT = a.ntap * SPT;
+    if (tid < 16) tapoff[tid] = tid < a.ntap ? (int)a.slot[j * 13 + tid] : 0;
+    const char* Ag = a.A + (size_t)mtile * (KT / 2) * FG_STAGE;
+    const char* Bt = a.B + (size_t)mt * a.nslot * a.KSt * FG_STAGE;      // this column tile's slots
+    const int nh = w8 >> 2;
+    const int wm = w >> 1, wn = w & 1;
+    const int wkg = w8 >> 2, wcb = w8 & 3;
+    const int la = wkg * 4096 + wcb * 1024 + lane * 16;
+    const int lb = la;
+    __syncthreads();
+    auto bsrc = [&](int s) -> const char* {
+        const int tap = s / SPT, within = s - tap * SPT;
+        const int sl = __builtin_amdgcn_readfirstlane(tapoff[tap]);
+        return Bt + (size_t)sl * a.KSt * FG_STAGE + step_off(within);
+    };
+
+    floatx16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][jj][e] = 0.f;
+
+    C8Scales sc;
+    sc.ah = 4.f; sc.al = 4.f / 2048.f; sc.bh = 1.f; sc.bl = 1.f; sc.mfma_b = 127;
+    if constexpr (FP8) {
+        const unsigned amax_bits = __builtin_amdgcn_readfirstlane(*a.amax);
+        int kexp = (int)(amax_bits >> 23) - 127 - 7;
+        kexp = kexp < -60 ? -60 : (kexp > 9 ? 9 : kexp);
+        sc.bh = __uint_as_float((unsigned)(kexp + 127) << 23); sc.bl = __uint_as_float((unsigned)(kexp - 11 + 127) << 23);
+        sc.mfma_b = 127 + kexp;
+    }
+    const int lane_a = (lane >> 5) * 4096 + (wm * 128 + (lane & 31)) * 16;
+    const int lane_b = 16384 + (lane >> 5) * 4096 + (nh * 128 + wn * 64 + (lane & 31)) * 16;
+
+    dma_step3(Ag, uniform_ptr(bsrc(0)), smem, la, lb, w, wkg, wcb);
+    dma_step3(Ag + step_off(1), uniform_ptr(bsrc(1)), smem + F3_BUF, la, lb, w, wkg, wcb);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    Frags8 c8;
+    if constexpr (FP8) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) c8.a[i][e] = 0;
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) c8.b[jj][e] = 0;
+    }
+    // fgemm3c's loop: step s lives in ring buffer s % 3; at its head the DMA of step s + 2 is issued into the buffer every wave finished
+    // reading before the barrier, the fragments of step s are read and the products issued; the two waves of a SIMD cover each other
+    int cur = 0, stg = 2 * F3_BUF;
+    int s = 0;
+    auto one_step = [&](auto parity) {
+        constexpr int PAR = decltype(parity)::value;
+        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            const int s2 = s + 2 < KT ? s + 2 : KT - 1;
+            dma_step3(uniform_ptr(Ag + step_off(s2)), uniform_ptr(bsrc(s2)), smem + stg, la, lb, w, wkg, wcb);
+        }
+        Frags2 f;
+        sfor<0, 12>([&](auto rc) { read_frag3<decltype(rc)::value>(smem + cur + lane_a, smem + cur + lane_b, f); });
+        if constexpr (FP8) step3c<PAR>(f, acc, c8, sc);
+        else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) acc[i][jj] = mfma_h(f.al[i], f.bh[jj], acc[i][jj]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) acc[i][jj] = mfma_h(f.ah[i], f.bl[jj], acc[i][jj]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) acc[i][jj] = mfma_h(f.ah[i], f.bh[jj], acc[i][jj]);
+        }
+        stg = cur;
+        cur = cur == 2 * F3_BUF ? 0 : cur + F3_BUF;
+        ++s;
+    };
+    for (int it = 0; it < KT; it += 2) {         // KT is even
+        one_step(std::integral_constant<int, 0>{});
+        one_step(std::integral_constant<int, 1>{});
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the re-staged tail pieces must not land in the LDS of the next workgroup
+
+    // ---- epilogue: D[row][col]: lane (col = lane & 31, half = lane >> 5), reg e -> row = (e & 3) + 8 * (e >> 2) + 4 * half.
+    // v = acc * descale + bias; the next layer's BN + ReLU; x H2_ASCALE; hi / lo planes; 8 bytes (4 channels) per plane and lane
+    const int half = lane >> 5, c32 = lane & 31;
+    const int g = a.outg[j];
+    unsigned top = 0u;
+#pragma unroll
+    for (int bi = 0; bi < 2; ++bi) {
+        const int m = mt * 256 + nh * 128 + wn * 64 + bi * 32 + c32;     // match
+        const bool ok = (m >> 5) < a.nT32 && (m >> 4) < a.nTiles16;
+#pragma unroll
+        for (int ai = 0; ai < 4; ++ai) {
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const int o = mtile * 256 + wm * 128 + ai * 32 + q4 * 8 + half * 4;
+                const floatx4 b4 = *reinterpret_cast<const floatx4*>(a.bias + o);
+                const floatx4 s4 = *reinterpret_cast<const floatx4*>(a.bn_s + o);
+                const floatx4 t4 = *reinterpret_cast<const floatx4*>(a.bn_t + o);
+                float y[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v = acc[ai][bi][4 * q4 + e] * a.descale + b4[e];
+                    y[e] = fmaxf(v * s4[e] + t4[e], 0.f) * H2_ASCALE;
+                    top = max(top, __float_as_uint(y[e]) & 0x7FFFFFFFu);
+                }
+                unsigned h0, l0, h1, l1;
+                cg_split_pair(y[0], y[1], h0, l0);
+                cg_split_pair(y[2], y[3], h1, l1);
+                if (ok) {
+                    char* dst = a.out + (((size_t)(m >> 4) * a.c8out + (o >> 3)) * 2) * 15360 + g * 256 + (m & 15) * 16 + half * 8;
+                    *reinterpret_cast<uint2*>(dst) = uint2{h0, h1};
+                    *reinterpret_cast<uint2*>(dst + 15360) = uint2{l0, l1};
+                }
+            }
+        }
+    }
+    note_range_bits(a.rflag, top, FP16_MAX);
+}
+
+int cgemm_init() {
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&cgemm_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, F3_LDS));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&cgemm_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, F3_LDS));
+    return 0;
+}
+
+// the cone layer L (cin -> cout, 13 taps) on M matches: Bstages as launch_gft16_invg left them, out = cone1's input planes;
+// slot[j * 13 + k] = cone slot of N[n_j][k], outg[j] = n_j; amax != null selects the fp8-correction kernel (needs L.wcg8)
+int launch_cgemm(const Layer& L, const char* Bstages, int nslot, const unsigned char* slot, const unsigned char* outg, int nT32, int nTiles16,
+                 char* out, hipStream_t s, int* rflag, const unsigned* amax) {
+    const bool fp8 = amax != nullptr;
+    if (!(fp8 ? L.wcg8 : L.wcg) || L.cin % 32 || L.cout % 256) { set_error("cgemm: needs the cone-GEMM weight pack, cin %% 32 == 0, cout %% 256 == 0"); return YOHO_EINVAL; }
+    if (nT32 == 0) return 0;
+    CGemmArgs a;
+    a.A = reinterpret_cast<const char*>(fp8 ? L.wcg8 : L.wcg); a.B = Bstages; a.bias = L.bias; a.bn_s = L.bn_s; a.bn_t = L.bn_t; a.out = out;
+    a.NTm = (nT32 + 7) / 8; a.MT = L.cout / 256; a.KSt = L.cin / 32; a.ntap = 13; a.nj = 13; a.nslot = nslot; a.c8out = L.cout / 8;
+    a.nT32 = nT32; a.nTiles16 = nTiles16; a.descale = L.wcg_descale; a.rflag = rflag; a.amax = amax;
+    std::memcpy(a.slot, slot, 169);
+    std::memset(a.outg, 0, 16);
+    std::memcpy(a.outg, outg, 13);
+    const int CT = a.nj * a.NTm;
+    const int grid = 8 * ((CT + 7) / 8) * a.MT;
+    if (fp8) hipLaunchKernelGGL(cgemm_kernel<true>, dim3(grid), dim3(512), F3_LDS, s, a);
+    else hipLaunchKernelGGL(cgemm_kernel<false>, dim3(grid), dim3(512), F3_LDS, s, a);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // fgemm3s: fgemm3's staging and K loop for layers with 32 output channels (32 d <= 160 live rows of the 256-row A tile).  In
 // fgemm3 the waves are arranged 2 (rows) x 4 (columns): the lower row half is padding, so half the waves - two of the four
 // SIMDs - idle and the other two issue 24 MFMAs per step on 128 rows of which 32 d are real.  Here the eight waves split the

@@ -90,7 +90,7 @@ __device__ __forceinline__ void stage_chunk(const float* in, int chunk, int C8, 
     for (int p = w; p < G; p += 4) __builtin_amdgcn_global_load_lds((gptr_t)(s + p * rs + lane * 16), (lptr_t)(dst + p * 1024), 16, 0, 0);
 }
 
-enum { G16_ACT32 = 0, G16_ACTP = 1, G16_INV = 2, G16_INVP = 3 };
+enum { G16_ACT32 = 0, G16_ACTP = 1, G16_INV = 2, G16_INVP = 3, G16_INVG = 4 };
 
 template <int MODE>
 __global__ __launch_bounds__(256, 1) void gft16_kernel(Gft16Args a) {
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256, 1) void gft16_kernel(Gft16Args a) {
             continue;
         }
 
-        if constexpr (MODE == G16_INVP) {
+        if constexpr (MODE == G16_INVP || MODE == G16_INVG) {
             // inverse transform + BN + ReLU, output in the group domain for the direct cone kernels (PartII)
             const int ch0 = c8 * 8 + (w >> 1) * 4 + 2 * (Lp & 1);
             const float d1 = 1.f / (F_SCALE * HF_ASCALE);
@@ -218,6 +218,24 @@ __global__ __launch_bounds__(256, 1) void gft16_kernel(Gft16Args a) {
                     }
                 }
             __syncthreads();
+            if constexpr (MODE == G16_INVG) {
+                // B-operand stage blocks of the cone GEMM (gemmf2.hip: cgemm_kernel): [column tile of 256 matches][cone slot][32-channel block]
+                // x 32 KiB = [plane][K16 sub-step][K8 group][col 256][8 ch]; slot = a.qstride[g] (< 0: the cone does not read this element)
+                const int cb = c8 >> 2, sub = (c8 >> 1) & 1, kgr = c8 & 1, nslot = a.nTiles16, CB = a.C8 >> 2;
+                char* dstg = a.planes + ((size_t)(tile32 >> 3) * nslot * CB + cb) * 32768 + ((sub * 2 + kgr) * 256 + (tile32 & 7) * 32) * 16;
+#pragma unroll
+                for (int i = 0; i < 15; ++i) {
+                    const int idx = i * 256 + tid;             // (plane, g, kp)
+                    const int pl = idx >= 1920 ? 1 : 0, rem = idx - pl * 1920;
+                    const int g = rem >> 5, kpp = rem & 31;
+                    const int sl = qs[g];
+                    const char* sp = cur + pl * 30720 + g * 512 + kpp * 8;
+                    const uint2 c03 = *reinterpret_cast<const uint2*>(sp);
+                    const uint2 c47 = *reinterpret_cast<const uint2*>(sp + 256);
+                    if (sl >= 0) *reinterpret_cast<uintx4*>(dstg + (size_t)sl * CB * 32768 + pl * 16384 + kpp * 16) = uintx4{c03.x, c03.y, c47.x, c47.y};
+                }
+                continue;
+            }
 #pragma unroll
             for (int i = 0; i < 15; ++i) {
                 const int idx = i * 256 + tid;                 // (plane, g, kp)
@@ -322,6 +340,15 @@ __global__ __launch_bounds__(256, 1) void gft16_kernel(Gft16Args a) {
         }
     }
     note_range_bits(a.rflag, top);
+    if constexpr (MODE == G16_INVG) {
+        // largest plane value written, for the fp8 scale of the cone GEMM's correction products (as gft16x leaves it for fgemm3c)
+        if (a.amax) {
+            unsigned m = top;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+            if (lane == 0 && m) atomicMax(a.amax, m);
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -607,6 +634,7 @@ int gft16_init() {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gft16_kernel<G16_ACTP>), hipFuncAttributeMaxDynamicSharedMemorySize, G16_LDS));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gft16_kernel<G16_INV>), hipFuncAttributeMaxDynamicSharedMemorySize, G16_LDS));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gft16_kernel<G16_INVP>), hipFuncAttributeMaxDynamicSharedMemorySize, G16_LDS));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gft16_kernel<G16_INVG>), hipFuncAttributeMaxDynamicSharedMemorySize, G16_LDS));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gft16x_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, G16X_LDS));
     return 0;
 }
@@ -777,6 +805,23 @@ int launch_gft16_invp(const float* in, float* res0, char* planes16, int nTiles16
     const int grid = a.nChunks < nCU ? a.nChunks : nCU;
     if (grid == 0) return 0;
     hipLaunchKernelGGL(gft16_kernel<G16_INVP>, dim3(grid), dim3(256), G16_LDS, s, a);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// The same with the activated values laid out as the B-operand stage blocks of the cone GEMM (cgemm_kernel, gemmf2.hip):
+// planesG [ceil(nTiles / 8) column tiles][nslot][C8 / 4][32 KiB]; slot_of[g] = the cone slot of group element g or -1; amax (or null)
+// receives the largest plane value written (atomicMax of float bit patterns; the caller zeroes it)
+int launch_gft16_invg(const float* in, float* res0, char* planesG, const int* slot_of, int nslot, const void* Ffrag, const float* bn_s,
+                      const float* bn_t, int nTiles, int C8, int nCU, hipStream_t s, int* rflag, unsigned* amax) {
+    Gft16Args a;
+    a.rflag = rflag; a.drain = 0; a.ctr = nullptr; a.amax = amax;
+    a.in = in; a.out32 = nullptr; a.planes = planesG; a.Ffrag = reinterpret_cast<const uintx4*>(Ffrag); a.bn_s = bn_s; a.bn_t = bn_t;
+    a.nChunks = nTiles * C8; a.C8 = C8; a.B = 0; a.res0 = res0; a.nTiles16 = nslot;
+    for (int q = 0; q < G; ++q) { a.qbase[q] = 0; a.qstride[q] = slot_of[q]; }
+    const int grid = a.nChunks < nCU ? a.nChunks : nCU;
+    if (grid == 0) return 0;
+    hipLaunchKernelGGL(gft16_kernel<G16_INVG>, dim3(grid), dim3(256), G16_LDS, s, a);
     HIPCHK(hipGetLastError());
     return 0;
 }

@@ -238,8 +238,8 @@ int yoho_register_pair(yoho_ctx* c, const float* feat0, const float* feat1, cons
         set_error("yoho_register_pair: bad argument"); return YOHO_EINVAL;
     }
     if (estimator == YOHO_ESTIMATOR_O && !c->has_partII) { set_error("yoho_register_pair: PartII weights not loaded"); return YOHO_ENOWEIGHTS; }
-    if (estimator == YOHO_ESTIMATOR_O && c->partII_mode != 2) {
-        set_error("yoho_register_pair: YOHO-O runs in the default PartII arithmetic mode only (the caller composes the staged entries otherwise)");
+    if (estimator == YOHO_ESTIMATOR_O && c->partII_mode < 2) {
+        set_error("yoho_register_pair: YOHO-O runs in the fp16x2 PartII arithmetic modes (2, 3, 4) only (the caller composes the staged entries otherwise)");
         return YOHO_EINVAL;
     }
     YOHO_NEED_ALIGNED("yoho_register_pair", 15, feat0, feat1, eqv0, eqv1, inv0, inv1);

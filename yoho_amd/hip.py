@@ -174,7 +174,8 @@ class YohoError(RuntimeError):
 
 
 GCONV_MODES = {"f32": 0, "bf16x3": 1, "fourier": 2, "fp16x2": 3, "fgemm": 4, "fgemm256": 5, "fgemm128": 6, "fgemm8": 7}
-PARTII_MODES = {"f32": 0, "bf16x3": 1, "fp16x2": 2}
+PARTII_MODES = {"f32": 0, "bf16x3": 1, "fp16x2": 2, "cgemm": 3, "cgemm8": 4}
+FP16_PARTII_MODES = ("fp16x2", "cgemm", "cgemm8")       # fp16 planes: Fourier first layer, row-indexed entries, the fp16 range guard
 FP16_GCONV_MODES = ("fp16x2", "fgemm", "fgemm256", "fgemm128", "fgemm8")      # arithmetic with fp16 planes: guarded by the range flag (yoho_range_status)
 MAX_PAIR_KEYPOINTS = 16384                  # yoho_partI_forward_pair takes both fragments in one pass up to this many rows
 
@@ -489,7 +490,7 @@ class Context:
 
     def supports_matched(self):
         """row-indexed PartII (yoho_partII_forward_indexed) exists for the default PartII mode"""
-        return self.partII_mode == "fp16x2"
+        return self.partII_mode in FP16_PARTII_MODES
 
     def partI_forward(self, x, want_inv=True, want_inv_np=False, check_range=True):
         """x (B,32,60) f32 cuda -> dict(eqv, inv[, inv_np]).  check_range: in the fp16x2 modes verify the range flag
@@ -601,7 +602,7 @@ class Context:
         return quat
 
     def partII_forward(self, before_eqv0, before_eqv1, after_eqv0, after_eqv1, pre_idx, check_range=True):
-        if check_range and self.partII_mode == "fp16x2":
+        if check_range and self.partII_mode in FP16_PARTII_MODES:
             args = (before_eqv0, before_eqv1, after_eqv0, after_eqv1, pre_idx)
             q = self.partII_forward(*args, check_range=False)
             if self.partII_overflow():
@@ -739,7 +740,8 @@ class Context:
         _check(self._lib.yoho_set_partI_schedule(self._h, int(chunk_kp), int(streams)))
 
     def set_partII_mode(self, mode):
-        """'f32', 'bf16x3' or 'fp16x2' for the two large cone layers of PartII."""
+        """'f32', 'bf16x3', 'fp16x2' (direct cone kernels), 'cgemm' (13-element cone layer as an implicit GEMM) or 'cgemm8' (cgemm with fp8
+        correction products) for PartII (include/yoho_hip.h: yoho_set_partII_mode)."""
         _check(self._lib.yoho_set_partII_mode(self._h, PARTII_MODES[mode]))
         self.partII_mode = mode
 
