@@ -116,6 +116,8 @@ def measure_traffic(mode, nkp):
         env = dict(os.environ, PMC_B=str(nkp), TMPDIR="/tmp")
         for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
             env.pop(k, None)
+        if any(k.startswith(("ROCPROF", "ROCP_")) or (k in ("HSA_TOOLS_LIB", "LD_PRELOAD") and "rocprof" in v) for k, v in env.items()):
+            return None, "this process itself runs under rocprofv3: the counter passes are not nested (run bench.py unprofiled for `traffic`)"
         for cnt in ("FETCH_SIZE", "WRITE_SIZE"):
             r = subprocess.run(["rocprofv3", "--kernel-trace", "--pmc", cnt, "--output-format", "csv", "-d", os.path.join(tmp, cnt), "--",
                                 sys.executable, os.path.join(REPO, "tools", "pmc_partI.py"), mode], env=env, cwd=tmp,

@@ -29,7 +29,7 @@ def body_of(path, drop_prefixes=("+ ", "fatal:")):
 
 
 def main(commit):
-    for name in ("kernel_trace_bench", "kernel_trace_bench_seq", "kernel_trace_extract", "pmc_traffic", "pmc_sq"):
+    for name in ("kernel_trace_bench", "kernel_trace_bench_seq", "kernel_trace_bench_timed", "kernel_trace_extract", "pmc_traffic", "pmc_sq"):
         src, dst = os.path.join(SRC, name + ".md"), os.path.join(DST, RND + "_" + name + ".md")
         if not os.path.exists(src):
             print("missing", src)

@@ -368,6 +368,7 @@ int yoho_ctx_create(int device, const float* R, const uint8_t* N, const uint8_t*
         c->env.fcgf_full_maps = is("YOHO_FCGF_MAPS", "full");
         c->env.fcgf_norm_staged = is("YOHO_FCGF_NORM", "staged");
         if (const char* e = std::getenv("YOHO_WS_LIMIT_MB")) c->env.ws_limit_mb = std::atoll(e);
+        if (is("YOHO_PARTII_L1", "3")) c->env.partII_l1_variant = 3;
     }
     if (const char* m = std::getenv("YOHO_FCGF_CELLS")) c->fcgf_cell_sort = std::atoi(m);
     if (const char* m = std::getenv("YOHO_FCGF_SORT")) c->fcgf_parity_sort = std::strcmp(m, "0") == 0 ? 0 : 1;
@@ -943,7 +944,7 @@ static int partII_pass16(yoho_ctx* c, const float* s0, const float* s1, const fl
         char* bP = (char*)(bQ + n32 * CHUNK_FLOATS);
         float* bC = (float*)(bP + szP);                 // raw Fourier coefficients of the first layer
         if ((rc = launch_head2(s0, s1, s2, s3, idx, c->dP, c->p2_init_bn_s, c->p2_init_bn_t, M, nT, bP, kppad, c->dF16, s, ridx, istride, rf))) return rc;
-        if ((rc = launch_fgemm(c->p2[0], bP, kppad, nT, nullptr, bC, 0, s, rf))) return rc;
+        if ((rc = launch_fgemm(c->p2[0], bP, kppad, nT, nullptr, bC, 0, s, rf, c->env.partII_l1_variant))) return rc;
         if (c->partII_mode >= 3 && c->p2[1].wcg && !c->env.partII_tail_staged && mlp_head_supported(c->p2[3], c->p2[4], c->p2[5])) {
             // modes 3 / 4: the 13-element cone layer as ONE implicit GEMM (cgemm_kernel, gemmf2.hip).  The inverse transform leaves the 45
             // cone elements of the first layer's output as B-operand stage blocks [column tile][slot][32-channel block][32 KiB] (in the

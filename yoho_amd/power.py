@@ -159,7 +159,8 @@ class ClockProbe:
         self.stream = torch.cuda.Stream(priority=-1)
         # one result buffer, zeroed once and synchronised: a per-probe torch.zeros would put a fill kernel on the CALLER's stream,
         # behind the kernels under test, and wipe the probe's answer when it finally runs
-        self.buf = torch.zeros((capacity, 3), dtype=torch.int64, device=f"cuda:{ctx.device}")
+        # (zeros made on the host and copied: no tensor-library fill kernel - bench.py --timed-only shows a trace without any)
+        self.buf = torch.zeros((capacity, 3), dtype=torch.int64).to(f"cuda:{ctx.device}")
         torch.cuda.synchronize()
         self.n = 0
         self.out = []
