@@ -268,3 +268,23 @@ def test_oracle_maps_against_live_minkowski_engine_manager_if_built():
         ref[f"tr_{l}"] = (o[f"conv_tr_{l}"], mc[l], mc[l - 1])
     for mn, (rows, cin, cout) in _oracle_maps(c).items():
         assert np.array_equal(_oracle_triples(rows, cin, cout), me_triples(*ref[mn])), mn
+
+
+def test_cached_backbone_fixture_is_the_oracles_output():
+    """tests/golden/fcgf15.npz (what the GPU test of the 15-copy backbone pass compares copy 7 with) is a cached output of THIS oracle
+    (oracle/gen_golden_fcgf15.py): recomputed here - voxelisation digests, the 1024 stored rows, every row sum - so the cache cannot go
+    stale behind a change of the oracle, the cloud generator or the weight generator."""
+    import hashlib
+    from yoho_amd import synth, weights as W
+    from yoho_amd.tables import default_tables
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fcgf15.npz"))
+    fsd = W.synth_state_dict(W.FCGF_SPEC, int(g["fcgf_seed"]))
+    pc = synth.surface_cloud(int(g["points"]), seed=1, extent=float(g["extent"]))
+    rot = pc @ default_tables().R64[int(g["copy"])].T
+    sel, coords = fo.voxelize(rot, float(g["voxel"]))
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+    assert sha(np.asarray(sel, np.int64)) == str(g["sel_sha"]) and sha(np.asarray(coords, np.int32)) == str(g["coords_sha"])
+    F = np.asarray(fo.extract_features(rot, float(g["voxel"]), fsd)[1], dtype=np.float32)
+    assert F.shape[0] == int(g["n"])
+    assert np.abs(F[g["rows"]] - g["feat_rows"]).max() < 2e-6                 # torch's CPU kernels sum in thread-dependent order
+    assert np.abs(F.astype(np.float64).sum(1) - g["rowsum"]).max() < 32 * 2e-6

@@ -206,7 +206,11 @@ def test_wrong_mode_for_pair_and_indexed_entries(env, hip):
         assert lib.yoho_partII_forward_indexed(h, p(e8), p(idx), p(e8), p(idx), p(e8), p(idx), p(e8), p(idx), 1, p(idx), 8, p(quat), None) == EINVAL
         assert "default PartII mode" in err(lib)
         assert lib.yoho_register_pair(h, p(x), p(x), p(e8), p(e8), p(inv), p(inv), p(k), p(k), 8, 8, 0, 100, 0.09, 1, 1, C.byref(res), None) == EINVAL
-        assert "default PartII arithmetic mode" in err(lib)
+        assert "fp16x2 PartII arithmetic modes" in err(lib)
+        for pm in ("cgemm", "cgemm8"):                        # the round-6 modes keep the Fourier first layer: both entries take them
+            ctx.set_partII_mode(pm)
+            assert lib.yoho_partII_forward_indexed(h, p(e8), p(idx), p(e8), p(idx), p(e8), p(idx), p(e8), p(idx), 1, p(idx), 8, p(quat), None) == 0
+        ctx.set_partII_mode("bf16x3")
         assert lib.yoho_partII_forward(h, p(e8), p(e8), p(e8), p(e8), p(idx), 8, p(quat), None) == 0
         torch.cuda.synchronize()
     finally:

@@ -456,18 +456,20 @@ def test_partII_cone_gemm_modes(hip, ctx, ctxh, sd1, sd2, tables, mode, tol):
     c.set_partII_mode(mode)
     assert c.supports_matched()
     worst = 0.0
+    feats = [synth.unit_features(700, seed=sd) for sd in (11, 12, 13, 14)]
     for M in (700, 1, 17, 40, 255, 256, 257, 300):           # the large pass first: the small ones then see its stale stage blocks
         rs = np.random.RandomState(900 + M)
-        mk = lambda sd: synth.unit_features(M, seed=sd)
-        a, b, c_, d = mk(11), mk(12), mk(13), mk(14)
+        a, b, c_, d = (np.ascontiguousarray(x[700 - M:]) for x in feats)
         dr = rs.randint(0, 60, size=M).astype(np.int64)
         args = [cu(x) for x in (a, b, c_, d)]
         q = c.partII_forward(*args, cu(dr)).cpu().numpy()
-        qo = orc.partII_forward(a, b, c_, d, dr, sd2, tables.N, tables.P)
-        qd = ctxh.partII_forward(*args, cu(dr)).cpu().numpy()
+        qd = ctxh.partII_forward(*args, cu(dr)).cpu().numpy()     # the direct cone kernel (pinned to the oracle by the tests above)
         assert q.shape == (M, 4) and np.isfinite(q).all()
-        worst = max(worst, rel(q, qo))
-        assert rel(q, qo) < tol and rel(q, qd) < tol, (M, rel(q, qo), rel(q, qd))
+        assert rel(q, qd) < tol, (M, rel(q, qd))
+        if M in (1, 40, 257):                                     # and the oracle itself around the tile boundaries
+            qo = orc.partII_forward(a, b, c_, d, dr, sd2, tables.N, tables.P)
+            worst = max(worst, rel(q, qo))
+            assert rel(q, qo) < tol, (M, rel(q, qo))
         assert np.array_equal(q, c.partII_forward(*args, cu(dr)).cpu().numpy()), M          # same bits on a repeat
     print("partII %s: worst rel err vs oracle %.3g" % (mode, worst))
     # the row-indexed entry (what run_pair / yoho_register_pair use): rows addressed through a match list
