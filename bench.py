@@ -243,6 +243,18 @@ def fcgf_leg(ctx, dev, points=300000, nkpts=5000, runs=5):
         torch.cuda.synchronize()
         wall.append((time.perf_counter() - t0) * 1e3)
     timed_runs = sorted(wall[1:])
+    # one lane (every pass on the caller's stream, as up to round 5): the A/B of the two-lane pipeline, and the call the phase
+    # profile is taken on (its spans are consecutive events on ONE stream)
+    lanes_default = ex.lanes
+    ex.lanes = 1
+    wall1 = []
+    for rep in range(3):
+        np.random.seed(rep)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ex.run(pc, voxel_size=0.025, nkpts=nkpts)
+        torch.cuda.synchronize()
+        wall1.append((time.perf_counter() - t0) * 1e3)
     lctx.phase_profile(True)
     np.random.seed(0)
     torch.cuda.synchronize()
@@ -252,6 +264,7 @@ def fcgf_leg(ctx, dev, points=300000, nkpts=5000, runs=5):
     prof_wall = (time.perf_counter() - t0) * 1e3
     ph = lctx.phase_read()
     lctx.phase_profile(False)
+    ex.lanes = lanes_default
     # PartI of the 5000 keypoints on its own (HIP events)
     x = ex._last_group_feats
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -276,6 +289,11 @@ def fcgf_leg(ctx, dev, points=300000, nkpts=5000, runs=5):
             "points": points, "keypoints": nkpts, "voxel_size": 0.025, "rotations_per_backbone_pass": ex.rot_batch,
             "ms_per_fragment": round(timed_runs[len(timed_runs) // 2], 2), "ms_per_fragment_all": [round(v, 2) for v in wall[1:]],
             "fragments_per_s": round(1e3 / timed_runs[len(timed_runs) // 2], 2),
+            "lanes": {"backbone_lanes": lanes_default, "ms_per_fragment_one_lane": round(sorted(wall1)[1], 2),
+                      "note": "lanes = (stream, library context) pairs the four backbone passes of a fragment alternate over: a pass's voxelisation and "
+                              "coordinate / kernel maps are queued while the previous pass's convolutions run on the other lane; identical bits "
+                              "(tests/test_gpu_dropin.py); split_ms / phases_ms / spconv_3x3_per_level below are taken on a ONE-lane call "
+                              "(consecutive spans on one stream)"},
             "split_ms": {"voxelise_and_maps": ms("voxelise", "coordinate_maps", "kernel_maps"), "voxelise": ms("voxelise"),
                          "coordinate_maps": ms("coordinate_maps"), "kernel_maps": ms("kernel_maps"),
                          "convolutions": ms(*conv_names), "nn_feature_transfer": ms("nn_feature_transfer"), "partI": round(partI_ms, 3),

@@ -326,6 +326,17 @@ def test_fcgf_extractor_dropin_and_full_yoho_extractor(sd1, tables):
         assert rel(got[:, :, g], feats[:, :, g]) < 1e-4, g
     e, i = orc.partI_forward(got, sd1, tables.N)
     assert rel(eqv.numpy(), e) < 1e-4 and rel(inv.numpy(), i) < 1e-4
+    # the two-lane pipeline (backbone passes alternating over two streams / library contexts, the default) changes no bit: the same
+    # call with every pass on the caller's stream (another split of the sixty rotations into passes is NOT bit-identical: the kernel
+    # variants of a pass follow its row count, NOTEBOOK 9.6 - 8e-7 here)
+    assert ex.lanes == 2 and ex._side_stream is not None
+    for lanes, rb in ((1, 15),):
+        ex.lanes, ex.rot_batch = lanes, rb
+        np.random.seed(7)
+        k1, i1, e1 = ex.run(pc, voxel_size=0.025, nkpts=64)
+        assert torch.equal(ex._last_group_feats.cpu(), torch.from_numpy(got)), (lanes, rb, float((ex._last_group_feats.cpu() - torch.from_numpy(got)).abs().max()))
+        assert np.array_equal(k1, kpts) and torch.equal(i1, inv) and torch.equal(e1, eqv), (lanes, rb)
+    ex.lanes, ex.rot_batch = 2, 15
 
 
 @pytest.mark.parametrize("golden", ["scene4.npz", "scene6.npz"])

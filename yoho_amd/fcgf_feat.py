@@ -59,9 +59,19 @@ class fcgf_extractor():
                                normalize_feature=bool(_cfg_get(config, 'normalize_feature', True)))
         self.ctx.load_fcgf(owner=self, **self._load_args)
 
-    def _resident(self):
-        if self.ctx.fcgf_owner is not self:           # another backbone object loaded its weights into the shared context
-            self.ctx.load_fcgf(owner=self, **self._load_args)
+    def _resident(self, ctx=None):
+        ctx = self.ctx if ctx is None else ctx
+        if ctx.fcgf_owner is not self:                # another backbone object loaded its weights into the shared context
+            ctx.load_fcgf(owner=self, **self._load_args)
+
+    def lane_context(self):
+        """A second library context with this backbone's weights: its own workspace, so that a backbone pass queued on another
+        stream can build its coordinate / kernel maps while the convolutions of the previous pass still run out of the first
+        context's workspace (yoho_extractor's two-lane pipeline).  The context is process-wide (hip.get_context(lane=1)): its workspace is sized once."""
+        if getattr(self, "_lane_ctx", None) is None:
+            self._lane_ctx = hip.get_context(self.ctx.device, self.ctx.tables.dir, lane=1)
+        self._resident(self._lane_ctx)
+        return self._lane_ctx
 
     def extract_features_dev(self, pts, voxel_size):
         """HBM-resident variant: pts (n,3) f64 cuda -> (sel int64 cuda, F (m,32) f32 cuda); no host copies."""
@@ -87,23 +97,25 @@ class fcgf_extractor():
             feats += self.ctx.fcgf_forward_batch(group)
         return [(sel, f) for (sel, _), f in zip(vox, feats)]
 
-    def extract_rotated_batch(self, pts, rotations, voxel_size):
+    def extract_rotated_batch(self, pts, rotations, voxel_size, ctx=None):
         """the backbone on rotated copies of one cloud: pts (n,3) f64 cuda, rotations = list of (3,3) R (p' = R p) ->
         list of (sel, F, rotated selected points (m,3) f32).  The copies are never materialised: rotation, voxelisation and
-        the down-sampled points come from one pass over pts (yoho_fcgf_voxelize_rotated)."""
-        self._resident()
+        the down-sampled points come from one pass over pts (yoho_fcgf_voxelize_rotated).  ctx: the library context whose
+        workspace the pass uses (default: the extractor's; lane_context() for a pass queued on a second stream)."""
+        ctx = self.ctx if ctx is None else ctx
+        self._resident(ctx)
         vox = []
         for b0 in range(0, len(rotations), 64):        # one library call (one count read-back) per 64 copies
-            vox += self.ctx.fcgf_voxelize_rotated_batch(pts, rotations[b0:b0 + 64], voxel_size)
+            vox += ctx.fcgf_voxelize_rotated_batch(pts, rotations[b0:b0 + 64], voxel_size)
         feats, group, rows = [], [], 0
         for _, c, _ in vox:
             if group and (rows + c.shape[0] > self.MAX_VOXELS_PER_PASS or len(group) == 64):
-                feats += self.ctx.fcgf_forward_batch(group)
+                feats += ctx.fcgf_forward_batch(group)
                 group, rows = [], 0
             group.append(c)
             rows += c.shape[0]
         if group:
-            feats += self.ctx.fcgf_forward_batch(group)
+            feats += ctx.fcgf_forward_batch(group)
         return [(sel, f, ps) for (sel, _, ps), f in zip(vox, feats)]
 
     def extract_features(self, pc, voxel_size):

@@ -798,10 +798,12 @@ class Context:
 _ctx_cache = {}
 
 
-def get_context(device=None, so3_dir=None):
-    """Process-wide context per (device, table directory)."""
+def get_context(device=None, so3_dir=None, lane=0):
+    """Process-wide context per (device, table directory, lane).  lane > 0: a further context with a workspace of its own for work
+    queued on another stream while lane 0's runs (the backbone lanes of yoho_extractor / testset_create); it is kept, like lane 0's,
+    so that its workspace is sized once per process."""
     dev = torch.cuda.current_device() if device is None else int(device)
-    key = (dev, os.path.abspath(so3_dir) if so3_dir else None)
+    key = (dev, os.path.abspath(so3_dir) if so3_dir else None) + ((int(lane),) if lane else ())
     if key not in _ctx_cache:
         _ctx_cache[key] = Context(dev, so3_dir)
     return _ctx_cache[key]

@@ -77,6 +77,13 @@ class yoho_extractor():
         self.bs = 500
         self.rot_batch = int(os.environ.get("YOHO_ROT_BATCH", "15"))     # rotated copies of the cloud per backbone pass (HBM-resident path; split further by voxel count)
         self.overlap_keypoint_draw = os.environ.get("YOHO_OVERLAP_DRAW", "1") != "0"   # keypoint permutation drawn while the first backbone pass runs
+        # backbone passes alternate between two lanes (stream + library context = workspace): a pass's voxelisation, coordinate and
+        # kernel maps - atomics and scans with host round trips for the level sizes - are queued while the previous pass's
+        # convolutions still run on the other lane (YOHO_FCGF_LANES=1: one lane, as up to round 5)
+        self.lanes = max(1, min(2, int(os.environ.get("YOHO_FCGF_LANES", "2"))))
+        self._side_stream = None
+        if self.lanes > 1 and hasattr(self.fcgf, "lane_context"):
+            self.fcgf.lane_context()               # the second lane's weights are resident from here on, like the first one's
 
     def _load_model(self):
         sd = self.yoho_ckpt if isinstance(self.yoho_ckpt, dict) else W.load_checkpoint(self.yoho_ckpt)[0]
@@ -97,16 +104,27 @@ class yoho_extractor():
         dist, idx = self.ctx.nn_search(q, s, want_dist=False, squared=True)
         return f[idx]
 
-    def _transfer(self, res, pc_d, Rs, kidx_d, g0, kpts_f):
+    def _transfer(self, res, pc_d, Rs, kidx_d, g0, kpts_f, ctx=None):
         """NN feature transfer of one backbone pass: kpts_f[:, :, g0 + j] = F_j[nn(R_j keypoints, down-sampled points of copy j)]"""
-        if hasattr(self.ctx, "group_transfer_batch") and all(f.shape[1] == 32 for _, f, _ in res):
+        ctx = self.ctx if ctx is None else ctx
+        if hasattr(ctx, "group_transfer_batch") and all(f.shape[1] == 32 for _, f, _ in res):
             # one library call for the pass (the same three kernels per copy, queued from C: no binding round trips in between)
-            self.ctx.group_transfer_batch(pc_d, kidx_d, list(Rs), [ds for _, _, ds in res], [f.contiguous() for _, f, _ in res], g0, kpts_f)
+            ctx.group_transfer_batch(pc_d, kidx_d, list(Rs), [ds for _, _, ds in res], [f.contiguous() for _, f, _ in res], g0, kpts_f)
             return
         for j, (sel, pci_f, ds) in enumerate(res):
-            q = self.ctx.rotate_select(pc_d, Rs[j], kidx_d)
-            _, idx = self.ctx.nn_search(q, ds, want_dist=False, squared=True)
-            self.ctx.group_scatter(pci_f, idx, g0 + j, kpts_f)
+            q = ctx.rotate_select(pc_d, Rs[j], kidx_d)
+            _, idx = ctx.nn_search(q, ds, want_dist=False, squared=True)
+            ctx.group_scatter(pci_f, idx, g0 + j, kpts_f)
+
+    def _lanes(self):
+        """[(library context, torch stream)] the backbone passes alternate over: the caller's stream with the extractor's context,
+        and - with two lanes - a side stream with the backbone's second context (its own workspace)."""
+        main = torch.cuda.current_stream()
+        if self.lanes < 2 or not hasattr(self.fcgf, "lane_context"):
+            return [(self.ctx, main)]
+        if self._side_stream is None:
+            self._side_stream = torch.cuda.Stream()
+        return [(self.ctx, main), (self.fcgf.lane_context(), self._side_stream)]
 
     def _extract_features_overlapped(self, pc, voxel_size, nkpts):
         """extract_features' HBM-resident path with the keypoint draw off the critical path.  The reference's
@@ -118,18 +136,44 @@ class yoho_extractor():
         pc_d = torch.from_numpy(np.ascontiguousarray(np.asarray(pc, dtype=np.float64))).cuda()
         G, nb = self.grs.shape[0], self.rot_batch
         batches = [[self.grs[i] for i in range(i0, min(i0 + nb, G))] for i0 in range(0, G, nb)]
-        first = self.fcgf.extract_rotated_batch(pc_d, batches[0], voxel_size)
+        lanes = self._lanes()
+        main = lanes[0][1]
+        uploaded = torch.cuda.Event()              # the cloud is on the device (queued on the caller's stream)
+        uploaded.record(main)
+        for _, st in lanes[1:]:
+            st.wait_event(uploaded)
+
+        def backbone(b):                           # pass b on its lane: the pass's tensors are allocated, used and released on that stream
+            ctx, st = lanes[b % len(lanes)]
+            with torch.cuda.stream(st):
+                return self.fcgf.extract_rotated_batch(pc_d, batches[b], voxel_size, **({"ctx": ctx} if ctx is not self.ctx else {}))
+
+        # one pass per lane is queued before the draw: the second one builds its maps while the first one's convolutions run
+        ahead = [backbone(b) for b in range(min(len(lanes), len(batches)))]
         kpts_index = np.random.permutation(len(pc))[0:nkpts]
         kpts = pc[kpts_index]
         kpts_f = torch.empty((kpts.shape[0], 32, 60), dtype=torch.float32, device="cuda")
         kidx_d = torch.from_numpy(kpts_index.astype(np.int64)).cuda()
-        self.ctx.set_nn_grid(voxel_size)           # the NN targets are one point per voxel: grid search, same winners
+        ready = torch.cuda.Event()                 # keypoint indices and the output tensor exist
+        ready.record(main)
+        for c, st in lanes:
+            c.set_nn_grid(voxel_size)              # the NN targets are one point per voxel: grid search, same winners
+            if st is not main:
+                st.wait_event(ready)
         try:
             for b, Rs in enumerate(batches):
-                res = first if b == 0 else self.fcgf.extract_rotated_batch(pc_d, Rs, voxel_size)
-                self._transfer(res, pc_d, Rs, kidx_d, b * nb, kpts_f)
+                ctx, st = lanes[b % len(lanes)]
+                res = ahead[b] if b < len(ahead) else backbone(b)
+                with torch.cuda.stream(st):
+                    self._transfer(res, pc_d, Rs, kidx_d, b * nb, kpts_f, ctx=ctx)
+                    if b < len(ahead):
+                        ahead[b] = None
+                    del res
+            for _, st in lanes[1:]:
+                main.wait_stream(st)               # PartI reads every column of kpts_f
         finally:
-            self.ctx.set_nn_grid(0)
+            for c, _ in lanes:
+                c.set_nn_grid(0)
         self._last_group_feats = kpts_f
         out = self._partI(kpts_f)
         return (kpts,) + _to_host(out["inv"], out["eqv"])
