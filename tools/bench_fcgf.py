@@ -44,6 +44,12 @@ if nb > 1:
     torch.cuda.synchronize()
     tb = (time.perf_counter() - t0) / reps * 1e3
     print(f"{nb} rotated copies, {sum(g.shape[0] for g in group)} voxels in one pass: {tb:.3f} ms ({tb / nb:.3f} ms per copy)")
+    ctx.phase_profile(True)
+    for _ in range(reps):
+        ctx.fcgf_forward_batch(group)
+    ph = ctx.phase_read()
+    ctx.phase_profile(False)
+    print("  phases, ms per pass: " + ", ".join(f"{k} {v['ms'] / reps:.3f}" for k, v in ph.items() if v["ms"] > 0))
 import hashlib
 print("sha256 of the single-cloud features:", hashlib.sha256(F.cpu().numpy().tobytes()).hexdigest()[:16])
 print(f"points {n} -> voxels {nv}: voxelize {tv:.3f} ms, backbone forward {tf:.3f} ms  ({nv / tf * 1e-3:.2f} M voxels/s); "

@@ -367,6 +367,7 @@ int yoho_ctx_create(int device, const float* R, const uint8_t* N, const uint8_t*
         c->env.fcgf_f32 = is("YOHO_FCGF", "f32");
         c->env.fcgf_full_maps = is("YOHO_FCGF_MAPS", "full");
         c->env.fcgf_norm_staged = is("YOHO_FCGF_NORM", "staged");
+        c->env.fcgf_heads_staged = is("YOHO_FCGF_HEADS", "staged");
         if (const char* e = std::getenv("YOHO_WS_LIMIT_MB")) c->env.ws_limit_mb = std::atoll(e);
         if (is("YOHO_PARTII_L1", "3")) c->env.partII_l1_variant = 3;
     }

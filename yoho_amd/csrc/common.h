@@ -253,6 +253,7 @@ struct yoho_env_switches {
     bool fcgf_f32 = false;             // YOHO_FCGF=f32: the backbone's weights are packed for the fp32-MFMA kernels at yoho_load_fcgf
     bool fcgf_full_maps = false;       // YOHO_FCGF_MAPS=full: every kernel map by its own probes (no mirrored / inverted maps)
     bool fcgf_norm_staged = false;     // YOHO_FCGF_NORM=staged: row normalisation as its own kernel behind the last convolution
+    bool fcgf_heads_staged = false;    // YOHO_FCGF_HEADS=staged: the decoder's two 1 x 1 heads as two launches (heads_fused_kernel off); identical bits
     int partII_l1_variant = 2;         // YOHO_PARTII_L1=3: PartII's first (Fourier) layer on fgemm3 (256 x 256 tiles, eight waves) instead of fgemm2
     long long ws_limit_mb = 0;         // YOHO_WS_LIMIT_MB=<n>: a workspace request above n MiB fails as an exhausted device would (0 = no limit):
                                        // lets a test walk the YOHO_ENOMEM recoveries of the backbone (hash-table attempt, table voxelisation)

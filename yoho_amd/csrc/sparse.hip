@@ -1204,6 +1204,142 @@ template <int NCB>
 __global__ __launch_bounds__(256) void spconv16w_ring4_kernel(SpConvArgs a) { spconv16w_body<NCB, 0, 4>(a); }      // the kernels up to round 4
 #endif
 
+// The decoder's two 1 x 1 heads in one kernel (resunet.py:181-187): f1 = relu(conv1_tr(x)) (32 NC1 -> 64 channels), out = final(f1) + bias
+// (64 -> 32), rows /= |row| `norm` times, the caller's row order.  As two launches of spconv16w_kernel the 64-channel intermediate is
+// written and read back once (2 x 336 MB of the 1.35 GB the two move per 1.3 M-voxel pass; both are HBM-bound).  Here it stays in LDS:
+// the accumulator tile of the first head (a lane = one channel of 16 rows) is written as rows, and read back in the A-operand
+// layout the gathers deliver (a lane = 8 + 8 channels of one row).  Both weight packs (24 + 8 KiB) stay in LDS for the life of the
+// workgroup, which walks 128-row tiles with a stride of the grid.  The same products in the same order, the same epilogue
+// expressions as the two launches: identical bits.
+struct HeadsArgs {
+    const float* in; int ldin;           // (n, ldin) rows; the first 32 NC1 columns are convolved
+    int n;
+    const void* W1; float descale1;      // pack_w16 planes, cout = 64
+    const void* W2; float descale2;      // cout = 32
+    const float* bias2;
+    float* out;                          // (n, 32)
+    int norm;
+    const int* operm;                    // output row -> caller's row, or null
+};
+template <int NC1>
+__global__ __launch_bounds__(256) void heads_fused_kernel(HeadsArgs a) {
+    constexpr int W1F = NC1 * 4 * 2 * 64, W2F = 2 * 4 * 64, LD1 = 68, EPI_LD = 36;
+    __shared__ uintx4s w1s[W1F];
+    __shared__ uintx4s w2s[W2F];
+    __shared__ __attribute__((aligned(16))) float tile[4][32 * LD1];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int li = lane & 31, h = lane >> 5;
+    for (int i = tid; i < W1F; i += 256) w1s[i] = reinterpret_cast<const uintx4s*>(a.W1)[i];
+    for (int i = tid; i < W2F; i += 256) w2s[i] = reinterpret_cast<const uintx4s*>(a.W2)[i];
+    __syncthreads();
+    const __amdgpu_buffer_rsrc_t rs = sp_rsrc(a.in);
+    float* et = tile[w];
+    const int er = lane >> 3, ep = lane & 7;
+    const int ntiles = (a.n + 127) / 128;
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int rbase = t * 128 + w * 32;
+        const int row = rbase + li;
+        const bool valid = row < a.n;
+        float av[NC1][16];
+#pragma unroll
+        for (int cc = 0; cc < NC1; ++cc) sp_gather16(rs, valid ? ((unsigned)row * (unsigned)a.ldin + cc * 32 + h * 8) * 4u : SP_OOB, av[cc]);
+        floatx16s acc1[2];
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc1[cb][r] = 0.f;
+#pragma unroll
+        for (int cc = 0; cc < NC1; ++cc) {
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                uintx4s ah, al, bh[2], bw[2];
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb) { bh[cb] = w1s[((cc * 4 + 2 * st + 0) * 2 + cb) * 64 + lane]; bw[cb] = w1s[((cc * 4 + 2 * st + 1) * 2 + cb) * 64 + lane]; }
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    unsigned hh, ll;
+                    split_pair_sp(av[cc][8 * st + 2 * p], av[cc][8 * st + 2 * p + 1], hh, ll);
+                    ah[p] = hh; al[p] = ll;
+                }
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb) acc1[cb] = mfma_sp16(al, bh[cb], acc1[cb]);
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb) acc1[cb] = mfma_sp16(ah, bw[cb], acc1[cb]);
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb) acc1[cb] = mfma_sp16(ah, bh[cb], acc1[cb]);
+            }
+        }
+        // f1 = relu(acc * descale + 0) as the first launch's epilogue writes it, kept as rows of 64 channels
+        {
+            const float sc = a.descale1, sh = 0.f;
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = acc1[cb][r];
+                    v = v * sc + sh;
+                    et[((r & 3) + 8 * (r >> 2) + 4 * h) * LD1 + cb * 32 + li] = fmaxf(v, 0.f);
+                }
+        }
+        __builtin_amdgcn_wave_barrier();
+        floatx16s acc2;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) {
+            float a2[16];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 v = *reinterpret_cast<const float4*>(et + li * LD1 + cc * 32 + h * 8 + (q >> 1) * 16 + (q & 1) * 4);
+                a2[4 * q] = v.x; a2[4 * q + 1] = v.y; a2[4 * q + 2] = v.z; a2[4 * q + 3] = v.w;
+            }
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                uintx4s ah, al;
+                const uintx4s bh = w2s[(cc * 4 + 2 * st + 0) * 64 + lane], bw = w2s[(cc * 4 + 2 * st + 1) * 64 + lane];
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    unsigned hh, ll;
+                    split_pair_sp(a2[8 * st + 2 * p], a2[8 * st + 2 * p + 1], hh, ll);
+                    ah[p] = hh; al[p] = ll;
+                }
+                acc2 = mfma_sp16(al, bh, acc2);
+                acc2 = mfma_sp16(ah, bw, acc2);
+                acc2 = mfma_sp16(ah, bh, acc2);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();                                  // every lane has read its row of f1
+#pragma unroll
+        for (int r = 0; r < 16; ++r) et[((r & 3) + 8 * (r >> 2) + 4 * h) * EPI_LD + li] = acc2[r];
+        __builtin_amdgcn_wave_barrier();
+        {
+            const int co = 4 * ep;
+            float4 sc = make_float4(a.descale2, a.descale2, a.descale2, a.descale2), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (a.bias2) sh = *reinterpret_cast<const float4*>(a.bias2 + co);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int orow = rbase + 8 * g + er;
+                if (orow < a.n) {
+                    float4 v = *reinterpret_cast<const float4*>(et + (8 * g + er) * EPI_LD + 4 * ep);
+                    v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+                    size_t drow = (size_t)orow;
+                    if (a.norm) {
+                        for (int pass = 0; pass < a.norm; ++pass) {
+                            float ss = fmaf(v.x, v.x, v.y * v.y) + fmaf(v.z, v.z, v.w * v.w);      // as in spconv16w_body's epilogue
+                            ss += __shfl_xor(ss, 1); ss += __shfl_xor(ss, 2); ss += __shfl_xor(ss, 4);
+                            const float nr = sqrtf(ss);
+                            v.x /= nr; v.y /= nr; v.z /= nr; v.w /= nr;
+                        }
+                        if (a.operm) drow = (size_t)a.operm[orow];
+                    }
+                    *reinterpret_cast<float4*>(a.out + drow * 32 + co) = v;
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();                                  // the tile is written again by the next iteration
+    }
+}
+
 // Cin < 32 (the first convolution: one input channel, 5^3 / 7^3 offsets): plain fp32, one thread per (row, channel)
 __global__ __launch_bounds__(256) void spconv_small_kernel(SpConvArgs a) {
     const int co = threadIdx.x % a.cout, rl = threadIdx.x / a.cout;
@@ -2196,6 +2332,20 @@ static int fcgf_forward_attempt(yoho_ctx* ctx, const FcgfNet* net, const int* co
     float* f2 = ar.take<float>((size_t)n0 * net->out_ch);
     if (ar.off > ar.cap) { set_error("fcgf_forward: workspace estimate too small"); return YOHO_ENOMEM; }
     conv_cat = 14;
+    // both heads in one launch where the fused kernel exists (96 -> 64 -> 32 channels, fp16x2 packs, a pass large enough for the fused
+    // normalisation): the 64-channel intermediate never leaves the CU (YOHO_FCGF_HEADS=staged: the two launches below)
+    const bool heads_fused = !ctx->env.fcgf_heads_staged && !ctx->env.fcgf_norm_staged && net->out_ch == 32 && T[1] == 64 && catw[0] == 96 &&
+                             net->conv1_tr.wh && net->final_k.wh && (n0 + 31) / 32 >= 1024 && !ctx->env.spconv_debug;
+    if (heads_fused) {
+        phase_mark(ctx, conv_cat, s);
+        HeadsArgs ha{cat[0], catw[0], n0, net->conv1_tr.wh, net->conv1_tr.descale, net->final_k.wh, net->final_k.descale, net->final_b, out,
+                     net->normalize ? 2 : 1, operm};
+        const int ntl = (n0 + 127) / 128;
+        hipLaunchKernelGGL((heads_fused_kernel<3>), dim3(std::min(ntl, 2 * (ctx->nCU > 0 ? ctx->nCU : 256))), dim3(256), 0, s, ha);
+        HIPCHK(hipGetLastError());
+        phase_mark(ctx, -1, s);
+        return 0;
+    }
     if ((rc = conv(cat[0], catw[0], catw[0], nullptr, 1, n0, net->conv1_tr, T[1], f1, T[1], 0, nullptr, nullptr, nullptr, 0, 0, 1))) return rc;
     // the feature head: 1 x 1 convolution to out_ch, rows /= |row| (once more for fcgf_feat.py:48), the caller's row order.  Fused into
     // the convolution's epilogue where that kernel exists (32 features, fp16x2 fine-level kernel: passes of >= 32768 voxels); the

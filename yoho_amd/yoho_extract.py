@@ -75,7 +75,10 @@ class yoho_extractor():
         self.yoho_ckpt = yoho_ckpt
         self._load_model()
         self.bs = 500
-        self.rot_batch = int(os.environ.get("YOHO_ROT_BATCH", "15"))     # rotated copies of the cloud per backbone pass (HBM-resident path; split further by voxel count)
+        # rotated copies of the cloud per backbone pass (HBM-resident path; split further by voxel count): one number, or a list
+        # "9,17,17,17" (the first pass's voxelisation and maps are the only ones nothing hides - a smaller first pass exposes less)
+        rb = [int(v) for v in os.environ.get("YOHO_ROT_BATCH", "15").split(",")]
+        self.rot_batch = rb[0] if len(rb) == 1 else rb
         self.overlap_keypoint_draw = os.environ.get("YOHO_OVERLAP_DRAW", "1") != "0"   # keypoint permutation drawn while the first backbone pass runs
         # backbone passes alternate between two lanes (stream + library context = workspace): a pass's voxelisation, coordinate and
         # kernel maps - atomics and scans with host round trips for the level sizes - are queued while the previous pass's
@@ -116,6 +119,19 @@ class yoho_extractor():
             _, idx = ctx.nn_search(q, ds, want_dist=False, squared=True)
             ctx.group_scatter(pci_f, idx, g0 + j, kpts_f)
 
+    def _pass_starts(self, G):
+        """first group element of every backbone pass, and G"""
+        rb = self.rot_batch
+        sizes = list(rb) if isinstance(rb, (list, tuple)) else [int(rb)] * ((G + int(rb) - 1) // int(rb))
+        starts = [0]
+        for n in sizes:
+            if starts[-1] >= G:
+                break
+            starts.append(min(G, starts[-1] + max(1, int(n))))
+        while starts[-1] < G:                      # a list that does not cover the group: its last size repeats
+            starts.append(min(G, starts[-1] + max(1, int(sizes[-1]))))
+        return starts
+
     def _lanes(self):
         """[(library context, torch stream)] the backbone passes alternate over: the caller's stream with the extractor's context,
         and - with two lanes - a side stream with the backbone's second context (its own workspace)."""
@@ -134,8 +150,9 @@ class yoho_extractor():
         device works while the host shuffles.  It is the only draw in this method, so the generator is consumed exactly as in
         the reference (same keypoints for the same seed)."""
         pc_d = torch.from_numpy(np.ascontiguousarray(np.asarray(pc, dtype=np.float64))).cuda()
-        G, nb = self.grs.shape[0], self.rot_batch
-        batches = [[self.grs[i] for i in range(i0, min(i0 + nb, G))] for i0 in range(0, G, nb)]
+        G = self.grs.shape[0]
+        starts = self._pass_starts(G)
+        batches = [[self.grs[i] for i in range(i0, i1)] for i0, i1 in zip(starts[:-1], starts[1:])]
         lanes = self._lanes()
         main = lanes[0][1]
         uploaded = torch.cuda.Event()              # the cloud is on the device (queued on the caller's stream)
@@ -165,7 +182,7 @@ class yoho_extractor():
                 ctx, st = lanes[b % len(lanes)]
                 res = ahead[b] if b < len(ahead) else backbone(b)
                 with torch.cuda.stream(st):
-                    self._transfer(res, pc_d, Rs, kidx_d, b * nb, kpts_f, ctx=ctx)
+                    self._transfer(res, pc_d, Rs, kidx_d, starts[b], kpts_f, ctx=ctx)
                     if b < len(ahead):
                         ahead[b] = None
                     del res
@@ -191,11 +208,12 @@ class yoho_extractor():
             # transfer of all 60 group elements run on the device (same operations as the loop below)
             pc_d = torch.from_numpy(np.ascontiguousarray(np.asarray(pc, dtype=np.float64))).cuda()
             kidx_d = torch.from_numpy(kpts_index.astype(np.int64)).cuda()
-            G, nb = self.grs.shape[0], self.rot_batch
+            G = self.grs.shape[0]
+            starts = self._pass_starts(G)
             self.ctx.set_nn_grid(voxel_size)       # the NN targets are one point per voxel: grid search, same winners
             try:
-                for i0 in range(0, G, nb):
-                    Rs = [self.grs[i] for i in range(i0, min(i0 + nb, G))]
+                for i0, i1 in zip(starts[:-1], starts[1:]):
+                    Rs = [self.grs[i] for i in range(i0, i1)]
                     if hasattr(self.fcgf, "extract_rotated_batch"):
                         # rotated copies never materialised: rotation + voxelisation + down-sampled points in one pass
                         res = self.fcgf.extract_rotated_batch(pc_d, Rs, voxel_size)
