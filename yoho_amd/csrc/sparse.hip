@@ -1236,13 +1236,24 @@ __global__ __launch_bounds__(256) void heads_fused_kernel(HeadsArgs a) {
     float* et = tile[w];
     const int er = lane >> 3, ep = lane & 7;
     const int ntiles = (a.n + 127) / 128;
+    // the rows of the next tile are fetched while this one is multiplied (a wave's tile is a dependent chain gather -> MFMA -> LDS -> MFMA
+    // -> store, and only eight waves share a CU)
+    float avn[NC1][16];
+    auto fetch = [&](int t) {
+        const int row = t * 128 + w * 32 + li;
+        const bool valid = t < ntiles && row < a.n;
+#pragma unroll
+        for (int cc = 0; cc < NC1; ++cc) sp_gather16(rs, valid ? ((unsigned)row * (unsigned)a.ldin + cc * 32 + h * 8) * 4u : SP_OOB, avn[cc]);
+    };
+    fetch(blockIdx.x);
     for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
         const int rbase = t * 128 + w * 32;
-        const int row = rbase + li;
-        const bool valid = row < a.n;
         float av[NC1][16];
 #pragma unroll
-        for (int cc = 0; cc < NC1; ++cc) sp_gather16(rs, valid ? ((unsigned)row * (unsigned)a.ldin + cc * 32 + h * 8) * 4u : SP_OOB, av[cc]);
+        for (int cc = 0; cc < NC1; ++cc)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) av[cc][e] = avn[cc][e];
+        fetch(t + gridDim.x);
         floatx16s acc1[2];
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb)
@@ -1626,6 +1637,7 @@ static int launch_spconv(const SpConvArgs& a_in, hipStream_t s) {
         } else {
             const dim3 grid((a.nslots + 127) / 128, ncbt / ncb);
 #ifdef YOHO_SPCONV_ABLATE
+            const int dbg = a.debug;
             if (a.Wh && ncb == 2 && (dbg & 4) && (dbg & 8) && (dbg & 16)) hipLaunchKernelGGL((spconv16w_kernel<2, 28>), grid, blk, 0, s, a);
             else if (a.Wh && ncb == 2 && (dbg & 32)) hipLaunchKernelGGL((spconv16w_kernel<2, 32>), grid, blk, 0, s, a);
             else if (a.Wh && ncb == 2 && (dbg & 64)) hipLaunchKernelGGL((spconv16w_kernel<2, 64>), grid, blk, 0, s, a);
