@@ -50,7 +50,7 @@
  *     YOHO_PARTI_CHUNK (yoho_set_partI_schedule), YOHO_NN=brute (yoho_set_nn_prefilter), YOHO_FCGF_SORT, YOHO_FCGF_CELLS,
  *     YOHO_FCGF_COORDS=hash (yoho_set_fcgf_sort).   A/B and diagnostic switches without a setter (struct yoho_env_switches in
  *     csrc/common.h; every value gives valid results):   YOHO_PARTII_TAIL=staged, YOHO_TRANSFER=staged, YOHO_XF_STEAL=0,
- *     YOHO_NN_SPLITS=<n>, YOHO_FCGF=f32 (takes effect at the context's yoho_load_fcgf), YOHO_FCGF_MAPS=full, YOHO_FCGF_NORM=staged, YOHO_PARTII_L1=3 (PartII's first layer on the 256 x 256-tile GEMM kernel),
+ *     YOHO_NN_SPLITS=<n>, YOHO_FCGF=f32 (takes effect at the context's yoho_load_fcgf), YOHO_FCGF_MAPS=full, YOHO_FCGF_NORM=staged, YOHO_FCGF_HEADS=staged, YOHO_PARTII_L1=3 (PartII's first layer on the 256 x 256-tile GEMM kernel),
  *     YOHO_WS_LIMIT_MB=<n> (workspace requests above n MiB fail with YOHO_ENOMEM as on an exhausted device: test hook for the recoveries),
  *     YOHO_SPCONV_DEBUG=<bits> (only in a -DYOHO_SPCONV_ABLATE build).   The timing experiments YOHO_PARTI_DEBUG / YOHO_FGEMM_DEBUG /
  *     YOHO_SPCONV_VAR exist only in the separate -DYOHO_EXPERIMENTS library, which no product code loads.
