@@ -613,7 +613,20 @@ def test_testset_create_from_point_clouds(tmp_path, tables):
 
     cfg = types.SimpleNamespace(model=ck, voxel_size=0.025, dataset="synth", output_dir=str(tmp_path), origin_dir=str(tmp_path),
                                 datasets={"wholesetname": "synth", "room": DS()})
-    testset_create(cfg).batch_feature_extraction()
+    tc = testset_create(cfg)
+    assert tc.lanes == 2                                    # default: backbone passes on two lanes, results written by the writer thread
+    tc.batch_feature_extraction()
+    assert tc.stats["fragments"] == 2
+    # one lane (every pass on the caller's stream, rounds 1-5) writes the same bytes; the single-fragment API joins its lanes
+    cfg1 = types.SimpleNamespace(**{**vars(cfg), "output_dir": str(tmp_path / "one_lane")})
+    tc1 = testset_create(cfg1)
+    tc1.lanes = 1
+    tc1.batch_feature_extraction()
+    for pid in ("0", "1"):
+        a = np.load(f"{tmp_path}/Testset/synth/room/FCGF_Input_Group_feature/{pid}.npy")
+        b = np.load(f"{tmp_path}/one_lane/Testset/synth/room/FCGF_Input_Group_feature/{pid}.npy")
+        assert np.array_equal(a, b), pid
+        assert np.array_equal(tc.fragment_group_features(clouds[pid], kps[pid]).cpu().numpy(), a), pid
     for pid in ("0", "1"):
         got = np.load(f"{tmp_path}/Testset/synth/room/FCGF_Input_Group_feature/{pid}.npy")
         assert got.shape == (40, 32, 60) and got.dtype == np.float32
