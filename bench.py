@@ -243,6 +243,16 @@ def fcgf_leg(ctx, dev, points=300000, nkpts=5000, runs=5):
         torch.cuda.synchronize()
         wall.append((time.perf_counter() - t0) * 1e3)
     timed_runs = sorted(wall[1:])
+    # streamed over fragments (yoho_extractor.run_many: PartI and the result copy of a fragment on a tail lane while the backbone lanes
+    # work on the next one): what a caller that describes many fragments pays per fragment
+    streamed = []
+    for rep in range(2):
+        np.random.seed(0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        nstream = sum(1 for _ in ex.run_many([pc] * 6, voxel_size=0.025, nkpts=nkpts))
+        torch.cuda.synchronize()
+        streamed.append((time.perf_counter() - t0) * 1e3 / nstream)
     # one lane (every pass on the caller's stream, as up to round 5): the A/B of the two-lane pipeline, and the call the phase
     # profile is taken on (its spans are consecutive events on ONE stream)
     lanes_default = ex.lanes
@@ -289,6 +299,8 @@ def fcgf_leg(ctx, dev, points=300000, nkpts=5000, runs=5):
             "points": points, "keypoints": nkpts, "voxel_size": 0.025, "rotations_per_backbone_pass": ex.rot_batch,
             "ms_per_fragment": round(timed_runs[len(timed_runs) // 2], 2), "ms_per_fragment_all": [round(v, 2) for v in wall[1:]],
             "fragments_per_s": round(1e3 / timed_runs[len(timed_runs) // 2], 2),
+            "ms_per_fragment_streamed": round(min(streamed), 2),
+            "streamed_note": "yoho_extractor.run_many over 6 fragments (identical values to run(), tests/test_gpu_dropin.py): wall / fragments, second of two runs",
             "lanes": {"backbone_lanes": lanes_default, "ms_per_fragment_one_lane": round(sorted(wall1)[1], 2),
                       "note": "lanes = (stream, library context) pairs the four backbone passes of a fragment alternate over: a pass's voxelisation and "
                               "coordinate / kernel maps are queued while the previous pass's convolutions run on the other lane; identical bits "

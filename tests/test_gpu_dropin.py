@@ -337,6 +337,17 @@ def test_fcgf_extractor_dropin_and_full_yoho_extractor(sd1, tables):
         assert torch.equal(ex._last_group_feats.cpu(), torch.from_numpy(got)), (lanes, rb, float((ex._last_group_feats.cpu() - torch.from_numpy(got)).abs().max()))
         assert np.array_equal(k1, kpts) and torch.equal(i1, inv) and torch.equal(e1, eqv), (lanes, rb)
     ex.lanes, ex.rot_batch = 2, 15
+    # streamed over several clouds (descriptor pass and result copy of a fragment on a tail lane while the backbone lanes work on the
+    # next one): the values run() returns, fragment by fragment, with the generator consumed in the same order
+    pcs = [pc, synth.surface_cloud(1900, seed=4), pc[:2000]]
+    np.random.seed(11)
+    one = [ex.run(p, voxel_size=0.025, nkpts=48) for p in pcs]
+    np.random.seed(11)
+    many = list(ex.run_many(pcs, voxel_size=0.025, nkpts=48))
+    assert len(many) == 3
+    for a, b in zip(one, many):
+        assert np.array_equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    assert list(ex.run_many([])) == []
 
 
 @pytest.mark.parametrize("golden", ["scene4.npz", "scene6.npz"])

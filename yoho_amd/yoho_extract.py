@@ -84,7 +84,7 @@ class yoho_extractor():
         # kernel maps - atomics and scans with host round trips for the level sizes - are queued while the previous pass's
         # convolutions still run on the other lane (YOHO_FCGF_LANES=1: one lane, as up to round 5)
         self.lanes = max(1, min(2, int(os.environ.get("YOHO_FCGF_LANES", "2"))))
-        self._side_stream = None
+        self._side_stream, self._tail = None, None
         if self.lanes > 1 and hasattr(self.fcgf, "lane_context"):
             self.fcgf.lane_context()               # the second lane's weights are resident from here on, like the first one's
 
@@ -142,13 +142,15 @@ class yoho_extractor():
             self._side_stream = torch.cuda.Stream()
         return [(self.ctx, main), (self.fcgf.lane_context(), self._side_stream)]
 
-    def _extract_features_overlapped(self, pc, voxel_size, nkpts):
-        """extract_features' HBM-resident path with the keypoint draw off the critical path.  The reference's
-        np.random.permutation(len(pc))[0:nkpts] on the global generator costs 5 ms of host time for 300 k points, and nothing on
-        the device depends on it until the first NN transfer: it is taken after the first backbone pass has been queued (the
-        library call returns once the last level size is known, with most of the pass still running on the device), so the
-        device works while the host shuffles.  It is the only draw in this method, so the generator is consumed exactly as in
-        the reference (same keypoints for the same seed)."""
+    def _queue_passes(self, pc, voxel_size, nkpts):
+        """Queue a fragment's backbone passes and NN feature transfers on the lanes; returns without joining them:
+        dict(kpts, kpts_f (K,32,60) cuda - complete once `done` has run -, done = one event per lane, keep = tensors that must outlive
+        `done`).  The keypoint draw sits off the critical path: the reference's np.random.permutation(len(pc))[0:nkpts] on the global
+        generator costs 5 ms of host time for 300 k points, and nothing on the device depends on it until the first NN transfer - it is
+        taken after one backbone pass per lane has been queued (a library call returns once the last level size is known, with most of
+        the pass still running on the device), so the device works while the host shuffles.  It is the only draw in this method, so the
+        generator is consumed exactly as in the reference (same keypoints for the same seed).  The backbone passes alternate over the
+        lanes of `_lanes()`; which lane a pass runs on changes no bit of its features."""
         pc_d = torch.from_numpy(np.ascontiguousarray(np.asarray(pc, dtype=np.float64))).cuda()
         G = self.grs.shape[0]
         starts = self._pass_starts(G)
@@ -186,14 +188,68 @@ class yoho_extractor():
                     if b < len(ahead):
                         ahead[b] = None
                     del res
-            for _, st in lanes[1:]:
-                main.wait_stream(st)               # PartI reads every column of kpts_f
         finally:
             for c, _ in lanes:
                 c.set_nn_grid(0)
-        self._last_group_feats = kpts_f
-        out = self._partI(kpts_f)
-        return (kpts,) + _to_host(out["inv"], out["eqv"])
+        done = []
+        for _, st in lanes:
+            e = torch.cuda.Event()
+            e.record(st)
+            done.append(e)
+        return {"kpts": kpts, "kpts_f": kpts_f, "done": done, "keep": (pc_d, kidx_d)}
+
+    def _extract_features_overlapped(self, pc, voxel_size, nkpts):
+        q = self._queue_passes(pc, voxel_size, nkpts)
+        main = torch.cuda.current_stream()
+        for e in q["done"]:
+            main.wait_event(e)                     # PartI reads every column of kpts_f
+        self._last_group_feats = q["kpts_f"]
+        out = self._partI(q["kpts_f"])
+        return (q["kpts"],) + _to_host(out["inv"], out["eqv"])
+
+    def run_many(self, pcs, voxel_size=0.025, nkpts=5000):
+        """run() over an iterable of clouds, streamed: yields (kpts, feat_inv, feat_eqv) per cloud, in order, the same values
+        run() returns for the same clouds and generator state.  The descriptor pass and the result copy of fragment f run on a tail
+        lane (its own stream and library context, driven by a helper thread) while the backbone lanes already work on fragment f + 1,
+        so that what a single run() call leaves exposed - the first pass's voxelisation and maps, PartI, the copy of 38 MB of results -
+        is hidden behind convolutions (`bench.py` fcgf leg: ms_per_fragment_streamed).  A fragment is yielded when the next one
+        has been queued; at most two are in flight."""
+        if self.fcgf is None or not (hasattr(self.fcgf, "extract_rotated_batch") and hasattr(self.fcgf, "lane_context")) or self.lanes < 2:
+            for pc in pcs:
+                yield self.run(pc, voxel_size=voxel_size, nkpts=nkpts)
+            return
+        if self._tail is None:
+            self._tail = (hip.get_context(self.ctx.device, self.ctx.tables.dir, lane=2), torch.cuda.Stream())
+        tctx, tst = self._tail
+
+        def finish(q):
+            with torch.cuda.stream(tst):
+                for e in q["done"]:
+                    tst.wait_event(e)
+                if tctx.partI_owner is not self:
+                    tctx.load_partI(self._sd, owner=self)
+                out = tctx.partI_forward(q["kpts_f"], want_inv=True)        # (its range check waits for the tail stream only)
+                self._last_group_feats = q["kpts_f"]
+                return (q["kpts"],) + _to_host(out["inv"], out["eqv"])
+
+        # finish(f) - PartI, its range check, the result copy: mostly waiting for the device - runs on a helper thread while this
+        # one queues the passes of f + 1 (the keypoint draws stay on this thread, in order)
+        from concurrent.futures import ThreadPoolExecutor
+        pool = ThreadPoolExecutor(max_workers=1)
+        try:
+            prev, fut = None, None
+            for pc in pcs:
+                cur = self._queue_passes(pc, voxel_size, nkpts)
+                if fut is not None:
+                    yield fut.result()
+                fut = pool.submit(finish, prev) if prev is not None else None
+                prev = cur
+            if fut is not None:
+                yield fut.result()
+            if prev is not None:
+                yield pool.submit(finish, prev).result()
+        finally:
+            pool.shutdown(wait=True)
 
     def extract_features(self, pc, voxel_size, nkpts=5000):
         if self.fcgf is None:
