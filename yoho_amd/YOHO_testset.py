@@ -43,30 +43,37 @@ class testset_create():
         # Across fragments the host never waits for the device: the result goes to a page-locked buffer by an asynchronous copy and
         # is written by a writer thread while the next fragments run; the next fragment's files are read ahead by a loader thread.
         self.lanes = max(1, min(2, int(os.environ.get("YOHO_FCGF_LANES", "2"))))
-        self._side_stream = None
+        self._main_stream, self._side_stream, self._side_of = None, None, None
         self.stats = {}
         if self.lanes > 1:
             self.fcgf.lane_context()                                 # the second lane's weights are resident from here on, like the first one's
 
     def _lanes(self):
-        main = torch.cuda.current_stream()
+        """as yoho_extractor._lanes: lane streams picked by measurement (no shared hardware queue), never the null stream"""
+        cur = torch.cuda.current_stream()
         if self.lanes < 2:
-            return [(self.ctx, main)]
-        if self._side_stream is None:
-            self._side_stream = torch.cuda.Stream()
-        return [(self.ctx, main), (self.fcgf.lane_context(), self._side_stream)]
+            return [(self.ctx, cur)]
+        if self._side_stream is None or self._side_of != cur.cuda_stream:
+            main = cur if cur.cuda_stream != 0 else hip.concurrent_stream(self.ctx, [cur])
+            self._main_stream, self._side_stream = main, hip.concurrent_stream(self.ctx, [cur, main] if main is not cur else [cur])
+            self._side_of = cur.cuda_stream
+        return [(self.ctx, self._main_stream), (self.fcgf.lane_context(), self._side_stream)]
 
     def fragment_group_features(self, pc, keys, join=True):
         """pc (N,3), keys (K,3) f64 -> (K,32,60) f32 cuda tensor (one fragment, all 60 group elements); complete on the caller's
         stream (the side lane is joined before the return).  join=False (Feature_extracting): the caller's stream is NOT made to
         wait for the side lane - the next fragment's first pass can then be queued under this fragment's last one; the result is
         complete once BOTH streams of `_lanes()` have run."""
-        pc_d = torch.from_numpy(np.ascontiguousarray(np.asarray(pc, dtype=np.float64))).cuda()
-        k_d = torch.from_numpy(np.ascontiguousarray(np.asarray(keys, dtype=np.float64))).cuda()
-        out = torch.empty((k_d.shape[0], 32, 60), dtype=torch.float32, device="cuda")
         nb = 15                                                      # rotated copies per backbone pass (split further by voxel count)
         lanes = self._lanes()
         main = lanes[0][1]
+        cur = torch.cuda.current_stream()
+        if main is not cur:
+            main.wait_stream(cur)                                    # lane 0 is a stream of our own (the caller is on the null stream)
+        with torch.cuda.stream(main):
+            pc_d = torch.from_numpy(np.ascontiguousarray(np.asarray(pc, dtype=np.float64))).cuda()
+            k_d = torch.from_numpy(np.ascontiguousarray(np.asarray(keys, dtype=np.float64))).cuda()
+            out = torch.empty((k_d.shape[0], 32, 60), dtype=torch.float32, device="cuda")
         ready = torch.cuda.Event()
         ready.record(main)
         for c, st in lanes:
@@ -89,6 +96,10 @@ class testset_create():
                 else:                                                # still in use there when this frame's references are dropped
                     for t in (pc_d, k_d, out):
                         t.record_stream(st)
+            if join and main is not cur:
+                cur.wait_stream(main)                                # complete on the caller's stream
+                for t in (pc_d, k_d, out):
+                    t.record_stream(cur)
         finally:
             for c, _ in lanes:
                 c.set_nn_grid(0)
@@ -131,7 +142,7 @@ class testset_create():
 
         tl, tw = threading.Thread(target=loader, daemon=True), threading.Thread(target=writer, daemon=True)
         tl.start(); tw.start()
-        copy_stream = torch.cuda.Stream()
+        copy_stream = hip.concurrent_stream(self.ctx, [st for _, st in self._lanes()])
         n = 0
         try:
             while True:

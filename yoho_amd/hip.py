@@ -798,6 +798,39 @@ class Context:
 _ctx_cache = {}
 
 
+def streams_overlap(ctx, s1, s2, microseconds=300):
+    """True when work queued on the torch streams s1 and s2 runs concurrently.  HIP multiplexes a process's streams over a few hardware
+    queues (four by default, dealt round-robin in creation order, the null stream among them): two streams that land on the same queue
+    run their kernels one after the other however independent they are - about one stream in four shares the null stream's queue
+    (measured: a 20 us kernel on such a stream waits for everything queued on the null stream).  Measured, not assumed: the one-wave
+    clock probe (yoho_clock_probe spins for `microseconds`) on both streams, timed together - ~1 x the probe when they overlap, 2 x when
+    they share a queue."""
+    import time
+    buf = torch.zeros((2, 3), dtype=torch.int64, device=f"cuda:{ctx.device}")
+    torch.cuda.synchronize(ctx.device)
+    best = None
+    for _ in range(3):
+        t0 = time.perf_counter()
+        ctx.clock_probe(microseconds, stream=s1, out=buf[0])
+        ctx.clock_probe(microseconds, stream=s2, out=buf[1])
+        s1.synchronize()
+        s2.synchronize()
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    return best < 1.6e-6 * microseconds
+
+
+def concurrent_stream(ctx, others, tries=8):
+    """a new torch stream (normal priority) that demonstrably overlaps every stream of `others` (streams_overlap): the first candidate
+    that passes is kept.  Falls back to the last candidate - correct, merely serialised - when none does."""
+    cand = None
+    for _ in range(tries):
+        cand = torch.cuda.Stream(device=ctx.device)
+        if all(streams_overlap(ctx, o, cand) for o in others):
+            return cand
+    return cand
+
+
 def get_context(device=None, so3_dir=None, lane=0):
     """Process-wide context per (device, table directory, lane).  lane > 0: a further context with a workspace of its own for work
     queued on another stream while lane 0's runs (the backbone lanes of yoho_extractor / testset_create); it is kept, like lane 0's,

@@ -84,7 +84,7 @@ class yoho_extractor():
         # kernel maps - atomics and scans with host round trips for the level sizes - are queued while the previous pass's
         # convolutions still run on the other lane (YOHO_FCGF_LANES=1: one lane, as up to round 5)
         self.lanes = max(1, min(2, int(os.environ.get("YOHO_FCGF_LANES", "2"))))
-        self._side_stream, self._tail = None, None
+        self._main_stream, self._side_stream, self._side_of, self._tail = None, None, None, None
         if self.lanes > 1 and hasattr(self.fcgf, "lane_context"):
             self.fcgf.lane_context()               # the second lane's weights are resident from here on, like the first one's
 
@@ -134,13 +134,20 @@ class yoho_extractor():
 
     def _lanes(self):
         """[(library context, torch stream)] the backbone passes alternate over: the caller's stream with the extractor's context,
-        and - with two lanes - a side stream with the backbone's second context (its own workspace)."""
-        main = torch.cuda.current_stream()
+        and - with two lanes - a side stream with the backbone's second context (its own workspace).  Two things are measured rather
+        than assumed (hip.concurrent_stream): HIP deals a process's streams round-robin onto four hardware queues, so one candidate in
+        four would run its kernels strictly behind the other lane's; and the NULL stream is never a lane - with it as lane 0 the
+        second lane's map kernels were found starved for the whole length of lane 0's convolutions in some processes (bench.py without
+        its dataset and sustained legs: 40.5 against 36.9 ms per fragment) - so a caller on the null stream gets a lane 0 stream of
+        the extractor's own, joined to the caller's stream on both sides."""
+        cur = torch.cuda.current_stream()
         if self.lanes < 2 or not hasattr(self.fcgf, "lane_context"):
-            return [(self.ctx, main)]
-        if self._side_stream is None:
-            self._side_stream = torch.cuda.Stream()
-        return [(self.ctx, main), (self.fcgf.lane_context(), self._side_stream)]
+            return [(self.ctx, cur)]
+        if self._side_stream is None or self._side_of != cur.cuda_stream:
+            main = cur if cur.cuda_stream != 0 else hip.concurrent_stream(self.ctx, [cur])
+            self._main_stream, self._side_stream = main, hip.concurrent_stream(self.ctx, [cur, main] if main is not cur else [cur])
+            self._side_of, self._tail = cur.cuda_stream, None
+        return [(self.ctx, self._main_stream), (self.fcgf.lane_context(), self._side_stream)]
 
     def _queue_passes(self, pc, voxel_size, nkpts):
         """Queue a fragment's backbone passes and NN feature transfers on the lanes; returns without joining them:
@@ -151,13 +158,17 @@ class yoho_extractor():
         the pass still running on the device), so the device works while the host shuffles.  It is the only draw in this method, so the
         generator is consumed exactly as in the reference (same keypoints for the same seed).  The backbone passes alternate over the
         lanes of `_lanes()`; which lane a pass runs on changes no bit of its features."""
-        pc_d = torch.from_numpy(np.ascontiguousarray(np.asarray(pc, dtype=np.float64))).cuda()
         G = self.grs.shape[0]
         starts = self._pass_starts(G)
         batches = [[self.grs[i] for i in range(i0, i1)] for i0, i1 in zip(starts[:-1], starts[1:])]
         lanes = self._lanes()
         main = lanes[0][1]
-        uploaded = torch.cuda.Event()              # the cloud is on the device (queued on the caller's stream)
+        cur = torch.cuda.current_stream()
+        if main is not cur:
+            main.wait_stream(cur)                  # lane 0 is the extractor's own stream (the caller is on the null stream)
+        with torch.cuda.stream(main):
+            pc_d = torch.from_numpy(np.ascontiguousarray(np.asarray(pc, dtype=np.float64))).cuda()
+        uploaded = torch.cuda.Event()              # the cloud is on the device (queued on lane 0)
         uploaded.record(main)
         for _, st in lanes[1:]:
             st.wait_event(uploaded)
@@ -171,8 +182,9 @@ class yoho_extractor():
         ahead = [backbone(b) for b in range(min(len(lanes), len(batches)))]
         kpts_index = np.random.permutation(len(pc))[0:nkpts]
         kpts = pc[kpts_index]
-        kpts_f = torch.empty((kpts.shape[0], 32, 60), dtype=torch.float32, device="cuda")
-        kidx_d = torch.from_numpy(kpts_index.astype(np.int64)).cuda()
+        with torch.cuda.stream(main):
+            kpts_f = torch.empty((kpts.shape[0], 32, 60), dtype=torch.float32, device="cuda")
+            kidx_d = torch.from_numpy(kpts_index.astype(np.int64)).cuda()
         ready = torch.cuda.Event()                 # keypoint indices and the output tensor exist
         ready.record(main)
         for c, st in lanes:
@@ -196,16 +208,20 @@ class yoho_extractor():
             e = torch.cuda.Event()
             e.record(st)
             done.append(e)
-        return {"kpts": kpts, "kpts_f": kpts_f, "done": done, "keep": (pc_d, kidx_d)}
+        return {"kpts": kpts, "kpts_f": kpts_f, "done": done, "keep": (pc_d, kidx_d), "main": main}
 
     def _extract_features_overlapped(self, pc, voxel_size, nkpts):
         q = self._queue_passes(pc, voxel_size, nkpts)
-        main = torch.cuda.current_stream()
-        for e in q["done"]:
-            main.wait_event(e)                     # PartI reads every column of kpts_f
-        self._last_group_feats = q["kpts_f"]
-        out = self._partI(q["kpts_f"])
-        return (q["kpts"],) + _to_host(out["inv"], out["eqv"])
+        cur, main = torch.cuda.current_stream(), q["main"]
+        with torch.cuda.stream(main):
+            for e in q["done"]:
+                main.wait_event(e)                 # PartI reads every column of kpts_f
+            self._last_group_feats = q["kpts_f"]
+            out = self._partI(q["kpts_f"])
+            res = (q["kpts"],) + _to_host(out["inv"], out["eqv"])       # (waits for lane 0)
+        if main is not cur:
+            cur.wait_stream(main)                  # what the caller queues next sees a finished call, as on one stream
+        return res
 
     def run_many(self, pcs, voxel_size=0.025, nkpts=5000):
         """run() over an iterable of clouds, streamed: yields (kpts, feat_inv, feat_eqv) per cloud, in order, the same values
@@ -218,8 +234,10 @@ class yoho_extractor():
             for pc in pcs:
                 yield self.run(pc, voxel_size=voxel_size, nkpts=nkpts)
             return
+        lanes = self._lanes()
         if self._tail is None:
-            self._tail = (hip.get_context(self.ctx.device, self.ctx.tables.dir, lane=2), torch.cuda.Stream())
+            self._tail = (hip.get_context(self.ctx.device, self.ctx.tables.dir, lane=2),
+                          hip.concurrent_stream(self.ctx, [torch.cuda.current_stream()] + [st for _, st in lanes]))
         tctx, tst = self._tail
 
         def finish(q):
