@@ -416,7 +416,9 @@ class ScenePairRunner:
 
         # two-stage device side: the H2D copies of group N + 1 run on a copy stream while PartI describes group N
         if self._copy_stream is None:
-            self._copy_stream = torch.cuda.Stream()
+            from . import hip
+            # (streams are dealt round-robin onto four hardware queues: one picked blindly may run strictly behind the caller's)
+            self._copy_stream = hip.concurrent_stream(self.ctx, [torch.cuda.current_stream()])
         copy, main = self._copy_stream, torch.cuda.current_stream()
 
         def upload(group):
@@ -574,7 +576,8 @@ class ScenePairRunner:
             c.set_partII_mode(self.ctx.partII_mode)
             if self.estimator == "yohoo":
                 c.load_partII(self._partII_sd)
-            ws.append((c, torch.cuda.Stream()))
+            # a worker's stream must overlap the caller's (fragments are described there meanwhile) and the other workers': measured
+            ws.append((c, hip.concurrent_stream(self.ctx, [torch.cuda.current_stream()] + [st for _, st in ws])))
         return ws
 
     def run_pairs(self, dataset, pairs, part=None):
