@@ -262,6 +262,19 @@ def test_partI_depth_first_schedule_is_bit_identical(hip, sd1):
     assert ticks > 0 and 100.0 < mhz < 3000.0
 
 
+def test_lane_streams_are_picked_by_measured_overlap(hip):
+    """hip.streams_overlap / concurrent_stream (the backbone lanes): a stream trivially does not overlap itself, a picked stream
+    overlaps every stream it was picked against, and is never the null stream"""
+    H = hip
+    c = H.get_context()
+    cur = torch.cuda.current_stream()
+    assert not H.streams_overlap(c, cur, cur)
+    a = H.concurrent_stream(c, [cur])
+    b = H.concurrent_stream(c, [cur, a])
+    assert a.cuda_stream != 0 and b.cuda_stream != 0 and a.cuda_stream != b.cuda_stream
+    assert H.streams_overlap(c, cur, a) and H.streams_overlap(c, cur, b) and H.streams_overlap(c, a, b)
+
+
 def test_contexts_with_different_group_tables_coexist(hip, sd1, tables, tmp_path):
     """The slot tables of the direct-conv kernels travel in the launch arguments (device memory of the context), so a second
     context on a RELABELLED copy of the group (element a <-> pi[a], identity fixed) lives beside the default one: its PartI on the

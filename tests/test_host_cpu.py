@@ -53,6 +53,34 @@ def test_backbone_batches_cap_at_64_clouds():
     assert [len(b) for b in ctx.batches] == [64, 64, 22]
 
 
+def test_extractor_pass_sizes_cover_the_group_once():
+    """yoho_extractor._pass_starts: YOHO_ROT_BATCH as one number or a list of pass sizes - every group element in exactly one pass"""
+    from yoho_amd.yoho_extract import yoho_extractor
+    ex = object.__new__(yoho_extractor)
+    for rb, want in ((15, [0, 15, 30, 45, 60]), (16, [0, 16, 32, 48, 60]), (60, [0, 60]), (100, [0, 60]), ([9, 17, 17, 17], [0, 9, 26, 43, 60]),
+                     ([30], [0, 30, 60]), ([7, 20], [0, 7, 27, 47, 60]), ([0, 59], [0, 1, 60]), ([70, 5], [0, 60])):
+        ex.rot_batch = rb
+        assert ex._pass_starts(60) == want, rb
+
+
+def test_lane_context_loads_the_backbone_once_per_context(monkeypatch):
+    """fcgf_extractor.lane_context(): the second lane's context is process-wide (hip.get_context(lane=1)) and gets this backbone's
+    weights when another object's are resident; a pass on it leaves the first context's residency alone"""
+    from yoho_amd import hip
+    main, lane = _FakeCtx([]), _FakeCtx([])
+    main.device, main.tables = 0, types.SimpleNamespace(dir="/nowhere")
+    asked = []
+    monkeypatch.setattr(hip, "get_context", lambda device=None, so3_dir=None, lane=0: (asked.append((device, so3_dir, lane)), lane_ctx)[1])
+    lane_ctx = lane
+    ex = _extractor(main, 1000)
+    main.fcgf_owner = ex
+    assert ex.lane_context() is lane and asked == [(0, "/nowhere", 1)] and lane.loads == 1 and lane.fcgf_owner is ex
+    assert ex.lane_context() is lane and lane.loads == 1 and len(asked) == 1          # kept, resident
+    lane.fcgf_owner = object()                                                         # another backbone used the shared lane context
+    ex.lane_context()
+    assert lane.loads == 2 and lane.fcgf_owner is ex and main.loads == 0
+
+
 def test_gather_sets_and_clears_the_grid_hint():
     from yoho_amd import gather
     calls = []
