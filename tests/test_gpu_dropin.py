@@ -648,6 +648,51 @@ def test_testset_create_from_point_clouds(tmp_path, tables):
             assert rel(got[:, :, g], ref) < 1e-4, (pid, g)
 
 
+def test_dataset_driver_from_point_clouds_equals_the_cache_route(tmp_path, sd1, tables):
+    """run_dataset.ScenePairRunner(backbone=testset_create): the FCGF group features computed from the fragments' point clouds on the
+    device (rotate, voxelise, backbone, NN gather) instead of read from FCGF_Input_Group_feature/*.npy - YOHO_testset.py's stage folded
+    into the evaluation, nothing between the raw cloud and the registration result on disk.  Same per-pair results as the two-stage
+    route (testset_create writes the cache, the driver reads it), bit for bit."""
+    from yoho_amd import run_dataset, hip
+    from yoho_amd.YOHO_testset import testset_create
+    fsd = W.synth_state_dict(W.FCGF_SPEC, 3)
+    ck = {"config": {"model": "ResUNetBN2C", "model_n_out": 32, "normalize_feature": True, "conv1_kernel_size": 7}, "state_dict": fsd}
+    base = synth.surface_cloud(4000, seed=21)
+    rs = np.random.RandomState(2)
+    clouds, kps = {}, {}
+    for i in range(3):                                        # three overlapping views of one surface, each in its own frame
+        Rg = tables.R64[(7 * i) % 60]
+        sub = base[rs.permutation(len(base))[:2600]]
+        clouds[str(i)] = sub @ Rg.T + rs.uniform(-0.2, 0.2, 3)
+        kps[str(i)] = clouds[str(i)][rs.permutation(2600)[:96]]
+
+    class DS:
+        name = "synth/room"
+        pc_ids = ["0", "1", "2"]
+        pair_ids = [("0", "1"), ("0", "2"), ("1", "2")]
+        get_pc = staticmethod(lambda i: clouds[i])
+        get_kps = staticmethod(lambda i: kps[i])
+
+    ds = DS()
+    cfg = types.SimpleNamespace(output_cache_fn=str(tmp_path), ransac_c_inlinerdist=0.07, ransac_o_inlinerdist=0.09)
+    tcfg = types.SimpleNamespace(model=ck, voxel_size=0.025, dataset="synth", output_dir=str(tmp_path), origin_dir=str(tmp_path),
+                                 datasets={"wholesetname": "synth", "room": ds})
+    ctx = hip.get_context()
+    ctx.load_partI(sd1)
+    tc = testset_create(tcfg, ctx=ctx)
+    tc.batch_feature_extraction()                            # route A, stage 1: the cache files
+    out = {}
+    for route, backbone in (("cache", None), ("clouds", tc)):
+        runner = run_dataset.ScenePairRunner(cfg, ctx, estimator="yohoc", max_iter=60, base_seed=5, pair_workers=1, backbone=backbone)
+        runner.setup_scene(ds, ds.pair_ids)
+        out[route] = [runner.run_pair(ds, p) for p in ds.pair_ids]
+        assert runner.stats["fragments"] == 3 and runner.stats["pairs"] == 3
+        assert (runner.stats["bytes_read"] == 0) == (route == "clouds") and (runner.stats["backbone_s"] > 0) == (route == "clouds")
+    for a, b in zip(out["cache"], out["clouds"]):
+        assert np.array_equal(a["trans"], b["trans"]) and a["recalltime"] == b["recalltime"] and a["matches"] == b["matches"] and a["inliers"] == b["inliers"]
+    assert all(r["matches"] >= 3 for r in out["clouds"])
+
+
 @pytest.mark.parametrize("estimator,part,it", [("yohoo", "PartII", 1000), ("yohoc", "PartI", 100)])
 def test_eval_sharded_world1_on_scene6(gold, tmp_path, sd1, sd2, tables, estimator, part, it):
     """The dataset driver's GPU worker (run_dataset.eval_sharded: load + describe every fragment once, HBM-resident pairs, pre.log,

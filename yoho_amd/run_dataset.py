@@ -279,7 +279,7 @@ class ScenePairRunner:
     `stats` accumulates where the time goes (seconds; device work is timed with a synchronise only when timing=True)."""
 
     def __init__(self, cfg, ctx, estimator="yohoo", max_iter=1000, base_seed=0, timing=False, write_npz=False, hypotheses="selected",
-                 pair_workers=2, partII_sd=None, fused=True, overlap=True):
+                 pair_workers=2, partII_sd=None, fused=True, overlap=True, backbone=None):
         import torch
         from . import pipeline
         self.torch, self.pipeline = torch, pipeline
@@ -311,6 +311,11 @@ class ScenePairRunner:
         self.part = _Part(None)         # the scene part set up last (run_parts keeps two alive: one being set up, one being run)
         self._made_dirs = set()
         self._copy_stream = None
+        # backbone: an object with fragment_group_features(pc (N,3), keys (K,3)) -> (K,32,60) f32 on the device, complete on the current
+        # stream (YOHO_testset.testset_create): the FCGF group features then come from the fragments' point clouds - rotated, voxelised,
+        # through the sparse backbone, NN-gathered at the keypoints, all on this GPU - instead of from the FCGF_Input_Group_feature cache
+        # files of a separate YOHO_testset.py run.  Nothing between the raw cloud and the registration result touches the disk.
+        self.backbone = backbone
         self._pin_pool = {}
         self._pin_lock = threading.Lock()
         # write_npz: this rank writes the {id0}-{id1}.npz of the pairs it ran (finish_writes, behind its last pair: 0.15 ms of
@@ -321,7 +326,7 @@ class ScenePairRunner:
         self._write_jobs = []
         self.timing = bool(timing)
         self.stats = {"fragments": 0, "pairs": 0, "load_s": 0.0, "load_wait_s": 0.0, "h2d_describe_s": 0.0, "setup_s": 0.0, "pairs_s": 0.0,
-                      "bytes_read": 0, "peak_resident_fragments": 0}
+                      "bytes_read": 0, "peak_resident_fragments": 0, "backbone_s": 0.0}
 
     def _feature_dir(self, dataset):
         from .utils import dataset_feature_name
@@ -378,6 +383,8 @@ class ScenePairRunner:
         if part is None:
             part = _Part(dataset.name, pairs)
         need = part.need
+        if self.backbone is not None:
+            return self._setup_scene_from_clouds(dataset, part, t_setup)
         fdir = self._feature_dir(dataset)
         q = queue.Queue(maxsize=6)
         NLOAD = 3                                       # loader threads (file reads release the GIL); results are consumed in order
@@ -499,6 +506,54 @@ class ScenePairRunner:
             self.stats["h2d_describe_s"] += time.perf_counter() - t0        # stream only: the pairs of the part before may be running)
         th.join()
         self.stats["peak_resident_fragments"] = max(self.stats["peak_resident_fragments"], len(part.frag))
+        self.stats["setup_s"] += time.perf_counter() - t_setup
+        self.part = part
+        return part
+
+    def _describe_group(self, part, dev):
+        """PartI over the fragments of `dev` = [(fid, group feature (K,32,60) cuda, keys (K,3) f64 cuda)], all valid on the current
+        stream; the fragments become resident in `part` and their pairs may start"""
+        torch = self.torch
+        main = torch.cuda.current_stream()
+        xs = torch.cat([g[1] for g in dev]) if len(dev) > 1 else dev[0][1]
+        out = self.ctx.partI_forward(xs.contiguous(), want_inv=False, want_inv_np=True)
+        o = 0
+        for fid, x, keys in dev:
+            n = x.shape[0]
+            part.frag[fid] = dict(feat=x, keys=keys, eqv=out["eqv"][o:o + n].clone(), inv_np=out["inv_np"][o:o + n].clone())
+            o += n
+        ev = torch.cuda.Event()
+        ev.record(main)
+        with part.cond:
+            for fid, _, _ in dev:
+                part.frag_ev[fid] = ev
+            part.cond.notify_all()
+        self.stats["fragments"] += len(dev)
+        self.stats["peak_resident_fragments"] = max(self.stats["peak_resident_fragments"], len(part.frag))
+
+    def _setup_scene_from_clouds(self, dataset, part, t_setup):
+        """setup_scene with the group features computed here (self.backbone) instead of read from the cache: per fragment the
+        backbone's sixty passes (two lanes), then PartI; the pairs of fragments already described run meanwhile on the worker streams"""
+        import time
+        torch = self.torch
+        main = torch.cuda.current_stream()
+        try:
+            for fid in part.need:
+                t0 = time.perf_counter()
+                keys_h = np.ascontiguousarray(dataset.get_kps(fid), dtype=np.float64)
+                x = self.backbone.fragment_group_features(dataset.get_pc(fid), keys_h)
+                keys = torch.from_numpy(keys_h).cuda()
+                self.stats["backbone_s"] += time.perf_counter() - t0
+                t0 = time.perf_counter()
+                self._describe_group(part, [(fid, x, keys)])
+                self.stats["h2d_describe_s"] += time.perf_counter() - t0
+        except BaseException:
+            part.fail()
+            raise
+        if self.timing:
+            t0 = time.perf_counter()
+            main.synchronize()
+            self.stats["h2d_describe_s"] += time.perf_counter() - t0
         self.stats["setup_s"] += time.perf_counter() - t_setup
         self.part = part
         return part
@@ -712,14 +767,18 @@ def load_and_broadcast_weights(cfg, ctx, need_partII):
 
 
 def eval_sharded(cfg, max_iter=1000, estimator="yohoo", datasets=None, base_seed=0, results_log=None, ctx=None, state_dicts=None,
-                 stats_out=None, hypotheses="selected", weights_loaded=False, pair_workers=2, fused=True, overlap=True):
+                 stats_out=None, hypotheses="selected", weights_loaded=False, pair_workers=2, fused=True, overlap=True, fcgf_model=None,
+                 voxel_size=0.025):
     """The sharded counterpart of Evaluator_PartI/II.eval (tests/evaluator.py:75-101,146-173): run every pair of the
     test set over the initialised process group (one rank per GPU), write npz / pre.log on rank 0 and return the
     Registration Recall there (None on the other ranks).  FCGF group features and keypoints are read from the
     reference's cache layout; descriptors, matches and hypotheses never touch the disk.  state_dicts: None = read and broadcast the
     checkpoints of cfg.model_fn, (PartI, PartII) = use these (weights_loaded=True: ctx already holds them).  pair_workers: pairs run
     concurrently per rank (ScenePairRunner.run_pairs).  stats_out: a dict that receives the
-    rank's ScenePairRunner.stats and the gathered per-pair results (tools/bench_dataset.py, tests)."""
+    rank's ScenePairRunner.stats and the gathered per-pair results (tools/bench_dataset.py, tests).
+    fcgf_model (an FCGF checkpoint path or dict, as YOHO_testset.py's --model): the group features are not read from the cache but
+    computed from the fragments' point clouds (dataset.get_pc) on this GPU - YOHO_testset.py's stage folded into the evaluation, with
+    voxel_size as its --voxel_size; every rank runs the backbone for the fragments of the parts it owns."""
     import torch
     from . import hip, RR_cal
     from .dataset import get_dataset
@@ -735,9 +794,15 @@ def eval_sharded(cfg, max_iter=1000, estimator="yohoo", datasets=None, base_seed
         if estimator == "yohoo":
             ctx.load_partII(state_dicts[1])
     # every rank writes the archives of the pairs it ran (one node: the cache directory is shared), rank 0 the pre.log files
+    backbone = None
+    if fcgf_model is not None:
+        import types
+        from .YOHO_testset import testset_create
+        backbone = testset_create(types.SimpleNamespace(model=fcgf_model, voxel_size=voxel_size, dataset=datasets.get("wholesetname", "testset"), datasets=datasets,
+                                                        output_dir=cfg.output_cache_fn, origin_dir=getattr(cfg, "origin_data_dir", ".")), ctx=ctx)
     runner = ScenePairRunner(cfg, ctx, estimator=estimator, max_iter=max_iter, base_seed=base_seed, timing=stats_out is not None, write_npz=True,
                              hypotheses=hypotheses, pair_workers=pair_workers, partII_sd=(state_dicts[1] if estimator == "yohoo" else None),
-                             fused=fused, overlap=overlap)
+                             fused=fused, overlap=overlap, backbone=backbone)
     cached = getattr(ctx, "_pair_workers_cache", None)           # worker contexts (PartII weight packing: 0.25 s each) live with ctx
     if cached is not None and cached[0] is state_dicts[1] and len(cached[1]) == runner.pair_workers:
         runner._workers = cached[1]
