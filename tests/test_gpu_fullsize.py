@@ -56,9 +56,12 @@ def test_run_pair_full_size_default_modes_vs_oracle(dctx, sd1, sd2, tables):
     tiles = [(0, 256), (2560, 2816), (4864, 5120), (9728, 9984), (9984, 10000)]
     for lo, hi in tiles:
         eo, _ = orc.partI_forward(both[lo:hi], sd1, tables.N)
-        err = np.abs(e_both[lo:hi].astype(np.float64) - eo).reshape(hi - lo, -1).max(axis=1) / np.abs(eo).max()
-        print("PartI fgemm at 10000 kp, column tile rows %d-%d: rel err vs oracle %.3g (worst row %d)" % (lo, hi - 1, err.max(), lo + int(err.argmax())))
-        assert err.max() < TOL, (lo, hi, lo + int(err.argmax()))
+        dabs = np.abs(e_both[lo:hi].astype(np.float64) - eo).reshape(hi - lo, -1).max(axis=1)
+        err = dabs / np.abs(eo).max()
+        err_row = dabs / np.abs(eo).reshape(hi - lo, -1).max(axis=1)         # every keypoint against its own magnitude
+        print("PartI fgemm at 10000 kp, column tile rows %d-%d: rel err vs oracle %.3g (worst row %d), against the row's own magnitude %.3g"
+              % (lo, hi - 1, err.max(), lo + int(err.argmax()), err_row.max()))
+        assert err.max() < TOL and err_row.max() < TOL, (lo, hi, lo + int(err.argmax()))
     ref_bits = [torch.cat([res.eqv[0][k], res.eqv[1][k]]) for k in ("eqv", "inv_np")]
     for rep in range(5):
         o0r, o1r = pipeline.describe_pair(dctx, f0, f1)
@@ -85,6 +88,8 @@ def test_run_pair_full_size_default_modes_vs_oracle(dctx, sd1, sd2, tables):
     print("Des2R at M=%d: %d near-ties (gap < 1e-4), %d index disagreements (all of them near-ties: %s)"
           % (M, int((gap < 1e-4).sum()), int(differ.sum()), bool((gap[differ] < 1e-4).all())))
     assert (gap[differ] < 1e-4).all()
+    # (against the ORACLE, whose BLAS sums the 1920 products of a row in another order: up to two near-ties may fall the other way; against
+    # the REFERENCE's own run of this pair tests/test_gpu_census.py demands - and gets - zero of 3233)
     assert differ.sum() <= 2
     # -- PartII (a9) for every match, default arithmetic
     qo = np.concatenate([orc.partII_forward(pr["feat1"][m1[s:s + 400]], pr["feat0"][m0[s:s + 400]], e1[m1[s:s + 400]], e0[m0[s:s + 400]],

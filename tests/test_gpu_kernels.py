@@ -19,6 +19,13 @@ def rel(a, b):
     return float(np.max(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64))) / max(np.max(np.abs(b)), 1e-30))
 
 
+def rel_rows(a, b):
+    """the worst ROW: every keypoint's (match's) error against that row's own magnitude - rel() above measures against the largest
+    value of the whole array, which a row of small values can hide behind"""
+    a, b = np.asarray(a, np.float64).reshape(len(a), -1), np.asarray(b, np.float64).reshape(len(b), -1)
+    return float(np.max(np.max(np.abs(a - b), axis=1) / np.maximum(np.max(np.abs(b), axis=1), 1e-30)))
+
+
 def cu(a):
     return torch.from_numpy(np.ascontiguousarray(a)).cuda()
 
@@ -39,6 +46,7 @@ def test_partI_golden(ctx, gold):
     out = ctx.partI_forward(cu(g["x"]), want_inv=True, want_inv_np=True)
     eqv, inv = out["eqv"].cpu().numpy(), out["inv"].cpu().numpy()
     assert rel(eqv, g["eqv"]) < TOL and rel(inv, g["inv"]) < TOL
+    assert rel_rows(eqv, g["eqv"]) < TOL and rel_rows(inv, g["inv"]) < TOL
     # numpy-order mean of OUR eqv must be bit-exact np.mean of our eqv
     assert np.array_equal(out["inv_np"].cpu().numpy(), np.mean(eqv, axis=-1))
     print("partI golden: rel err eqv %.3g inv %.3g" % (rel(eqv, g["eqv"]), rel(inv, g["inv"])))
@@ -100,8 +108,9 @@ def test_partI_split_golden_and_vs_f32(ctx, ctx_of, mode, dmax, gold, sd1, table
     g = gold("partI.npz")
     out = ctx16.partI_forward(cu(g["x"]), want_inv=True, want_inv_np=True)
     eqv, inv = out["eqv"].cpu().numpy(), out["inv"].cpu().numpy()
-    print("%s golden: rel err eqv %.3g inv %.3g" % (mode, rel(eqv, g["eqv"]), rel(inv, g["inv"])))
+    print("%s golden: rel err eqv %.3g inv %.3g; worst row %.3g / %.3g" % (mode, rel(eqv, g["eqv"]), rel(inv, g["inv"]), rel_rows(eqv, g["eqv"]), rel_rows(inv, g["inv"])))
     assert rel(eqv, g["eqv"]) < TOL and rel(inv, g["inv"]) < TOL
+    assert rel_rows(eqv, g["eqv"]) < TOL and rel_rows(inv, g["inv"]) < TOL
     assert np.array_equal(out["inv_np"].cpu().numpy(), np.mean(eqv, axis=-1))
     for B in (1, 2, 15, 16, 17, 33, 100):
         x = synth.unit_features(B, seed=200 + B)
@@ -138,8 +147,9 @@ def test_partI_group_fourier_mode(hip, ctx, gold, sd1, tables, fmode):
     g = gold("partI.npz")
     out = c.partI_forward(cu(g["x"]), want_inv=True, want_inv_np=True)
     eqv, inv = out["eqv"].cpu().numpy(), out["inv"].cpu().numpy()
-    print("%s golden: rel err eqv %.3g inv %.3g" % (fmode, rel(eqv, g["eqv"]), rel(inv, g["inv"])))
+    print("%s golden: rel err eqv %.3g inv %.3g; worst row %.3g / %.3g" % (fmode, rel(eqv, g["eqv"]), rel(inv, g["inv"]), rel_rows(eqv, g["eqv"]), rel_rows(inv, g["inv"])))
     assert rel(eqv, g["eqv"]) < TOL and rel(inv, g["inv"]) < TOL
+    assert rel_rows(eqv, g["eqv"]) < TOL and rel_rows(inv, g["inv"]) < TOL
     for B in (1, 31, 33, 100, 257):
         x = synth.unit_features(B, seed=300 + B)
         o = c.partI_forward(cu(x))
