@@ -348,6 +348,15 @@ def test_fcgf_extractor_dropin_and_full_yoho_extractor(sd1, tables):
     for a, b in zip(one, many):
         assert np.array_equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
     assert list(ex.run_many([])) == []
+    # leaving the stream early (queued fragments still running on the lanes) leaves nothing behind that the next call could trip over
+    np.random.seed(11)
+    g = ex.run_many(pcs, voxel_size=0.025, nkpts=48)
+    first = next(g)
+    g.close()
+    assert np.array_equal(first[0], one[0][0]) and torch.equal(first[2], one[0][2])
+    np.random.seed(11)
+    again = ex.run(pcs[0], voxel_size=0.025, nkpts=48)
+    assert np.array_equal(again[0], one[0][0]) and torch.equal(again[1], one[0][1]) and torch.equal(again[2], one[0][2])
 
 
 @pytest.mark.parametrize("golden", ["scene4.npz", "scene6.npz"])

@@ -100,6 +100,10 @@ class testset_create():
                 cur.wait_stream(main)                                # complete on the caller's stream
                 for t in (pc_d, k_d, out):
                     t.record_stream(cur)
+        except BaseException:
+            for _, st in lanes:                                      # queued work still uses the tensors of this frame
+                st.synchronize()
+            raise
         finally:
             for c, _ in lanes:
                 c.set_nn_grid(0)

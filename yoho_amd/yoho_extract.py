@@ -200,6 +200,10 @@ class yoho_extractor():
                     if b < len(ahead):
                         ahead[b] = None
                     del res
+        except BaseException:
+            for _, st in lanes:                    # work already queued on a lane still reads / writes the tensors of this frame
+                st.synchronize()
+            raise
         finally:
             for c, _ in lanes:
                 c.set_nn_grid(0)
@@ -240,6 +244,8 @@ class yoho_extractor():
                           hip.concurrent_stream(self.ctx, [torch.cuda.current_stream()] + [st for _, st in lanes]))
         tctx, tst = self._tail
 
+        queued = []                                # fragments whose lanes may still be running
+
         def finish(q):
             with torch.cuda.stream(tst):
                 for e in q["done"]:
@@ -248,7 +254,9 @@ class yoho_extractor():
                     tctx.load_partI(self._sd, owner=self)
                 out = tctx.partI_forward(q["kpts_f"], want_inv=True)        # (its range check waits for the tail stream only)
                 self._last_group_feats = q["kpts_f"]
-                return (q["kpts"],) + _to_host(out["inv"], out["eqv"])
+                res = (q["kpts"],) + _to_host(out["inv"], out["eqv"])       # (waits for the tail stream: the fragment is complete)
+            queued.remove(q)
+            return res
 
         # finish(f) - PartI, its range check, the result copy: mostly waiting for the device - runs on a helper thread while this
         # one queues the passes of f + 1 (the keypoint draws stay on this thread, in order)
@@ -258,6 +266,7 @@ class yoho_extractor():
             prev, fut = None, None
             for pc in pcs:
                 cur = self._queue_passes(pc, voxel_size, nkpts)
+                queued.append(cur)
                 if fut is not None:
                     yield fut.result()
                 fut = pool.submit(finish, prev) if prev is not None else None
@@ -268,6 +277,9 @@ class yoho_extractor():
                 yield pool.submit(finish, prev).result()
         finally:
             pool.shutdown(wait=True)
+            for q in queued:                       # left early (an error, or the caller stopped iterating): queued lanes still use the
+                for e in q["done"]:                # fragment's tensors - wait for them before this frame lets go of them (a finished
+                    e.synchronize()                # fragment's events have long completed: no cost on the normal path)
 
     def extract_features(self, pc, voxel_size, nkpts=5000):
         if self.fcgf is None:
