@@ -300,7 +300,7 @@ def fcgf_leg(ctx, dev, points=300000, nkpts=5000, runs=5):
             "ms_per_fragment": round(timed_runs[len(timed_runs) // 2], 2), "ms_per_fragment_all": [round(v, 2) for v in wall[1:]],
             "fragments_per_s": round(1e3 / timed_runs[len(timed_runs) // 2], 2),
             "ms_per_fragment_streamed": round(min(streamed), 2),
-            "streamed_note": "yoho_extractor.run_many over 6 fragments (identical values to run(), tests/test_gpu_dropin.py): wall / fragments, second of two runs",
+            "streamed_note": "yoho_extractor.run_many over 6 fragments (identical values to run(), tests/test_gpu_dropin.py): wall / fragments, the better of two runs",
             "lanes": {"backbone_lanes": lanes_default, "ms_per_fragment_one_lane": round(sorted(wall1)[1], 2),
                       "note": "lanes = (stream, library context) pairs the four backbone passes of a fragment alternate over: a pass's voxelisation and "
                               "coordinate / kernel maps are queued while the previous pass's convolutions run on the other lane; identical bits "
